@@ -1,0 +1,37 @@
+// Shared device helpers for the catgrasp_amd HIP kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+#define CG_OK 0
+#define CG_ERR_ARG (-1)
+#define CG_ERR_UNSUPPORTED (-2)
+
+// v_mfma_f32_32x32x2_f32: exact-f32 matrix FMA (A: lane l -> A[i=l&31][k=l>>5], B: lane l -> B[k=l>>5][j=l&31],
+// D: col j = l&31, row i = (reg&3) + 8*(reg>>2) + 4*(l>>5)).
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// row of accumulator register r for lane l in a 32x32 MFMA tile
+__device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+__device__ __forceinline__ float max16(const f32x16& c) {
+  float m0 = fmaxf(fmaxf(c[0], c[1]), fmaxf(c[2], c[3]));
+  float m1 = fmaxf(fmaxf(c[4], c[5]), fmaxf(c[6], c[7]));
+  float m2 = fmaxf(fmaxf(c[8], c[9]), fmaxf(c[10], c[11]));
+  float m3 = fmaxf(fmaxf(c[12], c[13]), fmaxf(c[14], c[15]));
+  return fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+}
+
+// float atomic max valid for any sign (buffer pre-filled with -inf)
+__device__ __forceinline__ void atomic_max_f32(float* addr, float v) {
+  if (v >= 0.f) atomicMax((int*)addr, __float_as_int(v));
+  else atomicMin((unsigned int*)addr, __float_as_uint(v));
+}
+
+static inline int cg_hip_status(hipError_t e) { return e == hipSuccess ? CG_OK : (int)e; }

@@ -1,0 +1,100 @@
+// Row-batched dense layer  Y = act(X . W^T + bias [+ row_bias[row / rows_per_group]]) [+ I_k]
+// on v_mfma_f32_32x32x2_f32 (exact f32).
+//
+// Replaces the reference's Linear -> BatchNorm1d -> ReLU tails of STN3d / STNkd / PointNetCls
+// (pointnet2.py:178-185, :216-223, :295-298; one row per candidate) and the Conv1d(k=1) -> BN -> ReLU
+// segmentation head of PointNetSeg (pointnet2.py:324-328; one row per point).  BatchNorm is folded
+// into W / bias on the host.  W is pre-packed into MFMA B-fragment order (see pack_b in
+// catgrasp_amd/folding.py): Wp[nb][ks][lane][4] = W[nb*32 + (lane&31)][ks*8 + (lane>>5)*4 + j].
+#include "cg_common.hpp"
+#include "../../include/catgrasp_amd.h"
+
+namespace {
+
+constexpr int BM = 64;       // rows per workgroup
+constexpr int BK = 64;       // K chunk staged in LDS
+constexpr int SA = BK + 4;   // LDS row stride (floats)
+
+struct GemmArgs {
+  const float* x; int M; int K; int ldx;
+  const float* wp; int N; int nblocks;   // nblocks = ceil(N/32) (packed, zero padded)
+  const float* bias;                      // (N) or null
+  const float* row_bias; int rows_per_group; int ld_rb;  // optional per-group bias (groups = row / rows_per_group)
+  int relu; int eye_k;                    // eye_k>0: add identity of a flattened k x k matrix
+  float* y; int ldy;
+};
+
+__global__ __launch_bounds__(256) void gemm_bias_act_kernel(GemmArgs a) {
+  __shared__ __attribute__((aligned(16))) float xs[BM * SA];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int row0 = blockIdx.x * BM;
+  const int nb = blockIdx.y * 4 + w;            // this wave's 32-channel block
+  const bool active = nb < a.nblocks;
+  const int ksteps_total = a.K / 8;             // K is a multiple of 8 (checked on the host)
+  f32x16 c0 = {0}, c1 = {0};
+  for (int k0 = 0; k0 < a.K; k0 += BK) {
+    const int kc = min(BK, a.K - k0);
+    __syncthreads();
+    // stage X[row0:row0+64, k0:k0+kc] (rows clamped; columns are multiples of 4)
+    for (int i = tid; i < BM * (BK / 4); i += 256) {
+      const int r = i / (BK / 4), cq = i - r * (BK / 4);
+      if (cq * 4 < kc) {
+        int row = row0 + r; if (row >= a.M) row = a.M - 1;
+        f32x4 v = *(const f32x4*)(a.x + (size_t)row * a.ldx + k0 + cq * 4);
+        *(f32x4*)(xs + r * SA + cq * 4) = v;
+      }
+    }
+    __syncthreads();
+    if (active) {
+      const f32x4* bp = (const f32x4*)a.wp + ((size_t)nb * ksteps_total + k0 / 8) * 64 + lane;
+      const float* ar0 = xs + l31 * SA + lhi * 4;
+      const float* ar1 = ar0 + 32 * SA;
+      const int nks = kc / 8;
+#pragma unroll 4
+      for (int ks = 0; ks < nks; ++ks) {
+        f32x4 bv = bp[ks * 64];
+        f32x4 a0 = *(const f32x4*)(ar0 + ks * 8);
+        f32x4 a1 = *(const f32x4*)(ar1 + ks * 8);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { c0 = mfma32(a0[j], bv[j], c0); c1 = mfma32(a1[j], bv[j], c1); }
+      }
+    }
+  }
+  if (!active) return;
+  const int col = nb * 32 + l31;
+  if (col >= a.N) return;
+  float bias = a.bias ? a.bias[col] : 0.f;
+  if (a.eye_k > 0 && (col % (a.eye_k + 1)) == 0) bias += 1.f;   // flattened identity: col = i*k + i
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = row0 + half * 32 + acc_row(r, lane);
+      if (row < a.M) {
+        float v = (half ? c1[r] : c0[r]) + bias;
+        if (a.row_bias) v += a.row_bias[(size_t)(row / a.rows_per_group) * a.ld_rb + col];
+        if (a.relu) v = fmaxf(v, 0.f);
+        a.y[(size_t)row * a.ldy + col] = v;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int cg_gemm_bias_act(const float* x, int M, int K, int ldx, const float* w_packed, int N,
+                                const float* bias, const float* row_bias, int rows_per_group, int ld_rb,
+                                int relu, int eye_k, float* y, int ldy, void* stream) {
+  if (!x || !w_packed || !y) return CG_ERR_ARG;
+  if (M < 0 || N <= 0 || K <= 0 || (K % 8) != 0 || (ldx % 4) != 0 || ldx < K || ldy < N) return CG_ERR_ARG;
+  if (((uintptr_t)x & 15) != 0) return CG_ERR_ARG;
+  if (row_bias && (rows_per_group <= 0 || ld_rb < N)) return CG_ERR_ARG;
+  if (M == 0) return CG_OK;
+  GemmArgs a{x, M, K, ldx, w_packed, N, (N + 31) / 32, bias, row_bias, rows_per_group, ld_rb, relu, eye_k, y, ldy};
+  dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((a.nblocks + 3) / 4)), block(256);
+  hipLaunchKernelGGL(gemm_bias_act_kernel, grid, block, 0, (hipStream_t)stream, a);
+  return cg_hip_status(hipGetLastError());
+}

@@ -1,0 +1,65 @@
+"""Device forward passes of PointNetCls / PointNetSeg assembled from the HIP kernels.
+
+Call graph per PointNetCls.forward (pointnet2.py:289-299), B samples of N points:
+  pass A  cg_pointmlp_max(mid 0)          STN3d conv1..3 + max                 (B,1024)
+          3x cg_gemm_bias_act             STN3d fc1,fc2,fc3 + I3               (B,9)
+  pass B  cg_pointmlp_max(mid 1, t3)      enc.conv1 -> STNkd conv1..3 + max    (B,1024)
+          3x cg_gemm_bias_act             STNkd fc1,fc2,fc3 + I64              (B,4096)
+  pass C  cg_pointmlp_max(mid 2, t3,t64)  enc.conv1, .T64, conv2, conv3, max   (B,1024)
+          3x cg_gemm_bias_act             fc1,fc2,fc3                          (B,n_out)
+"""
+import torch
+
+from . import ops
+
+
+def _nsplit(B, N):
+    """Workgroups per sample: keep >= ~1024 workgroups in flight for small batches."""
+    ntiles = (N + 63) // 64
+    if B >= 1024:
+        return 1
+    return max(1, min(ntiles, (1024 + B - 1) // B))
+
+
+def encoder_forward(W, x, want_pointfeat=False):
+    """x:(B,N,6) cuda f32 -> global feature (B,1024), trans (B,9), trans_feat (B,4096) [, pointfeat]."""
+    B, N, _ = x.shape
+    ns = _nsplit(B, N)
+    g = ops.pointmlp_max(x, W['stn.w1'], W['stn.b1'], W['stn.w2'], W['stn.b2'], W['stn.w3'], W['stn.b3'], True,
+                         nsplit=ns)
+    h = ops.gemm_bias_act(g, W['stn.fc1'], 512, W['stn.fc1b'], relu=True)
+    h = ops.gemm_bias_act(h, W['stn.fc2'], 256, W['stn.fc2b'], relu=True)
+    t3 = ops.gemm_bias_act(h, W['stn.fc3'], 9, W['stn.fc3b'], eye_k=3)
+    g = ops.pointmlp_max(x, W['enc.w1'], W['enc.b1'], W['fstn.w2'], W['fstn.b2'], W['fstn.w3'], W['fstn.b3'], True,
+                         t3=t3, mid_mode=1, wm=W['fstn.wm'], bm=W['fstn.bm'], nsplit=ns)
+    h = ops.gemm_bias_act(g, W['fstn.fc1'], 512, W['fstn.fc1b'], relu=True)
+    h = ops.gemm_bias_act(h, W['fstn.fc2'], 256, W['fstn.fc2b'], relu=True)
+    t64 = ops.gemm_bias_act(h, W['fstn.fc3'], 4096, W['fstn.fc3b'], eye_k=64)
+    r = ops.pointmlp_max(x, W['enc.w1'], W['enc.b1'], W['enc.w2'], W['enc.b2'], W['enc.w3'], W['enc.b3'], False,
+                         t3=t3, mid_mode=2, t64=t64, nsplit=ns, pointfeat=want_pointfeat)
+    if want_pointfeat:
+        return r[0], t3, t64, r[1]
+    return r, t3, t64
+
+
+def cls_forward(W, x):
+    """PointNetCls.forward in eval mode.  x:(B,N,6) -> logits (B,n_out), trans_feat (B,64,64)."""
+    B = x.shape[0]
+    g, t3, t64 = encoder_forward(W, x)
+    h = ops.gemm_bias_act(g, W['head.fc1'], 512, W['head.fc1b'], relu=True)
+    h = ops.gemm_bias_act(h, W['head.fc2'], 256, W['head.fc2b'], relu=True)
+    logits = ops.gemm_bias_act(h, W['head.fc3'], W.n_out, W['head.fc3b'])
+    return logits, t64.view(B, 64, 64)
+
+
+def seg_forward(W, x):
+    """PointNetSeg.forward in eval mode.  x:(B,N,6) -> (B,N,n_out), trans_feat (B,64,64)."""
+    B, N, _ = x.shape
+    g, t3, t64, pf = encoder_forward(W, x, want_pointfeat=True)
+    # conv1 over cat([global(1024) repeated, pointfeat(64)]) = Wg.g (per cloud) + Wp.pointfeat (per point)
+    gb = ops.gemm_bias_act(g, W['seg.c1g'], 512, W['seg.c1b'])
+    h = ops.gemm_bias_act(pf.view(B * N, 64), W['seg.c1p'], 512, None, relu=True, row_bias=gb, rows_per_group=N)
+    h = ops.gemm_bias_act(h, W['seg.c2'], 256, W['seg.c2b'], relu=True)
+    h = ops.gemm_bias_act(h, W['seg.c3'], 128, W['seg.c3b'], relu=True)
+    y = ops.gemm_bias_act(h, W['seg.c4'], W.n_out, W['seg.c4b'])
+    return y.view(B, N, W.n_out), t64.view(B, 64, 64)

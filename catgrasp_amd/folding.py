@@ -1,0 +1,128 @@
+"""Host-side weight preparation: eval-mode BatchNorm folding and MFMA B-fragment packing.
+
+BN fold (torch defaults eps=1e-5, pointnet2.py:164-168):
+    W' = W * g / sqrt(var + eps),   b' = (b - mean) * g / sqrt(var + eps) + beta
+computed in float64 and rounded once to float32.
+"""
+import numpy as np
+import torch
+
+BN_EPS = 1e-5
+
+
+def fold_bn(w, b, bn=None):
+    """w:(O,I) b:(O); bn = (weight, bias, running_mean, running_var) or None -> float64 arrays."""
+    w = np.asarray(w, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    if bn is None:
+        return w, b
+    g, beta, mu, var = [np.asarray(t, dtype=np.float64) for t in bn]
+    s = g / np.sqrt(var + BN_EPS)
+    return w * s[:, None], (b - mu) * s + beta
+
+
+def pack_b(w):
+    """W:(N,K) (K % 8 == 0) -> flat float32 array in B-fragment order
+    Wp[nb][ks][lane][j] = W[nb*32 + (lane&31)][ks*8 + (lane>>5)*4 + j], rows zero padded to 32."""
+    w = np.asarray(w, dtype=np.float32)
+    n, k = w.shape
+    assert k % 8 == 0, k
+    nb = (n + 31) // 32
+    wp = np.zeros((nb * 32, k), dtype=np.float32)
+    wp[:n] = w
+    # [nb, 32(l31), ks, 2(lhi), 4(j)] -> [nb, ks, lhi, l31, j]
+    wp = wp.reshape(nb, 32, k // 8, 2, 4).transpose(0, 2, 3, 1, 4)
+    return np.ascontiguousarray(wp).reshape(-1)
+
+
+def _get(sd, name):
+    return sd[name].detach().cpu().double().numpy()
+
+
+def _bn(sd, p):
+    return (_get(sd, p + '.weight'), _get(sd, p + '.bias'), _get(sd, p + '.running_mean'), _get(sd, p + '.running_var'))
+
+
+def _conv(sd, name):
+    w = _get(sd, name + '.weight')
+    return w.reshape(w.shape[0], -1), _get(sd, name + '.bias')
+
+
+class DeviceWeights:
+    """Folded + packed weights of one PointNet encoder (+ head) resident in HBM."""
+
+    def __init__(self, device):
+        self.device = device
+        self.t = {}
+
+    def put(self, name, arr):
+        self.t[name] = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32)).to(self.device)
+
+    def __getitem__(self, k):
+        return self.t[k]
+
+
+def prepare_encoder(sd, prefix, device, out=None):
+    """Fold/pack PointNetEncoder(feature_transform=True) weights (pointnet2.py:226-238)."""
+    W = out or DeviceWeights(device)
+    p = prefix
+
+    def stn(q, tag, k):
+        w, b = fold_bn(*_conv(sd, q + 'conv1'), _bn(sd, q + 'bn1'))
+        if k == 3:
+            W.put(tag + '.w1', w); W.put(tag + '.b1', b)          # 6 -> 64 on VALU, unpacked
+        else:
+            W.put(tag + '.wm', pack_b(w)); W.put(tag + '.bm', b)   # 64 -> 64, packed
+        w, b = fold_bn(*_conv(sd, q + 'conv2'), _bn(sd, q + 'bn2'))
+        W.put(tag + '.w2', pack_b(w)); W.put(tag + '.b2', b)
+        w, b = fold_bn(*_conv(sd, q + 'conv3'), _bn(sd, q + 'bn3'))
+        W.put(tag + '.w3', pack_b(w)); W.put(tag + '.b3', b)
+        w, b = fold_bn(_get(sd, q + 'fc1.weight'), _get(sd, q + 'fc1.bias'), _bn(sd, q + 'bn4'))
+        W.put(tag + '.fc1', pack_b(w)); W.put(tag + '.fc1b', b)
+        w, b = fold_bn(_get(sd, q + 'fc2.weight'), _get(sd, q + 'fc2.bias'), _bn(sd, q + 'bn5'))
+        W.put(tag + '.fc2', pack_b(w)); W.put(tag + '.fc2b', b)
+        w, b = _get(sd, q + 'fc3.weight'), _get(sd, q + 'fc3.bias')
+        W.put(tag + '.fc3', pack_b(w)); W.put(tag + '.fc3b', b)
+
+    stn(p + 'stn.', 'stn', 3)
+    stn(p + 'fstn.', 'fstn', 64)
+    w, b = fold_bn(*_conv(sd, p + 'conv1'), _bn(sd, p + 'bn1'))
+    W.put('enc.w1', w); W.put('enc.b1', b)
+    w, b = fold_bn(*_conv(sd, p + 'conv2'), _bn(sd, p + 'bn2'))
+    W.put('enc.w2', pack_b(w)); W.put('enc.b2', b)
+    w, b = fold_bn(*_conv(sd, p + 'conv3'), _bn(sd, p + 'bn3'))
+    W.put('enc.w3', pack_b(w)); W.put('enc.b3', b)
+    return W
+
+
+def prepare_cls(sd, device):
+    """PointNetCls (pointnet2.py:275-299)."""
+    sd = {k.replace('module.', ''): v for k, v in sd.items()}
+    W = prepare_encoder(sd, 'feat.', device)
+    w, b = fold_bn(_get(sd, 'fc1.weight'), _get(sd, 'fc1.bias'), _bn(sd, 'bn1'))
+    W.put('head.fc1', pack_b(w)); W.put('head.fc1b', b)
+    w, b = fold_bn(_get(sd, 'fc2.weight'), _get(sd, 'fc2.bias'), _bn(sd, 'bn2'))
+    W.put('head.fc2', pack_b(w)); W.put('head.fc2b', b)
+    w, b = _get(sd, 'fc3.weight'), _get(sd, 'fc3.bias')
+    W.put('head.fc3', pack_b(w)); W.put('head.fc3b', b)
+    W.n_out = w.shape[0]
+    return W
+
+
+def prepare_seg(sd, device):
+    """PointNetSeg (pointnet2.py:302-329).  conv1 (1088->512) is split into the global-feature part
+    (first 1024 input channels, evaluated once per cloud and used as a per-cloud bias) and the
+    point-feature part (last 64 channels), exactly the cat([global, pointfeat]) order of :271."""
+    sd = {k.replace('module.', ''): v for k, v in sd.items()}
+    W = prepare_encoder(sd, 'feat.', device)
+    w, b = fold_bn(*_conv(sd, 'conv1'), _bn(sd, 'bn1'))
+    W.put('seg.c1g', pack_b(w[:, :1024])); W.put('seg.c1b', b)
+    W.put('seg.c1p', pack_b(w[:, 1024:]))
+    w, b = fold_bn(*_conv(sd, 'conv2'), _bn(sd, 'bn2'))
+    W.put('seg.c2', pack_b(w)); W.put('seg.c2b', b)
+    w, b = fold_bn(*_conv(sd, 'conv3'), _bn(sd, 'bn3'))
+    W.put('seg.c3', pack_b(w)); W.put('seg.c3b', b)
+    w, b = _conv(sd, 'conv4')
+    W.put('seg.c4', pack_b(w)); W.put('seg.c4b', b)
+    W.n_out = w.shape[0]
+    return W

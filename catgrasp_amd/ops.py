@@ -1,0 +1,93 @@
+"""Thin torch-tensor wrappers over the C ABI (device memory + stream plumbing only)."""
+import ctypes
+
+import torch
+
+from . import _lib as L
+from ._lib import _p, _stream, check, f32c, i32c, require_cuda
+
+_c_int = ctypes.c_int
+_c_long = ctypes.c_long
+
+
+def pointmlp_max(x, w1, b1, w2p, b2, w3p, b3, relu3, t3=None, mid_mode=0, wm=None, bm=None, t64=None,
+                 nsplit=1, pointfeat=False):
+    """x:(B,N,6) -> (B,1024) [, pointfeat (B,N,64)].  See cg_pointmlp_max in include/catgrasp_amd.h."""
+    require_cuda(x)
+    f32c(x)
+    B, N, D = x.shape
+    assert D == 6
+    out = torch.empty((B, 1024), dtype=torch.float32, device=x.device)
+    pf = torch.empty((B, N, 64), dtype=torch.float32, device=x.device) if pointfeat else None
+    st = L.lib().cg_pointmlp_max(_p(x), _c_int(B), _c_int(N), _p(t3), _p(w1), _p(b1), _c_int(mid_mode), _p(wm), _p(bm),
+                                 _p(t64), _p(w2p), _p(b2), _p(w3p), _p(b3), _c_int(int(relu3)), _c_int(nsplit),
+                                 _p(out), _p(pf), _stream())
+    check(st, 'cg_pointmlp_max')
+    return (out, pf) if pointfeat else out
+
+
+def gemm_bias_act(x, wp, n_out, bias=None, relu=False, eye_k=0, row_bias=None, rows_per_group=1):
+    """act(x @ W^T + bias [+ row_bias[row // rows_per_group]]) with packed W.  x:(M,K)."""
+    require_cuda(x)
+    f32c(x)
+    M, K = x.shape
+    y = torch.empty((M, n_out), dtype=torch.float32, device=x.device)
+    ld_rb = row_bias.shape[1] if row_bias is not None else 0
+    st = L.lib().cg_gemm_bias_act(_p(x), _c_int(M), _c_int(K), _c_int(K), _p(wp), _c_int(n_out), _p(bias),
+                                  _p(row_bias), _c_int(rows_per_group), _c_int(ld_rb), _c_int(int(relu)),
+                                  _c_int(eye_k), _p(y), _c_int(n_out), _stream())
+    check(st, 'cg_gemm_bias_act')
+    return y
+
+
+def softmax_pg(logits):
+    """logits:(B,C) -> probs (B,C), label (B) int32, confidence (B), p_G (B)."""
+    require_cuda(logits)
+    f32c(logits)
+    B, C = logits.shape
+    probs = torch.empty_like(logits)
+    label = torch.empty((B,), dtype=torch.int32, device=logits.device)
+    conf = torch.empty((B,), dtype=torch.float32, device=logits.device)
+    pg = torch.empty((B,), dtype=torch.float32, device=logits.device)
+    check(L.lib().cg_softmax_pg(_p(logits), _c_int(B), _c_int(C), _p(probs), _p(label), _p(conf), _p(pg), _stream()),
+          'cg_softmax_pg')
+    return probs, label, conf, pg
+
+
+def nunocs_decode(logits, nbins):
+    """logits:(P,3*nbins) -> coords (P,3), conf_z (P)."""
+    require_cuda(logits)
+    f32c(logits)
+    P = logits.shape[0]
+    assert logits.shape[1] == 3 * nbins
+    coords = torch.empty((P, 3), dtype=torch.float32, device=logits.device)
+    conf = torch.empty((P,), dtype=torch.float32, device=logits.device)
+    check(L.lib().cg_nunocs_decode(_p(logits), _c_long(P), _c_int(nbins), _p(coords), _p(conf), _stream()),
+          'cg_nunocs_decode')
+    return coords, conf
+
+
+def build_grasp_input(cloud_xyz, cloud_normal, ids, pose_inv, mean=None, inv_std=None, out=None):
+    """(n_cloud,3),(n_cloud,3),(G,n_pts) i32,(G,12) -> (G,n_pts,6)."""
+    require_cuda(cloud_xyz, cloud_normal, ids, pose_inv)
+    f32c(cloud_xyz); f32c(cloud_normal); i32c(ids); f32c(pose_inv)
+    G, n_pts = ids.shape
+    assert pose_inv.shape == (G, 12)
+    if out is None:
+        out = torch.empty((G, n_pts, 6), dtype=torch.float32, device=ids.device)
+    check(L.lib().cg_build_grasp_input(_p(cloud_xyz), _p(cloud_normal), _c_int(cloud_xyz.shape[0]), _p(ids), _p(pose_inv),
+                                       _p(mean), _p(inv_std), _c_int(G), _c_int(n_pts), _p(out), _stream()),
+          'cg_build_grasp_input')
+    return out
+
+
+def build_nunocs_input(cloud_xyz, cloud_normal, ids, mean=None, inv_std=None):
+    """(n_cloud,3),(n_cloud,3),(B,n_pts) i32 -> (B,n_pts,6)."""
+    require_cuda(cloud_xyz, cloud_normal, ids)
+    f32c(cloud_xyz); f32c(cloud_normal); i32c(ids)
+    B, n_pts = ids.shape
+    out = torch.empty((B, n_pts, 6), dtype=torch.float32, device=ids.device)
+    check(L.lib().cg_build_nunocs_input(_p(cloud_xyz), _p(cloud_normal), _c_int(cloud_xyz.shape[0]), _p(ids),
+                                        _p(mean), _p(inv_std), _c_int(B), _c_int(n_pts), _p(out), _stream()),
+          'cg_build_nunocs_input')
+    return out

@@ -1,0 +1,258 @@
+"""TEST INFRASTRUCTURE ONLY (oracle) -- CPU restatement of the reference `pointnet2.py`.
+
+Every function cites the reference lines it follows (paths relative to the reference
+checkout, wenbowen123/catgrasp @ v1).  The restatement is written with explicit
+matmul / batch-norm arithmetic (no ``torch.nn`` modules) so the arithmetic the HIP
+kernels must reproduce is visible, and it runs in float32 (the reference's dtype,
+`predicter.py:84`) or float64 (a "truth" leg used to bound both implementations).
+
+Pinned against the reference itself: ``tests/golden/make_golden.py`` imports the real
+``/root/reference/pointnet2.py`` (with empty ``cv2`` / ``torchvision`` stubs), runs it on
+seeded inputs and commits the outputs under ``tests/golden/``;
+``tests/test_oracle_golden.py`` checks this restatement against those vectors.
+"""
+import numpy as np
+import torch
+
+BN_EPS = 1e-5  # torch.nn.BatchNorm1d default; pointnet2.py:164-168 constructs BN with no overrides
+
+
+# --------------------------------------------------------------------------------------
+# PointNet++ primitives (pointnet2.py:14-149)
+# --------------------------------------------------------------------------------------
+def square_distance(src, dst):
+    """pointnet2.py:14-33.  -2*src@dst^T + |src|^2 + |dst|^2, evaluated in that order."""
+    src = torch.as_tensor(src)
+    dst = torch.as_tensor(dst)
+    B, N, _ = src.shape
+    _, M, _ = dst.shape
+    dist = -2 * torch.matmul(src, dst.permute(0, 2, 1))
+    dist = dist + torch.sum(src ** 2, -1).view(B, N, 1)
+    dist = dist + torch.sum(dst ** 2, -1).view(B, 1, M)
+    return dist
+
+
+def index_points(points, idx):
+    """pointnet2.py:35-51.  Batched gather points[b, idx[b, ...], :]."""
+    points = torch.as_tensor(points)
+    idx = torch.as_tensor(idx).long()
+    B = points.shape[0]
+    flat = idx.reshape(B, -1)
+    out = torch.stack([points[b, flat[b]] for b in range(B)], 0)
+    return out.reshape(*idx.shape, points.shape[-1])
+
+
+def farthest_point_sample(xyz, npoint, start):
+    """pointnet2.py:54-75 with the `torch.randint` start index (`:66`) made explicit.
+
+    distance is initialised to 1e10, updated with `dist < distance`, and the next centroid
+    is `torch.max(distance, -1)[1]` (first index of the maximum).
+    """
+    xyz = torch.as_tensor(xyz)
+    B, N, _ = xyz.shape
+    centroids = torch.zeros(B, npoint, dtype=torch.long)
+    distance = torch.ones(B, N, dtype=xyz.dtype) * 1e10
+    farthest = torch.as_tensor(start).long().clone()
+    bidx = torch.arange(B)
+    for i in range(npoint):
+        centroids[:, i] = farthest
+        centroid = xyz[bidx, farthest, :].view(B, 1, 3)
+        dist = torch.sum((xyz - centroid) ** 2, -1)
+        mask = dist < distance
+        distance[mask] = dist[mask]
+        # first index of the maximum (torch.max on CPU returns the first occurrence)
+        farthest = torch.argmax(distance, -1)
+    return centroids
+
+
+def query_ball_point(radius, nsample, xyz, new_xyz, sqrdists=None):
+    """pointnet2.py:78-98.  First `nsample` in-radius indices in ascending index order,
+    padded with the first hit; a query with no hit keeps the sentinel N (as the reference
+    does: group_first == N there)."""
+    xyz = torch.as_tensor(xyz)
+    new_xyz = torch.as_tensor(new_xyz)
+    B, N, _ = xyz.shape
+    _, S, _ = new_xyz.shape
+    group_idx = torch.arange(N, dtype=torch.long).view(1, 1, N).repeat([B, S, 1])
+    if sqrdists is None:
+        sqrdists = square_distance(new_xyz, xyz)
+    group_idx[sqrdists > radius ** 2] = N
+    group_idx = group_idx.sort(dim=-1)[0][:, :, :nsample]
+    group_first = group_idx[:, :, 0].view(B, S, 1).repeat([1, 1, group_idx.shape[-1]])
+    mask = group_idx == N
+    group_idx[mask] = group_first[mask]
+    return group_idx
+
+
+def sample_and_group(npoint, radius, nsample, xyz, points, start):
+    """pointnet2.py:101-129 (returnfps=True form) with explicit FPS start."""
+    xyz = torch.as_tensor(xyz)
+    B, N, C = xyz.shape
+    S = npoint
+    fps_idx = farthest_point_sample(xyz, npoint, start)
+    new_xyz = index_points(xyz, fps_idx)
+    idx = query_ball_point(radius, nsample, xyz, new_xyz)
+    grouped_xyz = index_points(xyz, idx)
+    grouped_xyz_norm = grouped_xyz - new_xyz.view(B, S, 1, C)
+    if points is not None:
+        grouped_points = index_points(torch.as_tensor(points), idx)
+        new_points = torch.cat([grouped_xyz_norm, grouped_points], dim=-1)
+    else:
+        new_points = grouped_xyz_norm
+    return new_xyz, new_points, grouped_xyz, fps_idx
+
+
+def sample_and_group_all(xyz, points):
+    """pointnet2.py:132-149."""
+    xyz = torch.as_tensor(xyz)
+    B, N, C = xyz.shape
+    new_xyz = torch.zeros(B, 1, C, dtype=xyz.dtype)
+    grouped_xyz = xyz.view(B, 1, N, C)
+    if points is not None:
+        new_points = torch.cat([grouped_xyz, torch.as_tensor(points).view(B, 1, N, -1)], dim=-1)
+    else:
+        new_points = grouped_xyz
+    return new_xyz, new_points
+
+
+# --------------------------------------------------------------------------------------
+# PointNet models (pointnet2.py:153-329), eval mode, from a reference-layout state_dict
+# --------------------------------------------------------------------------------------
+def _sd(sd, dtype):
+    return {k.replace('module.', ''): torch.as_tensor(v).to(dtype) for k, v in sd.items()
+            if not k.endswith('num_batches_tracked')}
+
+
+def _conv_bn(x, sd, conv, bn, relu):
+    """Conv1d(k=1) -> BatchNorm1d(eval) -> optional ReLU on x:(B,C,N).  pointnet2.py:172-174."""
+    w = sd[conv + '.weight'][:, :, 0]
+    y = torch.matmul(w, x) + sd[conv + '.bias'].view(1, -1, 1)
+    if bn is not None:
+        y = (y - sd[bn + '.running_mean'].view(1, -1, 1)) / torch.sqrt(sd[bn + '.running_var'].view(1, -1, 1) + BN_EPS)
+        y = y * sd[bn + '.weight'].view(1, -1, 1) + sd[bn + '.bias'].view(1, -1, 1)
+    return torch.relu(y) if relu else y
+
+
+def _fc_bn(x, sd, fc, bn, relu):
+    """Linear -> BatchNorm1d(eval) -> optional ReLU on x:(B,C).  pointnet2.py:178-180."""
+    y = torch.matmul(x, sd[fc + '.weight'].t()) + sd[fc + '.bias']
+    if bn is not None:
+        y = (y - sd[bn + '.running_mean']) / torch.sqrt(sd[bn + '.running_var'] + BN_EPS)
+        y = y * sd[bn + '.weight'] + sd[bn + '.bias']
+    return torch.relu(y) if relu else y
+
+
+def stn_forward(sd, p, x, k):
+    """STN3d / STNkd forward (pointnet2.py:170-185, :208-223).  x:(B,C,N) -> (B,k,k)."""
+    x = _conv_bn(x, sd, p + 'conv1', p + 'bn1', True)
+    x = _conv_bn(x, sd, p + 'conv2', p + 'bn2', True)
+    x = _conv_bn(x, sd, p + 'conv3', p + 'bn3', True)
+    x = torch.max(x, 2)[0]
+    x = _fc_bn(x, sd, p + 'fc1', p + 'bn4', True)
+    x = _fc_bn(x, sd, p + 'fc2', p + 'bn5', True)
+    x = _fc_bn(x, sd, p + 'fc3', None, False)
+    x = x + torch.eye(k, dtype=x.dtype).reshape(1, k * k)
+    return x.view(-1, k, k)
+
+
+def encoder_forward(sd, p, x, global_feat):
+    """PointNetEncoder.forward (pointnet2.py:240-271), feature_transform=True.  x:(B,D,N)."""
+    B, D, N = x.shape
+    trans = stn_forward(sd, p + 'stn.', x, 3)
+    xt = x.transpose(2, 1)
+    feature = xt[:, :, 3:]
+    xyz = torch.bmm(xt[:, :, :3], trans)          # normals are NOT rotated (pointnet2.py:245-250)
+    xt = torch.cat([xyz, feature], dim=2)
+    x = xt.transpose(2, 1)
+    x = _conv_bn(x, sd, p + 'conv1', p + 'bn1', True)
+    trans_feat = stn_forward(sd, p + 'fstn.', x, 64)
+    x = torch.bmm(x.transpose(2, 1), trans_feat).transpose(2, 1)
+    pointfeat = x
+    x = _conv_bn(x, sd, p + 'conv2', p + 'bn2', True)
+    x = _conv_bn(x, sd, p + 'conv3', p + 'bn3', False)   # no ReLU after bn3 (pointnet2.py:264)
+    g = torch.max(x, 2)[0]
+    if global_feat:
+        return g, trans, trans_feat
+    return torch.cat([g.view(-1, 1024, 1).repeat(1, 1, N), pointfeat], 1), trans, trans_feat
+
+
+def pointnet_cls_forward(state_dict, x, dtype=torch.float32):
+    """PointNetCls.forward (pointnet2.py:289-299), eval (dropout = identity).
+    x:(B,N,D) -> (logits (B,n_out), trans_feat (B,64,64))."""
+    sd = _sd(state_dict, dtype)
+    x = torch.as_tensor(x).to(dtype).permute(0, 2, 1)
+    g, trans, trans_feat = encoder_forward(sd, 'feat.', x, True)
+    y = _fc_bn(g, sd, 'fc1', 'bn1', True)
+    y = _fc_bn(y, sd, 'fc2', 'bn2', True)
+    y = _fc_bn(y, sd, 'fc3', None, False)
+    return y, trans_feat
+
+
+def pointnet_seg_forward(state_dict, x, dtype=torch.float32):
+    """PointNetSeg.forward (pointnet2.py:316-329).  x:(B,N,D) -> ((B,N,n_out), trans_feat)."""
+    sd = _sd(state_dict, dtype)
+    x = torch.as_tensor(x).to(dtype).permute(0, 2, 1)
+    f, trans, trans_feat = encoder_forward(sd, 'feat.', x, False)
+    y = _conv_bn(f, sd, 'conv1', 'bn1', True)
+    y = _conv_bn(y, sd, 'conv2', 'bn2', True)
+    y = _conv_bn(y, sd, 'conv3', 'bn3', True)
+    y = _conv_bn(y, sd, 'conv4', None, False)
+    return y.permute(0, 2, 1), trans_feat
+
+
+# --------------------------------------------------------------------------------------
+# synthetic reference-layout weights (SURVEY.md §8(d) "Weights")
+# --------------------------------------------------------------------------------------
+def _stn_shapes(p, cin, k):
+    s = {}
+    for name, (o, i) in {'conv1': (64, cin), 'conv2': (128, 64), 'conv3': (1024, 128)}.items():
+        s[p + name + '.weight'] = (o, i, 1); s[p + name + '.bias'] = (o,)
+    for name, (o, i) in {'fc1': (512, 1024), 'fc2': (256, 512), 'fc3': (k * k, 256)}.items():
+        s[p + name + '.weight'] = (o, i); s[p + name + '.bias'] = (o,)
+    for name, c in {'bn1': 64, 'bn2': 128, 'bn3': 1024, 'bn4': 512, 'bn5': 256}.items():
+        s[p + name] = c
+    return s
+
+
+def model_shapes(kind, n_in, n_out):
+    """Parameter / buffer names and shapes of PointNetCls / PointNetSeg (pointnet2.py:275-329)."""
+    s = {}
+    s.update(_stn_shapes('feat.stn.', n_in, 3))
+    for name, (o, i) in {'conv1': (64, n_in), 'conv2': (128, 64), 'conv3': (1024, 128)}.items():
+        s['feat.' + name + '.weight'] = (o, i, 1); s['feat.' + name + '.bias'] = (o,)
+    for name, c in {'bn1': 64, 'bn2': 128, 'bn3': 1024}.items():
+        s['feat.' + name] = c
+    s.update(_stn_shapes('feat.fstn.', 64, 64))
+    if kind == 'cls':
+        for name, (o, i) in {'fc1': (512, 1024), 'fc2': (256, 512), 'fc3': (n_out, 256)}.items():
+            s[name + '.weight'] = (o, i); s[name + '.bias'] = (o,)
+        s['bn1'] = 512; s['bn2'] = 256
+    else:
+        for name, (o, i) in {'conv1': (512, 1088), 'conv2': (256, 512), 'conv3': (128, 256), 'conv4': (n_out, 128)}.items():
+            s[name + '.weight'] = (o, i, 1); s[name + '.bias'] = (o,)
+        s['bn1'] = 512; s['bn2'] = 256; s['bn3'] = 128
+    return s
+
+
+def make_state_dict(kind, n_in, n_out, seed=0, prefix='', gain=1.6):
+    """Seeded synthetic checkpoint with non-trivial BN statistics so folding is exercised.
+    Weights ~ U(-gain/sqrt(fan_in), gain/sqrt(fan_in)); gain=1 is torch's default init, the
+    default gain=1.6 keeps activations O(1) through the stack so logits are O(1-10), not ~0."""
+    rng = np.random.default_rng(seed)
+    sd = {}
+    for name, shp in model_shapes(kind, n_in, n_out).items():
+        if isinstance(shp, int):
+            c = shp
+            sd[prefix + name + '.weight'] = torch.from_numpy(rng.uniform(0.5, 1.5, c).astype(np.float32))
+            sd[prefix + name + '.bias'] = torch.from_numpy(rng.normal(0, 0.1, c).astype(np.float32))
+            sd[prefix + name + '.running_mean'] = torch.from_numpy(rng.normal(0, 0.1, c).astype(np.float32))
+            sd[prefix + name + '.running_var'] = torch.from_numpy(rng.uniform(0.5, 1.5, c).astype(np.float32))
+            sd[prefix + name + '.num_batches_tracked'] = torch.tensor(100, dtype=torch.long)
+        else:
+            fan_in = shp[1] if len(shp) > 1 else None
+            if fan_in is None:   # bias: fan_in of the matching weight
+                wshape = model_shapes(kind, n_in, n_out)[name.replace('.bias', '.weight')]
+                fan_in = wshape[1]
+            b = gain / np.sqrt(fan_in)
+            sd[prefix + name] = torch.from_numpy(rng.uniform(-b, b, shp).astype(np.float32))
+    return sd

