@@ -1,0 +1,244 @@
+"""Drop-in for the reference's `my_cpp` pybind module (my_cpp/pybind.cpp:11-23) on MI355X.
+
+Same names, argument order and meaning as the reference:
+  * ``CollisionManager`` -- registerMesh / registerPointCloud / setTransform / isAnyCollision
+    (my_cpp/collision_manager.h:55-69)
+  * ``filterGraspPose(...20 args...)`` -> list of surviving 4x4 float32 grasp_in_cam
+    (my_cpp/common.h:60; callers dexnet/grasping/grasp_sampler.py:216,:345)
+  * ``augmentGraspPoses`` / ``makeOccupancyGridFromCloudScan`` (my_cpp/common.h:58,61)
+plus ``filterGraspPoseDetailed`` (new): the same evaluation in *input order* with a per-evaluation reject
+code -- the deterministic "collision mask" the reference's unordered list cannot give
+(its OpenMP merge order is non-deterministic, my_cpp/common.cpp:303-313).
+
+Errors: the reference `printf`s and `exit(1)`s on wrong shapes (collision_manager.cpp:17-26); here a
+ValueError is raised instead -- wrong shapes are never silently accepted.
+All collision arithmetic runs in the HIP library; there is no CPU fallback.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from ._lib import _p, _stream, check
+
+_c_int = ctypes.c_int
+_c_long = ctypes.c_long
+_F16 = ctypes.c_float * 16
+
+_ik_solver = None
+
+
+def set_ik_solver(fn):
+    """Register the host IK feasibility callback used when filter_ik=True:
+    fn(ee_in_base: (E,4,4) float32, upper: list[7], lower: list[7]) -> bool array (E,).
+    (The reference links a generated IKFast solver for the KUKA iiwa14, my_cpp/common.cpp:9-72; it is a
+    robot-specific fp64 host routine and is not part of this library.)"""
+    global _ik_solver
+    _ik_solver = fn
+
+
+def _device():
+    if not torch.cuda.is_available():
+        raise L.CatgraspAmdError('catgrasp_amd.my_cpp needs a HIP device (no CPU fallback)')
+    return torch.device('cuda', torch.cuda.current_device())
+
+
+def _mat4(x, name):
+    a = np.asarray(x)
+    if a.shape != (4, 4):
+        raise ValueError(f'{name} shape wrong: {a.shape}')
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _h16(a):
+    return _F16(*a.reshape(-1).tolist())
+
+
+def _mesh(V, F, what):
+    V = np.asarray(V); F = np.asarray(F)
+    if V.ndim != 2 or V.shape[1] != 3:
+        raise ValueError(f'{what} vertices shape wrong: {V.shape}')
+    if F.ndim != 2 or F.shape[1] != 3:
+        raise ValueError(f'{what} faces shape wrong: {F.shape}')
+    if F.size and (F.min() < 0 or F.max() >= len(V)):
+        raise ValueError(f'{what} faces index out of range')
+    return np.ascontiguousarray(V, dtype=np.float32), np.ascontiguousarray(F, dtype=np.int32)
+
+
+def voxelize(pts, resolution, device=None):
+    """registerPointCloud (collision_manager.cpp:55-79): occupied octomap leaves of `pts` at `resolution`
+    as a device (n,4) int16 tensor (key-32768 per axis), unique and sorted."""
+    device = device or _device()
+    if isinstance(pts, torch.Tensor):
+        t = pts.to(device=device, dtype=torch.float32).contiguous()
+    else:
+        a = np.asarray(pts)
+        if a.ndim != 2 or a.shape[1] != 3:
+            raise ValueError(f'point cloud shape wrong: {a.shape}')
+        t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(device)
+    if t.ndim != 2 or t.shape[1] != 3:
+        raise ValueError(f'point cloud shape wrong: {tuple(t.shape)}')
+    P = t.shape[0]
+    packed = torch.empty((P,), dtype=torch.int64, device=device)
+    check(L.lib().cg_voxel_keys(_p(t), _c_long(P), ctypes.c_float(resolution), _p(packed), _stream()), 'cg_voxel_keys')
+    uniq = torch.unique(packed)            # sorted
+    uniq = uniq[uniq >= 0].contiguous()
+    n = uniq.shape[0]
+    keys = torch.empty((n, 4), dtype=torch.int16, device=device)
+    check(L.lib().cg_unpack_voxel_keys(_p(uniq), _c_long(n), _p(keys), _stream()), 'cg_unpack_voxel_keys')
+    return keys
+
+
+class CollisionManager:
+    """my_cpp.CollisionManager (collision_manager.h:55-69).  Objects are triangle meshes (posed by
+    setTransform) and voxelised point clouds (identity pose only: the reference never moves the octree).
+    isAnyCollision tests every mesh/cloud pair; mesh/mesh and cloud/cloud pairs, which the reference
+    pipeline never registers together, raise NotImplementedError."""
+
+    def __init__(self):
+        self._obs = []
+        self._dev = _device()
+
+    def registerMesh(self, V, F):
+        V, F = _mesh(V, F, 'mesh')
+        self._obs.append({'kind': 'mesh', 'V': torch.from_numpy(V).to(self._dev), 'F': torch.from_numpy(F).to(self._dev),
+                          'pose': np.eye(4, dtype=np.float32)})
+        return len(self._obs) - 1
+
+    def registerPointCloud(self, pts, resolution):
+        keys = voxelize(pts, float(resolution), self._dev)
+        self._obs.append({'kind': 'cloud', 'keys': keys, 'res': float(np.float32(resolution)), 'pose': np.eye(4, dtype=np.float32)})
+        return len(self._obs) - 1
+
+    def setTransform(self, pose, ob_id):
+        pose = _mat4(pose, 'pose')
+        ob = self._obs[ob_id]
+        if ob['kind'] == 'cloud' and not np.array_equal(pose, np.eye(4, dtype=np.float32)):
+            raise NotImplementedError('posing a registered point cloud is not supported (reference never does)')
+        ob['pose'] = pose
+
+    def isAnyCollision(self):
+        for i in range(len(self._obs)):
+            for j in range(i + 1, len(self._obs)):
+                a, b = self._obs[i], self._obs[j]
+                if a['kind'] == b['kind']:
+                    raise NotImplementedError(f"{a['kind']}/{b['kind']} pairs are not supported")
+                mesh, cloud = (a, b) if a['kind'] == 'mesh' else (b, a)
+                pose = torch.from_numpy(mesh['pose'].reshape(1, 16)).to(self._dev)
+                out = torch.zeros((1,), dtype=torch.uint8, device=self._dev)
+                check(L.lib().cg_mesh_voxels_collide(_p(mesh['V']), _p(mesh['F']), _c_int(mesh['F'].shape[0]), _p(pose), _c_long(1),
+                                                     _p(cloud['keys']), _c_int(cloud['keys'].shape[0]), ctypes.c_float(cloud['res']),
+                                                     _p(out), _stream()), 'cg_mesh_voxels_collide')
+                if bool(out.item()):
+                    return True
+        return False
+
+
+class GripperScene:
+    """Device-resident inputs of filterGraspPose that do not change between calls on one object:
+    gripper meshes and the two voxelised collision clouds.  Build once, filter many pose batches."""
+
+    def __init__(self, gripper_vertices, gripper_faces, gripper_enclosed_vertices, gripper_enclosed_faces,
+                 gripper_collision_pts, gripper_enclosed_collision_pts, octo_resolution, device=None):
+        dev = device or _device()
+        self.device = dev
+        V, F = _mesh(gripper_vertices, gripper_faces, 'gripper')
+        Ve, Fe = _mesh(gripper_enclosed_vertices, gripper_enclosed_faces, 'gripper_enclosed')
+        self.V = torch.from_numpy(V).to(dev); self.F = torch.from_numpy(F).to(dev)
+        self.Ve = torch.from_numpy(Ve).to(dev); self.Fe = torch.from_numpy(Fe).to(dev)
+        self.res = float(np.float32(octo_resolution))
+        self.keys_open = voxelize(gripper_collision_pts, self.res, dev)
+        self.keys_bg = voxelize(gripper_enclosed_collision_pts, self.res, dev)
+
+
+def filter_on_device(scene, grasp_poses, symmetry_tfs, nocs_pose, canonical_to_nocs_transform, cam_in_world, ee_in_grasp,
+                     gripper_in_grasp, filter_approach_dir_face_camera, filter_ik, adjust_collision_pose, upper=None, lower=None):
+    """Device-tensor form: grasp_poses (n,4,4)/(n,16) and symmetry_tfs (m,4,4) float32 cuda tensors (or arrays).
+    Returns codes (E) int8, poses (E,4,4) float32, nudge (E) int8 as cuda tensors, E = n*m in input order."""
+    dev = scene.device
+
+    def dev_poses(x, name):
+        if isinstance(x, torch.Tensor):
+            t = x.to(device=dev, dtype=torch.float32)
+        else:
+            a = np.asarray(x, dtype=np.float64 if len(x) else np.float32)
+            t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+        if t.numel() == 0:
+            return t.reshape(0, 16)
+        if t.shape[-2:] != (4, 4) and t.shape[-1] != 16:
+            raise ValueError(f'{name} shape wrong: {tuple(t.shape)}')
+        return t.reshape(-1, 16).contiguous()
+
+    gp = dev_poses(grasp_poses, 'grasp_poses')
+    st = dev_poses(symmetry_tfs, 'symmetry_tfs')
+    n_pose, n_sym = gp.shape[0], st.shape[0]
+    E = n_pose * n_sym
+    mats = [_mat4(m, nm) for m, nm in ((nocs_pose, 'nocs_pose'), (canonical_to_nocs_transform, 'canonical_to_nocs_transform'),
+                                       (cam_in_world, 'cam_in_world'), (ee_in_grasp, 'ee_in_grasp'), (gripper_in_grasp, 'gripper_in_grasp'))]
+    hm = [_h16(m) for m in mats]
+    codes = torch.empty((E,), dtype=torch.int8, device=dev)
+    poses = torch.empty((E, 16), dtype=torch.float32, device=dev)
+    nudge = torch.empty((E,), dtype=torch.int8, device=dev)
+
+    def launch(ik_ok, ee_out):
+        check(L.lib().cg_filter_grasp_pose(
+            _p(gp), _c_int(n_pose), _p(st), _c_int(n_sym), hm[0], hm[1], hm[2], hm[3], hm[4],
+            _c_int(int(bool(filter_approach_dir_face_camera))), _c_int(int(bool(adjust_collision_pose))), _p(ik_ok),
+            _p(scene.V), _p(scene.F), _c_int(scene.F.shape[0]), _p(scene.Ve), _p(scene.Fe), _c_int(scene.Fe.shape[0]),
+            _p(scene.keys_open), _c_int(scene.keys_open.shape[0]), _p(scene.keys_bg), _c_int(scene.keys_bg.shape[0]),
+            ctypes.c_float(scene.res), _p(codes), _p(poses), _p(nudge), _p(ee_out), _stream()), 'cg_filter_grasp_pose')
+
+    ik_ok = None
+    if filter_ik and E > 0:
+        if _ik_solver is None:
+            raise NotImplementedError('filter_ik=True needs a host IK callback: catgrasp_amd.my_cpp.set_ik_solver(fn)')
+        ee = torch.empty((E, 16), dtype=torch.float32, device=dev)
+        launch(None, ee)
+        ok = np.asarray(_ik_solver(ee.cpu().numpy().reshape(E, 4, 4), list(upper), list(lower))).astype(np.uint8).reshape(E)
+        ik_ok = torch.from_numpy(ok).to(dev)
+    if E > 0:
+        launch(ik_ok, None)
+    return codes, poses.view(E, 4, 4), nudge
+
+
+def filterGraspPoseDetailed(grasp_poses, symmetry_tfs, nocs_pose, canonical_to_nocs_transform, cam_in_world, ee_in_grasp,
+                            gripper_in_grasp, filter_approach_dir_face_camera, filter_ik, adjust_collision_pose, upper, lower,
+                            gripper_vertices, gripper_faces, gripper_enclosed_vertices, gripper_enclosed_faces,
+                            gripper_collision_pts, gripper_enclosed_collision_pts, octo_resolution, verbose=False):
+    """filterGraspPose in input order: returns (codes (E,) int8, poses (E,4,4) float32, nudge (E,) int8) numpy,
+    E = len(grasp_poses)*len(symmetry_tfs), e = i*len(symmetry_tfs)+j.
+    codes: 0 keep, 1 approach-dir, 2 IK, 3 open-gripper collision / no nudge found, 4 enclosed-gripper collision."""
+    scene = GripperScene(gripper_vertices, gripper_faces, gripper_enclosed_vertices, gripper_enclosed_faces,
+                         gripper_collision_pts, gripper_enclosed_collision_pts, octo_resolution)
+    codes, poses, nudge = filter_on_device(scene, grasp_poses, symmetry_tfs, nocs_pose, canonical_to_nocs_transform, cam_in_world,
+                                           ee_in_grasp, gripper_in_grasp, filter_approach_dir_face_camera, filter_ik,
+                                           adjust_collision_pose, upper, lower)
+    codes = codes.cpu().numpy(); poses = poses.cpu().numpy(); nudge = nudge.cpu().numpy()
+    if verbose:
+        # counters of common.cpp:316-319
+        print('n_approach_dir_rej=%d, n_ik_rej=%d, n_open_gripper_rej=%d, n_close_gripper_rej=%d' % (
+            int((codes == 1).sum()), int((codes == 2).sum()), int((codes == 3).sum()), int((codes == 4).sum())))
+    return codes, poses, nudge
+
+
+def filterGraspPose(grasp_poses, symmetry_tfs, nocs_pose, canonical_to_nocs_transform, cam_in_world, ee_in_grasp,
+                    gripper_in_grasp, filter_approach_dir_face_camera, filter_ik, adjust_collision_pose, upper, lower,
+                    gripper_vertices, gripper_faces, gripper_enclosed_vertices, gripper_enclosed_faces,
+                    gripper_collision_pts, gripper_enclosed_collision_pts, octo_resolution, verbose):
+    """my_cpp.filterGraspPose (common.cpp:156-321): list of surviving grasp_in_cam 4x4 float32 matrices
+    (here in deterministic input order; the reference's order is thread-dependent)."""
+    codes, poses, _ = filterGraspPoseDetailed(grasp_poses, symmetry_tfs, nocs_pose, canonical_to_nocs_transform, cam_in_world,
+                                              ee_in_grasp, gripper_in_grasp, filter_approach_dir_face_camera, filter_ik,
+                                              adjust_collision_pose, upper, lower, gripper_vertices, gripper_faces,
+                                              gripper_enclosed_vertices, gripper_enclosed_faces, gripper_collision_pts,
+                                              gripper_enclosed_collision_pts, octo_resolution, verbose)
+    return [poses[e].copy() for e in np.nonzero(codes == 0)[0]]
+
+
+def augmentGraspPoses(*args, **kwargs):
+    raise NotImplementedError('augmentGraspPoses is exported by the reference but has no caller (SURVEY.md §8 a21); not built yet')
+
+
+def makeOccupancyGridFromCloudScan(*args, **kwargs):
+    raise NotImplementedError('makeOccupancyGridFromCloudScan (SURVEY.md §8(f) N2) is a "next" row; not built yet')

@@ -76,6 +76,50 @@ int cg_build_grasp_input(const float* cloud_xyz, const float* cloud_normal, int 
 int cg_build_nunocs_input(const float* cloud_xyz, const float* cloud_normal, int n_cloud, const int* ids,
                           const float* mean, const float* inv_std, int B, int n_pts, float* out, void* stream);
 
+
+/* ---------------------------------------------------------------------------------------------
+ * Collision filter: my_cpp (my_cpp/pybind.cpp:11-23).
+ * A point cloud registered at `resolution` (CollisionManager::registerPointCloud,
+ * my_cpp/collision_manager.cpp:55-79) is the set of occupied octomap depth-16 leaves; it is held in
+ * HBM as (n,4) int16 rows (key-32768 per axis, 4th lane unused), unique and sorted.
+ * ------------------------------------------------------------------------------------------- */
+
+/* octomap coordToKeyChecked per point: packed[i] = kx<<32 | ky<<16 | kz (keys in [0,65536)) or -1 for a
+ * point outside the tree (updateNode ignores it).  The caller de-duplicates (sort/unique). */
+int cg_voxel_keys(const float* pts, long n_pts, float resolution, long long* packed, void* stream);
+/* packed unique keys -> (n,4) int16 rows. */
+int cg_unpack_voxel_keys(const long long* packed, long n, short* keys4, void* stream);
+
+/* CollisionManager::setTransform + isAnyCollision (my_cpp/collision_manager.cpp:81-111) for n_poses
+ * independent poses (n_poses,16 row-major 4x4) of one triangle mesh (registerMesh, :15-52) against one
+ * voxelised cloud.  out[i] = 1 iff some occupied leaf box intersects some posed triangle. */
+int cg_mesh_voxels_collide(const float* vertices, const int* faces, int n_faces, const float* poses, long n_poses,
+                           const short* keys, int n_keys, float resolution, unsigned char* out, void* stream);
+
+/* filterGraspPose (my_cpp/common.cpp:156-321; declaration my_cpp/common.h:60) for every
+ * (grasp pose i, symmetry transform j) pair, in input order e = i*n_sym + j.
+ *  grasp_poses (n_pose,16), symmetry_tfs (n_sym,16): device, row-major float32 4x4.
+ *  h_*: HOST pointers to 16 floats (row-major 4x4): nocs_pose, canonical_to_nocs_transform, cam_in_world,
+ *       ee_in_grasp, gripper_in_grasp.
+ *  ik_ok: optional (E) u8 produced by the host IK pass (0 => rejected with code 2); NULL => filter_ik=false.
+ *  gripper / enclosed mesh: vertices (nv,3) f32, faces (nf,3) i32 (registerMesh inputs, common.cpp:177,181).
+ *  open_keys / bg_keys: voxelised gripper_collision_pts / gripper_enclosed_collision_pts (common.cpp:178,182).
+ * Outputs: codes (E) i8 {0 keep, 1 approach-dir, 2 IK, 3 open-gripper collision or no nudge found,
+ *  4 enclosed-gripper collision}; poses_out (E,16) surviving grasp_in_cam (after column normalisation and
+ *  nudge; zero if rejected); nudge (E) i8 accepted nudge index {0:0, 1:+1mm, 2:-1mm, 3:+2mm, 4:-2mm} or -1.
+ * If ee_in_base_out != NULL the call only runs the pre-IK stage: it writes ee_in_base = cam_in_world .
+ * grasp_in_cam . ee_in_grasp (E,16) (common.cpp:216) and codes {0,1}, for the host-side IK pass. */
+int cg_filter_grasp_pose(const float* grasp_poses, int n_pose, const float* symmetry_tfs, int n_sym,
+                         const float* h_nocs_pose, const float* h_canonical_to_nocs, const float* h_cam_in_world,
+                         const float* h_ee_in_grasp, const float* h_gripper_in_grasp,
+                         int filter_approach_dir_face_camera, int adjust_collision_pose,
+                         const unsigned char* ik_ok,
+                         const float* gripper_vertices, const int* gripper_faces, int n_gripper_faces,
+                         const float* enclosed_vertices, const int* enclosed_faces, int n_enclosed_faces,
+                         const short* open_keys, int n_open_keys, const short* bg_keys, int n_bg_keys,
+                         float resolution, signed char* codes, float* poses_out, signed char* nudge,
+                         float* ee_in_base_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

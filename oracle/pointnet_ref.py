@@ -198,61 +198,3 @@ def pointnet_seg_forward(state_dict, x, dtype=torch.float32):
     y = _conv_bn(y, sd, 'conv3', 'bn3', True)
     y = _conv_bn(y, sd, 'conv4', None, False)
     return y.permute(0, 2, 1), trans_feat
-
-
-# --------------------------------------------------------------------------------------
-# synthetic reference-layout weights (SURVEY.md §8(d) "Weights")
-# --------------------------------------------------------------------------------------
-def _stn_shapes(p, cin, k):
-    s = {}
-    for name, (o, i) in {'conv1': (64, cin), 'conv2': (128, 64), 'conv3': (1024, 128)}.items():
-        s[p + name + '.weight'] = (o, i, 1); s[p + name + '.bias'] = (o,)
-    for name, (o, i) in {'fc1': (512, 1024), 'fc2': (256, 512), 'fc3': (k * k, 256)}.items():
-        s[p + name + '.weight'] = (o, i); s[p + name + '.bias'] = (o,)
-    for name, c in {'bn1': 64, 'bn2': 128, 'bn3': 1024, 'bn4': 512, 'bn5': 256}.items():
-        s[p + name] = c
-    return s
-
-
-def model_shapes(kind, n_in, n_out):
-    """Parameter / buffer names and shapes of PointNetCls / PointNetSeg (pointnet2.py:275-329)."""
-    s = {}
-    s.update(_stn_shapes('feat.stn.', n_in, 3))
-    for name, (o, i) in {'conv1': (64, n_in), 'conv2': (128, 64), 'conv3': (1024, 128)}.items():
-        s['feat.' + name + '.weight'] = (o, i, 1); s['feat.' + name + '.bias'] = (o,)
-    for name, c in {'bn1': 64, 'bn2': 128, 'bn3': 1024}.items():
-        s['feat.' + name] = c
-    s.update(_stn_shapes('feat.fstn.', 64, 64))
-    if kind == 'cls':
-        for name, (o, i) in {'fc1': (512, 1024), 'fc2': (256, 512), 'fc3': (n_out, 256)}.items():
-            s[name + '.weight'] = (o, i); s[name + '.bias'] = (o,)
-        s['bn1'] = 512; s['bn2'] = 256
-    else:
-        for name, (o, i) in {'conv1': (512, 1088), 'conv2': (256, 512), 'conv3': (128, 256), 'conv4': (n_out, 128)}.items():
-            s[name + '.weight'] = (o, i, 1); s[name + '.bias'] = (o,)
-        s['bn1'] = 512; s['bn2'] = 256; s['bn3'] = 128
-    return s
-
-
-def make_state_dict(kind, n_in, n_out, seed=0, prefix='', gain=1.6):
-    """Seeded synthetic checkpoint with non-trivial BN statistics so folding is exercised.
-    Weights ~ U(-gain/sqrt(fan_in), gain/sqrt(fan_in)); gain=1 is torch's default init, the
-    default gain=1.6 keeps activations O(1) through the stack so logits are O(1-10), not ~0."""
-    rng = np.random.default_rng(seed)
-    sd = {}
-    for name, shp in model_shapes(kind, n_in, n_out).items():
-        if isinstance(shp, int):
-            c = shp
-            sd[prefix + name + '.weight'] = torch.from_numpy(rng.uniform(0.5, 1.5, c).astype(np.float32))
-            sd[prefix + name + '.bias'] = torch.from_numpy(rng.normal(0, 0.1, c).astype(np.float32))
-            sd[prefix + name + '.running_mean'] = torch.from_numpy(rng.normal(0, 0.1, c).astype(np.float32))
-            sd[prefix + name + '.running_var'] = torch.from_numpy(rng.uniform(0.5, 1.5, c).astype(np.float32))
-            sd[prefix + name + '.num_batches_tracked'] = torch.tensor(100, dtype=torch.long)
-        else:
-            fan_in = shp[1] if len(shp) > 1 else None
-            if fan_in is None:   # bias: fan_in of the matching weight
-                wshape = model_shapes(kind, n_in, n_out)[name.replace('.bias', '.weight')]
-                fan_in = wshape[1]
-            b = gain / np.sqrt(fan_in)
-            sd[prefix + name] = torch.from_numpy(rng.uniform(-b, b, shp).astype(np.float32))
-    return sd

@@ -1,0 +1,188 @@
+"""GPU parity (bit-exact): HIP filterGraspPose / CollisionManager / voxelisation vs the C oracle
+(oracle/collision_ref.c), same seeded inputs.  Integer/boolean outputs must be identical; surviving
+poses must be bit-identical float32."""
+import numpy as np
+import pytest
+import torch
+
+from catgrasp_amd import synth
+from oracle import collision_oracle as co
+
+pytestmark = pytest.mark.gpu
+I4 = np.eye(4)
+
+
+def _scene(seed=0, n_obj=6, pts=2500):
+    objs = synth.make_scene(n_obj, pts, seed)
+    g = synth.make_gripper()
+    bg = synth.background_points(objs, 0, g['diameter'])
+    return objs, g, bg
+
+
+def _args(P, sym, nocs, g, obj_pts, bg, dirf, adj, res=0.0005):
+    return (P, sym, nocs, I4, I4, I4, g['gripper_in_grasp'], dirf, False, adj, [0] * 7, [0] * 7, g['vertices'], g['faces'],
+            g['enclosed_vertices'], g['enclosed_faces'], obj_pts, bg, res)
+
+
+def _oracle(P, sym, nocs, g, obj_pts, bg, dirf, adj, res=0.0005):
+    return co.filter_grasp_pose(P, sym, nocs, I4, I4, I4, g['gripper_in_grasp'], dirf, 0, adj, g['vertices'], g['faces'],
+                                g['enclosed_vertices'], g['enclosed_faces'], obj_pts, bg, res)
+
+
+def _check(dev, ora):
+    codes, poses, nudge = dev
+    ocodes, oposes, onudge = ora
+    assert np.array_equal(codes, ocodes), f'{(codes != ocodes).sum()} of {len(codes)} codes differ'
+    assert np.array_equal(nudge, onudge)
+    assert np.array_equal(poses.view(np.uint32), oposes.view(np.uint32)), 'surviving poses are not bit-identical'
+
+
+def test_voxelize_matches_octomap_keys(cuda_device):
+    from catgrasp_amd import my_cpp
+    rng = np.random.default_rng(3)
+    pts = rng.uniform(-0.2, 0.8, (5000, 3)).astype(np.float32)
+    # exact voxel boundaries, negatives, duplicates, out-of-tree points (ignored by updateNode)
+    extra = np.array([[0.0005 * 7, -0.0005 * 3, 0.0], [0.0005 * 7, -0.0005 * 3, 0.0], [-1e-9, 1e-9, 0.6], [99999, 99999, 99999],
+                      [16.3839, -16.3840, 0], [16.3841, 0, 0], [0, -16.39, 0]], dtype=np.float32)
+    pts = np.concatenate([pts, extra])
+    for res in (0.0005, 0.001, 0.0025):
+        keys = my_cpp.voxelize(pts, res).cpu().numpy()
+        okeys = co.voxelize(pts, res)
+        assert keys.shape[0] == okeys.shape[0]
+        assert np.array_equal(keys[:, :3].astype(np.int32), okeys)
+    assert my_cpp.voxelize(np.ones((1, 3)) * 99999, 0.0005).shape[0] == 0     # generate_grasp.py:97 sentinel cloud
+
+
+@pytest.mark.parametrize('adjust', [False, True])
+def test_filter_cone_sampler_path(cuda_device, adjust):
+    """grasp_sampler.py:216 call shape: symmetry=[I], nocs_pose=I, approach-dir filter on."""
+    from catgrasp_amd import my_cpp
+    objs, g, bg = _scene(0)
+    P = synth.make_candidates(objs[0], 600, np.random.default_rng(1))
+    dev = my_cpp.filterGraspPoseDetailed(*_args(P, [I4], I4, g, objs[0]['xyz'], bg, True, adjust))
+    ora = _oracle(P, [I4], I4, g, objs[0]['xyz'], bg, 1, int(adjust))
+    _check(dev, ora)
+    assert (dev[0] == 0).sum() > 0 and (dev[0] == 3).sum() > 0      # both outcomes exercised
+    lst = my_cpp.filterGraspPose(*_args(P, [I4], I4, g, objs[0]['xyz'], bg, True, adjust), False)
+    assert len(lst) == int((ora[0] == 0).sum())
+    for m, e in zip(lst, np.nonzero(ora[0] == 0)[0]):
+        assert m.dtype == np.float32 and np.array_equal(m, ora[1][e])
+
+
+def test_filter_nocs_transfer_path_symmetry_and_scale(cuda_device):
+    """grasp_sampler.py:345 call shape: 12 nut symmetries, a 9-D (anisotropically scaled) nocs_pose,
+    adjust_collision_pose=True, no approach-dir filter."""
+    from catgrasp_amd import my_cpp
+    objs, g, bg = _scene(2)
+    rng = np.random.default_rng(5)
+    obj = objs[0]
+    T = obj['pose']
+    scale = np.diag([0.016, 0.016, 0.006, 1.0])
+    nocs_pose = T @ scale                                   # canonical (unit NUNOCS cube) -> camera
+    # canonical grasps: object-frame candidates mapped into the canonical frame
+    P_cam = synth.make_candidates(obj, 40, rng)
+    P_can = np.linalg.inv(nocs_pose) @ P_cam
+    sym = []
+    for xa in (0, np.pi):
+        for za in np.arange(0, 360, 60) / 180 * np.pi:
+            Rx = np.array([[1, 0, 0], [0, np.cos(xa), -np.sin(xa)], [0, np.sin(xa), np.cos(xa)]])
+            Rz = np.array([[np.cos(za), -np.sin(za), 0], [np.sin(za), np.cos(za), 0], [0, 0, 1]])
+            S = np.eye(4); S[:3, :3] = Rx @ Rz
+            sym.append(S)
+    dev = my_cpp.filterGraspPoseDetailed(*_args(P_can, sym, nocs_pose, g, obj['xyz'], bg, False, True))
+    ora = _oracle(P_can, sym, nocs_pose, g, obj['xyz'], bg, 0, 1)
+    assert len(dev[0]) == 40 * 12
+    _check(dev, ora)
+
+
+def test_filter_edge_cases(cuda_device):
+    from catgrasp_amd import my_cpp
+    objs, g, bg = _scene(4, n_obj=3, pts=800)
+    P = synth.make_candidates(objs[0], 64, np.random.default_rng(7))
+    sentinel = np.ones((1, 3)) * 99999
+    # offline generate_grasp.py:97 path: sentinel clouds => nothing collides
+    dev = my_cpp.filterGraspPoseDetailed(*_args(P, [I4], I4, g, sentinel, sentinel, True, False))
+    ora = _oracle(P, [I4], I4, g, sentinel, sentinel, 1, 0)
+    _check(dev, ora)
+    assert set(np.unique(dev[0])) <= {0, 1}
+    # empty pose list
+    codes, poses, nudge = my_cpp.filterGraspPoseDetailed(*_args(np.zeros((0, 4, 4)), [I4], I4, g, objs[0]['xyz'], bg, True, True))
+    assert codes.shape == (0,) and poses.shape == (0, 4, 4)
+    assert my_cpp.filterGraspPose(*_args([], [I4], I4, g, objs[0]['xyz'], bg, True, True), False) == []
+    # wrong shapes raise instead of exit(1)
+    with pytest.raises(ValueError):
+        my_cpp.filterGraspPoseDetailed(*_args(P, [I4], I4, dict(g, vertices=g['vertices'][:, :2]), objs[0]['xyz'], bg, True, False))
+    # coarser resolution + a finely tessellated gripper (> one LDS triangle chunk)
+    V, F = g['vertices'], g['faces']
+    for _ in range(2):     # 36 -> 144 -> 576 triangles
+        nv = len(V); newV = [V]; newF = []
+        for f in F:
+            a, b, c = V[f[0]], V[f[1]], V[f[2]]
+            m = np.stack([(a + b) / 2, (b + c) / 2, (c + a) / 2]).astype(np.float32)
+            i0 = nv; nv += 3; newV.append(m)
+            newF += [[f[0], i0, i0 + 2], [i0, f[1], i0 + 1], [i0 + 2, i0 + 1, f[2]], [i0, i0 + 1, i0 + 2]]
+        V = np.concatenate(newV).astype(np.float32); F = np.array(newF, dtype=np.int32)
+    g2 = dict(g, vertices=V, faces=F)
+    dev = my_cpp.filterGraspPoseDetailed(*_args(P, [I4], I4, g2, objs[0]['xyz'], bg, True, False, 0.001))
+    ora = _oracle(P, [I4], I4, g2, objs[0]['xyz'], bg, 1, 0, 0.001)
+    _check(dev, ora)
+
+
+def test_collision_manager_api(cuda_device):
+    """my_cpp.CollisionManager surface (collision_manager.h:60-65)."""
+    from catgrasp_amd import my_cpp
+    objs, g, bg = _scene(6, n_obj=2, pts=1500)
+    cm = my_cpp.CollisionManager()
+    gid = cm.registerMesh(g['vertices'], g['faces'])
+    cid = cm.registerPointCloud(objs[0]['xyz'].astype(np.float32), 0.0005)
+    assert (gid, cid) == (0, 1)
+    okeys = co.voxelize(objs[0]['xyz'], 0.0005)
+    P = synth.make_candidates(objs[0], 24, np.random.default_rng(9))
+    n_hit = 0
+    for p in P:
+        pose = (p @ g['gripper_in_grasp']).astype(np.float32)
+        cm.setTransform(pose, gid)
+        got = cm.isAnyCollision()
+        exp = co.mesh_voxels_collide(g['vertices'], g['faces'], pose, okeys, 0.0005)
+        assert got == exp
+        n_hit += int(got)
+    assert 0 < n_hit < len(P)
+    with pytest.raises(ValueError):
+        cm.setTransform(np.eye(3), gid)
+    with pytest.raises(ValueError):
+        cm.registerMesh(np.zeros((4, 2)), np.zeros((1, 3), dtype=np.int32))
+
+
+def test_tri_box_predicate_random_and_grazing(cuda_device):
+    """The SAT predicate itself on random and near-touching configurations, via single-voxel clouds."""
+    from catgrasp_amd import my_cpp
+    rng = np.random.default_rng(11)
+    res = 0.001
+    V = np.array([[0, 0, 0], [0.004, 0, 0], [0, 0.003, 0]], dtype=np.float32)
+    F = np.array([[0, 1, 2]], dtype=np.int32)
+    vox = np.array([[0.0105, 0.0205, 0.0305]], dtype=np.float32)        # centre of key (10,20,30)
+    keys = co.voxelize(vox, res)
+    dkeys = my_cpp.voxelize(vox, res)
+    poses = []
+    for _ in range(4000):
+        R = synth.random_rotation(rng)
+        t = vox[0] + rng.normal(0, 0.0012, 3)
+        T = np.eye(4); T[:3, :3] = R; T[:3, 3] = t - R @ np.array([0.0013, 0.001, 0])
+        poses.append(T)
+    # grazing: triangle plane exactly on / one ulp off a voxel face
+    for dz in (0.0, 1e-9, -1e-9, 6e-8, -6e-8):
+        T = np.eye(4); T[:3, 3] = [0.0095, 0.0195, 0.031 + dz]
+        poses.append(T)
+    poses = np.array(poses, dtype=np.float32)
+    import ctypes
+    from catgrasp_amd import _lib as L
+    dev = torch.device('cuda:0')
+    dV = torch.from_numpy(V).to(dev); dF = torch.from_numpy(F).to(dev)
+    dP = torch.from_numpy(poses.reshape(-1, 16)).to(dev)
+    out = torch.zeros((len(poses),), dtype=torch.uint8, device=dev)
+    L.check(L.lib().cg_mesh_voxels_collide(L._p(dV), L._p(dF), ctypes.c_int(1), L._p(dP), ctypes.c_long(len(poses)), L._p(dkeys),
+                                           ctypes.c_int(dkeys.shape[0]), ctypes.c_float(res), L._p(out), L._stream()), 'collide')
+    got = out.cpu().numpy().astype(bool)
+    exp = np.array([co.mesh_voxels_collide(V, F, p, keys, res) for p in poses])
+    assert np.array_equal(got, exp)
+    assert 0.05 < exp.mean() < 0.95

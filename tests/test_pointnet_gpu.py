@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 import torch
 
+from catgrasp_amd import synth
 from oracle import pointnet_ref as oref
 
 pytestmark = pytest.mark.gpu
@@ -26,7 +27,7 @@ def _inputs(B, N, seed, scale=0.5):
 @pytest.mark.parametrize('B,N,gain', [(3, 256, 1.6), (2, 2048, 1.6), (5, 100, 1.0), (1, 64, 1.6), (70, 130, 1.7)])
 def test_cls_forward_matches_oracle(cuda_device, B, N, gain):
     from catgrasp_amd import engine, folding
-    sd = oref.make_state_dict('cls', 6, 10, seed=11, gain=gain)
+    sd = synth.make_state_dict('cls', 6, 10, seed=11, gain=gain)
     x = _inputs(B, N, 5)
     ref_logits, ref_tf = oref.pointnet_cls_forward(sd, x)
     W = folding.prepare_cls(sd, cuda_device)
@@ -48,7 +49,7 @@ def test_cls_forward_matches_oracle(cuda_device, B, N, gain):
 @pytest.mark.parametrize('B,N', [(1, 512), (2, 1000), (1, 8192)])
 def test_seg_forward_matches_oracle(cuda_device, B, N):
     from catgrasp_amd import engine, folding
-    sd = oref.make_state_dict('seg', 6, 300, seed=12)
+    sd = synth.make_state_dict('seg', 6, 300, seed=12)
     x = _inputs(B, N, 6)
     ref_y, ref_tf = oref.pointnet_seg_forward(sd, x)
     W = folding.prepare_seg(sd, cuda_device)
