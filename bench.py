@@ -1,0 +1,212 @@
+#!/usr/bin/env python
+"""bench.py -- grasp candidates scored + collision-checked per second (BASELINE.json metric).
+
+One "step" = one pass of the hot path over one batch of synthetic input on every rank:
+  NUNOCS net over the scene's objects  ->  filterGraspPose over the rank's candidates  ->
+  grasp-Q net (input transform + PointNetCls + softmax + p_G) over the same candidates
+  [-> one RCCL all_gather of the packed (p_G, code) records when --gpus > 1].
+Workload (config.workload): BASELINE.json configs[1] scale -- nut clutter pile, 20k-pt scene
+(8 objects x 2500 pts), 10k candidates per GPU, fp32 -- with the configs[2] stages (NUNOCS + collision)
+included because the metric is "scored + collision-checked".  All inputs are resident in HBM before
+the timed region; weights are seeded random (the reference ships no checkpoints), data synthetic.
+
+Launch: python bench.py --gpus 1 --steps K --warmup W
+        python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MAC_PER_POINT_ENC = 9 + 384 + 4096 + 8192 + 131072      # pointmlp_max_kernel<2>: T3, conv1, .T64, conv2, conv3
+PEAK_F32_MFMA_TFLOPS = 157.3                            # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+
+
+def build_workload(device, G, seed, n_objects=8, pts_per_object=2500):
+    from catgrasp_amd import my_cpp, synth, transforms
+    objs = synth.make_scene(n_objects, pts_per_object, seed=0)           # same scene on every rank
+    gripper = synth.make_gripper()
+    rng = np.random.default_rng(1000 + seed)
+    per = [G // n_objects + (1 if k < G % n_objects else 0) for k in range(n_objects)]
+    clouds, offsets, pose_rows, poses_dev, scenes, ids = [], [], [], [], [], []
+    off = 0
+    gen = torch.Generator(device=device); gen.manual_seed(1234 + seed)
+    for k, ob in enumerate(objs):
+        dc = transforms.DeviceCloud(ob['xyz'], ob['normal'], device)
+        clouds.append(dc); offsets.append(off)
+        P = synth.make_candidates(ob, per[k], rng, gripper['hand_depth'], gripper['init_bite'])
+        pose_rows.append(transforms.pose_inverse_rows(P, dc.center))
+        poses_dev.append(torch.from_numpy(P.astype(np.float32).reshape(-1, 16)).to(device))
+        bg = synth.background_points(objs, k, gripper['diameter'])
+        scenes.append(my_cpp.GripperScene(gripper['vertices'], gripper['faces'], gripper['enclosed_vertices'],
+                                          gripper['enclosed_faces'], ob['xyz'], bg, 0.0005, device))
+        ids.append(transforms.draw_ids_device(dc.n, 2048, per[k], device, gen) + off)
+        off += dc.n
+    wl = {
+        'objs': objs, 'gripper': gripper, 'per': per, 'scenes': scenes, 'poses_dev': poses_dev,
+        'cloud_xyz': torch.cat([c.xyz for c in clouds]).contiguous(),
+        'cloud_normal': torch.cat([c.normal for c in clouds]).contiguous(),
+        'ids': torch.cat(ids).contiguous(),
+        'pose_inv': torch.from_numpy(np.concatenate(pose_rows)).to(device),
+        'nunocs_ids': torch.stack([transforms.draw_ids_device(c.n, 8192, 1, device, gen)[0] + o
+                                   for c, o in zip(clouds, offsets)]).contiguous(),
+        'G': G,
+    }
+    return wl
+
+
+def run_step(wl, gp, npred, gather_buf=None, world=1):
+    from catgrasp_amd import my_cpp
+    I4 = np.eye(4, dtype=np.float32)
+    # (1) NUNOCS canonicaliser over every object cloud of the scene
+    coords, conf, _ = npred.nocs_on_device(wl['cloud_xyz'], wl['cloud_normal'], wl['nunocs_ids'])
+    # (2) collision filter (cone-sampler call shape: symmetry=[I], nocs_pose=I, approach-dir filter on)
+    codes = []
+    sym = wl.setdefault('_sym', torch.eye(4, device=wl['cloud_xyz'].device).reshape(1, 16).contiguous())
+    for k, sc in enumerate(wl['scenes']):
+        c, _, _ = my_cpp.filter_on_device(sc, wl['poses_dev'][k], sym, I4, I4, I4, I4, wl['gripper']['gripper_in_grasp'],
+                                          True, False, False)
+        codes.append(c)
+    codes = torch.cat(codes)
+    # (3) grasp-Q scoring of every candidate
+    probs, label, conf_q, p_g = gp.score_on_device(wl['cloud_xyz'], wl['cloud_normal'], wl['ids'], wl['pose_inv'])
+    # (4) packed per-candidate record: p_G (f32) + code (as f32 lane) -> one all_gather over xGMI
+    rec = torch.stack([p_g, codes.float()], dim=1).contiguous()
+    if world > 1:
+        torch.distributed.all_gather_into_tensor(gather_buf, rec)
+        return gather_buf
+    return rec
+
+
+def cpu_baseline(wl, sd_cls, sd_seg, n_score=96, n_coll=2048):
+    """The CPU oracle (a port of the reference path, oracle/) timed on this box's host cores on a bounded
+    sample: python GraspDataset.transform loop + PointNetCls fp32 forward in chunks of 200
+    (predicter.py:67-91), the C/OpenMP filterGraspPose restatement, and the NUNOCS forward amortised."""
+    from oracle import collision_oracle as co
+    from oracle import pointnet_ref as oref
+    from oracle import transforms_ref as tref
+    from catgrasp_amd import synth
+    torch.set_num_threads(os.cpu_count())
+    ob = wl['objs'][0]; g = wl['gripper']
+    rng = np.random.default_rng(7)
+    P = synth.make_candidates(ob, max(n_score, n_coll), rng, g['hand_depth'], g['init_bite'])
+    t0 = time.time()
+    xs = []
+    for i in range(n_score):
+        ids = tref.draw_ids(len(ob['xyz']), 2048)
+        xs.append(tref.grasp_transform(ob['xyz'].copy(), ob['normal'].copy(), P[i], ids)['input'])
+    x = torch.from_numpy(np.stack(xs)).float()
+    with torch.no_grad():
+        logits, _ = oref.pointnet_cls_forward(sd_cls, x)
+    tref.predict_batch_post(logits.numpy())
+    t_score = (time.time() - t0) / n_score
+    bg = synth.background_points(wl['objs'], 0, g['diameter'])
+    I4 = np.eye(4)
+    t0 = time.time()
+    co.filter_grasp_pose(P[:n_coll], [I4], I4, I4, I4, I4, g['gripper_in_grasp'], 1, 0, 0, g['vertices'], g['faces'],
+                         g['enclosed_vertices'], g['enclosed_faces'], ob['xyz'], bg, 0.0005)
+    t_coll = (time.time() - t0) / n_coll
+    t0 = time.time()
+    ids = tref.draw_ids(len(ob['xyz']), 8192)
+    xin = tref.nunocs_transform(ob['xyz'].copy(), ob['normal'].copy(), ids)['input']
+    with torch.no_grad():
+        lg, _ = oref.pointnet_seg_forward(sd_seg, torch.from_numpy(xin[None]).float())
+    tref.nunocs_decode(lg[0].numpy(), 100)
+    t_nunocs = (time.time() - t0) * len(wl['objs']) / wl['G']
+    per_cand = t_score + t_coll + t_nunocs
+    return {'value': round(1.0 / per_cand, 2), 'unit': 'candidates/s', 'cores': os.cpu_count(), 'kind': 'port',
+            'sample': f'{n_score} candidates scored (python transform loop + fp32 torch oracle, {os.cpu_count()} threads) '
+                      f'+ {n_coll} candidates collision-filtered (C/OpenMP oracle) + 1 NUNOCS forward amortised over {wl["G"]}',
+            'score_ms_per_candidate': round(t_score * 1e3, 3), 'collision_ms_per_candidate': round(t_coll * 1e3, 4)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--candidates', type=int, default=10000, help='grasp candidates per GPU per step')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a HIP device')
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        torch.distributed.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+
+    from catgrasp_amd import ops, synth
+    from catgrasp_amd.predicter import DEFAULT_GRASP_CFG, DEFAULT_NUNOCS_CFG, GraspPredicter, NunocsPredicter
+    sd_cls = synth.make_state_dict('cls', 6, 10, seed=0)
+    sd_seg = synth.make_state_dict('seg', 6, 300, seed=1)
+    gp = GraspPredicter('nut', cfg=DEFAULT_GRASP_CFG, state_dict=sd_cls, device=device)
+    npred = NunocsPredicter('nut', cfg=DEFAULT_NUNOCS_CFG, state_dict=sd_seg, device=device)
+    G = args.candidates
+    wl = build_workload(device, G, seed=rank)
+    gather_buf = torch.empty((world * G, 2), dtype=torch.float32, device=device) if world > 1 else None
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            run_step(wl, gp, npred, gather_buf, world)
+        barrier()
+        ops.KERNEL_TIMER = {'mid_mode': 2, 'events': []}
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = run_step(wl, gp, npred, gather_buf, world)
+        barrier()
+        dt = time.perf_counter() - t0
+        timer, ops.KERNEL_TIMER = ops.KERNEL_TIMER, None
+    t = torch.tensor([dt], dtype=torch.float64, device=device)
+    if world > 1:
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    dt = float(t.item())
+
+    if rank == 0:
+        ms_step = dt / args.steps * 1e3
+        value = world * G * args.steps / dt
+        ev = timer['events']
+        k_ms = [a.elapsed_time(b) for a, b, _ in ev]
+        k_flops = [2.0 * MAC_PER_POINT_ENC * B * N for _, _, (B, N) in ev]
+        avg_ms = float(np.mean(k_ms)) if k_ms else float('nan')
+        achieved = float(np.mean(k_flops)) / (avg_ms * 1e-3) / 1e12 if k_ms else float('nan')
+        line = {
+            'metric': 'grasp candidates scored+collision-checked /sec, 20k-pt clutter scene',
+            'value': round(value, 1), 'unit': 'candidates/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(ms_step, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic (seeded clouds/candidates/gripper, random-init weights)',
+            'config': {'workload': 'nut clutter pile, 20k-pt scene (8 objects x 2500 pts), '
+                                   f'{G} candidates/GPU: NUNOCS(8x8192) + filterGraspPose + grasp-Q PointNetCls(2048x6) fp32',
+                       'candidates_per_gpu': G, 'scene_points': int(wl['cloud_xyz'].shape[0]), 'parallelism': f'candidate-shard x{world}'},
+            'roofline': {'bound': 'mfma', 'kernel': 'pointmlp_max_kernel<2> (encoder pass: conv1, x.T64, conv2, conv3, max)',
+                         'achieved': round(achieved, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': None,
+                         'avg_launch_ms': round(avg_ms, 4), 'launches': len(k_ms),
+                         'flop_per_candidate_launch': 2 * MAC_PER_POINT_ENC * 2048},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(wl, sd_cls, sd_seg)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -9,6 +9,11 @@ from ._lib import _p, _stream, check, f32c, i32c, require_cuda
 _c_int = ctypes.c_int
 _c_long = ctypes.c_long
 
+# bench.py hook: when set to {'mid_mode': m, 'events': []}, every cg_pointmlp_max launch with that mid_mode is
+# bracketed by HIP events on the launch stream (torch's current stream) so the kernel's average duration can be
+# measured live over the timed region.
+KERNEL_TIMER = None
+
 
 def pointmlp_max(x, w1, b1, w2p, b2, w3p, b3, relu3, t3=None, mid_mode=0, wm=None, bm=None, t64=None,
                  nsplit=1, pointfeat=False):
@@ -19,9 +24,16 @@ def pointmlp_max(x, w1, b1, w2p, b2, w3p, b3, relu3, t3=None, mid_mode=0, wm=Non
     assert D == 6
     out = torch.empty((B, 1024), dtype=torch.float32, device=x.device)
     pf = torch.empty((B, N, 64), dtype=torch.float32, device=x.device) if pointfeat else None
+    timer = KERNEL_TIMER if (KERNEL_TIMER is not None and KERNEL_TIMER['mid_mode'] == mid_mode) else None
+    if timer is not None:
+        ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
+        ev0.record()
     st = L.lib().cg_pointmlp_max(_p(x), _c_int(B), _c_int(N), _p(t3), _p(w1), _p(b1), _c_int(mid_mode), _p(wm), _p(bm),
                                  _p(t64), _p(w2p), _p(b2), _p(w3p), _p(b3), _c_int(int(relu3)), _c_int(nsplit),
                                  _p(out), _p(pf), _stream())
+    if timer is not None:
+        ev1.record()
+        timer['events'].append((ev0, ev1, (B, N)))
     check(st, 'cg_pointmlp_max')
     return (out, pf) if pointfeat else out
 

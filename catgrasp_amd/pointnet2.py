@@ -1,0 +1,183 @@
+"""Drop-in for the reference's `pointnet2` module (star-imported at predicter.py:19,
+trainer_grasp.py:15, trainer_nunocs.py:16, run_grasp_simulation.py:26).
+
+Same public names, constructor signatures, forward signatures and -- crucially -- the same
+parameter / buffer names (``feat.stn.conv1.weight`` ... ``fc3.bias``), so reference checkpoints load
+through ``Utils.load_model`` unchanged.
+
+Execution:
+  * eval mode + no grad + CUDA tensor  -> hand-written HIP kernels (catgrasp_amd.engine); weights are
+    BN-folded / packed once per parameter version and cached on the device.
+  * training mode (or grad enabled)    -> ordinary differentiable torch ops, so the reference trainers
+    keep working (training is out of scope of the HIP path).
+  * eval mode on a CPU tensor           -> RuntimeError: there is no CPU inference fallback.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import engine, folding
+from . import primitives as _prim
+
+__all__ = ['square_distance', 'index_points', 'farthest_point_sample', 'query_ball_point', 'sample_and_group',
+           'sample_and_group_all', 'STN3d', 'STNkd', 'PointNetEncoder', 'PointNetCls', 'PointNetSeg']
+
+# PointNet++ primitives (pointnet2.py:14-149): HIP implementations with the reference's tensor signatures
+square_distance = _prim.square_distance
+index_points = _prim.index_points
+farthest_point_sample = _prim.farthest_point_sample
+query_ball_point = _prim.query_ball_point
+sample_and_group = _prim.sample_and_group
+sample_and_group_all = _prim.sample_and_group_all
+
+
+def _use_hip(module, x):
+    if module.training or torch.is_grad_enabled():
+        return False
+    if not x.is_cuda:
+        raise RuntimeError('catgrasp_amd.pointnet2: eval-mode inference needs a CUDA/HIP tensor '
+                           '(the HIP kernels are the only inference path; there is no CPU fallback)')
+    return True
+
+
+class _TNet(nn.Module):
+    """Shared body of STN3d / STNkd: per-point MLP cin->64->128->1024, max-pool, 1024->512->256->k*k, + I."""
+
+    def __init__(self, cin, k):
+        super().__init__()
+        widths = [cin, 64, 128, 1024]
+        for i in range(3):
+            setattr(self, f'conv{i + 1}', nn.Conv1d(widths[i], widths[i + 1], 1))
+        self.fc1 = nn.Linear(1024, 512)
+        self.fc2 = nn.Linear(512, 256)
+        self.fc3 = nn.Linear(256, k * k)
+        self.relu = nn.ReLU()
+        for i, c in enumerate([64, 128, 1024, 512, 256]):
+            setattr(self, f'bn{i + 1}', nn.BatchNorm1d(c))
+        self._k = k
+
+    def forward(self, x):
+        for i in (1, 2, 3):
+            x = F.relu(getattr(self, f'bn{i}')(getattr(self, f'conv{i}')(x)))
+        x = x.max(dim=2)[0]
+        x = F.relu(self.bn4(self.fc1(x)))
+        x = F.relu(self.bn5(self.fc2(x)))
+        x = self.fc3(x) + torch.eye(self._k, device=x.device, dtype=x.dtype).reshape(1, -1)
+        return x.view(-1, self._k, self._k)
+
+
+class STN3d(_TNet):
+    def __init__(self, channel):
+        super().__init__(channel, 3)
+
+
+class STNkd(_TNet):
+    def __init__(self, k=64):
+        super().__init__(k, k)
+        self.k = k
+
+
+class PointNetEncoder(nn.Module):
+    def __init__(self, global_feat=True, feature_transform=False, channel=3):
+        super().__init__()
+        self.stn = STN3d(channel)
+        self.conv1 = nn.Conv1d(channel, 64, 1)
+        self.conv2 = nn.Conv1d(64, 128, 1)
+        self.conv3 = nn.Conv1d(128, 1024, 1)
+        self.bn1 = nn.BatchNorm1d(64)
+        self.bn2 = nn.BatchNorm1d(128)
+        self.bn3 = nn.BatchNorm1d(1024)
+        self.global_feat = global_feat
+        self.feature_transform = feature_transform
+        if feature_transform:
+            self.fstn = STNkd(k=64)
+
+    def forward(self, x):
+        """Differentiable torch path (training).  x:(B,D,N)."""
+        B, D, N = x.shape
+        trans = self.stn(x)
+        pts = x.transpose(2, 1)
+        xyz = torch.bmm(pts[:, :, :3], trans)
+        pts = torch.cat([xyz, pts[:, :, 3:]], dim=2) if D > 3 else xyz
+        h = F.relu(self.bn1(self.conv1(pts.transpose(2, 1))))
+        trans_feat = None
+        if self.feature_transform:
+            trans_feat = self.fstn(h)
+            h = torch.bmm(h.transpose(2, 1), trans_feat).transpose(2, 1)
+        pointfeat = h
+        h = F.relu(self.bn2(self.conv2(h)))
+        h = self.bn3(self.conv3(h))
+        g = h.max(dim=2)[0]
+        if self.global_feat:
+            return g, trans, trans_feat
+        return torch.cat([g.unsqueeze(2).expand(-1, -1, N), pointfeat], 1), trans, trans_feat
+
+
+class _HipCached(nn.Module):
+    """Caches the folded/packed device weights, keyed on parameter versions + device."""
+
+    _kind = None
+
+    def _device_weights(self, device):
+        key = (str(device),) + tuple(int(t._version) for t in self.state_dict().values())
+        cache = self.__dict__.get('_cg_cache')
+        if cache is None or cache[0] != key:
+            prep = folding.prepare_cls if self._kind == 'cls' else folding.prepare_seg
+            cache = (key, prep(self.state_dict(), device))
+            self.__dict__['_cg_cache'] = cache
+        return cache[1]
+
+
+class PointNetCls(_HipCached):
+    """Grasp-Q classifier (pointnet2.py:275-299).  forward(x:(B,N,D)) -> (logits (B,n_out), trans_feat (B,64,64))."""
+    _kind = 'cls'
+
+    def __init__(self, n_in, n_out):
+        super().__init__()
+        self.feat = PointNetEncoder(global_feat=True, feature_transform=True, channel=n_in)
+        self.fc1 = nn.Linear(1024, 512)
+        self.fc2 = nn.Linear(512, 256)
+        self.fc3 = nn.Linear(256, n_out)
+        self.dropout = nn.Dropout(p=0.4)
+        self.bn1 = nn.BatchNorm1d(512)
+        self.bn2 = nn.BatchNorm1d(256)
+        self.relu = nn.ReLU()
+        self._n_in = n_in
+
+    def forward(self, x):
+        if _use_hip(self, x):
+            if self._n_in != 6:
+                raise NotImplementedError('HIP path is built for the 6-channel (xyz+normal) input of config_grasp.yml')
+            return engine.cls_forward(self._device_weights(x.device), x.float().contiguous())
+        g, _, trans_feat = self.feat(x.permute(0, 2, 1))
+        h = F.relu(self.bn1(self.fc1(g)))
+        h = F.relu(self.bn2(self.fc2(self.dropout(h))))
+        return self.fc3(h), trans_feat
+
+
+class PointNetSeg(_HipCached):
+    """NUNOCS per-point classifier (pointnet2.py:302-329).  forward(x:(B,N,D)) -> ((B,N,n_out), trans_feat)."""
+    _kind = 'seg'
+
+    def __init__(self, n_in, n_out):
+        super().__init__()
+        self.feat = PointNetEncoder(global_feat=False, feature_transform=True, channel=n_in)
+        self.conv1 = nn.Conv1d(1088, 512, 1)
+        self.conv2 = nn.Conv1d(512, 256, 1)
+        self.conv3 = nn.Conv1d(256, 128, 1)
+        self.conv4 = nn.Conv1d(128, n_out, 1)
+        self.bn1 = nn.BatchNorm1d(512)
+        self.bn2 = nn.BatchNorm1d(256)
+        self.bn3 = nn.BatchNorm1d(128)
+        self._n_in = n_in
+
+    def forward(self, x):
+        if _use_hip(self, x):
+            if self._n_in != 6:
+                raise NotImplementedError('HIP path is built for the 6-channel (xyz+normal) input of config_nunocs.yml')
+            return engine.seg_forward(self._device_weights(x.device), x.float().contiguous())
+        f, _, trans_feat = self.feat(x.permute(0, 2, 1))
+        h = F.relu(self.bn1(self.conv1(f)))
+        h = F.relu(self.bn2(self.conv2(h)))
+        h = F.relu(self.bn3(self.conv3(h)))
+        return self.conv4(h).permute(0, 2, 1), trans_feat

@@ -1,0 +1,196 @@
+"""Drop-in for the reference's `predicter.GraspPredicter` / `predicter.NunocsPredicter`
+(predicter.py:39-203) on MI355X: same constructor argument, attributes and method results, with the
+per-candidate python transform loop (predicter.py:71-74), the chunk-of-200 forward (predicter.py:76-91)
+and the NUNOCS decode (predicter.py:144-150) replaced by device kernels.
+
+Extra keyword arguments (all optional) let a caller supply what the reference reads from
+`artifacts/artifacts-<id>/` (config, normalizer, checkpoint) directly -- the artifacts are external
+downloads that are not part of the reference repository.
+"""
+import os
+import pickle
+
+import numpy as np
+import torch
+import yaml
+
+from . import engine, folding, ops, transforms
+
+DEFAULT_GRASP_CFG = {'n_pts': 2048, 'input_channel': 6,
+                     'classes': [0, 0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8, 0.9, 1.01]}   # config_grasp.yml:9,14,15
+DEFAULT_NUNOCS_CFG = {'n_pts': 8192, 'input_channel': 6, 'ce_loss_bins': 100}             # config_nunocs.yml:10,15,16
+
+
+def load_state_dict(ckpt_dir):
+    """Utils.load_model (Utils.py:135-148): accepts {'state_dict': ...} or a bare state dict and strips
+    the DataParallel 'module.' prefix."""
+    sd = torch.load(ckpt_dir, map_location='cpu', weights_only=False)
+    if 'state_dict' in sd:
+        sd = sd['state_dict']
+    sd = {k.replace('module.', ''): v for k, v in sd.items()}
+    assert len(sd) > 0
+    return sd
+
+
+def _load_artifacts(artifact_dir, cfg_name, cfg, state_dict, normalizer):
+    if cfg is None:
+        with open(f'{artifact_dir}/{cfg_name}', 'r') as ff:
+            cfg = yaml.safe_load(ff)
+    cfg = dict(cfg)
+    if normalizer is None and artifact_dir is not None and os.path.exists(f'{artifact_dir}/normalizer.pkl'):
+        with open(f'{artifact_dir}/normalizer.pkl', 'rb') as ff:
+            normalizer = pickle.load(ff)
+    if normalizer is not None:
+        cfg['mean'] = np.asarray(normalizer['mean'])
+        cfg['std'] = np.asarray(normalizer['std'])
+    if state_dict is None:
+        state_dict = load_state_dict(f'{artifact_dir}/best_val.pth.tar')
+    return cfg, state_dict
+
+
+def _device(device):
+    if device is not None:
+        return torch.device(device)
+    if not torch.cuda.is_available():
+        raise RuntimeError('catgrasp_amd predicters need a HIP device (no CPU fallback)')
+    return torch.device('cuda', torch.cuda.current_device())
+
+
+class _TransformOnly:
+    """Stand-in for the `.dataset` attribute of the reference predicters (predicter.py:60,127): keeps cfg /
+    phase; the transform itself runs on the device inside predict*()."""
+
+    def __init__(self, cfg, phase, class_name=None):
+        self.cfg = cfg
+        self.phase = phase
+        self.class_name = class_name
+
+
+class GraspPredicter:
+    class_name_to_artifact_id = {'nut': 47, 'hnm': 51, 'screw': 50}          # predicter.py:41-45
+
+    def __init__(self, class_name, artifact_dir=None, cfg=None, state_dict=None, normalizer=None, device=None,
+                 chunk=4096):
+        self.class_name = class_name
+        if artifact_dir is None and (cfg is None or state_dict is None):
+            code_dir = os.path.dirname(os.path.realpath(__file__))
+            artifact_dir = f"{code_dir}/artifacts/artifacts-{self.class_name_to_artifact_id[class_name]}"
+            print('GraspPredicter artifact_dir', artifact_dir)
+        self.cfg, sd = _load_artifacts(artifact_dir, 'config_grasp.yml', cfg, state_dict, normalizer)
+        self.device = _device(device)
+        self.dataset = _TransformOnly(self.cfg, 'test', class_name)
+        from .pointnet2 import PointNetCls
+        self.model = PointNetCls(n_in=self.cfg['input_channel'], n_out=len(self.cfg['classes']) - 1)
+        self.model.load_state_dict(sd)
+        self.model.to(self.device).eval()
+        self._W = folding.prepare_cls(sd, self.device)
+        self._mean, self._inv_std = transforms.normalizer_device(self.cfg, self.device)
+        self.chunk = int(chunk)
+
+    # ---- device-resident API (what bench.py and the multi-GPU path use) ----
+    def upload_cloud(self, data):
+        return transforms.DeviceCloud(data['cloud_xyz'], data['cloud_normal'], self.device)
+
+    def score_on_device(self, cloud_xyz, cloud_normal, ids, pose_inv):
+        """cloud_xyz/normal (M,3) f32 cuda; ids (G,n_pts) i32 cuda; pose_inv (G,12) f32 cuda.
+        -> probs (G,C), label (G) i32, confidence (G), p_G (G) cuda tensors."""
+        G = ids.shape[0]
+        C = len(self.cfg['classes']) - 1
+        logits = torch.empty((G, C), dtype=torch.float32, device=self.device)
+        for s in range(0, G, self.chunk):
+            e = min(G, s + self.chunk)
+            x = ops.build_grasp_input(cloud_xyz, cloud_normal, ids[s:e], pose_inv[s:e], self._mean, self._inv_std)
+            logits[s:e] = engine.cls_forward(self._W, x)[0]
+        return ops.softmax_pg(logits)
+
+    # ---- reference API ----
+    def predict_batch(self, data, grasp_poses, ids=None):
+        """predicter.py:67-94.  Returns [[pred_label, confidence, probs(10,) float32], ...] per grasp pose.
+        `ids` (G,n_pts): explicit resample indices into the z>=0.1 filtered cloud; by default they are drawn
+        from numpy's global RNG exactly like the reference (one np.random.choice per pose)."""
+        with torch.no_grad():
+            G = len(grasp_poses)
+            if G == 0:
+                return []
+            cloud = self.upload_cloud(data)
+            if ids is None:
+                ids = transforms.draw_ids_reference(cloud.n, self.cfg['n_pts'], G)
+            ids_d = torch.from_numpy(np.ascontiguousarray(ids, dtype=np.int32)).to(self.device)
+            pinv = torch.from_numpy(transforms.pose_inverse_rows(grasp_poses, cloud.center)).to(self.device)
+            probs, label, conf, _ = self.score_on_device(cloud.xyz, cloud.normal, ids_d, pinv)
+            probs = probs.cpu().numpy(); label = label.cpu().numpy(); conf = conf.cpu().numpy()
+        return [[label[b], conf[b], probs[b]] for b in range(G)]
+
+
+class NunocsPredicter:
+    class_name_to_artifact_id = {'nut': 78, 'hnm': 73, 'screw': 76}          # predicter.py:101-105
+
+    def __init__(self, class_name, artifact_dir=None, cfg=None, state_dict=None, normalizer=None, device=None, align_fn=None):
+        self.class_name = class_name
+        if self.class_name == 'nut':                                         # predicter.py:106-114
+            self.min_scale = [0.005, 0.005, 0.001]
+            self.max_scale = [0.05, 0.05, 0.05]
+        else:
+            self.min_scale = [0.005, 0.005, 0.005]
+            self.max_scale = [0.15, 0.05, 0.05]
+        if artifact_dir is None and (cfg is None or state_dict is None):
+            code_dir = os.path.dirname(os.path.realpath(__file__))
+            artifact_dir = f"{code_dir}/artifacts/artifacts-{self.class_name_to_artifact_id[class_name]}"
+            print('NunocsPredicter artifact_dir', artifact_dir)
+        self.cfg, sd = _load_artifacts(artifact_dir, 'config_nunocs.yml', cfg, state_dict, normalizer)
+        self.device = _device(device)
+        self.dataset = _TransformOnly(self.cfg, 'test')
+        from .pointnet2 import PointNetSeg
+        self.model = PointNetSeg(n_in=self.cfg['input_channel'], n_out=3 * self.cfg['ce_loss_bins'])
+        self.model.load_state_dict(sd)
+        self.model.to(self.device).eval()
+        self._W = folding.prepare_seg(sd, self.device)
+        self._mean, self._inv_std = transforms.normalizer_device(self.cfg, self.device)
+        self.align_fn = align_fn      # estimate9DTransform (aligning.py:83-119): CPU RANSAC, out of scope
+
+    def nocs_on_device(self, cloud_xyz, cloud_normal, ids):
+        """cloud (M,3) f32 cuda, ids (B,n_pts) i32 cuda -> coords (B,n_pts,3) in {k/bins-0.5}, conf_z (B,n_pts), logits."""
+        x = ops.build_nunocs_input(cloud_xyz, cloud_normal, ids, self._mean, self._inv_std)
+        logits = engine.seg_forward(self._W, x)[0]
+        B, N, _ = logits.shape
+        nb = self.cfg['ce_loss_bins']
+        coords, conf = ops.nunocs_decode(logits.view(B * N, 3 * nb), nb)
+        return coords.view(B, N, 3), conf.view(B, N), logits
+
+    def predict_nocs(self, data, ids=None):
+        """The network + decode part of predict (predicter.py:135-150): returns (nocs_cloud (n_pts,3) float32,
+        confidence_z (n_pts,), data_transformed dict with 'cloud_xyz_original', 'keep_ids')."""
+        with torch.no_grad():
+            cloud = transforms.DeviceCloud(data['cloud_xyz'], data['cloud_normal'], self.device)
+            if ids is None:
+                ids = transforms.draw_ids_reference(cloud.n, self.cfg['n_pts'], 1)[0]
+            ids = np.ascontiguousarray(ids, dtype=np.int32).reshape(1, -1)
+            coords, conf, _ = self.nocs_on_device(cloud.xyz, cloud.normal, torch.from_numpy(ids).to(self.device))
+            self.data_transformed = {'cloud_xyz_original': cloud.xyz64[ids[0]].copy(), 'keep_ids': cloud.keep_ids[ids[0]],
+                                     'cloud_normal': cloud.normal64[ids[0]].copy()}
+            return coords[0].cpu().numpy(), conf[0].cpu().numpy(), self.data_transformed
+
+    def predict(self, data, ids=None):
+        """predicter.py:135-203: (nocs_cloud, 4x4 nocs_pose) or (None, None).  The 9-D RANSAC alignment
+        (predicter.py:159-203 -> aligning.estimate9DTransform, OpenCV on the CPU) is delegated to `align_fn`."""
+        nocs_cloud, _, dt = self.predict_nocs(data, ids)
+        if self.align_fn is None:
+            raise NotImplementedError('NunocsPredicter.predict needs align_fn (aligning.estimate9DTransform); '
+                                      'use predict_nocs() for the network + decode part')
+        ori = dt['cloud_xyz_original']
+        best_ratio, best_transform = 0, None
+        for thres in [0.003, 0.005]:                                        # predicter.py:167-198
+            transform, _ = self.align_fn(source=nocs_cloud.copy(), target=ori.copy(), PassThreshold=thres, max_iter=10000,
+                                         use_kdtree_for_eval=False, kdtree_eval_resolution=0.003, max_scale=self.max_scale,
+                                         min_scale=self.min_scale, max_dimensions=np.array([1.2, 1.2, 1.2]))
+            if transform is None or np.linalg.det(transform[:3, :3]) < 0:
+                continue
+            transformed = (transform @ np.concatenate([nocs_cloud, np.ones((len(nocs_cloud), 1))], 1).T).T[:, :3]
+            ratio = np.sum(np.linalg.norm(transformed - ori, axis=1) <= 0.003) / len(ori)
+            if ratio > best_ratio:
+                best_ratio, best_transform = ratio, transform.copy()
+        if best_transform is None:
+            return None, None
+        self.best_ratio = best_ratio
+        self.nocs_pose = best_transform.copy()
+        return nocs_cloud, best_transform

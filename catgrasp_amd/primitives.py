@@ -1,0 +1,120 @@
+"""PointNet++ primitives of the reference's pointnet2.py:14-149 with the same tensor signatures,
+executed by the HIP kernels in csrc/primitives.hip.  CUDA tensors only (no CPU fallback)."""
+import ctypes
+
+import torch
+
+from . import _lib as L
+from ._lib import _p, _stream, check, require_cuda
+
+_c_int = ctypes.c_int
+_c_long = ctypes.c_long
+
+
+def _f32(t):
+    return t.contiguous().float()
+
+
+def square_distance(src, dst):
+    """src (B,N,C=3), dst (B,M,3) -> (B,N,M) squared distances (-2ab + a^2 + b^2, pointnet2.py:30-32)."""
+    require_cuda(src, dst)
+    src = _f32(src); dst = _f32(dst)
+    B, N, C = src.shape
+    M = dst.shape[1]
+    if C != 3 or dst.shape[2] != 3:
+        raise NotImplementedError('square_distance HIP kernel is built for 3-D points')
+    out = torch.empty((B, N, M), dtype=torch.float32, device=src.device)
+    check(L.lib().cg_square_distance(_p(src), _p(dst), _c_int(B), _c_int(N), _c_int(M), _p(out), _stream()), 'cg_square_distance')
+    return out
+
+
+def _raise_if(err, what):
+    if int(err.item()) != 0:
+        raise IndexError(f'{what}: index out of range')
+
+
+def index_points(points, idx):
+    """points (B,N,C), idx (B,S) or (B,S,K) int64 -> (B,S[,K],C) (pointnet2.py:35-51)."""
+    require_cuda(points, idx)
+    points = _f32(points)
+    idx = idx.contiguous().long()
+    B, N, C = points.shape
+    S = idx[0].numel() if B > 0 else 0
+    out = torch.empty(tuple(idx.shape) + (C,), dtype=torch.float32, device=points.device)
+    err = torch.zeros((1,), dtype=torch.int32, device=points.device)
+    check(L.lib().cg_index_points(_p(points), _p(idx), _c_int(B), _c_int(N), _c_int(C), _c_long(S), _p(out), _p(err), _stream()),
+          'cg_index_points')
+    _raise_if(err, 'index_points')
+    return out
+
+
+def farthest_point_sample(xyz, npoint, start=None):
+    """xyz (B,N,3) -> centroids (B,npoint) int64 (pointnet2.py:54-75).  `start` defaults to the reference's
+    draw, `torch.randint(0, N, (B,), dtype=torch.long)` on the CPU generator (:66), so seeding torch
+    reproduces the reference's samples exactly."""
+    require_cuda(xyz)
+    xyz = _f32(xyz)
+    B, N, C = xyz.shape
+    if C != 3:
+        raise NotImplementedError('farthest_point_sample HIP kernel is built for 3-D points')
+    if start is None:
+        start = torch.randint(0, N, (B,), dtype=torch.long)
+    start = torch.as_tensor(start).long().to(xyz.device).contiguous()
+    if start.numel() != B or (B > 0 and (int(start.min()) < 0 or int(start.max()) >= N)):
+        raise ValueError('start must hold one valid point index per cloud')
+    out = torch.empty((B, npoint), dtype=torch.int64, device=xyz.device)
+    scratch = torch.empty((B, N), dtype=torch.float32, device=xyz.device) if N > 24576 else None
+    check(L.lib().cg_farthest_point_sample(_p(xyz), _p(start), _c_int(B), _c_int(N), _c_int(npoint), _p(scratch), _p(out), _stream()),
+          'cg_farthest_point_sample')
+    return out
+
+
+def query_ball_point(radius, nsample, xyz, new_xyz):
+    """-> group_idx (B,S,nsample) int64: first nsample in-radius indices in ascending order, padded with
+    the first (pointnet2.py:78-98).  The reference slices a length-N sorted row, so nsample > N gives N
+    columns; that degenerate case is reproduced."""
+    require_cuda(xyz, new_xyz)
+    xyz = _f32(xyz); new_xyz = _f32(new_xyz)
+    B, N, _ = xyz.shape
+    S = new_xyz.shape[1]
+    ns = min(int(nsample), N)
+    out = torch.empty((B, S, ns), dtype=torch.int64, device=xyz.device)
+    r2 = float(torch.tensor(radius ** 2, dtype=torch.float32))     # the comparison is made in float32
+    check(L.lib().cg_query_ball_point(_p(xyz), _p(new_xyz), _c_int(B), _c_int(N), _c_int(S), ctypes.c_float(r2), _c_int(ns), _p(out),
+                                      _stream()), 'cg_query_ball_point')
+    return out
+
+
+def sample_and_group(npoint, radius, nsample, xyz, points, returnfps=False, start=None):
+    """pointnet2.py:101-129: FPS -> gather centroids -> ball query -> grouped, centred xyz ++ point features."""
+    require_cuda(xyz)
+    xyz = _f32(xyz)
+    B, N, C = xyz.shape
+    S = npoint
+    fps_idx = farthest_point_sample(xyz, npoint, start)
+    new_xyz = index_points(xyz, fps_idx)
+    idx = query_ball_point(radius, nsample, xyz, new_xyz)
+    K = idx.shape[2]
+    D = 0
+    if points is not None:
+        points = _f32(points)
+        D = points.shape[2]
+    new_points = torch.empty((B, S, K, 3 + D), dtype=torch.float32, device=xyz.device)
+    grouped_xyz = torch.empty((B, S, K, 3), dtype=torch.float32, device=xyz.device) if returnfps else None
+    err = torch.zeros((1,), dtype=torch.int32, device=xyz.device)
+    check(L.lib().cg_group_points(_p(xyz), _p(points), _p(new_xyz), _p(idx), _c_int(B), _c_int(N), _c_int(S), _c_int(K), _c_int(D),
+                                  _p(new_points), _p(grouped_xyz), _p(err), _stream()), 'cg_group_points')
+    _raise_if(err, 'sample_and_group (a query ball was empty)')
+    if returnfps:
+        return new_xyz, new_points, grouped_xyz, fps_idx
+    return new_xyz, new_points
+
+
+def sample_and_group_all(xyz, points):
+    """pointnet2.py:132-149: one group holding every point (a view + concat; no arithmetic)."""
+    B, N, C = xyz.shape
+    new_xyz = torch.zeros(B, 1, C, device=xyz.device, dtype=xyz.dtype)
+    grouped_xyz = xyz.view(B, 1, N, C)
+    if points is not None:
+        return new_xyz, torch.cat([grouped_xyz, points.view(B, 1, N, -1)], dim=-1)
+    return new_xyz, grouped_xyz

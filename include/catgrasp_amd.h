@@ -120,6 +120,34 @@ int cg_filter_grasp_pose(const float* grasp_poses, int n_pose, const float* symm
                          float resolution, signed char* codes, float* poses_out, signed char* nudge,
                          float* ee_in_base_out, void* stream);
 
+
+/* ---------------------------------------------------------------------------------------------
+ * PointNet++ grouping primitives (pointnet2.py:14-149).  Index tensors are int64 like the reference's.
+ * ------------------------------------------------------------------------------------------- */
+
+/* square_distance (pointnet2.py:14-33): src (B,N,3), dst (B,M,3) -> out (B,N,M) = -2 s.d + |s|^2 + |d|^2. */
+int cg_square_distance(const float* src, const float* dst, int B, int N, int M, float* out, void* stream);
+
+/* index_points (pointnet2.py:35-51): points (B,N,C), idx (B,S) [S may be S*K flattened] -> out (B,S,C).
+ * *err_flag (device int, pre-zeroed) is set to 1 on an out-of-range index (the reference raises IndexError). */
+int cg_index_points(const float* points, const long long* idx, int B, int N, int C, long S, float* out, int* err_flag,
+                    void* stream);
+
+/* farthest_point_sample (pointnet2.py:54-75) with the `torch.randint` start index (:66) as an explicit
+ * input: xyz (B,N,3), start (B) -> out (B,npoint).  dist_scratch: (B,N) floats, required only if N > 24576. */
+int cg_farthest_point_sample(const float* xyz, const long long* start, int B, int N, int npoint, float* dist_scratch,
+                             long long* out, void* stream);
+
+/* query_ball_point (pointnet2.py:78-98): first `nsample` indices (ascending) with d^2 <= radius_sq, padded
+ * with the first hit; an empty ball yields N in every slot, as the reference does.  out (B,S,nsample). */
+int cg_query_ball_point(const float* xyz, const float* new_xyz, int B, int N, int S, float radius_sq, int nsample,
+                        long long* out, void* stream);
+
+/* sample_and_group tail (pointnet2.py:116-123): new_points (B,S,K,3+D) = cat(xyz[idx] - new_xyz, points[idx]);
+ * optional grouped_xyz (B,S,K,3).  points may be NULL when D == 0. */
+int cg_group_points(const float* xyz, const float* points, const float* new_xyz, const long long* idx, int B, int N, int S,
+                    int K, int D, float* new_points, float* grouped_xyz, int* err_flag, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
