@@ -1,0 +1,147 @@
+"""CPU tests (no GPU): the C-ABI library loads and exports every declared symbol; host-side logic
+(BN folding, fragment packing, pose inversion, RNG semantics, sharding) is correct; the product refuses to
+run without its HIP path instead of falling back."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from catgrasp_amd import _lib, folding, synth, transforms
+from catgrasp_amd import distributed as cgd
+from oracle import transforms_ref as tref
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    syms = _lib.declared_symbols()
+    assert len(syms) >= 16 and 'cg_filter_grasp_pose' in syms and 'cg_pointmlp_max' in syms
+    lib = _lib.lib()                      # raises if the .so is missing or lacks a symbol
+    for s in syms:
+        assert hasattr(lib, s)
+    assert b'gfx950' in lib.cg_version()
+
+
+def test_argument_errors_are_reported_not_crashed():
+    """Argument validation happens before any device work, so it can be exercised without a GPU."""
+    lib = _lib.lib()
+    null = ctypes.c_void_p(0)
+    one = ctypes.c_void_p(16)
+    assert lib.cg_gemm_bias_act(one, 4, 7, 8, one, 8, null, null, 0, 0, 0, 0, one, 8, null) == -1      # K % 8 != 0
+    assert lib.cg_gemm_bias_act(null, 4, 8, 8, one, 8, null, null, 0, 0, 0, 0, one, 8, null) == -1     # null x
+    assert lib.cg_pointmlp_max(null, 1, 64, null, null, null, 0, null, null, null, null, null, null, null, 0, 1, null, null, null) == -1
+    assert lib.cg_filter_grasp_pose(null, -1, null, 1, null, null, null, null, null, 0, 0, null, null, null, 0, null, null, 0,
+                                    null, 0, null, 0, ctypes.c_float(0.0005), null, null, null, null, null) == -1
+    assert lib.cg_voxel_keys(one, ctypes.c_long(5), ctypes.c_float(-1.0), one, null) == -1
+    # zero-sized work is a successful no-op
+    assert lib.cg_softmax_pg(one, 0, 10, one, one, one, one, null) == 0
+    assert lib.cg_voxel_keys(null, ctypes.c_long(0), ctypes.c_float(0.001), null, null) == 0
+
+
+def test_product_fails_loudly_without_hip_path():
+    from catgrasp_amd import my_cpp, pointnet2
+    m = pointnet2.PointNetCls(6, 10).eval()
+    with torch.no_grad():
+        with pytest.raises(RuntimeError):
+            m(torch.zeros(1, 64, 6))                 # CPU tensor in eval mode: no fallback
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError):
+            my_cpp.CollisionManager()
+        with pytest.raises(RuntimeError):
+            my_cpp.filterGraspPose([np.eye(4)], [np.eye(4)], *[np.eye(4)] * 5, True, False, False, [0] * 7, [0] * 7,
+                                   np.zeros((3, 3)), np.zeros((1, 3), dtype=np.int32), np.zeros((3, 3)), np.zeros((1, 3), dtype=np.int32),
+                                   np.zeros((1, 3)), np.zeros((1, 3)), 0.0005, False)
+    # a missing shared object is an error, not a silent fallback
+    saved = _lib.LIB_PATH, _lib._lib
+    try:
+        _lib.LIB_PATH, _lib._lib = '/nonexistent/libcatgrasp_amd.so', None
+        with pytest.raises(_lib.CatgraspAmdError):
+            _lib.lib()
+    finally:
+        _lib.LIB_PATH, _lib._lib = saved
+
+
+def test_training_mode_uses_differentiable_torch_path():
+    from catgrasp_amd import pointnet2
+    m = pointnet2.PointNetCls(6, 10).train()
+    y, tf = m(torch.randn(4, 50, 6))
+    y.sum().backward()
+    assert y.shape == (4, 10) and tf.shape == (4, 64, 64) and m.fc3.weight.grad is not None
+    s = pointnet2.PointNetSeg(6, 30).train()
+    ys, _ = s(torch.randn(2, 40, 6))
+    assert ys.shape == (2, 40, 30)
+    assert len(m.state_dict()) == 111                 # 111 tensors in the PointNetCls checkpoint
+
+
+def test_fold_bn_matches_torch_batchnorm():
+    rng = np.random.default_rng(0)
+    w = rng.normal(size=(16, 8)); b = rng.normal(size=16)
+    bn = torch.nn.BatchNorm1d(16).double().eval()
+    with torch.no_grad():
+        bn.weight.copy_(torch.from_numpy(rng.uniform(0.5, 1.5, 16))); bn.bias.copy_(torch.from_numpy(rng.normal(size=16)))
+        bn.running_mean.copy_(torch.from_numpy(rng.normal(size=16))); bn.running_var.copy_(torch.from_numpy(rng.uniform(0.5, 2, 16)))
+    wf, bf = folding.fold_bn(w, b, (bn.weight.detach().numpy(), bn.bias.detach().numpy(), bn.running_mean.numpy(), bn.running_var.numpy()))
+    x = rng.normal(size=(5, 8))
+    with torch.no_grad():
+        ref = bn(torch.from_numpy(x @ w.T + b)).numpy()
+    assert np.abs((x @ wf.T + bf) - ref).max() < 1e-12
+
+
+def test_pack_b_fragment_order():
+    n, k = 40, 16                                       # 40 rows -> 2 blocks of 32 (zero padded)
+    w = np.arange(n * k, dtype=np.float32).reshape(n, k)
+    wp = folding.pack_b(w).reshape(2, k // 8, 64, 4)
+    for nb in range(2):
+        for ks in range(k // 8):
+            for lane in (0, 1, 31, 32, 63):
+                for j in range(4):
+                    row, col = nb * 32 + (lane & 31), ks * 8 + (lane >> 5) * 4 + j
+                    assert wp[nb, ks, lane, j] == (w[row, col] if row < n else 0.0)
+
+
+def test_pose_inverse_rows_reproduce_grasp_transform():
+    """x_grasp = R x_centred + t equals dataset_grasp.py:69-70 evaluated in float64."""
+    ob = synth.make_scene(1, 500, 3)[0]
+    P = synth.make_candidates(ob, 5, np.random.default_rng(1))
+    center = ob['xyz'].mean(0)
+    rows = transforms.pose_inverse_rows(P, center).astype(np.float64).reshape(-1, 3, 4)
+    ids = np.arange(500)
+    for i in range(5):
+        ref = tref.grasp_transform(ob['xyz'].copy(), ob['normal'].copy(), P[i], ids)['input']
+        xg = (ob['xyz'] - center) @ rows[i, :, :3].T + rows[i, :, 3]
+        ng = ob['normal'] @ rows[i, :, :3].T
+        assert np.abs(np.concatenate([xg, ng], 1) - ref).max() < 5e-8       # float32 rounding of the 12 pose entries
+
+
+def test_draw_ids_reference_consumes_numpy_global_rng_like_the_reference():
+    np.random.seed(5)
+    a = transforms.draw_ids_reference(2500, 2048, 3)
+    np.random.seed(5)
+    b = np.stack([tref.draw_ids(2500, 2048) for _ in range(3)])
+    assert np.array_equal(a, b) and len(np.unique(a[0])) == 2048           # without replacement when M >= n_pts
+    np.random.seed(6)
+    c = transforms.draw_ids_reference(700, 2048, 2)
+    np.random.seed(6)
+    d = np.stack([tref.draw_ids(700, 2048) for _ in range(2)])
+    assert np.array_equal(c, d) and c.max() < 700                          # with replacement when M < n_pts
+
+
+def test_device_cloud_applies_z_mask_and_centres():
+    xyz = np.array([[0, 0, 0.05], [0.01, 0, 0.6], [0, 0.02, 0.62], [0, 0, 0.099]], dtype=np.float64)
+    dc = transforms.DeviceCloud(xyz, np.ones_like(xyz), torch.device('cpu'))
+    assert dc.n == 2 and np.array_equal(dc.keep_ids, [1, 2])               # dataset_grasp.py:64 z >= 0.1
+    assert np.allclose(dc.xyz.numpy().mean(0), 0, atol=1e-7)
+
+
+def test_shard_bounds_cover_all_candidates():
+    for n, w in [(10000, 8), (10, 4), (3, 8), (0, 2), (200001, 8)]:
+        per, b = cgd.shard_bounds(n, w)
+        assert b[0][0] == 0 and b[-1][1] == n and all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+        assert all(hi - lo <= per for lo, hi in b)
+
+
+def test_synthetic_checkpoint_layout():
+    sd = synth.make_state_dict('cls', 6, 10, seed=0)
+    assert len(sd) == 111 and sd['feat.fstn.fc3.weight'].shape == (4096, 256)
+    assert torch.equal(sd['fc1.weight'], synth.make_state_dict('cls', 6, 10, seed=0)['fc1.weight'])
+    assert sum(v.numel() for k, v in sd.items() if 'num_batches' not in k and 'running' not in k) == 3464147 + 0  # params

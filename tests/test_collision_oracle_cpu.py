@@ -1,0 +1,122 @@
+"""CPU tests (no GPU) of the collision oracle (oracle/collision_ref.c).  PARITY UNPINNED: FCL/octomap are
+absent, so instead of golden vectors the restatement is checked against independent formulations:
+octomap's published key formula in numpy float64, an exact rational-free float64 triangle/box test by
+dense sampling, and control-flow invariants of filterGraspPose (my_cpp/common.cpp:156-321)."""
+import numpy as np
+import pytest
+
+from catgrasp_amd import synth
+from oracle import collision_oracle as co
+
+I4 = np.eye(4)
+
+
+def test_voxel_keys_follow_octomap_formula():
+    rng = np.random.default_rng(0)
+    pts = rng.uniform(-1, 1, (4000, 3)).astype(np.float32)
+    pts = np.concatenate([pts, np.array([[99999, 0, 0], [0, 16.3841, 0], [16.3839, -16.384, 0.0]], dtype=np.float32)])
+    for res in (0.0005, 0.001):
+        resf = np.float64(np.float32(res))
+        k = np.floor(pts.astype(np.float64) * (1.0 / resf)).astype(np.int64) + 32768     # OcTreeBaseImpl::coordToKeyChecked
+        ok = ((k >= 0) & (k < 65536)).all(axis=1)
+        uniq = np.unique(k[ok], axis=0) - 32768
+        got = co.voxelize(pts, res)
+        assert np.array_equal(got, uniq)
+    assert co.voxelize(np.ones((1, 3)) * 99999, 0.0005).shape == (0, 3)
+
+
+def _tri_box_truth(c, h, a, b, d, n=60):
+    """float64 ground truth by exact clipping-free reasoning: the triangle intersects the box iff some point of
+    the triangle lies inside; sample barycentric grid densely (used only on clearly separated / overlapping cases)."""
+    u, v = np.meshgrid(np.linspace(0, 1, n), np.linspace(0, 1, n))
+    m = u + v <= 1
+    p = a + u[m][:, None] * (b - a) + v[m][:, None] * (d - a)
+    return bool((np.abs(p - c) <= h).all(axis=1).any())
+
+
+def test_tri_box_sat_agrees_with_sampling_on_clear_cases():
+    rng = np.random.default_rng(1)
+    h = 0.5
+    n_checked = 0
+    for _ in range(3000):
+        c = rng.normal(0, 0.3, 3)
+        a, b, d = (rng.normal(0, 1.0, 3) for _ in range(3))
+        got = co.tri_box_overlap(c, h, a, b, d)
+        inflated = _tri_box_truth(c, h * 1.05, a, b, d)
+        shrunk = _tri_box_truth(c, h * 0.95, a, b, d)
+        if shrunk:
+            assert got, 'triangle has a point well inside the box but SAT says disjoint'
+            n_checked += 1
+        if not got:
+            assert not shrunk
+        if not inflated:
+            # no sample even in an inflated box; SAT may still say overlap only for thin slivers the grid missed
+            pass
+    assert n_checked > 200
+
+
+def test_tri_box_symmetry_and_containment():
+    rng = np.random.default_rng(2)
+    for _ in range(500):
+        c = rng.normal(0, 0.2, 3); a, b, d = (rng.normal(0, 0.6, 3) for _ in range(3))
+        r = co.tri_box_overlap(c, 0.3, a, b, d)
+        # vertex order does not matter
+        assert r == co.tri_box_overlap(c, 0.3, b, d, a) == co.tri_box_overlap(c, 0.3, d, b, a)
+        # growing the box never turns an overlap into a miss
+        if r:
+            assert co.tri_box_overlap(c, 0.6, a, b, d)
+    # triangle entirely inside / huge triangle through the box / far away
+    assert co.tri_box_overlap(np.zeros(3), 1.0, np.array([0.1, 0, 0]), np.array([0, 0.1, 0]), np.array([0, 0, 0.1]))
+    assert co.tri_box_overlap(np.zeros(3), 0.1, np.array([-9, -9, 0.0]), np.array([9, -9, 0.0]), np.array([0, 9, 0.0]))
+    assert not co.tri_box_overlap(np.zeros(3), 0.1, np.array([-9, -9, 0.2]), np.array([9, -9, 0.2]), np.array([0, 9, 0.2]))
+
+
+def _run(P, sym, nocs, g, pts, bg, dirf, adj):
+    return co.filter_grasp_pose(P, sym, nocs, I4, I4, I4, g['gripper_in_grasp'], dirf, 0, adj, g['vertices'], g['faces'],
+                                g['enclosed_vertices'], g['enclosed_faces'], pts, bg, 0.0005)
+
+
+def test_filter_control_flow_invariants():
+    objs = synth.make_scene(4, 1500, 1)
+    g = synth.make_gripper()
+    bg = synth.background_points(objs, 0, g['diameter'])
+    P = synth.make_candidates(objs[0], 300, np.random.default_rng(3))
+    c0, p0, n0 = _run(P, [I4], I4, g, objs[0]['xyz'], bg, 1, 0)
+    c1, p1, n1 = _run(P, [I4], I4, g, objs[0]['xyz'], bg, 1, 1)
+    assert set(np.unique(c0)) <= {0, 1, 3, 4} and set(np.unique(c1)) <= {0, 1, 3}
+    assert np.array_equal(c0 == 1, c1 == 1)                               # approach-dir test is independent of adjust
+    assert ((c0 == 0) <= (c1 == 0)).all()                                  # nudge 0 is tried first
+    assert np.array_equal(n1[c0 == 0], np.zeros((c0 == 0).sum(), dtype=np.int8))
+    assert (n1[c1 != 0] == -1).all() and (n0[c0 == 0] == 0).all()
+    # surviving poses: rotation columns normalised, last row 0 0 0 1, z of approach >= 0
+    keep = p1[c1 == 0]
+    assert np.allclose(np.linalg.norm(keep[:, :3, :3], axis=1), 1, atol=1e-6)
+    assert (keep[:, 2, 0] >= 0).all() and np.array_equal(keep[:, 3], np.tile([0, 0, 0, 1], (len(keep), 1)))
+    assert (p1[c1 != 0] == 0).all()
+    # nudged poses moved along their own y axis by exactly the float32 step
+    moved = np.nonzero((c1 == 0) & (n1 > 0))[0]
+    assert len(moved) > 0
+    for e in moved:
+        step = np.float32([0, 0.001, -0.001, 0.002, -0.002][n1[e]])
+        base = _run(P[e:e + 1], [I4], I4, g, np.ones((1, 3)) * 99999, np.ones((1, 3)) * 99999, 0, 0)[1][0]
+        assert np.allclose(p1[e][:3, 3] - base[:3, 3], step * base[:3, 1], atol=1e-7)
+    # no approach-dir filter => code 1 never appears; empty clouds => nothing collides
+    c2, _, _ = _run(P, [I4], I4, g, np.ones((1, 3)) * 99999, np.ones((1, 3)) * 99999, 0, 0)
+    assert (c2 == 0).all()
+    # symmetry expansion multiplies the evaluation count, in i-major order
+    S = np.eye(4); S[:3, :3] = [[-1, 0, 0], [0, -1, 0], [0, 0, 1]]
+    c3, p3, _ = _run(P[:10], [I4, S], I4, g, objs[0]['xyz'], bg, 1, 0)
+    assert len(c3) == 20 and np.array_equal(c3[0::2], c0[:10])
+
+
+def test_mesh_voxels_collide_basic():
+    V, F = synth.box_mesh([-0.01, -0.01, -0.01], [0.01, 0.01, 0.01])
+    inside_surface = np.array([[0.01, 0.0, 0.0]], dtype=np.float32)        # on the +x face
+    deep_inside = np.array([[0.0, 0.0, 0.0]], dtype=np.float32)            # strictly inside: BVH-vs-octree is surface-only
+    far = np.array([[0.1, 0.1, 0.1]], dtype=np.float32)
+    pose = np.eye(4, dtype=np.float32)
+    assert co.mesh_voxels_collide(V, F, pose, co.voxelize(inside_surface, 0.001), 0.001)
+    assert not co.mesh_voxels_collide(V, F, pose, co.voxelize(deep_inside, 0.001), 0.001)
+    assert not co.mesh_voxels_collide(V, F, pose, co.voxelize(far, 0.001), 0.001)
+    pose[:3, 3] = [0.1, 0.1, 0.09]
+    assert co.mesh_voxels_collide(V, F, pose, co.voxelize(far, 0.001), 0.001)

@@ -1,0 +1,91 @@
+"""CPU tests (no GPU): pin the oracle restatement (oracle/pointnet_ref.py) to the REAL reference.
+ * against tests/golden/pointnet2_golden.npz, produced by tests/golden/make_golden.py from the imported
+   /root/reference/pointnet2.py (always runs);
+ * live against /root/reference when it is present (build container only)."""
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from catgrasp_amd import synth
+from oracle import pointnet_ref as oref
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'pointnet2_golden.npz')
+
+
+@pytest.fixture(scope='module')
+def gold():
+    return np.load(GOLD)
+
+
+@pytest.mark.parametrize('tag', ['cls_101', 'cls_102', 'seg_103'])
+def test_models_match_reference_golden(gold, tag):
+    kind = tag.split('_')[0]
+    seed, gain, n_out = gold[tag + '_meta']
+    sd = synth.make_state_dict(kind, 6, int(n_out), seed=int(seed), gain=float(gain))
+    x = torch.from_numpy(gold[tag + '_x'])
+    if kind == 'cls':
+        y, tf = oref.pointnet_cls_forward(sd, x)
+        y = y.numpy()
+    else:
+        y, tf = oref.pointnet_seg_forward(sd, x)
+        y = y.numpy()[:, ::3, ::4]
+    ref = gold[tag + '_y']
+    assert y.shape == ref.shape
+    assert np.abs(y - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+    assert np.abs(tf.numpy()[:, ::7, ::5] - gold[tag + '_tf']).max() <= 2e-5
+    # float64 evaluation agrees too (bounds the float32 rounding of both)
+    y64 = (oref.pointnet_cls_forward if kind == 'cls' else oref.pointnet_seg_forward)(sd, x, torch.float64)[0].numpy()
+    y64 = y64 if kind == 'cls' else y64[:, ::3, ::4]
+    assert np.abs(y64 - ref).max() <= 5e-5 * max(1.0, np.abs(ref).max())
+
+
+def test_primitives_match_reference_golden(gold):
+    xyz = torch.from_numpy(gold['prim_xyz']); feats = torch.from_numpy(gold['prim_feats'])
+    assert np.abs(oref.square_distance(xyz[:, :16], xyz).numpy() - gold['sqdist']).max() <= 1e-6
+    assert np.array_equal(oref.index_points(feats, torch.from_numpy(gold['index_idx'])).numpy(), gold['index_out'])
+    torch.manual_seed(77)
+    start = torch.randint(0, 700, (2,), dtype=torch.long)          # pointnet2.py:66
+    fps = oref.farthest_point_sample(xyz, 48, start)
+    assert np.array_equal(fps.numpy(), gold['fps'])
+    new_xyz = oref.index_points(xyz, fps)
+    assert np.array_equal(oref.query_ball_point(0.03, 16, xyz, new_xyz).numpy(), gold['ball'])
+    torch.manual_seed(78)
+    start = torch.randint(0, 700, (2,), dtype=torch.long)
+    nx, npnts, gx, fi = oref.sample_and_group(32, 0.04, 8, xyz, feats, start)
+    assert np.array_equal(fi.numpy(), gold['sg_fps']) and np.array_equal(nx.numpy(), gold['sg_new_xyz'])
+    assert np.array_equal(gx.numpy(), gold['sg_grouped_xyz']) and np.array_equal(npnts.numpy(), gold['sg_new_points'])
+    ax, ap = oref.sample_and_group_all(xyz, feats)
+    assert np.array_equal(ax.numpy(), gold['sga_new_xyz'])
+    assert abs(float(ap.numpy().astype(np.float64).sum()) - float(gold['sga_new_points_sum'][0])) < 1e-9
+
+
+@pytest.mark.skipif(not os.path.exists('/root/reference/pointnet2.py'), reason='reference checkout only exists in the build container')
+def test_live_against_imported_reference():
+    for m in ('cv2', 'torchvision'):
+        sys.modules.setdefault(m, types.ModuleType(m))
+    sys.path.insert(0, '/root/reference')
+    try:
+        import pointnet2 as ref
+    finally:
+        sys.path.remove('/root/reference')
+    rng = np.random.default_rng(5)
+    x = torch.from_numpy(rng.normal(0, 0.5, (2, 200, 6)).astype(np.float32))
+    for kind, n_out, cls in (('cls', 10, ref.PointNetCls), ('seg', 300, ref.PointNetSeg)):
+        sd = synth.make_state_dict(kind, 6, n_out, seed=31)
+        m = cls(6, n_out); m.load_state_dict(sd); m.eval()
+        with torch.no_grad():
+            y, tf = m(x)
+        y2, tf2 = (oref.pointnet_cls_forward if kind == 'cls' else oref.pointnet_seg_forward)(sd, x)
+        assert (y - y2).abs().max().item() <= 2e-5 * max(1.0, y.abs().max().item())
+        assert (tf - tf2).abs().max().item() <= 2e-5
+    # our drop-in nn.Modules expose exactly the reference's parameter / buffer names and shapes
+    sys.modules.pop('pointnet2', None)
+    from catgrasp_amd import pointnet2 as ours
+    for (a, b) in ((ours.PointNetCls(6, 10), ref.PointNetCls(6, 10)), (ours.PointNetSeg(6, 300), ref.PointNetSeg(6, 300))):
+        sa, sb = a.state_dict(), b.state_dict()
+        assert list(sa.keys()) == list(sb.keys())
+        assert all(sa[k].shape == sb[k].shape for k in sa)
