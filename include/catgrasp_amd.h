@@ -148,6 +148,25 @@ int cg_query_ball_point(const float* xyz, const float* new_xyz, int B, int N, in
 int cg_group_points(const float* xyz, const float* points, const float* new_xyz, const long long* idx, int B, int N, int S,
                     int K, int D, float* new_points, float* grouped_xyz, int* err_flag, void* stream);
 
+
+/* ---------------------------------------------------------------------------------------------
+ * Signed distance field (meshpy Sdf3D, meshpy/meshpy/sdf.py:216-389).  grid: (nx,ny,nz) f32 row-major
+ * (x slowest), the `data_[i][j][k]` layout produced by SdfFile._read_3d (meshpy/meshpy/sdf_file.py:59-87).
+ * coords are in GRID units, component-major (B,3,N) like the reference's (3,N)/(B,3,N) arrays.
+ * ------------------------------------------------------------------------------------------- */
+
+/* mode 0: Sdf3D._signed_distance(coords, fast=False) trilinear (sdf.py:312-343);
+ * mode 1: fast=True / _signed_distance_batch nearest voxel, round-half-even (sdf.py:318-321,351-357). */
+int cg_sdf_lookup(const float* grid, int nx, int ny, int nz, const float* coords, long B, long N, int mode, float* out,
+                  void* stream);
+/* Sdf3D.is_any_points_inside (sdf.py:377-389): *flag (device int, pre-zeroed) |= any(sd[round(coords)] < 0) over
+ * the points that fall inside the grid. */
+int cg_sdf_any_inside(const float* grid, int nx, int ny, int nz, const float* coords, long N, int* flag, void* stream);
+/* Per-candidate form (transform_pt_obj_to_grid_batch + is_any_points_inside, sdf.py:362-389): cam_to_grid (E,12)
+ * rows [A|t] map camera-frame scene points pts (n_pts,3) into candidate e's gripper grid; out[e] = any inside. */
+int cg_sdf_points_inside_batch(const float* grid, int nx, int ny, int nz, const float* cam_to_grid, long E,
+                               const float* pts, int n_pts, unsigned char* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -120,3 +120,19 @@ def test_mesh_voxels_collide_basic():
     assert not co.mesh_voxels_collide(V, F, pose, co.voxelize(far, 0.001), 0.001)
     pose[:3, 3] = [0.1, 0.1, 0.09]
     assert co.mesh_voxels_collide(V, F, pose, co.voxelize(far, 0.001), 0.001)
+
+
+def test_sdf_oracle_trilinear_reproduces_linear_fields_and_lattice_values():
+    """oracle/sdf_ref.py: trilinear interpolation is exact on a (tri)linear field and at lattice points."""
+    from oracle import sdf_ref
+    rng = np.random.default_rng(0)
+    i, j, k = np.meshgrid(np.arange(9), np.arange(8), np.arange(7), indexing='ij')
+    data = 0.3 * i - 0.2 * j + 0.05 * k + 1.0
+    c = rng.uniform(0, 6, (3, 200))
+    ref = 0.3 * c[0] - 0.2 * c[1] + 0.05 * c[2] + 1.0
+    assert np.abs(sdf_ref.signed_distance(data, c) - ref).max() < 1e-12
+    lat = np.stack([rng.integers(0, 9, 50), rng.integers(0, 8, 50), rng.integers(0, 7, 50)]).astype(float)
+    assert np.allclose(sdf_ref.signed_distance(data, lat), data[lat[0].astype(int), lat[1].astype(int), lat[2].astype(int)])
+    assert np.array_equal(sdf_ref.signed_distance(data, np.array([[0.5], [1.5], [2.5]]), fast=True), data[0, 2, 2:3])  # half-even
+    g, origin, res = sdf_ref.box_sdf_grid([0, 0, 0], [0.01, 0.02, 0.005], 0.001, 5)
+    assert g.shape == (30, 30, 30) and g.min() < 0 < g.max()
