@@ -8,14 +8,27 @@ Call graph per PointNetCls.forward (pointnet2.py:289-299), B samples of N points
   pass C  cg_pointmlp_max(mid 2, t3,t64)  enc.conv1, .T64, conv2, conv3, max   (B,1024)
           3x cg_gemm_bias_act             fc1,fc2,fc3                          (B,n_out)
 """
+import os
+
 import torch
 
 from . import ops
 
+# 'f32'   : exact-f32 MFMA kernels (default; bitwise an fmaf chain per dot product)
+# 'bf16x3': split-bf16 MFMA kernels for the per-point MLP chain (3 bf16 MFMAs per product block, f32 accumulate)
+PRECISION = os.environ.get('CATGRASP_AMD_PRECISION', 'f32')
+TILE_POINTS = int(os.environ.get('CATGRASP_AMD_TILE_POINTS', '256'))
 
-def _nsplit(B, N):
+
+def set_precision(p):
+    global PRECISION
+    assert p in ('f32', 'bf16x3'), p
+    PRECISION = p
+
+
+def _nsplit(B, N, tp=64):
     """Workgroups per sample: keep >= ~1024 workgroups in flight for small batches."""
-    ntiles = (N + 63) // 64
+    ntiles = (N + tp - 1) // tp
     if B >= 1024:
         return 1
     return max(1, min(ntiles, (1024 + B - 1) // B))
@@ -23,6 +36,8 @@ def _nsplit(B, N):
 
 def encoder_forward(W, x, want_pointfeat=False):
     """x:(B,N,6) cuda f32 -> global feature (B,1024), trans (B,9), trans_feat (B,4096) [, pointfeat]."""
+    if PRECISION == 'bf16x3':
+        return _encoder_forward_split(W, x, want_pointfeat)
     B, N, _ = x.shape
     ns = _nsplit(B, N)
     g = ops.pointmlp_max(x, W['stn.w1'], W['stn.b1'], W['stn.w2'], W['stn.b2'], W['stn.w3'], W['stn.b3'], True,
@@ -37,6 +52,28 @@ def encoder_forward(W, x, want_pointfeat=False):
     t64 = ops.gemm_bias_act(h, W['fstn.fc3'], 4096, W['fstn.fc3b'], eye_k=64)
     r = ops.pointmlp_max(x, W['enc.w1'], W['enc.b1'], W['enc.w2'], W['enc.b2'], W['enc.w3'], W['enc.b3'], False,
                          t3=t3, mid_mode=2, t64=t64, nsplit=ns, pointfeat=want_pointfeat)
+    if want_pointfeat:
+        return r[0], t3, t64, r[1]
+    return r, t3, t64
+
+
+def _encoder_forward_split(W, x, want_pointfeat=False):
+    """encoder_forward with the bf16x3 per-point MLP kernels (the FC tails stay exact f32)."""
+    B, N, _ = x.shape
+    tp = TILE_POINTS
+    ns = _nsplit(B, N, tp)
+    kw = dict(nsplit=ns, split=True, tile_points=tp)
+    g = ops.pointmlp_max(x, W['stn.w1'], W['stn.b1'], W['stn.w2.s'], W['stn.b2'], W['stn.w3.s'], W['stn.b3'], True, **kw)
+    h = ops.gemm_bias_act(g, W['stn.fc1'], 512, W['stn.fc1b'], relu=True)
+    h = ops.gemm_bias_act(h, W['stn.fc2'], 256, W['stn.fc2b'], relu=True)
+    t3 = ops.gemm_bias_act(h, W['stn.fc3'], 9, W['stn.fc3b'], eye_k=3)
+    g = ops.pointmlp_max(x, W['enc.w1'], W['enc.b1'], W['fstn.w2.s'], W['fstn.b2'], W['fstn.w3.s'], W['fstn.b3'], True,
+                         t3=t3, mid_mode=1, wm=W['fstn.wm.s'], bm=W['fstn.bm'], **kw)
+    h = ops.gemm_bias_act(g, W['fstn.fc1'], 512, W['fstn.fc1b'], relu=True)
+    h = ops.gemm_bias_act(h, W['fstn.fc2'], 256, W['fstn.fc2b'], relu=True)
+    t64 = ops.gemm_bias_act(h, W['fstn.fc3'], 4096, W['fstn.fc3b'], eye_k=64)
+    r = ops.pointmlp_max(x, W['enc.w1'], W['enc.b1'], W['enc.w2.s'], W['enc.b2'], W['enc.w3.s'], W['enc.b3'], False,
+                         t3=t3, mid_mode=2, t64=t64, pointfeat=want_pointfeat, **kw)
     if want_pointfeat:
         return r[0], t3, t64, r[1]
     return r, t3, t64

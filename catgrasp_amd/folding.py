@@ -35,6 +35,34 @@ def pack_b(w):
     return np.ascontiguousarray(wp).reshape(-1)
 
 
+def bf16_split(w):
+    """float32 array -> (hi, lo) uint16 bf16 bit patterns, round-to-nearest-even, lo = bf16(w - hi)."""
+    def rne(x):
+        bits = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)
+        return (((bits + 0x7fff + ((bits >> 16) & 1)) >> 16) & 0xffff).astype(np.uint16)
+    w = np.asarray(w, dtype=np.float32)
+    hi = rne(w)
+    hi_f = (hi.astype(np.uint32) << 16).view(np.float32)
+    lo = rne(w - hi_f)
+    return hi, lo
+
+
+def pack_b_bf16x3(w):
+    """W:(N,K) (K % 16 == 0) -> flat uint16 array Wp[nb][kc][2 (hi,lo)][lane][8],
+    element e of lane l = W[nb*32 + (l&31)][kc*16 + (l>>5)*8 + e], rows zero padded to 32 (see pointmlp_bf16x3.hip)."""
+    w = np.asarray(w, dtype=np.float32)
+    n, k = w.shape
+    assert k % 16 == 0, k
+    nb = (n + 31) // 32
+    wp = np.zeros((nb * 32, k), dtype=np.float32)
+    wp[:n] = w
+    hi, lo = bf16_split(wp)
+    out = np.stack([hi, lo], 0)                                   # (2, nb*32, k)
+    # [2, nb, 32(l31), kc, 2(lhi), 8(e)] -> [nb, kc, 2, lhi, l31, e]
+    out = out.reshape(2, nb, 32, k // 16, 2, 8).transpose(1, 3, 0, 4, 2, 5)
+    return np.ascontiguousarray(out).reshape(-1)
+
+
 def _get(sd, name):
     return sd[name].detach().cpu().double().numpy()
 
@@ -58,6 +86,13 @@ class DeviceWeights:
     def put(self, name, arr):
         self.t[name] = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32)).to(self.device)
 
+    def put_split(self, name, w):
+        """bf16x3 image of a (N,K) weight matrix (int16 storage of the bf16 bit patterns)."""
+        self.t[name] = torch.from_numpy(pack_b_bf16x3(w).view(np.int16)).to(self.device)
+
+    def __contains__(self, k):
+        return k in self.t
+
     def __getitem__(self, k):
         return self.t[k]
 
@@ -73,10 +108,11 @@ def prepare_encoder(sd, prefix, device, out=None):
             W.put(tag + '.w1', w); W.put(tag + '.b1', b)          # 6 -> 64 on VALU, unpacked
         else:
             W.put(tag + '.wm', pack_b(w)); W.put(tag + '.bm', b)   # 64 -> 64, packed
+            W.put_split(tag + '.wm.s', w)
         w, b = fold_bn(*_conv(sd, q + 'conv2'), _bn(sd, q + 'bn2'))
-        W.put(tag + '.w2', pack_b(w)); W.put(tag + '.b2', b)
+        W.put(tag + '.w2', pack_b(w)); W.put(tag + '.b2', b); W.put_split(tag + '.w2.s', w)
         w, b = fold_bn(*_conv(sd, q + 'conv3'), _bn(sd, q + 'bn3'))
-        W.put(tag + '.w3', pack_b(w)); W.put(tag + '.b3', b)
+        W.put(tag + '.w3', pack_b(w)); W.put(tag + '.b3', b); W.put_split(tag + '.w3.s', w)
         w, b = fold_bn(_get(sd, q + 'fc1.weight'), _get(sd, q + 'fc1.bias'), _bn(sd, q + 'bn4'))
         W.put(tag + '.fc1', pack_b(w)); W.put(tag + '.fc1b', b)
         w, b = fold_bn(_get(sd, q + 'fc2.weight'), _get(sd, q + 'fc2.bias'), _bn(sd, q + 'bn5'))
@@ -89,9 +125,9 @@ def prepare_encoder(sd, prefix, device, out=None):
     w, b = fold_bn(*_conv(sd, p + 'conv1'), _bn(sd, p + 'bn1'))
     W.put('enc.w1', w); W.put('enc.b1', b)
     w, b = fold_bn(*_conv(sd, p + 'conv2'), _bn(sd, p + 'bn2'))
-    W.put('enc.w2', pack_b(w)); W.put('enc.b2', b)
+    W.put('enc.w2', pack_b(w)); W.put('enc.b2', b); W.put_split('enc.w2.s', w)
     w, b = fold_bn(*_conv(sd, p + 'conv3'), _bn(sd, p + 'bn3'))
-    W.put('enc.w3', pack_b(w)); W.put('enc.b3', b)
+    W.put('enc.w3', pack_b(w)); W.put('enc.b3', b); W.put_split('enc.w3.s', w)
     return W
 
 
