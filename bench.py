@@ -68,13 +68,22 @@ def run_step(wl, gp, npred, gather_buf=None, world=1):
     I4 = np.eye(4, dtype=np.float32)
     # (1) NUNOCS canonicaliser over every object cloud of the scene
     coords, conf, _ = npred.nocs_on_device(wl['cloud_xyz'], wl['cloud_normal'], wl['nunocs_ids'])
-    # (2) collision filter (cone-sampler call shape: symmetry=[I], nocs_pose=I, approach-dir filter on)
+    # (2) collision filter (cone-sampler call shape: symmetry=[I], nocs_pose=I, approach-dir filter on).
+    #     One call per object as in the reference; the per-object kernels are small (1250 wavefronts each), so they are
+    #     issued on separate HIP streams and run concurrently, then joined back into the main stream.
     codes = []
     sym = wl.setdefault('_sym', torch.eye(4, device=wl['cloud_xyz'].device).reshape(1, 16).contiguous())
+    side = wl.setdefault('_streams', [torch.cuda.Stream(device=wl['cloud_xyz'].device) for _ in range(len(wl['scenes']))])
+    main = torch.cuda.current_stream()
+    fork = torch.cuda.Event(); fork.record(main)
     for k, sc in enumerate(wl['scenes']):
-        c, _, _ = my_cpp.filter_on_device(sc, wl['poses_dev'][k], sym, I4, I4, I4, I4, wl['gripper']['gripper_in_grasp'],
-                                          True, False, False)
+        with torch.cuda.stream(side[k]):
+            side[k].wait_event(fork)
+            c, _, _ = my_cpp.filter_on_device(sc, wl['poses_dev'][k], sym, I4, I4, I4, I4, wl['gripper']['gripper_in_grasp'],
+                                              True, False, False)
         codes.append(c)
+    for st in side:
+        main.wait_stream(st)
     codes = torch.cat(codes)
     # (3) grasp-Q scoring of every candidate
     probs, label, conf_q, p_g = gp.score_on_device(wl['cloud_xyz'], wl['cloud_normal'], wl['ids'], wl['pose_inv'])

@@ -10,7 +10,7 @@ import re
 import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, 'libcatgrasp_amd.so')
+LIB_PATH = os.environ.get('CATGRASP_AMD_LIB', os.path.join(_PKG, 'libcatgrasp_amd.so'))   # override: dev ablation builds only
 HEADER_PATH = os.path.join(_PKG, '..', 'include', 'catgrasp_amd.h')
 _lib = None
 
