@@ -262,6 +262,16 @@ __global__ __launch_bounds__(NT, 2) void pointmlp_max_bf16x3_kernel(ArgsB a) {
             for (int r = 0; r < G; ++r) c[st * G + r] = mfma_bf16(sh[sc][r], bl[cur], c[st * G + r]);
 #pragma unroll
             for (int r = 0; r < G; ++r) c[st * G + r] = mfma_bf16(sh[sc][r], bh[cur], c[st * G + r]);
+            // interleave: M M D M D M D M D M  (6 MFMAs of this stage, 4 LDS fragment reads of the next)
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
           }
         }
         float m = max16(c[0]);
