@@ -28,7 +28,7 @@ struct Args {
   const float* t3;                  // (B,9) or null
   const float* w1; const float* b1; // (64,6) row-major, (64)
   const float* wm; const float* bm; // packed 64->64 (MID==1)
-  const float* t64;                 // (B,64,64) (MID==2)  h' = h . T
+  const float* t64;                 // (B,64,64) (MID==2), TRANSPOSED: t64[b][n][k] = T_b[k][n];  h' = h . T
   const float* w2; const float* b2; // packed 64->128
   const float* w3; const float* b3; // packed 128->1024
   int relu3;
@@ -126,8 +126,8 @@ __global__ __launch_bounds__(256) void pointmlp_max_kernel(Args a) {
         if (MID == 1) {
           bv = ((const f32x4*)a.wm)[(nb * 8 + ks) * 64 + lane];
         } else {
-          const float* tp = a.t64 + (size_t)b * 4096 + (ks * 8 + lhi * 4) * 64 + nb * 32 + l31;
-          bv[0] = tp[0]; bv[1] = tp[64]; bv[2] = tp[128]; bv[3] = tp[192];
+          // t64 is stored TRANSPOSED (Tt[n][k] = T[k][n]): the lane's 4 consecutive k are one 16-byte load
+          bv = *(const f32x4*)(a.t64 + (size_t)b * 4096 + (nb * 32 + l31) * 64 + ks * 8 + lhi * 4);
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) c = mfma32(av[j], bv[j], c);

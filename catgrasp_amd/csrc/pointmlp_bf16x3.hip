@@ -37,7 +37,7 @@ struct ArgsB {
   const float* t3;
   const float* w1; const float* b1;
   const unsigned short* wm; const float* bm;     // split-packed 64->64 (MID==1)
-  const float* t64;                              // (B,64,64) f32 (MID==2)
+  const float* t64;                              // (B,64,64) f32, TRANSPOSED: t64[b][n][k] = T_b[k][n] (MID==2)
   const unsigned short* w2; const float* b2;     // split-packed 64->128
   const unsigned short* w3; const float* b3;     // split-packed 128->1024
   int relu3; int nsplit;
@@ -157,10 +157,11 @@ __global__ __launch_bounds__(NT, 2) void pointmlp_max_bf16x3_kernel(ArgsB a) {
           load_b(wm_t, 0, kc, 4, lane, b0h, b0l);
           load_b(wm_t, 1, kc, 4, lane, b1h, b1l);
         } else {
-          const float* tp = t64_t + (size_t)b * 4096 + (kc * 16 + lhi * 8) * 64 + l31;
-          split8(f32x4{tp[0], tp[64], tp[128], tp[192]}, f32x4{tp[256], tp[320], tp[384], tp[448]}, b0h, b0l);
-          tp += 32;
-          split8(f32x4{tp[0], tp[64], tp[128], tp[192]}, f32x4{tp[256], tp[320], tp[384], tp[448]}, b1h, b1l);
+          // t64 is stored TRANSPOSED (Tt[n][k] = T[k][n]): a lane's 8 consecutive k are two 16-byte loads
+          const float* tp = t64_t + (size_t)b * 4096 + l31 * 64 + kc * 16 + lhi * 8;
+          split8(*(const f32x4*)tp, *(const f32x4*)(tp + 4), b0h, b0l);
+          tp += 32 * 64;
+          split8(*(const f32x4*)tp, *(const f32x4*)(tp + 4), b1h, b1l);
         }
         c0 = mfma_bf16(alo, b0h, c0); c1 = mfma_bf16(alo, b1h, c1);
         c0 = mfma_bf16(ahi, b0l, c0); c1 = mfma_bf16(ahi, b1l, c1);

@@ -34,7 +34,7 @@ def _nsplit(B, N, tp=64):
 
 
 def encoder_forward(W, x, want_pointfeat=False):
-    """x:(B,N,6) cuda f32 -> global feature (B,1024), trans (B,9), trans_feat (B,4096) [, pointfeat]."""
+    """x:(B,N,6) cuda f32 -> global feature (B,1024), trans (B,9), trans_feat TRANSPOSED (B,4096) [, pointfeat]."""
     if PRECISION == 'bf16x3':
         return _encoder_forward_split(W, x, want_pointfeat)
     B, N, _ = x.shape
@@ -84,7 +84,7 @@ def cls_forward(W, x):
     h = ops.gemm_bias_act(g, W['head.fc1'], 512, W['head.fc1b'], relu=True)
     h = ops.gemm_bias_act(h, W['head.fc2'], 256, W['head.fc2b'], relu=True)
     logits = ops.gemm_bias_act(h, W['head.fc3'], W.n_out, W['head.fc3b'])
-    return logits, t64.view(B, 64, 64)
+    return logits, t64.view(B, 64, 64).transpose(1, 2)      # the FC kernel emits the transform transposed
 
 
 def seg_forward(W, x):
@@ -97,4 +97,4 @@ def seg_forward(W, x):
     h = ops.gemm_bias_act(h, W['seg.c2'], 256, W['seg.c2b'], relu=True)
     h = ops.gemm_bias_act(h, W['seg.c3'], 128, W['seg.c3b'], relu=True)
     y = ops.gemm_bias_act(h, W['seg.c4'], W.n_out, W['seg.c4b'])
-    return y.view(B, N, W.n_out), t64.view(B, 64, 64)
+    return y.view(B, N, W.n_out), t64.view(B, 64, 64).transpose(1, 2)

@@ -118,6 +118,11 @@ def prepare_encoder(sd, prefix, device, out=None):
         w, b = fold_bn(_get(sd, q + 'fc2.weight'), _get(sd, q + 'fc2.bias'), _bn(sd, q + 'bn5'))
         W.put(tag + '.fc2', pack_b(w)); W.put(tag + '.fc2b', b)
         w, b = _get(sd, q + 'fc3.weight'), _get(sd, q + 'fc3.bias')
+        if k == 64:
+            # emit the 64x64 feature transform transposed (column j*64+i holds T[i][j]) so the point kernels read a
+            # lane's consecutive-k operand elements with 16-byte loads; the identity stays on the diagonal.
+            perm = np.arange(4096).reshape(64, 64).T.reshape(-1)
+            w, b = w[perm], b[perm]
         W.put(tag + '.fc3', pack_b(w)); W.put(tag + '.fc3b', b)
 
     stn(p + 'stn.', 'stn', 3)

@@ -34,7 +34,8 @@ const char* cg_version(void);
  *                                          encoder conv1 :243-252 with t3 = learned 3x3 input transform)
  *   PointNetEncoder conv1,bmm,conv2,conv3,max  pointnet2.py:243-266 (mid_mode 2: t64 = learned 64x64
  *                                          feature transform; relu3 = 0)
- * x: (B,N,6) f32.  t3: (B,9) or NULL.  w1: (64,6) row-major, b1: (64).  t64: (B,64,64), h' = h.T.
+ * x: (B,N,6) f32.  t3: (B,9) or NULL.  w1: (64,6) row-major, b1: (64).  t64: (B,64,64) holding the feature
+ * transform TRANSPOSED, t64[b][n][k] = T_b[k][n] (h' = h.T_b); the host permutes fstn.fc3 so the FC kernel emits it so.
  * out: (B,1024).  pointfeat (optional, mid_mode 2): (B,N,64) = transformed point features
  * (PointNetEncoder `pointfeat`, pointnet2.py:261).  nsplit: workgroups per sample (>=1); the point
  * tiles of one sample are divided between them and combined with atomic max. */
