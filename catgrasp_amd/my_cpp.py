@@ -236,8 +236,44 @@ def filterGraspPose(grasp_poses, symmetry_tfs, nocs_pose, canonical_to_nocs_tran
     return [poses[e].copy() for e in np.nonzero(codes == 0)[0]]
 
 
-def augmentGraspPoses(*args, **kwargs):
-    raise NotImplementedError('augmentGraspPoses is exported by the reference but has no caller (SURVEY.md §8 a21); not built yet')
+def _float_loop_count(limit, step):
+    """Trip count of `for (float v=0; v<limit; v+=step)` with float32 accumulation (common.cpp:123,144)."""
+    step = np.float32(step); limit = np.float32(limit)
+    if not step > 0:
+        raise ValueError('step must be positive')
+    v = np.float32(0); n = 0
+    while v < limit:
+        v = np.float32(v + step); n += 1
+    return n
+
+
+def augmentGraspPoses(R0, selected_point, sphere_pts, inplane_rot_step, hand_depth, approach_step, init_bite):
+    """my_cpp.augmentGraspPoses (common.cpp:118-153) -> list of 4x4 float32 poses.
+    Note: the reference loops `i < sphere_pts.size()` (= 3*rows, common.cpp:119) and reads rows past the end of the
+    matrix; only the valid rows are used here."""
+    dev = _device()
+    R0 = np.ascontiguousarray(np.asarray(R0, dtype=np.float32))
+    if R0.shape != (3, 3):
+        raise ValueError(f'R0 shape wrong: {R0.shape}')
+    p = np.ascontiguousarray(np.asarray(selected_point, dtype=np.float32).reshape(-1))
+    if p.shape != (3,):
+        raise ValueError(f'selected_point shape wrong: {p.shape}')
+    sp = np.asarray(sphere_pts, dtype=np.float32)
+    if sp.size and (sp.ndim != 2 or sp.shape[1] != 3):
+        raise ValueError(f'sphere_pts shape wrong: {sp.shape}')
+    sp = np.ascontiguousarray(sp.reshape(-1, 3))
+    n_rot = _float_loop_count(180.0, inplane_rot_step)
+    n_depth = _float_loop_count(hand_depth, approach_step)
+    total = (1 + len(sp) * n_rot) * n_depth
+    out = torch.empty((total, 16), dtype=torch.float32, device=dev)
+    sp_d = torch.from_numpy(sp).to(dev)
+    F9 = (ctypes.c_float * 9)(*R0.reshape(-1).tolist())
+    F3 = (ctypes.c_float * 3)(*p.tolist())
+    check(L.lib().cg_augment_grasp_poses(F9, F3, _p(sp_d), _c_int(len(sp)), _c_int(n_rot), ctypes.c_float(inplane_rot_step), _c_int(n_depth),
+                                         ctypes.c_float(approach_step), ctypes.c_float(init_bite), _p(out), _stream()),
+          'cg_augment_grasp_poses')
+    poses = out.cpu().numpy().reshape(total, 4, 4)
+    return [poses[i].copy() for i in range(total)]
 
 
 def makeOccupancyGridFromCloudScan(*args, **kwargs):

@@ -177,6 +177,16 @@ int cg_sdf_any_inside(const float* grid, int nx, int ny, int nz, const float* co
 int cg_sdf_points_inside_batch(const float* grid, int nx, int ny, int nz, const float* cam_to_grid, long E,
                                const float* pts, int n_pts, unsigned char* out, void* stream);
 
+
+/* augmentGraspPoses (my_cpp/common.cpp:118-153, declaration my_cpp/common.h:58): poses for R in
+ * {R0} U {R0.directionVecToRotation(sphere_pt,(1,0,0)).Rx(q*inplane_rot_step)} (nearest rotation of each) and depths
+ * d = 0, approach_step, ... : out ((1+n_sphere*n_rot)*n_depth, 16) row-major 4x4, rotation-major then depth.
+ * h_R0 (9) and h_selected_point (3) are HOST pointers; sphere_pts (n_sphere,3) device.  n_rot / n_depth are the trip
+ * counts of the reference's float loops (`x_rot<180`, `d<hand_depth`), evaluated by the caller. */
+int cg_augment_grasp_poses(const float* h_R0, const float* h_selected_point, const float* sphere_pts, int n_sphere,
+                           int n_rot, float inplane_rot_step, int n_depth, float approach_step, float init_bite,
+                           float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

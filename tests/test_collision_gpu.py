@@ -186,3 +186,23 @@ def test_tri_box_predicate_random_and_grazing(cuda_device):
     exp = np.array([co.mesh_voxels_collide(V, F, p, keys, res) for p in poses])
     assert np.array_equal(got, exp)
     assert 0.05 < exp.mean() < 0.95
+
+
+def test_augment_grasp_poses(cuda_device):
+    """my_cpp.augmentGraspPoses (common.cpp:118-153) vs the numpy/SVD restatement; float tolerance 1e-5."""
+    from catgrasp_amd import my_cpp
+    from oracle import augment_ref
+    rng = np.random.default_rng(13)
+    R0 = synth.random_rotation(rng)
+    p = np.array([0.01, -0.02, 0.6])
+    sph = rng.normal(size=(7, 3)); sph /= np.linalg.norm(sph, axis=1, keepdims=True)
+    sph[0] = [1, 0, 0]                       # parallel to the reference axis -> identity branch (:79-82)
+    sph[1] = [-1, 1e-7, 0]                   # anti-parallel: |v| < 1e-5 also returns identity in the reference
+    got = np.array(my_cpp.augmentGraspPoses(R0, p, sph, 30.0, 0.04, 0.002, 0.005))
+    ref = augment_ref.augment_grasp_poses(R0, p, sph, 30.0, 0.04, 0.002, 0.005)
+    assert got.shape == ref.shape == ((1 + 7 * 6) * 20, 4, 4) and got.dtype == np.float32
+    assert np.abs(got - ref).max() <= 1e-5
+    assert np.abs(np.linalg.det(got[:, :3, :3]) - 1).max() < 1e-5
+    with pytest.raises(ValueError):
+        my_cpp.augmentGraspPoses(np.eye(4), p, sph, 30.0, 0.04, 0.002, 0.005)
+    assert my_cpp.augmentGraspPoses(R0, p, np.zeros((0, 3)), 30.0, 0.04, 0.002, 0.005)[0].shape == (4, 4)
