@@ -276,5 +276,47 @@ def augmentGraspPoses(R0, selected_point, sphere_pts, inplane_rot_step, hand_dep
     return [poses[i].copy() for i in range(total)]
 
 
-def makeOccupancyGridFromCloudScan(*args, **kwargs):
-    raise NotImplementedError('makeOccupancyGridFromCloudScan (SURVEY.md §8(f) N2) is a "next" row; not built yet')
+def makeOccupancyGridFromCloudScan(pts, K, resolution, return_tensor=False):
+    """my_cpp.makeOccupancyGridFromCloudScan (common.cpp:324-431): every point of the 5 mm-padded lattice around the
+    scan that lies at or behind the observed surface along its camera ray -> (Q,3) float32.
+    `K` is accepted for signature compatibility (the reference only uses it for unused pixel bounds, :336-347).
+    Output is in lattice order (x slowest); the reference's order is thread-dependent."""
+    dev = _device()
+    a = np.asarray(pts)
+    if a.ndim != 2 or a.shape[1] != 3:
+        raise ValueError(f'point cloud shape wrong: {a.shape}')
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if len(a) == 0:
+        return np.zeros((0, 3), dtype=np.float32)
+    res = np.float32(resolution)
+    keys = voxelize(a, float(res), dev)
+    if keys.shape[0] == 0:
+        return np.zeros((0, 3), dtype=np.float32)
+    kmin = keys[:, :3].min(dim=0).values.cpu().numpy().astype(np.int64)
+    kmax = keys[:, :3].max(dim=0).values.cpu().numpy().astype(np.int64)
+    dims = (kmax - kmin + 1)
+    nbits = int(dims[0]) * int(dims[1]) * int(dims[2])
+    if nbits > (1 << 33):
+        raise MemoryError(f'occupancy bitmap of {nbits} bits is too large; use a coarser resolution')
+    bits = torch.zeros(((nbits + 31) // 32,), dtype=torch.int32, device=dev)
+    check(L.lib().cg_occupancy_set_bits(_p(keys), _c_long(keys.shape[0]), _p(bits), _c_int(int(kmin[0])), _c_int(int(kmin[1])),
+                                        _c_int(int(kmin[2])), _c_int(int(dims[0])), _c_int(int(dims[1])), _c_int(int(dims[2])), _stream()),
+          'cg_occupancy_set_bits')
+    # lattice bounds exactly as common.cpp:353-376 (float32 arithmetic)
+    mx = a.max(axis=0); mn = a.min(axis=0)
+    pad = np.float32(0.005)
+    n = [int(np.float32(np.float32(np.float32(mx[i] + pad) - np.float32(mn[i] - pad)) / res)) for i in range(3)]
+    origin = [np.float32(mn[i] - pad) for i in range(3)]
+    max_range = float(np.float32(np.sqrt(float(np.float32(mx[0] + pad)) ** 2 + float(np.float32(mx[1] + pad)) ** 2 +
+                                         float(np.float32(mx[2] + pad)) ** 2)))
+    total = max(n[0], 0) * max(n[1], 0) * max(n[2], 0)
+    if total == 0:
+        return np.zeros((0, 3), dtype=np.float32)
+    lattice = torch.empty((total, 3), dtype=torch.float32, device=dev)
+    keep = torch.empty((total,), dtype=torch.uint8, device=dev)
+    check(L.lib().cg_occupancy_grid_rays(_p(bits), _c_int(int(kmin[0])), _c_int(int(kmin[1])), _c_int(int(kmin[2])), _c_int(int(dims[0])),
+                                         _c_int(int(dims[1])), _c_int(int(dims[2])), ctypes.c_float(origin[0]), ctypes.c_float(origin[1]),
+                                         ctypes.c_float(origin[2]), ctypes.c_float(res), _c_int(n[0]), _c_int(n[1]), _c_int(n[2]),
+                                         ctypes.c_double(max_range), _p(lattice), _p(keep), _stream()), 'cg_occupancy_grid_rays')
+    out = lattice[keep.bool()]
+    return out if return_tensor else out.cpu().numpy()

@@ -187,6 +187,19 @@ int cg_augment_grasp_poses(const float* h_R0, const float* h_selected_point, con
                            int n_rot, float inplane_rot_step, int n_depth, float approach_step, float init_bite,
                            float* out, void* stream);
 
+
+/* makeOccupancyGridFromCloudScan (my_cpp/common.cpp:324-431, declaration my_cpp/common.h:61).
+ * cg_occupancy_set_bits: occupied leaves (n,4) int16 (key-32768) -> dense bitmap over the key box
+ *   [x0,x0+dx) x [y0,y0+dy) x [z0,z0+dz) (bit index ((kx-x0)*dy + ky-y0)*dz + kz-z0; `bits` pre-zeroed).
+ * cg_occupancy_grid_rays: for every point of the (nx,ny,nz) lattice origin + i*resolution (x slowest) cast the
+ *   octomap ray from the sensor origin (castRay, ignoreUnknownCells=true, max_range) and set keep[i] = 1 iff it hits
+ *   an occupied leaf whose centre is not farther than the lattice point; lattice (nx*ny*nz,3) receives the coordinates. */
+int cg_occupancy_set_bits(const short* keys4, long n_keys, unsigned int* bits, int x0, int y0, int z0, int dx, int dy,
+                          int dz, void* stream);
+int cg_occupancy_grid_rays(const unsigned int* bits, int x0, int y0, int z0, int dx, int dy, int dz, float origin_x,
+                           float origin_y, float origin_z, float resolution, int nx, int ny, int nz, double max_range,
+                           float* lattice, unsigned char* keep, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

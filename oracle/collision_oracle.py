@@ -78,3 +78,15 @@ def filter_grasp_pose(grasp_poses, symmetry_tfs, nocs_pose, canonical_to_nocs, c
 
 def num_threads():
     return lib().cr_num_threads()
+
+
+def make_occupancy_grid(pts, resolution):
+    """makeOccupancyGridFromCloudScan restatement (K is only used by the reference for unused u/v bounds) -> (Q,3) f32
+    in lattice order."""
+    pts = _f(np.asarray(pts).reshape(-1, 3))
+    lib().cr_make_occupancy_grid.restype = ctypes.c_long
+    n = lib().cr_make_occupancy_grid(_fp(pts), ctypes.c_int(len(pts)), ctypes.c_float(resolution), None, ctypes.c_long(0))
+    out = np.zeros((max(n, 1), 3), dtype=np.float32)
+    n2 = lib().cr_make_occupancy_grid(_fp(pts), ctypes.c_int(len(pts)), ctypes.c_float(resolution), _fp(out), ctypes.c_long(n))
+    assert n2 == n
+    return out[:n]

@@ -251,3 +251,133 @@ int cr_num_threads(void) {
   return 1;
 #endif
 }
+
+/* ---------------- makeOccupancyGridFromCloudScan (my_cpp/common.cpp:324-431) ----------------
+ * PARITY UNPINNED (octomap absent).  Restated from the call site plus octomap's published behaviour:
+ *  - insertPointCloud(p, origin): every scan point's leaf becomes occupied (hit log-odds +0.85 >= threshold);
+ *    leaves only traversed by rays become free; a leaf that is both stays occupied.  castRay(...,
+ *    ignoreUnknownCells=true, ...) skips free and unknown leaves alike, so only the occupied set matters.
+ *  - OccupancyOcTreeBase::castRay: Amanatides-Woo DDA over the key lattice in double precision, first occupied
+ *    leaf -> end = leaf centre (float), stops at maxRange (distance of the leaf centre from the origin) or at
+ *    the tree border.
+ *  - a lattice point (x,y,z) is emitted iff its viewing ray hits and |end| <= |(x,y,z)| (float).
+ * Output order here is lattice order (xi, yi, zi); the reference's is thread-dependent (omp critical merge). */
+
+typedef struct { uint64_t* slots; size_t cap; } keyset_t;
+
+static uint64_t pack_key(int kx, int ky, int kz) { return ((uint64_t)kx << 32) | ((uint64_t)ky << 16) | (uint64_t)kz; }
+
+static void keyset_init(keyset_t* s, size_t n) {
+  size_t cap = 16; while (cap < 2 * n + 1) cap <<= 1;
+  s->cap = cap; s->slots = (uint64_t*)malloc(cap * sizeof(uint64_t));
+  for (size_t i = 0; i < cap; ++i) s->slots[i] = ~(uint64_t)0;
+}
+static void keyset_insert(keyset_t* s, uint64_t k) {
+  size_t h = (size_t)(k * 0x9E3779B97F4A7C15ull) & (s->cap - 1);
+  while (s->slots[h] != ~(uint64_t)0 && s->slots[h] != k) h = (h + 1) & (s->cap - 1);
+  s->slots[h] = k;
+}
+static int keyset_has(const keyset_t* s, uint64_t k) {
+  size_t h = (size_t)(k * 0x9E3779B97F4A7C15ull) & (s->cap - 1);
+  while (s->slots[h] != ~(uint64_t)0) { if (s->slots[h] == k) return 1; h = (h + 1) & (s->cap - 1); }
+  return 0;
+}
+
+/* castRay from the origin (0,0,0) along `dirf` (float, already normalised by the caller, normalised again here
+ * like octomap does).  Returns 1 and the hit leaf centre (float) on a hit. */
+static int cast_ray_origin(const keyset_t* occ, const float dirf[3], double resolution, double max_range, float end[3]) {
+  int key[3] = {TREE_MAX_VAL, TREE_MAX_VAL, TREE_MAX_VAL};                 /* coordToKey(0) = floor(0) + 32768 */
+  if (keyset_has(occ, pack_key(key[0], key[1], key[2]))) {
+    for (int i = 0; i < 3; ++i) end[i] = (float)(((double)key[i] - TREE_MAX_VAL + 0.5) * resolution);
+    return 1;
+  }
+  /* octomath::Vector3::normalized(): len = sqrt(x*x+y*y+z*z) (float products, double sqrt), components / (float)len */
+  float d[3];
+  {
+    const double len = sqrt((double)(dirf[0] * dirf[0] + dirf[1] * dirf[1] + dirf[2] * dirf[2]));
+    for (int i = 0; i < 3; ++i) d[i] = (len > 0) ? dirf[i] / (float)len : dirf[i];
+  }
+  int step[3]; double tmax[3], tdelta[3];
+  for (int i = 0; i < 3; ++i) {
+    step[i] = d[i] > 0.0f ? 1 : (d[i] < 0.0f ? -1 : 0);
+    if (step[i] != 0) {
+      double border = ((double)key[i] - TREE_MAX_VAL + 0.5) * resolution;
+      border += (double)(step[i] * resolution * 0.5);
+      tmax[i] = (border - 0.0) / (double)d[i];
+      tdelta[i] = resolution / fabs((double)d[i]);
+    } else { tmax[i] = 1.7976931348623157e308; tdelta[i] = 1.7976931348623157e308; }
+  }
+  if (step[0] == 0 && step[1] == 0 && step[2] == 0) return 0;
+  const double max_range_sq = max_range * max_range;
+  for (;;) {
+    int dim;
+    if (tmax[0] < tmax[1]) dim = (tmax[0] < tmax[2]) ? 0 : 2; else dim = (tmax[1] < tmax[2]) ? 1 : 2;
+    if ((step[dim] < 0 && key[dim] == 0) || (step[dim] > 0 && key[dim] == 2 * TREE_MAX_VAL - 1)) return 0;
+    key[dim] += step[dim];
+    tmax[dim] += tdelta[dim];
+    for (int i = 0; i < 3; ++i) end[i] = (float)(((double)key[i] - TREE_MAX_VAL + 0.5) * resolution);
+    if (max_range > 0.0) {
+      double dsq = 0.0;
+      for (int i = 0; i < 3; ++i) dsq += ((double)end[i] - 0.0) * ((double)end[i] - 0.0);
+      if (dsq > max_range_sq) return 0;
+    }
+    if (keyset_has(occ, pack_key(key[0], key[1], key[2]))) return 1;
+  }
+}
+
+/* Returns the number of occupied lattice points written to out (capacity cap points, (x,y,z) float each);
+ * if more would be produced the count is still returned (call again with a larger buffer). */
+long cr_make_occupancy_grid(const float* pts, int P, float resolution, float* out, long cap) {
+  if (P <= 0) return 0;
+  const double res_d = (double)resolution, res_factor = 1.0 / res_d;
+  keyset_t occ; keyset_init(&occ, (size_t)P);
+  float mx[3] = {-INFINITY, -INFINITY, -INFINITY}, mn[3] = {INFINITY, INFINITY, INFINITY};
+  for (int i = 0; i < P; ++i) {
+    int k[3], ok = 1;
+    for (int a = 0; a < 3; ++a) {
+      ok &= coord_to_key(pts[i * 3 + a], res_factor, &k[a]);
+      mx[a] = fmaxf(mx[a], pts[i * 3 + a]); mn[a] = fminf(mn[a], pts[i * 3 + a]);
+    }
+    if (ok) keyset_insert(&occ, pack_key(k[0], k[1], k[2]));
+  }
+  const float pad = 0.005f;
+  const int max_xi = (int)((mx[0] + pad - (mn[0] - pad)) / resolution);
+  const int max_yi = (int)((mx[1] + pad - (mn[1] - pad)) / resolution);
+  const int max_zi = (int)((mx[2] + pad - (mn[2] - pad)) / resolution);
+  /* float max_range = std::sqrt(std::pow(xmax+pad,2) + ...): pow/sqrt in double, result stored in a float */
+  const float max_range = (float)sqrt(pow((double)(mx[0] + pad), 2) + pow((double)(mx[1] + pad), 2) + pow((double)(mx[2] + pad), 2));
+  long n = 0;
+  long* counts = (long*)calloc((size_t)(max_xi > 0 ? max_xi : 1), sizeof(long));
+  /* pass 1: count per x-slab, pass 2: write at prefix offsets (deterministic lattice order) */
+  for (int pass = 0; pass < 2; ++pass) {
+    long* offs = NULL;
+    if (pass == 1) {
+      offs = (long*)malloc(sizeof(long) * (size_t)(max_xi > 0 ? max_xi : 1));
+      long acc = 0; for (int xi = 0; xi < max_xi; ++xi) { offs[xi] = acc; acc += counts[xi]; }
+      n = acc;
+    }
+#pragma omp parallel for schedule(dynamic)
+    for (int xi = 0; xi < max_xi; ++xi) {
+      long c = 0;
+      for (int yi = 0; yi < max_yi; ++yi)
+        for (int zi = 0; zi < max_zi; ++zi) {
+          const float x = mn[0] - pad + xi * resolution, y = mn[1] - pad + yi * resolution, z = mn[2] - pad + zi * resolution;
+          float dir[3] = {x, y, z};
+          const float sq = (x * x + y * y) + z * z;
+          if (sq > 0.0f) { const float nrm = sqrtf(sq); dir[0] = x / nrm; dir[1] = y / nrm; dir[2] = z / nrm; }
+          float end[3];
+          if (!cast_ray_origin(&occ, dir, res_d, (double)max_range, end)) continue;
+          const float dist_query = sqrtf(x * x + y * y + z * z);
+          const float dist = (float)sqrt((double)(end[0] * end[0] + end[1] * end[1] + end[2] * end[2]));
+          if (dist <= dist_query) {
+            if (pass == 1 && offs[xi] + c < cap) { float* o = out + (offs[xi] + c) * 3; o[0] = x; o[1] = y; o[2] = z; }
+            ++c;
+          }
+        }
+      if (pass == 0) counts[xi] = c;
+    }
+    if (offs) free(offs);
+  }
+  free(counts); free(occ.slots);
+  return n;
+}

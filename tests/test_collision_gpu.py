@@ -206,3 +206,23 @@ def test_augment_grasp_poses(cuda_device):
     with pytest.raises(ValueError):
         my_cpp.augmentGraspPoses(np.eye(4), p, sph, 30.0, 0.04, 0.002, 0.005)
     assert my_cpp.augmentGraspPoses(R0, p, np.zeros((0, 3)), 30.0, 0.04, 0.002, 0.005)[0].shape == (4, 4)
+
+
+def test_make_occupancy_grid_from_cloud_scan(cuda_device):
+    """my_cpp.makeOccupancyGridFromCloudScan (common.cpp:324-431): identical lattice-point set to the C oracle."""
+    from catgrasp_amd import my_cpp
+    objs = synth.make_scene(3, 1500, 5)
+    pts = np.concatenate([o['xyz'] for o in objs[:2]]).astype(np.float32)
+    K = np.array([[600, 0, 320], [0, 600, 240], [0, 0, 1.0]])
+    for res in (0.001, 0.002):
+        got = my_cpp.makeOccupancyGridFromCloudScan(pts, K, res)
+        ref = co.make_occupancy_grid(pts, res)
+        assert got.dtype == np.float32 and got.shape == ref.shape and len(ref) > 100
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    # every scan point has an emitted lattice point within ~1.5 voxels (the surface itself is "at or behind")
+    from scipy.spatial import cKDTree
+    d, _ = cKDTree(my_cpp.makeOccupancyGridFromCloudScan(pts, K, 0.001)).query(pts)
+    assert d.max() < 0.002
+    assert my_cpp.makeOccupancyGridFromCloudScan(np.zeros((0, 3)), K, 0.001).shape == (0, 3)
+    with pytest.raises(ValueError):
+        my_cpp.makeOccupancyGridFromCloudScan(np.zeros((4, 2)), K, 0.001)
