@@ -90,3 +90,19 @@ def make_occupancy_grid(pts, resolution):
     n2 = lib().cr_make_occupancy_grid(_fp(pts), ctypes.c_int(len(pts)), ctypes.c_float(resolution), _fp(out), ctypes.c_long(n))
     assert n2 == n
     return out[:n]
+
+
+_IK_SO = os.path.join(_DIR, '_ref', 'libikfast_ref.so')
+
+
+def ikfast_available():
+    return os.path.exists(_IK_SO)
+
+
+def ikfast_within_limits(ee_in_base, upper, lower):
+    """oracle/_ref: the reference's IKFast solver behind get_ik_within_limits (common.cpp:9-72).
+    ee_in_base (E,4,4) float32 -> bool (E,)."""
+    l = ctypes.CDLL(_IK_SO)
+    ee = _f(np.asarray(ee_in_base).reshape(-1, 16))
+    up = np.ascontiguousarray(upper, dtype=np.float64); lo = np.ascontiguousarray(lower, dtype=np.float64)
+    return np.array([bool(l.ik_within_limits(_fp(ee[i]), _fp(up), _fp(lo))) for i in range(len(ee))])

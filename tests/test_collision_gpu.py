@@ -226,3 +226,34 @@ def test_make_occupancy_grid_from_cloud_scan(cuda_device):
     assert my_cpp.makeOccupancyGridFromCloudScan(np.zeros((0, 3)), K, 0.001).shape == (0, 3)
     with pytest.raises(ValueError):
         my_cpp.makeOccupancyGridFromCloudScan(np.zeros((4, 2)), K, 0.001)
+
+
+@pytest.mark.skipif(not co.ikfast_available(), reason='oracle/_ref/libikfast_ref.so is built from /root/reference in the build container')
+def test_filter_with_ik_stage(cuda_device):
+    """filter_ik=True (common.cpp:214-226): pre-IK device stage -> host IK (the reference's own IKFast solver, oracle/_ref)
+    -> collision stage; codes incl. the IK rejections must equal the oracle driven by the same solver."""
+    from catgrasp_amd import my_cpp
+    objs, g, bg = _scene(8, n_obj=3, pts=1200)
+    P = synth.make_candidates(objs[0], 200, np.random.default_rng(17))
+    upper = [2.96, 2.09, 2.96, 2.09, 2.96, 2.09, 3.05]            # iiwa14 joint limits (rad)
+    lower = [-u for u in upper]
+    cam_in_world = np.eye(4); cam_in_world[:3, :3] = [[0, -1, 0], [-1, 0, 0], [0, 0, -1]]; cam_in_world[:3, 3] = [0.55, 0.0, 0.95]
+    ee_in_grasp = np.eye(4); ee_in_grasp[0, 3] = -0.15
+    my_cpp.set_ik_solver(co.ikfast_within_limits)
+    try:
+        dev = my_cpp.filterGraspPoseDetailed(P, [I4], I4, I4, cam_in_world, ee_in_grasp, g['gripper_in_grasp'], True, True, False, upper, lower,
+                                             g['vertices'], g['faces'], g['enclosed_vertices'], g['enclosed_faces'], objs[0]['xyz'], bg, 0.0005)
+    finally:
+        my_cpp.set_ik_solver(None)
+    up = np.array(upper); lo = np.array(lower)
+
+    def ik_cb(ee_ptr, _user):
+        ee = np.ctypeslib.as_array(ee_ptr, shape=(16,)).copy()
+        return int(co.ikfast_within_limits(ee.reshape(1, 4, 4), up, lo)[0])
+    ora = co.filter_grasp_pose(P, [I4], I4, I4, cam_in_world, ee_in_grasp, g['gripper_in_grasp'], 1, 1, 0, g['vertices'], g['faces'],
+                               g['enclosed_vertices'], g['enclosed_faces'], objs[0]['xyz'], bg, 0.0005, ik_fn=ik_cb)
+    _check(dev, ora)
+    assert (ora[0] == 2).sum() > 0 and (ora[0] == 0).sum() > 0
+    with pytest.raises(NotImplementedError):       # no silent skipping of the IK test
+        my_cpp.filterGraspPoseDetailed(*_args(P, [I4], I4, g, objs[0]['xyz'], bg, True, False)[:8], True, False, upper, lower,
+                                       g['vertices'], g['faces'], g['enclosed_vertices'], g['enclosed_faces'], objs[0]['xyz'], bg, 0.0005)
