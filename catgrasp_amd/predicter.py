@@ -146,7 +146,10 @@ class NunocsPredicter:
         self.model.to(self.device).eval()
         self._W = folding.prepare_seg(sd, self.device)
         self._mean, self._inv_std = transforms.normalizer_device(self.cfg, self.device)
-        self.align_fn = align_fn      # estimate9DTransform (aligning.py:83-119): CPU RANSAC, out of scope
+        if align_fn is None:          # estimate9DTransform (aligning.py:83-119): device RANSAC (catgrasp_amd/aligning.py, row N1)
+            from . import aligning
+            align_fn = aligning.estimate9DTransform
+        self.align_fn = align_fn
 
     def nocs_on_device(self, cloud_xyz, cloud_normal, ids):
         """cloud (M,3) f32 cuda, ids (B,n_pts) i32 cuda -> coords (B,n_pts,3) in {k/bins-0.5}, conf_z (B,n_pts), logits."""
@@ -172,11 +175,8 @@ class NunocsPredicter:
 
     def predict(self, data, ids=None):
         """predicter.py:135-203: (nocs_cloud, 4x4 nocs_pose) or (None, None).  The 9-D RANSAC alignment
-        (predicter.py:159-203 -> aligning.estimate9DTransform, OpenCV on the CPU) is delegated to `align_fn`."""
+        (predicter.py:159-203 -> aligning.estimate9DTransform) runs on the device by default (`align_fn`)."""
         nocs_cloud, _, dt = self.predict_nocs(data, ids)
-        if self.align_fn is None:
-            raise NotImplementedError('NunocsPredicter.predict needs align_fn (aligning.estimate9DTransform); '
-                                      'use predict_nocs() for the network + decode part')
         ori = dt['cloud_xyz_original']
         best_ratio, best_transform = 0, None
         for thres in [0.003, 0.005]:                                        # predicter.py:167-198

@@ -200,6 +200,23 @@ int cg_occupancy_grid_rays(const unsigned int* bits, int x0, int y0, int z0, int
                            float origin_y, float origin_z, float resolution, int nx, int ny, int nz, double max_range,
                            float* lattice, unsigned char* keep, void* stream);
 
+
+/* ---------------------------------------------------------------------------------------------
+ * NUNOCS -> camera 9-D pose RANSAC: aligning.estimate9DTransform (aligning.py:33-119; caller predicter.py:164).
+ * ------------------------------------------------------------------------------------------- */
+
+/* Evaluate H hypotheses: src (nocs cloud) / dst (observed cloud) (N,3) float64 device arrays, ids (H,4) i32 sampled
+ * correspondences (aligning.py:89-93).  Per hypothesis: exact affine through the 4 pairs (cv2.estimateAffine3D on 4
+ * points), scale bounds, singular values in [0.8,1.2], nearest rotation, det>0, optional canonical extent check
+ * (h_max_dimensions, NULL to skip), inlier count with `threshold` (aligning.py:36-68).
+ * counts (H) = inliers or -1 if rejected; transforms (H,16) row-major 4x4 float64.  h_* are HOST pointers (3 doubles). */
+int cg_ransac_9d(const double* src, const double* dst, int N, const int* ids, int H, double threshold,
+                 const double* h_min_scale, const double* h_max_scale, const double* h_max_dimensions,
+                 int* counts, double* transforms, void* stream);
+/* mask[p] = |T src_p - dst_p| <= threshold for one transform (device pointer to 16 doubles). */
+int cg_similarity_inliers(const double* src, const double* dst, int N, const double* transform16, double threshold,
+                          unsigned char* mask, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -92,8 +92,8 @@ def test_nunocs_predict_nocs(cuda_device):
     assert np.array_equal(nocs[clear], rcoords[clear])
     zclear = clear[:, 2]
     assert np.abs(conf[zclear] - rconf[zclear]).max() <= 1e-4
-    with pytest.raises(NotImplementedError):
-        npred.predict(data)
+    out = npred.predict(data)       # device RANSAC; random weights -> either outcome of the reference contract
+    assert out == (None, None) or (out[0].shape == (8192, 3) and out[1].shape == (4, 4))
 
 
 def test_pointnet2_modules_dropin(cuda_device):
