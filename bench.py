@@ -28,6 +28,11 @@ sys.path.insert(0, ROOT)
 MAC_PER_POINT_ENC = 9 + 384 + 4096 + 8192 + 131072      # encoder pass (mid_mode 2): T3, conv1, .T64, conv2, conv3
 PEAK_F32_MFMA_TFLOPS = 157.3                            # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0                          # MI355X_MICROARCH.md: bf16 MFMA dense peak (~2.5 PF)
+# HBM bytes per candidate of the encoder-pass kernel from the PMC passes in profiles/r1_pmc_pointmlp_*.csv
+# (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate runs, B=4096): 2*FETCH_SIZE (gfx950 correction for wide
+# coalesced reads, MI355X_MICROARCH.md §HBM) + WRITE_SIZE, divided by 4096.  Algorithmic: 49152 B x + 16384 B transform
+# + 4096 B out = 69632 B/candidate; the excess is the kernel's scratch (register-spill) footprint being written once.
+PMC_HBM_BYTES_PER_CANDIDATE = {'bf16x3': (2 * 149820.8 + 211424.3) * 1024 / 4096, 'f32': None}
 
 
 def build_workload(device, G, seed, n_objects=8, pts_per_object=2500):
@@ -204,31 +209,36 @@ def main():
         k_flops = [2.0 * MAC_PER_POINT_ENC * B * N for _, _, (B, N) in ev]
         avg_ms = float(np.mean(k_ms)) if k_ms else float('nan')
         achieved = float(np.mean(k_flops)) / (avg_ms * 1e-3) / 1e12 if k_ms else float('nan')
-        return dt, avg_ms, achieved, len(k_ms), out
+        avg_B = float(np.mean([B * N / 2048.0 for _, _, (B, N) in ev])) if ev else None
+        return dt, avg_ms, achieved, len(k_ms), out, avg_B
 
-    def roofline(precision, achieved, avg_ms, n):
+    def roofline(precision, achieved, avg_ms, n, avg_B=None):
+        def traffic(prec):
+            per = PMC_HBM_BYTES_PER_CANDIDATE.get(prec)
+            return None if (per is None or avg_B is None) else int(per * avg_B)
         if precision == 'f32':
             return {'bound': 'mfma', 'kernel': 'pointmlp_max_kernel<2> (encoder pass: conv1, x.T64, conv2, conv3, max; exact-f32 MFMA)',
                     'achieved': round(achieved, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                    'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': None, 'avg_launch_ms': round(avg_ms, 4),
+                    'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': traffic('f32'), 'avg_launch_ms': round(avg_ms, 4),
                     'launches': n, 'flop_per_candidate_launch': 2 * MAC_PER_POINT_ENC * 2048}
-        return {'bound': 'mfma', 'kernel': 'pointmlp_max_bf16x3_kernel<2,8> (encoder pass; 3 bf16 MFMAs per algorithmic product block)',
+        return {'bound': 'mfma', 'kernel': 'pointmlp_max_bf16x3_kernel<2> (encoder pass; 3 bf16 MFMAs per algorithmic product block)',
                 'achieved': round(achieved, 2), 'peak': PEAK_BF16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': round(achieved / PEAK_BF16_MFMA_TFLOPS, 4), 'traffic': None, 'avg_launch_ms': round(avg_ms, 4),
+                'frac': round(achieved / PEAK_BF16_MFMA_TFLOPS, 4), 'traffic': traffic('bf16x3'), 'traffic_unit': 'HBM bytes per launch (PMC)',
+                'avg_launch_ms': round(avg_ms, 4),
                 'launches': n, 'flop_per_candidate_launch': 2 * MAC_PER_POINT_ENC * 2048,
                 'issued_mfma_tflops': round(3 * achieved, 1), 'issued_frac': round(3 * achieved / PEAK_BF16_MFMA_TFLOPS, 4),
                 'note': 'achieved counts ALGORITHMIC flops; the split issues 3 bf16 MFMA flops per algorithmic flop on the K>=64 layers, '
                         'so the ceiling for algorithmic flops is peak/3 = 833 TFLOP/s'}
 
-    dt, avg_ms, achieved, n_launch, out = measure(args.precision)
+    dt, avg_ms, achieved, n_launch, out, avg_B = measure(args.precision)
     secondary = None
     if not args.no_secondary:
         other = 'f32' if args.precision == 'bf16x3' else 'bf16x3'
         ref_out = out.clone()
-        dt2, avg2, ach2, n2, out2 = measure(other)
+        dt2, avg2, ach2, n2, out2, avg_B2 = measure(other)
         pg_diff = float((out2[:, 0] - ref_out[:, 0]).abs().max().item())
         secondary = {'precision': other, 'value': round(world * G * args.steps / dt2, 1), 'ms_per_step': round(dt2 / args.steps * 1e3, 3),
-                     'roofline': roofline(other, ach2, avg2, n2), 'max_abs_p_G_difference_between_precisions': pg_diff,
+                     'roofline': roofline(other, ach2, avg2, n2, avg_B2), 'max_abs_p_G_difference_between_precisions': pg_diff,
                      'codes_identical': bool(torch.equal(out2[:, 1], ref_out[:, 1]))}
         engine.set_precision(args.precision)
 
@@ -244,7 +254,7 @@ def main():
             'config': {'workload': 'nut clutter pile, 20k-pt scene (8 objects x 2500 pts), '
                                    f'{G} candidates/GPU: NUNOCS(8x8192) + filterGraspPose + grasp-Q PointNetCls(2048x6)',
                        'candidates_per_gpu': G, 'scene_points': int(wl['cloud_xyz'].shape[0]), 'parallelism': f'candidate-shard x{world}'},
-            'roofline': roofline(args.precision, achieved, avg_ms, n_launch),
+            'roofline': roofline(args.precision, achieved, avg_ms, n_launch, avg_B),
         }
         if secondary is not None:
             line['secondary'] = secondary
