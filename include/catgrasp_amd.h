@@ -217,6 +217,23 @@ int cg_ransac_9d(const double* src, const double* dst, int N, const int* ids, in
 int cg_similarity_inliers(const double* src, const double* dst, int N, const double* transform16, double threshold,
                           unsigned char* mask, void* stream);
 
+
+/* ---------------------------------------------------------------------------------------------
+ * Grasp affordance P(T|G) (row N3): run_grasp_simulation.py:50-107 compute_grasp_affordance[_worker] with
+ * pybullet_env/env_grasp.py:243-283 get_finger_contact_area.  float64 throughout, like the reference.
+ * ------------------------------------------------------------------------------------------- */
+
+/* cam_in_finger (G,12): rows [R|t] of inv(finger_mesh_in_grasp) . inv(grasp_in_cam) per grasp (run_grasp_simulation.py:52).
+ * pts / normals (P,3): canonical cloud in the camera frame (voxel-downsampled, :97-99); point_affordance (P): affordance of
+ * each point's nearest neighbour in the full canonical cloud (the kd-tree lookup of :63-64, grasp independent).
+ * h_finger_extents (n_fingers,4) HOST {xmin,xmax,zmin,zmax} of each finger mesh; h_grip_signs (n_fingers) HOST +1 / -1 for
+ * grip_dir (0,+-1,0).  Out: p_t_given_g (G) (NaN = the reference drops the grasp), optional contact_counts (G,n_fingers). */
+int cg_grasp_affordance(const double* cam_in_finger, long G, const double* pts, const double* normals, const double* point_affordance,
+                        int P, int n_fingers, const double* h_finger_extents, const int* h_grip_signs, double surface_tol,
+                        double* p_t_given_g, int* contact_counts, void* stream);
+/* idx[q] = index of the nearest ref point (float64, first minimum): the cKDTree.query of run_grasp_simulation.py:63. */
+int cg_nearest_neighbor(const double* query, long Q, const double* ref, int R, int* idx, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
