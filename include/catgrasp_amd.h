@@ -234,6 +234,24 @@ int cg_grasp_affordance(const double* cam_in_finger, long G, const double* pts, 
 /* idx[q] = index of the nearest ref point (float64, first minimum): the cKDTree.query of run_grasp_simulation.py:63. */
 int cg_nearest_neighbor(const double* query, long Q, const double* ref, int R, int* idx, void* stream);
 
+
+/* ---------------------------------------------------------------------------------------------
+ * Cone grasp-candidate generation (row N3): PointConeGraspSampler (dexnet/grasping/grasp_sampler.py:155-298), float64.
+ * ------------------------------------------------------------------------------------------- */
+
+/* sample_one_surface_point local frame (grasp_sampler.py:225-266) for K sampled points sample_ids (K) of pts/normals (P,3).
+ * mode 0: out_doublings[k] = number of `r_ball *= 2` retries point k needs starting from r0 (:243-247);
+ * mode 1: frames (K,9) row-major R0 = [approach | major | minor] using radius r_ball[k]. */
+int cg_cone_frames(const double* pts, const double* normals, int P, const int* sample_ids, int K, const double* r_ball, double r0,
+                   int mode, int* out_doublings, double* frames, void* stream);
+/* pose fan-out (grasp_sampler.py:268-289): per point {R0} U {R0.directionVecToRotation(sphere_pt).Rx(q*rot_step_deg)}, column
+ * normalised, depths d = q*approach_step: out (K*(1+S*n_rot)*n_depth, 16) float64 row-major 4x4. */
+int cg_cone_poses(const double* pts, const int* sample_ids, const double* frames, int K, const double* sphere_pts, int S, int n_rot,
+                  double rot_step_deg, int n_depth, double approach_step, double init_bite, double* out, void* stream);
+/* center_ob_between_gripper (grasp_sampler.py:189-198): each pose is shifted along its own y axis to the middle of the
+ * object's y-extent in the grasp frame (poses must be rigid).  In place. */
+int cg_center_grasps(double* poses, long G, const double* pts, int P, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -37,3 +37,42 @@ def test_affordance_matches_reference_semantics(cuda_device):
     with pytest.raises(RuntimeError):
         affordance.compute_grasp_affordance(model, poses[:2], finger_mesh_in_grasp, finger_V, [[1, 0, 0], [0, 1, 0]])
     assert affordance.compute_grasp_affordance(model, np.zeros((0, 4, 4)), finger_mesh_in_grasp, finger_V, grip_dirs).shape == (0,)
+
+
+def test_cone_grasp_candidate_generation(cuda_device):
+    """PointConeGraspSampler pose fan-out (grasp_sampler.py:225-298) vs the numpy/scipy restatement.  The minor principal
+    direction is an eigenvector whose SIGN is LAPACK's choice, so each point's block must match for one of the two signs."""
+    from catgrasp_amd import grasp_sampler
+    from oracle import grasp_sampler_ref as gref
+    rng = np.random.default_rng(4)
+    ob = synth.make_scene(1, 1500, 7)[0]
+    pts, nrm = ob['xyz'].copy(), ob['normal'].copy()
+    pts = np.concatenate([pts, [[0.2, 0.2, 0.9]]]); nrm = np.concatenate([nrm, [[0, 0, 1.0]]])     # an isolated point: forces r_ball doubling
+    local_n = (ob['normal'] @ ob['pose'][:3, :3])                          # normals in the object frame
+    side = np.flatnonzero(np.abs(local_n[:, 2]) < 0.1)                     # cylindrical faces: curved -> unique minor direction
+    sample_ids = np.array([side[3], side[40], len(pts) - 1, side[77], side[150], 11])
+    sph = rng.normal(size=(6, 3)); sph /= np.linalg.norm(sph, axis=1, keepdims=True); sph[0] = [1, 0, 0]
+    kw = dict(r_ball=0.003, hand_depth=0.04, init_bite=0.005, approach_step=0.004)
+    got = grasp_sampler.cone_grasp_poses(pts, nrm, sample_ids, sph, **kw)
+    per = (1 + 6 * 6) * 10
+    assert got.shape == (len(sample_ids) * per, 4, 4) and got.dtype == np.float64
+    s0 = gref.ConeSampler(**kw); s1 = gref.ConeSampler(**kw)
+    n_checked = 0
+    for k, sid in enumerate(sample_ids):
+        blk = got[k * per:(k + 1) * per]
+        r0 = s0.sample_one_surface_point(pts[sid], nrm[sid], pts, nrm, sph, flip_minor=False)
+        r1 = s1.sample_one_surface_point(pts[sid], nrm[sid], pts, nrm, sph, flip_minor=True)
+        ev = s0.last_eigvals
+        # approach axis, positions of the un-rotated frame and the block layout never depend on the eigenvector
+        assert np.abs(blk[:10, :3, 0] - r0[:10, :3, 0]).max() < 1e-12 and np.abs(blk[:10, :3, 3] - r0[:10, :3, 3]).max() < 1e-12
+        if ev[1] - ev[0] > 1e-3 * max(ev[2], 1e-12):                       # a repeated smallest eigenvalue has no unique eigenvector
+            e = min(np.abs(blk - r0).max(), np.abs(blk - r1).max())
+            assert e < 1e-8, (k, e)
+            n_checked += 1
+    assert n_checked >= 3
+    assert s0.r_ball > 0.003 * 8                                           # the isolated point doubled the radius, persistently
+    # centring between the fingers
+    sub = got[::37][:40]
+    cen = grasp_sampler.cone_grasp_poses(pts, nrm, sample_ids, sph, center_ob_between_gripper=True, **kw)[::37][:40]
+    assert np.abs(cen - gref.center_between_gripper(sub, pts)).max() < 1e-9
+    assert grasp_sampler.cone_grasp_poses(pts, nrm, np.zeros((0,), dtype=np.int32), sph, **kw).shape == (0, 4, 4)
