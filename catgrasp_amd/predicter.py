@@ -70,7 +70,7 @@ class GraspPredicter:
     class_name_to_artifact_id = {'nut': 47, 'hnm': 51, 'screw': 50}          # predicter.py:41-45
 
     def __init__(self, class_name, artifact_dir=None, cfg=None, state_dict=None, normalizer=None, device=None,
-                 chunk=4096):
+                 chunk=16384):
         self.class_name = class_name
         if artifact_dir is None and (cfg is None or state_dict is None):
             code_dir = os.path.dirname(os.path.realpath(__file__))
