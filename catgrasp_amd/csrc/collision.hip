@@ -83,12 +83,77 @@ __device__ __forceinline__ bool tri_box_overlap(const float* c, float h, const f
   return plane_box_overlap(n, v0, h);
 }
 
-struct Mesh { const float* V; const int* F; int nf; };
+// Optional broad phase: a uniform grid in the MESH frame; cell (i,j,k) lists every triangle whose box, inflated by the
+// grid's build margin, overlaps the cell (CSR: cell_start, tri_ids).  Built on the host (my_cpp.build_mesh_grid).
+struct Grid { float ox, oy, oz, inv_cell; int nx, ny, nz; const int* cell_start; const int* tri_ids; float res_built; };
+struct Mesh { const float* V; const int* F; int nf; Grid grid; int has_grid; };
 struct Voxels { const short* keys; int nk; };   // (nk,4) int16: key-32768 per axis, 4th unused
 
 // wave-level: does the mesh posed by T (row-major 4x4, wave-uniform) hit any occupied voxel?
+// Broad-phase path.  The grid lists are built for voxels of resolution `res_built` and poses whose linear part A
+// satisfies sigma_min(A) >= 0.5: a leaf box that touches a posed triangle has its centre within r = res*sqrt(3)/2 of it
+// in the camera frame, hence within r/sigma_min <= 2r in the mesh frame, which is the build margin (plus slack for the
+// float32 inverse).  The narrow phase is the SAME float32 SAT on the SAME posed vertices as the exhaustive path, so the
+// result is identical; poses that do not satisfy the bound take the exhaustive path.
+__device__ bool wave_grid_collide(const Mesh& mesh, const float* T, const Voxels& vox, float res, int lane, bool* usable) {
+  const Grid& g = mesh.grid;
+  const float a00 = T[0], a01 = T[1], a02 = T[2], a10 = T[4], a11 = T[5], a12 = T[6], a20 = T[8], a21 = T[9], a22 = T[10];
+  const float c00 = a11 * a22 - a12 * a21, c01 = a12 * a20 - a10 * a22, c02 = a10 * a21 - a11 * a20;
+  const float det = a00 * c00 + a01 * c01 + a02 * c02;
+  *usable = false;
+  if (!(fabsf(det) > 1e-12f) || res != g.res_built) return false;
+  const float id = 1.0f / det;
+  float I[9];
+  I[0] = c00 * id; I[1] = (a02 * a21 - a01 * a22) * id; I[2] = (a01 * a12 - a02 * a11) * id;
+  I[3] = c01 * id; I[4] = (a00 * a22 - a02 * a20) * id; I[5] = (a02 * a10 - a00 * a12) * id;
+  I[6] = c02 * id; I[7] = (a01 * a20 - a00 * a21) * id; I[8] = (a00 * a11 - a01 * a10) * id;
+  float fro = 0.f;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) fro += I[k] * I[k];
+  if (!(fro <= 3.96f)) return false;            // 1/||A^-1||_F >= 0.5025  =>  sigma_min(A) >= 0.5 (with margin)
+  *usable = true;
+  const float h = 0.5f * res;
+  const float tx = T[3], ty = T[7], tz = T[11];
+  for (int v0 = 0; v0 < vox.nk; v0 += 64) {
+    const int v = v0 + lane;
+    bool hv = false;
+    if (v < vox.nk) {
+      const short4 k = ((const short4*)vox.keys)[v];
+      float c[3];
+      c[0] = ((float)k.x + 0.5f) * res; c[1] = ((float)k.y + 0.5f) * res; c[2] = ((float)k.z + 0.5f) * res;
+      const float dx = c[0] - tx, dy = c[1] - ty, dz = c[2] - tz;
+      const float qx = I[0] * dx + I[1] * dy + I[2] * dz, qy = I[3] * dx + I[4] * dy + I[5] * dz, qz = I[6] * dx + I[7] * dy + I[8] * dz;
+      const float fx = (qx - g.ox) * g.inv_cell, fy = (qy - g.oy) * g.inv_cell, fz = (qz - g.oz) * g.inv_cell;
+      if (fx >= 0.f && fy >= 0.f && fz >= 0.f && fx < (float)g.nx && fy < (float)g.ny && fz < (float)g.nz) {
+        const int cell = ((int)fx * g.ny + (int)fy) * g.nz + (int)fz;
+        const int e0 = g.cell_start[cell], e1 = g.cell_start[cell + 1];
+        for (int e = e0; e < e1 && !hv; ++e) {
+          const int t = g.tri_ids[e];
+          float pv[9];
+#pragma unroll
+          for (int kk = 0; kk < 3; ++kk) {
+            const float* vtx = mesh.V + 3 * (size_t)mesh.F[(size_t)t * 3 + kk];
+            const float vx = vtx[0], vy = vtx[1], vz = vtx[2];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+              pv[kk * 3 + r] = fmaf(T[r * 4 + 0], vx, fmaf(T[r * 4 + 1], vy, fmaf(T[r * 4 + 2], vz, T[r * 4 + 3])));
+          }
+          hv = tri_box_overlap(c, h, pv, pv + 3, pv + 6);
+        }
+      }
+    }
+    if (__ballot(hv) != 0ull) return true;
+  }
+  return false;
+}
+
 __device__ bool wave_mesh_voxels_collide(const Mesh& mesh, const float* T, const Voxels& vox, float res, float* tl, int lane) {
   if (vox.nk == 0 || mesh.nf == 0) return false;
+  if (mesh.has_grid) {
+    bool usable;
+    const bool r = wave_grid_collide(mesh, T, vox, res, lane, &usable);
+    if (usable) return r;
+  }
   const float h = 0.5f * res;
   const float slack = 1e-5f;     // conservative culls only; never changes the predicate
   bool hit = false;
@@ -277,11 +342,21 @@ __global__ void unpack_keys_kernel(const long long* __restrict__ packed, long n,
   ((short4*)keys4)[i] = k;
 }
 
+inline Mesh make_mesh(const float* V, const int* F, int nf, const cg_mesh_grid* hg) {
+  Mesh m; m.V = V; m.F = F; m.nf = nf; m.has_grid = 0; m.grid = Grid{};
+  if (hg && hg->cell_start && hg->tri_ids && hg->cell > 0.f) {
+    m.grid = Grid{hg->origin[0], hg->origin[1], hg->origin[2], 1.0f / hg->cell, hg->dims[0], hg->dims[1], hg->dims[2], hg->cell_start,
+                  hg->tri_ids, hg->resolution};
+    m.has_grid = 1;
+  }
+  return m;
+}
+
 inline Mat4 load_mat(const float* h) { Mat4 m; for (int i = 0; i < 16; ++i) m.m[i] = h[i]; return m; }
 
 }  // namespace
 
-extern "C" int cg_filter_grasp_pose(const float* grasp_poses, int n_pose, const float* symmetry_tfs, int n_sym,
+extern "C" int cg_filter_grasp_pose_accel(const float* grasp_poses, int n_pose, const float* symmetry_tfs, int n_sym,
                                     const float* h_nocs_pose, const float* h_canonical_to_nocs, const float* h_cam_in_world,
                                     const float* h_ee_in_grasp, const float* h_gripper_in_grasp,
                                     int filter_approach_dir_face_camera, int adjust_collision_pose,
@@ -290,7 +365,7 @@ extern "C" int cg_filter_grasp_pose(const float* grasp_poses, int n_pose, const 
                                     const float* enclosed_vertices, const int* enclosed_faces, int n_enclosed_faces,
                                     const short* open_keys, int n_open_keys, const short* bg_keys, int n_bg_keys,
                                     float resolution, signed char* codes, float* poses_out, signed char* nudge,
-                                    float* ee_in_base_out, void* stream) {
+                                    float* ee_in_base_out, const cg_mesh_grid* h_open_grid, const cg_mesh_grid* h_enc_grid, void* stream) {
   if (n_pose < 0 || n_sym < 0) return CG_ERR_ARG;
   if ((long)n_pose * n_sym == 0) return CG_OK;
   if (!grasp_poses || !symmetry_tfs || !h_nocs_pose || !h_canonical_to_nocs || !h_cam_in_world || !h_ee_in_grasp ||
@@ -310,8 +385,8 @@ extern "C" int cg_filter_grasp_pose(const float* grasp_poses, int n_pose, const 
   a.cam_in_world = load_mat(h_cam_in_world); a.ee_in_grasp = load_mat(h_ee_in_grasp);
   a.gripper_in_grasp = load_mat(h_gripper_in_grasp);
   a.filter_dir = filter_approach_dir_face_camera; a.adjust = adjust_collision_pose; a.ik_ok = ik_ok;
-  a.open_mesh = Mesh{gripper_vertices, gripper_faces, n_gripper_faces};
-  a.enc_mesh = Mesh{enclosed_vertices, enclosed_faces, n_enclosed_faces};
+  a.open_mesh = make_mesh(gripper_vertices, gripper_faces, n_gripper_faces, h_open_grid);
+  a.enc_mesh = make_mesh(enclosed_vertices, enclosed_faces, n_enclosed_faces, h_enc_grid);
   a.vox_open = Voxels{open_keys, n_open_keys}; a.vox_bg = Voxels{bg_keys, n_bg_keys};
   a.res = resolution; a.codes = codes; a.poses_out = poses_out; a.nudge = nudge; a.ee_out = ee_in_base_out;
   long blocks = (E + WAVES - 1) / WAVES;
@@ -329,7 +404,7 @@ extern "C" int cg_mesh_voxels_collide(const float* vertices, const int* faces, i
   long blocks = (n_poses + WAVES - 1) / WAVES;
   if (blocks > 256 * 16) blocks = 256 * 16;
   hipLaunchKernelGGL(mesh_voxels_collide_kernel, dim3((unsigned)blocks), dim3(64 * WAVES), 0, (hipStream_t)stream,
-                     Mesh{vertices, faces, n_faces}, poses, n_poses, Voxels{keys, n_keys}, resolution, out);
+                     make_mesh(vertices, faces, n_faces, nullptr), poses, n_poses, Voxels{keys, n_keys}, resolution, out);
   return cg_hip_status(hipGetLastError());
 }
 
@@ -349,4 +424,20 @@ extern "C" int cg_unpack_voxel_keys(const long long* packed, long n, short* keys
   if (!packed || !keys4) return CG_ERR_ARG;
   hipLaunchKernelGGL(unpack_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, packed, n, keys4);
   return cg_hip_status(hipGetLastError());
+}
+
+extern "C" int cg_filter_grasp_pose(const float* grasp_poses, int n_pose, const float* symmetry_tfs, int n_sym,
+                                    const float* h_nocs_pose, const float* h_canonical_to_nocs, const float* h_cam_in_world,
+                                    const float* h_ee_in_grasp, const float* h_gripper_in_grasp,
+                                    int filter_approach_dir_face_camera, int adjust_collision_pose,
+                                    const unsigned char* ik_ok,
+                                    const float* gripper_vertices, const int* gripper_faces, int n_gripper_faces,
+                                    const float* enclosed_vertices, const int* enclosed_faces, int n_enclosed_faces,
+                                    const short* open_keys, int n_open_keys, const short* bg_keys, int n_bg_keys,
+                                    float resolution, signed char* codes, float* poses_out, signed char* nudge,
+                                    float* ee_in_base_out, void* stream) {
+  return cg_filter_grasp_pose_accel(grasp_poses, n_pose, symmetry_tfs, n_sym, h_nocs_pose, h_canonical_to_nocs, h_cam_in_world, h_ee_in_grasp,
+                                    h_gripper_in_grasp, filter_approach_dir_face_camera, adjust_collision_pose, ik_ok, gripper_vertices,
+                                    gripper_faces, n_gripper_faces, enclosed_vertices, enclosed_faces, n_enclosed_faces, open_keys, n_open_keys,
+                                    bg_keys, n_bg_keys, resolution, codes, poses_out, nudge, ee_in_base_out, nullptr, nullptr, stream);
 }

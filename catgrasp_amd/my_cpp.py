@@ -135,12 +135,57 @@ class CollisionManager:
         return False
 
 
+class _MeshGridC(ctypes.Structure):
+    """cg_mesh_grid (include/catgrasp_amd.h)."""
+    _fields_ = [('origin', ctypes.c_float * 3), ('cell', ctypes.c_float), ('dims', ctypes.c_int * 3),
+                ('cell_start', ctypes.c_void_p), ('tri_ids', ctypes.c_void_p), ('resolution', ctypes.c_float)]
+
+
+class MeshGrid:
+    """Broad phase for filterGraspPose on large gripper meshes: a uniform grid in the mesh frame whose cells list the
+    triangles that can touch a voxel centred in the cell (see cg_mesh_grid).  Purely an accelerator: the narrow phase and
+    therefore every result is unchanged."""
+
+    def __init__(self, V, F, resolution, device, cell=None):
+        V = np.asarray(V, dtype=np.float64); F = np.asarray(F, dtype=np.int64)
+        res = float(np.float32(resolution))
+        inflate = 2.0 * (res * np.sqrt(3.0) / 2.0) + 3e-5          # sigma_min >= 0.5, plus float32 slack
+        if cell is None:
+            cell = max(4.0 * res, 0.002)
+        lo = V.min(axis=0) - inflate - 1e-6
+        hi = V.max(axis=0) + inflate + 1e-6
+        dims = np.maximum(np.ceil((hi - lo) / cell).astype(np.int64), 1)
+        tri = V[F]                                                   # (nf,3,3)
+        tlo = np.clip(np.floor((tri.min(axis=1) - inflate - lo) / cell).astype(np.int64), 0, dims - 1)
+        thi = np.clip(np.floor((tri.max(axis=1) + inflate - lo) / cell).astype(np.int64), 0, dims - 1)
+        cells, tids = [], []
+        for t in range(len(F)):
+            ii, jj, kk = np.meshgrid(np.arange(tlo[t, 0], thi[t, 0] + 1), np.arange(tlo[t, 1], thi[t, 1] + 1),
+                                     np.arange(tlo[t, 2], thi[t, 2] + 1), indexing='ij')
+            c = ((ii * dims[1] + jj) * dims[2] + kk).reshape(-1)
+            cells.append(c); tids.append(np.full(len(c), t, dtype=np.int32))
+        cells = np.concatenate(cells) if cells else np.zeros((0,), dtype=np.int64)
+        tids = np.concatenate(tids) if tids else np.zeros((0,), dtype=np.int32)
+        order = np.argsort(cells, kind='stable')
+        ncell = int(dims[0] * dims[1] * dims[2])
+        counts = np.bincount(cells, minlength=ncell)
+        start = np.zeros(ncell + 1, dtype=np.int32); start[1:] = np.cumsum(counts)
+        self.cell_start = torch.from_numpy(start).to(device)
+        self.tri_ids = torch.from_numpy(np.ascontiguousarray(tids[order], dtype=np.int32) if len(tids) else np.zeros((1,), np.int32)).to(device)
+        self.c = _MeshGridC()
+        for i in range(3):
+            self.c.origin[i] = float(lo[i]); self.c.dims[i] = int(dims[i])
+        self.c.cell = float(cell); self.c.resolution = res
+        self.c.cell_start = self.cell_start.data_ptr(); self.c.tri_ids = self.tri_ids.data_ptr()
+        self.n_entries = int(len(tids))
+
+
 class GripperScene:
     """Device-resident inputs of filterGraspPose that do not change between calls on one object:
     gripper meshes and the two voxelised collision clouds.  Build once, filter many pose batches."""
 
     def __init__(self, gripper_vertices, gripper_faces, gripper_enclosed_vertices, gripper_enclosed_faces,
-                 gripper_collision_pts, gripper_enclosed_collision_pts, octo_resolution, device=None):
+                 gripper_collision_pts, gripper_enclosed_collision_pts, octo_resolution, device=None, accel=True):
         dev = device or _device()
         self.device = dev
         V, F = _mesh(gripper_vertices, gripper_faces, 'gripper')
@@ -150,6 +195,9 @@ class GripperScene:
         self.res = float(np.float32(octo_resolution))
         self.keys_open = voxelize(gripper_collision_pts, self.res, dev)
         self.keys_bg = voxelize(gripper_enclosed_collision_pts, self.res, dev)
+        # broad-phase grids (result-neutral accelerator; accel=False forces the exhaustive kernel path)
+        self.grid_open = MeshGrid(V, F, self.res, dev) if accel and len(F) else None
+        self.grid_enc = MeshGrid(Ve, Fe, self.res, dev) if accel and len(Fe) else None
 
 
 def filter_on_device(scene, grasp_poses, symmetry_tfs, nocs_pose, canonical_to_nocs_transform, cam_in_world, ee_in_grasp,
@@ -182,12 +230,14 @@ def filter_on_device(scene, grasp_poses, symmetry_tfs, nocs_pose, canonical_to_n
     nudge = torch.empty((E,), dtype=torch.int8, device=dev)
 
     def launch(ik_ok, ee_out):
-        check(L.lib().cg_filter_grasp_pose(
+        go = ctypes.byref(scene.grid_open.c) if scene.grid_open is not None else None
+        ge = ctypes.byref(scene.grid_enc.c) if scene.grid_enc is not None else None
+        check(L.lib().cg_filter_grasp_pose_accel(
             _p(gp), _c_int(n_pose), _p(st), _c_int(n_sym), hm[0], hm[1], hm[2], hm[3], hm[4],
             _c_int(int(bool(filter_approach_dir_face_camera))), _c_int(int(bool(adjust_collision_pose))), _p(ik_ok),
             _p(scene.V), _p(scene.F), _c_int(scene.F.shape[0]), _p(scene.Ve), _p(scene.Fe), _c_int(scene.Fe.shape[0]),
             _p(scene.keys_open), _c_int(scene.keys_open.shape[0]), _p(scene.keys_bg), _c_int(scene.keys_bg.shape[0]),
-            ctypes.c_float(scene.res), _p(codes), _p(poses), _p(nudge), _p(ee_out), _stream()), 'cg_filter_grasp_pose')
+            ctypes.c_float(scene.res), _p(codes), _p(poses), _p(nudge), _p(ee_out), go, ge, _stream()), 'cg_filter_grasp_pose_accel')
 
     ik_ok = None
     if filter_ik and E > 0:
@@ -205,12 +255,12 @@ def filter_on_device(scene, grasp_poses, symmetry_tfs, nocs_pose, canonical_to_n
 def filterGraspPoseDetailed(grasp_poses, symmetry_tfs, nocs_pose, canonical_to_nocs_transform, cam_in_world, ee_in_grasp,
                             gripper_in_grasp, filter_approach_dir_face_camera, filter_ik, adjust_collision_pose, upper, lower,
                             gripper_vertices, gripper_faces, gripper_enclosed_vertices, gripper_enclosed_faces,
-                            gripper_collision_pts, gripper_enclosed_collision_pts, octo_resolution, verbose=False):
+                            gripper_collision_pts, gripper_enclosed_collision_pts, octo_resolution, verbose=False, accel=True):
     """filterGraspPose in input order: returns (codes (E,) int8, poses (E,4,4) float32, nudge (E,) int8) numpy,
     E = len(grasp_poses)*len(symmetry_tfs), e = i*len(symmetry_tfs)+j.
     codes: 0 keep, 1 approach-dir, 2 IK, 3 open-gripper collision / no nudge found, 4 enclosed-gripper collision."""
     scene = GripperScene(gripper_vertices, gripper_faces, gripper_enclosed_vertices, gripper_enclosed_faces,
-                         gripper_collision_pts, gripper_enclosed_collision_pts, octo_resolution)
+                         gripper_collision_pts, gripper_enclosed_collision_pts, octo_resolution, accel=accel)
     codes, poses, nudge = filter_on_device(scene, grasp_poses, symmetry_tfs, nocs_pose, canonical_to_nocs_transform, cam_in_world,
                                            ee_in_grasp, gripper_in_grasp, filter_approach_dir_face_camera, filter_ik,
                                            adjust_collision_pose, upper, lower)

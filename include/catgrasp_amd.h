@@ -106,6 +106,17 @@ int cg_unpack_voxel_keys(const long long* packed, long n, short* keys4, void* st
 int cg_mesh_voxels_collide(const float* vertices, const int* faces, int n_faces, const float* poses, long n_poses,
                            const short* keys, int n_keys, float resolution, unsigned char* out, void* stream);
 
+/* Optional broad phase for a gripper mesh: a uniform grid in the MESH frame (host descriptor, device arrays).
+ * Cell (i,j,k) -> index (i*dims[1] + j)*dims[2] + k; tri_ids[cell_start[c] .. cell_start[c+1]) lists every triangle whose
+ * bounding box inflated by 2*(resolution*sqrt(3)/2) + slack overlaps the cell.  Valid for point clouds registered at
+ * exactly `resolution` and poses with sigma_min >= 0.5; other calls use the exhaustive path.  Results are identical. */
+typedef struct cg_mesh_grid {
+  float origin[3]; float cell; int dims[3];
+  const int* cell_start;   /* device, prod(dims)+1 */
+  const int* tri_ids;      /* device */
+  float resolution;
+} cg_mesh_grid;
+
 /* filterGraspPose (my_cpp/common.cpp:156-321; declaration my_cpp/common.h:60) for every
  * (grasp pose i, symmetry transform j) pair, in input order e = i*n_sym + j.
  *  grasp_poses (n_pose,16), symmetry_tfs (n_sym,16): device, row-major float32 4x4.
@@ -129,6 +140,17 @@ int cg_filter_grasp_pose(const float* grasp_poses, int n_pose, const float* symm
                          const short* open_keys, int n_open_keys, const short* bg_keys, int n_bg_keys,
                          float resolution, signed char* codes, float* poses_out, signed char* nudge,
                          float* ee_in_base_out, void* stream);
+/* Same, with optional broad-phase grids (HOST descriptors, NULL = exhaustive) for the open / enclosed gripper mesh. */
+int cg_filter_grasp_pose_accel(const float* grasp_poses, int n_pose, const float* symmetry_tfs, int n_sym,
+                               const float* h_nocs_pose, const float* h_canonical_to_nocs, const float* h_cam_in_world,
+                               const float* h_ee_in_grasp, const float* h_gripper_in_grasp,
+                               int filter_approach_dir_face_camera, int adjust_collision_pose,
+                               const unsigned char* ik_ok,
+                               const float* gripper_vertices, const int* gripper_faces, int n_gripper_faces,
+                               const float* enclosed_vertices, const int* enclosed_faces, int n_enclosed_faces,
+                               const short* open_keys, int n_open_keys, const short* bg_keys, int n_bg_keys,
+                               float resolution, signed char* codes, float* poses_out, signed char* nudge,
+                               float* ee_in_base_out, const cg_mesh_grid* h_open_grid, const cg_mesh_grid* h_enc_grid, void* stream);
 
 
 /* ---------------------------------------------------------------------------------------------

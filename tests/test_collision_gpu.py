@@ -257,3 +257,36 @@ def test_filter_with_ik_stage(cuda_device):
     with pytest.raises(NotImplementedError):       # no silent skipping of the IK test
         my_cpp.filterGraspPoseDetailed(*_args(P, [I4], I4, g, objs[0]['xyz'], bg, True, False)[:8], True, False, upper, lower,
                                        g['vertices'], g['faces'], g['enclosed_vertices'], g['enclosed_faces'], objs[0]['xyz'], bg, 0.0005)
+
+
+def test_broad_phase_grid_is_result_neutral(cuda_device):
+    """The mesh-frame grid broad phase (cg_mesh_grid) must not change a single code/pose: exhaustive vs accelerated vs oracle,
+    on the box gripper, a finely tessellated gripper (2304 triangles), symmetric + sheared poses (which fall back)."""
+    from catgrasp_amd import my_cpp
+    objs, g, bg = _scene(10, n_obj=4, pts=2000)
+    P = synth.make_candidates(objs[0], 300, np.random.default_rng(21))
+    V, F = g['vertices'], g['faces']
+    for _ in range(3):     # 36 -> 2304 triangles
+        nv = len(V); newV = [V]; newF = []
+        for f in F:
+            a, b, c = V[f[0]], V[f[1]], V[f[2]]
+            m = np.stack([(a + b) / 2, (b + c) / 2, (c + a) / 2]).astype(np.float32)
+            i0 = nv; nv += 3; newV.append(m)
+            newF += [[f[0], i0, i0 + 2], [i0, f[1], i0 + 1], [i0 + 2, i0 + 1, f[2]], [i0, i0 + 1, i0 + 2]]
+        V = np.concatenate(newV).astype(np.float32); F = np.array(newF, dtype=np.int32)
+    g_fine = dict(g, vertices=V, faces=F)
+    for gg, adj in ((g, True), (g_fine, False)):
+        a = my_cpp.filterGraspPoseDetailed(*_args(P, [I4], I4, gg, objs[0]['xyz'], bg, True, adj), accel=True)
+        b = my_cpp.filterGraspPoseDetailed(*_args(P, [I4], I4, gg, objs[0]['xyz'], bg, True, adj), accel=False)
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+    ora = _oracle(P, [I4], I4, g_fine, objs[0]['xyz'], bg, 1, 0)
+    _check(a, ora)
+    # anisotropic nocs_pose: sheared gripper poses (sigma_min < 0.5 for some) -> exhaustive fallback inside the same launch
+    T = objs[0]['pose']
+    nocs_pose = T @ np.diag([0.03, 0.012, 0.004, 1.0])
+    P_can = np.linalg.inv(nocs_pose) @ P[:60]
+    S = np.eye(4); S[:3, :3] = [[0, -1, 0], [1, 0, 0], [0, 0, 1]]
+    a = my_cpp.filterGraspPoseDetailed(*_args(P_can, [I4, S], nocs_pose, g, objs[0]['xyz'], bg, False, True), accel=True)
+    ora = _oracle(P_can, [I4, S], nocs_pose, g, objs[0]['xyz'], bg, 0, 1)
+    _check(a, ora)
