@@ -8,7 +8,8 @@
 // error on the grasp-Q logits is ~1e-5 (tests/test_pointnet_gpu.py), inside the 1e-4 parity bar.
 //
 // Layout: one workgroup = 8 waves owns one sample (or a slice of its point tiles).  A tile of 256 points is
-// carried through 6->64 (f32 VALU) -> [64->64] -> 64->128 -> 128->1024 inside LDS (148 KB, one workgroup per CU).
+// carried through 6->64 (f32 VALU) -> [64->64] -> 64->128 -> 128->1024 inside LDS (148 KB, one workgroup per CU;
+// a 128-point / 4-wave geometry with two workgroups per CU is also instantiated).
 //  * Front layers are WAVE-PRIVATE: wave w takes rows [32w, 32w+32) of the tile through the whole chain with no
 //    workgroup barrier.  Its f32 scratch ([32][68] floats twice) aliases exactly its own 32 rows of the two
 //    bf16 images of the 128-wide activation (32 rows x 272 B == 32 x 68 floats), which it overwrites last.
@@ -24,13 +25,17 @@ namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int RT = 8;          // 32-row tiles per workgroup tile
-constexpr int TP = 32 * RT;    // 256 points
 constexpr int SH = 136;        // bf16 elements per row of the h2 hi / lo images
 constexpr int S64 = 68;        // floats per row of the f32 scratch tiles
 constexpr int XS = 8;
-constexpr int NT = 512;        // threads per workgroup (8 waves)
-constexpr size_t LDS_BYTES = (size_t)2 * TP * SH * 2 + 1024 * 4 + (size_t)TP * XS * 4;
+// Two geometries: RT = 8 row tiles (256 points, 8 waves, 148 KB LDS, one workgroup per CU; the default) and RT = 4
+// (128 points, 4 waves, 78 KB, two workgroups per CU; measured 7 % slower: twice the weight traffic).  One wave per 32-row tile.
+template <int RT> struct Geo {
+  static constexpr int TP = 32 * RT;
+  static constexpr int NT = 64 * RT;
+  static constexpr int NBW = 32 / RT;       // 32-channel blocks of the 1024-wide layer owned by each wave
+  static constexpr size_t LDS_BYTES = (size_t)2 * TP * SH * 2 + 1024 * 4 + (size_t)TP * XS * 4;
+};
 
 struct ArgsB {
   const float* x; int B; int N;
@@ -70,8 +75,9 @@ __device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmc
 // does not hoist 48 KB of weight-fragment loads out of the loop and spill them.
 __device__ __forceinline__ int opaque_zero() { int z; asm volatile("s_mov_b32 %0, 0" : "=s"(z)); return z; }
 
-template <int MID>
-__global__ __launch_bounds__(NT, 2) void pointmlp_max_bf16x3_kernel(ArgsB a) {
+template <int MID, int RT>
+__global__ __launch_bounds__(64 * RT, 2) void pointmlp_max_bf16x3_kernel(ArgsB a) {
+  constexpr int TP = Geo<RT>::TP, NT = Geo<RT>::NT, NBW = Geo<RT>::NBW;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   __bf16* h2hi = (__bf16*)smem_raw;
   __bf16* h2lo = h2hi + TP * SH;
@@ -229,8 +235,8 @@ __global__ __launch_bounds__(NT, 2) void pointmlp_max_bf16x3_kernel(ArgsB a) {
       constexpr int NST = RT / G;          // stages per k chunk
       const __bf16* ahi_base = h2hi + l31 * SH + lhi * 8;
       const __bf16* alo_base = h2lo + l31 * SH + lhi * 8;
-      for (int q = 0; q < 4; ++q) {
-        const int nb = w * 4 + q;
+      for (int q = 0; q < NBW; ++q) {
+        const int nb = w * NBW + q;
         f32x16 c[RT];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) c[rt] = f32x16{0};
@@ -303,9 +309,11 @@ __global__ void fill_kernel_b(float* p, size_t n, float v) {
   if (i < n) p[i] = v;
 }
 
-template <int MID>
+template <int MID, int RT>
 int launch(const ArgsB& a, hipStream_t s) {
-  auto kern = pointmlp_max_bf16x3_kernel<MID>;
+  constexpr int NT = Geo<RT>::NT;
+  constexpr size_t LDS_BYTES = Geo<RT>::LDS_BYTES;
+  auto kern = pointmlp_max_bf16x3_kernel<MID, RT>;
   static bool attr_set = false;     // per instantiation
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
@@ -321,14 +329,15 @@ int launch(const ArgsB& a, hipStream_t s) {
 extern "C" int cg_pointmlp_max_bf16x3(const float* x, int B, int N, const float* t3, const float* w1, const float* b1,
                                       int mid_mode, const unsigned short* wm_split, const float* bm, const float* t64,
                                       const unsigned short* w2_split, const float* b2, const unsigned short* w3_split,
-                                      const float* b3, int relu3, int nsplit, float* out, float* pointfeat, void* stream) {
-  if (B < 0 || N <= 0 || mid_mode < 0 || mid_mode > 2) return CG_ERR_ARG;
+                                      const float* b3, int relu3, int nsplit, int tile_points, float* out, float* pointfeat,
+                                      void* stream) {
+  if (B < 0 || N <= 0 || mid_mode < 0 || mid_mode > 2 || (tile_points != 128 && tile_points != 256)) return CG_ERR_ARG;
   if (B == 0) return CG_OK;
   if (!x || !w1 || !b1 || !w2_split || !b2 || !w3_split || !b3 || !out) return CG_ERR_ARG;
   if (mid_mode == 1 && (!wm_split || !bm)) return CG_ERR_ARG;
   if (mid_mode == 2 && !t64) return CG_ERR_ARG;
   if (pointfeat && mid_mode != 2) return CG_ERR_ARG;
-  const int ntiles = (N + TP - 1) / TP;
+  const int ntiles = (N + tile_points - 1) / tile_points;
   if (nsplit < 1) nsplit = 1;
   if (nsplit > ntiles) nsplit = ntiles;
   hipStream_t s = (hipStream_t)stream;
@@ -337,7 +346,12 @@ extern "C" int cg_pointmlp_max_bf16x3(const float* x, int B, int N, const float*
     hipLaunchKernelGGL(fill_kernel_b, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, out, n, -INFINITY);
   }
   ArgsB a{x, B, N, t3, w1, b1, wm_split, bm, t64, w2_split, b2, w3_split, b3, relu3, nsplit, out, pointfeat};
-  if (mid_mode == 0) return launch<0>(a, s);
-  if (mid_mode == 1) return launch<1>(a, s);
-  return launch<2>(a, s);
+  if (tile_points == 256) {
+    if (mid_mode == 0) return launch<0, 8>(a, s);
+    if (mid_mode == 1) return launch<1, 8>(a, s);
+    return launch<2, 8>(a, s);
+  }
+  if (mid_mode == 0) return launch<0, 4>(a, s);
+  if (mid_mode == 1) return launch<1, 4>(a, s);
+  return launch<2, 4>(a, s);
 }

@@ -17,6 +17,7 @@ from . import ops
 # 'f32'   : exact-f32 MFMA kernels (default; bitwise an fmaf chain per dot product)
 # 'bf16x3': split-bf16 MFMA kernels for the per-point MLP chain (3 bf16 MFMAs per product block, f32 accumulate)
 PRECISION = os.environ.get('CATGRASP_AMD_PRECISION', 'f32')
+TILE_POINTS = int(os.environ.get('CATGRASP_AMD_TILE_POINTS', '256'))   # bf16x3 kernel geometry: 256 or 128 points per workgroup tile
 
 
 def set_precision(p):
@@ -59,8 +60,8 @@ def encoder_forward(W, x, want_pointfeat=False):
 def _encoder_forward_split(W, x, want_pointfeat=False):
     """encoder_forward with the bf16x3 per-point MLP kernels (the FC tails stay exact f32)."""
     B, N, _ = x.shape
-    ns = _nsplit(B, N, 256)
-    kw = dict(nsplit=ns, split=True)
+    ns = _nsplit(B, N, TILE_POINTS)
+    kw = dict(nsplit=ns, split=True, tile_points=TILE_POINTS)
     g = ops.pointmlp_max(x, W['stn.w1'], W['stn.b1'], W['stn.w2.s'], W['stn.b2'], W['stn.w3.s'], W['stn.b3'], True, **kw)
     h = ops.gemm_bias_act(g, W['stn.fc1'], 512, W['stn.fc1b'], relu=True)
     h = ops.gemm_bias_act(h, W['stn.fc2'], 256, W['stn.fc2b'], relu=True)

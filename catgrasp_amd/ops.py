@@ -16,7 +16,7 @@ KERNEL_TIMER = None
 
 
 def pointmlp_max(x, w1, b1, w2p, b2, w3p, b3, relu3, t3=None, mid_mode=0, wm=None, bm=None, t64=None,
-                 nsplit=1, pointfeat=False, split=False):
+                 nsplit=1, pointfeat=False, split=False, tile_points=256):
     """x:(B,N,6) -> (B,1024) [, pointfeat (B,N,64)].  See cg_pointmlp_max / cg_pointmlp_max_bf16x3 in
     include/catgrasp_amd.h.  split=True: w2p/w3p/wm are the bf16x3 images (folding.pack_b_bf16x3)."""
     require_cuda(x)
@@ -32,7 +32,7 @@ def pointmlp_max(x, w1, b1, w2p, b2, w3p, b3, relu3, t3=None, mid_mode=0, wm=Non
             ev0.record()
         st = L.lib().cg_pointmlp_max_bf16x3(_p(x), _c_int(B), _c_int(N), _p(t3), _p(w1), _p(b1), _c_int(mid_mode), _p(wm), _p(bm),
                                             _p(t64), _p(w2p), _p(b2), _p(w3p), _p(b3), _c_int(int(relu3)), _c_int(nsplit),
-                                            _p(out), _p(pf), _stream())
+                                            _c_int(tile_points), _p(out), _p(pf), _stream())
         if timer is not None:
             ev1.record()
             timer['events'].append((ev0, ev1, (B, N)))

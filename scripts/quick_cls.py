@@ -11,6 +11,8 @@ W = folding.prepare_cls(sd, dev)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 if len(sys.argv) > 2:
     engine.PRECISION = sys.argv[2]
+if len(sys.argv) > 3:
+    engine.TILE_POINTS = int(sys.argv[3])
 x = (torch.randn(B, 2048, 6) * 0.5).to(dev)
 for _ in range(2):
     engine.cls_forward(W, x)
@@ -20,4 +22,4 @@ for _ in range(n):
     engine.cls_forward(W, x)
 torch.cuda.synchronize()
 dt = (time.time() - t) / n
-print(f'{engine.PRECISION} B={B} {dt*1e3:.2f} ms  {B/dt:.0f} cand/s  {B*1.7541e9/dt/1e12:.1f} TFLOP/s')
+print(f'{engine.PRECISION} tp={engine.TILE_POINTS} B={B} {dt*1e3:.2f} ms  {B/dt:.0f} cand/s  {B*1.7541e9/dt/1e12:.1f} TFLOP/s')
