@@ -32,6 +32,13 @@ def load_state_dict(ckpt_dir):
     return sd
 
 
+def artifact_root():
+    """The reference reads `<dir of predicter.py>/artifacts/artifacts-<id>/` (predicter.py:47-48).  Here the root is
+    $CATGRASP_ARTIFACTS if set, else the directory that contains this package (the reference checkout when
+    `catgrasp_amd/` is dropped into it)."""
+    return os.environ.get('CATGRASP_ARTIFACTS', os.path.join(os.path.dirname(os.path.dirname(os.path.realpath(__file__))), 'artifacts'))
+
+
 def _load_artifacts(artifact_dir, cfg_name, cfg, state_dict, normalizer):
     if cfg is None:
         with open(f'{artifact_dir}/{cfg_name}', 'r') as ff:
@@ -73,8 +80,7 @@ class GraspPredicter:
                  chunk=16384):
         self.class_name = class_name
         if artifact_dir is None and (cfg is None or state_dict is None):
-            code_dir = os.path.dirname(os.path.realpath(__file__))
-            artifact_dir = f"{code_dir}/artifacts/artifacts-{self.class_name_to_artifact_id[class_name]}"
+            artifact_dir = f"{artifact_root()}/artifacts-{self.class_name_to_artifact_id[class_name]}"
             print('GraspPredicter artifact_dir', artifact_dir)
         self.cfg, sd = _load_artifacts(artifact_dir, 'config_grasp.yml', cfg, state_dict, normalizer)
         self.device = _device(device)
@@ -134,8 +140,7 @@ class NunocsPredicter:
             self.min_scale = [0.005, 0.005, 0.005]
             self.max_scale = [0.15, 0.05, 0.05]
         if artifact_dir is None and (cfg is None or state_dict is None):
-            code_dir = os.path.dirname(os.path.realpath(__file__))
-            artifact_dir = f"{code_dir}/artifacts/artifacts-{self.class_name_to_artifact_id[class_name]}"
+            artifact_dir = f"{artifact_root()}/artifacts-{self.class_name_to_artifact_id[class_name]}"
             print('NunocsPredicter artifact_dir', artifact_dir)
         self.cfg, sd = _load_artifacts(artifact_dir, 'config_nunocs.yml', cfg, state_dict, normalizer)
         self.device = _device(device)

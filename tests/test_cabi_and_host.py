@@ -145,3 +145,28 @@ def test_synthetic_checkpoint_layout():
     assert len(sd) == 111 and sd['feat.fstn.fc3.weight'].shape == (4096, 256)
     assert torch.equal(sd['fc1.weight'], synth.make_state_dict('cls', 6, 10, seed=0)['fc1.weight'])
     assert sum(v.numel() for k, v in sd.items() if 'num_batches' not in k and 'running' not in k) == 3464147 + 0  # params
+
+
+def test_reference_checkpoint_and_artifact_layout(tmp_path, monkeypatch):
+    """Utils.load_model semantics (Utils.py:135-148) on the reference's checkpoint format: legacy (non-zip) torch.save of
+    {'epoch','state_dict','best_res'} with DataParallel 'module.' prefixes (trainer_grasp.py:66-70), plus the
+    artifacts-<id>/{config_grasp.yml, normalizer.pkl, best_val.pth.tar} layout (predicter.py:46-63)."""
+    import pickle
+    import yaml
+    from catgrasp_amd import predicter
+    sd = synth.make_state_dict('cls', 6, 10, seed=5, prefix='module.')
+    d = tmp_path / 'artifacts-47'
+    d.mkdir()
+    torch.save({'epoch': 3, 'state_dict': sd, 'best_res': 0.5}, str(d / 'best_val.pth.tar'), _use_new_zipfile_serialization=False)
+    with open(d / 'config_grasp.yml', 'w') as f:
+        yaml.safe_dump({'n_pts': 2048, 'input_channel': 6, 'classes': [0, 0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8, 0.9, 1.01]}, f)
+    with open(d / 'normalizer.pkl', 'wb') as f:
+        pickle.dump({'mean': np.arange(6) * 0.01, 'std': np.ones(6) * 0.5}, f)
+    loaded = predicter.load_state_dict(str(d / 'best_val.pth.tar'))
+    assert set(loaded.keys()) == {k.replace('module.', '') for k in sd} and torch.equal(loaded['fc3.bias'], sd['module.fc3.bias'])
+    monkeypatch.setenv('CATGRASP_ARTIFACTS', str(tmp_path))
+    assert predicter.artifact_root() == str(tmp_path)
+    cfg, sd2 = predicter._load_artifacts(str(d), 'config_grasp.yml', None, None, None)
+    assert cfg['n_pts'] == 2048 and np.allclose(cfg['std'], 0.5) and len(sd2) == 111
+    m = __import__('catgrasp_amd.pointnet2', fromlist=['x']).PointNetCls(6, 10)
+    m.load_state_dict(sd2)                              # reference parameter names
