@@ -276,6 +276,28 @@ int cg_cone_poses(const double* pts, const int* sample_ids, const double* frames
  * object's y-extent in the grasp frame (poses must be rigid).  In place. */
 int cg_center_grasps(double* poses, long G, const double* pts, int P, void* stream);
 
+
+/* ---------------------------------------------------------------------------------------------
+ * Row N4: PointGroup/lib/pointgroup_ops CUDA ops on the reference's inference path (predicter.py:285-304), forward only.
+ * ------------------------------------------------------------------------------------------- */
+
+/* ballquery_batch_p (src/bfs_cluster/bfs_cluster.cu:15-91): neighbours with d^2 < radius^2 inside the point's own batch
+ * (batch_offsets), at most 1000 per point, ascending index.  Two passes: pass 0 writes counts (n); the caller scans them
+ * into start/len (and applies the n*meanActive cap); pass 1 fills idx[start[p] .. start[p]+len[p]). */
+int cg_pg_ballquery_batch_p(const float* xyz, const int* batch_idxs, const int* batch_offsets, int n, float radius, int pass,
+                            const int* start, const int* len, int* counts, int* idx, void* stream);
+/* sec_mean / sec_min / sec_max (src/sec_mean/sec_mean.cu) and roipool_fp (src/roipool/roipool.cu:12-40):
+ * inp (N,C), offsets (n_segments+1); mode 0 mean, 1 min, 2 max, 3 max + argmax (row index, -1 for an empty segment). */
+int cg_pg_segment_reduce(const float* inp, const int* offsets, int n_segments, int C, int mode, float* out, int* argmax,
+                         void* stream);
+/* get_iou (src/get_iou/get_iou.cu:12-37): proposals (CSR idx/offset) x instances -> (nProposal,nInstance) IoU. */
+int cg_pg_get_iou(const int* proposals_idx, const int* proposals_offset, const long long* instance_labels,
+                  const int* instance_pointnum, int nProposal, int nInstance, float* proposals_iou, void* stream);
+/* voxelization forward (src/voxelize/voxelize.cu:10-34): out (n_rows,C, pre-zeroed) += mean/sum of feats rows listed in
+ * rules (n_rows, 1+max_active) = [count, idx...]. */
+int cg_pg_voxelize_fp(const float* feats, const int* rules, int n_rows, int max_active, int C, int average, float* out,
+                      void* stream);
+
 #ifdef __cplusplus
 }
 #endif
