@@ -20,10 +20,25 @@ def draw_hypothesis_ids(n_points, max_iter):
     return out
 
 
+def draw_hypothesis_ids_fast(n_points, max_iter):
+    """Vectorised draw of 4 distinct indices per hypothesis from numpy's global generator (same distribution as the
+    reference's per-iteration np.random.choice, ~1000x faster, but NOT the same random stream)."""
+    ids = np.random.randint(0, n_points, size=(max_iter, 4))
+    while True:
+        s = np.sort(ids, axis=1)
+        dup = (s[:, 1:] == s[:, :-1]).any(axis=1)
+        if not dup.any():
+            return ids.astype(np.int32)
+        ids[dup] = np.random.randint(0, n_points, size=(int(dup.sum()), 4))
+
+
 def estimate9DTransform(source, target, PassThreshold, max_iter=1000, use_kdtree_for_eval=False, kdtree_eval_resolution=None,
-                        max_scale=np.array([99, 99, 99]), min_scale=np.array([0, 0, 0]), max_dimensions=None, ids=None, device=None):
+                        max_scale=np.array([99, 99, 99]), min_scale=np.array([0, 0, 0]), max_dimensions=None, ids=None, device=None,
+                        sampling='reference'):
     """-> (4x4 float64 transform, inlier index array) or (None, None), like aligning.py:83-119.
-    `ids` (max_iter,4): explicit hypothesis samples; default = the reference's numpy-global-RNG draw."""
+    `ids` (max_iter,4): explicit hypothesis samples; otherwise sampling='reference' reproduces the reference's
+    numpy-global-RNG draw call by call (slow: 10,000 python-level np.random.choice calls), sampling='fast' draws the same
+    distribution vectorised."""
     if use_kdtree_for_eval:
         raise NotImplementedError('use_kdtree_for_eval=True is not built (the reference pipeline passes False, predicter.py:162)')
     if device is None:
@@ -35,7 +50,7 @@ def estimate9DTransform(source, target, PassThreshold, max_iter=1000, use_kdtree
     assert src.shape == dst.shape
     N = len(src)
     if ids is None:
-        ids = draw_hypothesis_ids(N, max_iter)
+        ids = draw_hypothesis_ids(N, max_iter) if sampling == 'reference' else draw_hypothesis_ids_fast(N, max_iter)
     ids = np.ascontiguousarray(ids, dtype=np.int32).reshape(-1, 4)
     H = len(ids)
     if H == 0:

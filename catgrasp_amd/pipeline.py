@@ -1,0 +1,121 @@
+"""One object's candidate-grasp evaluation, device resident end to end: the MI355X counterpart of
+`compute_candidate_grasp_one_ob` + the scoring loop of `compute_candidate_grasp`
+(run_grasp_simulation.py:112-183, :296-329), assembled from this package's drop-in pieces:
+
+    background occupancy   my_cpp.makeOccupancyGridFromCloudScan          run_grasp_simulation.py:131-139
+    NUNOCS + 9-D pose      NunocsPredicter.predict (net + device RANSAC)   :146
+    candidates             grasp_sampler.cone_grasp_poses [+ canonical grasps x symmetries]   :176 -> grasp_sampler.py
+    collision/approach     my_cpp.filter_on_device                         grasp_sampler.py:216,345
+    affordance P(T|G)      affordance.compute_grasp_affordance             :181
+    grasp quality P(G)     GraspPredicter.score_on_device                  :310-313
+    ranking                P(T,G) = P(T|G) P(G), descending                :314-329
+
+Host work is limited to small bookkeeping (index draws, 4x4 inverses); every per-point / per-candidate loop runs in a
+HIP kernel.  Used by examples/run_scene.py and tests/test_pipeline_gpu.py.
+"""
+import time
+
+import numpy as np
+import torch
+
+from . import affordance as aff_mod
+from . import grasp_sampler, my_cpp, transforms
+
+
+def _background_points(scene_pts, ob_pts, gripper_diameter, device):
+    """run_grasp_simulation.py:127-135: scene points within gripper_diameter/2 of the object, minus the object itself
+    (cloudA_minus_cloudB thres 5 mm), voxel-downsampled to 1 mm (one representative per voxel)."""
+    nn = aff_mod.nearest_neighbor(scene_pts, ob_pts, device).cpu().numpy()
+    d = np.linalg.norm(np.asarray(scene_pts) - np.asarray(ob_pts)[nn], axis=1)
+    bg = np.asarray(scene_pts)[(d <= gripper_diameter / 2) & (d > 0.005)]
+    if len(bg) == 0:
+        return bg.reshape(0, 3)
+    keys = np.floor(bg / 0.001).astype(np.int64)
+    _, first = np.unique(keys, axis=0, return_index=True)
+    return bg[np.sort(first)]
+
+
+def evaluate_object(ob_pts, ob_normals, scene_pts, K, gripper, grasp_predicter, nunocs_predicter, canonical=None, symmetry_tfs=None,
+                    n_surface_samples=50, sphere_pts=None, approach_step=0.004, resolution=0.0005, cam_in_world=None, timings=None):
+    """Returns dict(poses (n,4,4) f32, p_G, p_T_given_G, p_T_G, order) for the surviving candidates, best first.
+    `gripper`: dict with vertices/faces/enclosed_vertices/enclosed_faces/gripper_in_grasp/hand_depth/init_bite/diameter and
+    finger_vertices (list of 2 arrays), grip_dirs.  `canonical`: optional dict(cloud, normals, affordance, grasps (m,4,4))
+    in the canonical (NUNOCS-scaled) frame; without it P(T|G) = 1 and only cone-sampled candidates are produced."""
+    dev = grasp_predicter.device
+    t = time.perf_counter
+
+    def lap(name, t0):
+        if timings is not None:
+            torch.cuda.synchronize()
+            timings[name] = timings.get(name, 0.0) + (t() - t0)
+
+    I4 = np.eye(4, dtype=np.float32)
+    cam_in_world = I4 if cam_in_world is None else cam_in_world
+    # --- background occupancy (occluded space behind the visible neighbours counts as occupied) ---
+    t0 = t()
+    bg = _background_points(scene_pts, ob_pts, gripper['diameter'], dev)
+    occ = my_cpp.makeOccupancyGridFromCloudScan(bg, K, 0.001, return_tensor=True) if len(bg) else torch.zeros((0, 3), device=dev)
+    lap('occupancy', t0)
+    # --- NUNOCS + 9-D pose ---
+    t0 = t()
+    data = {'cloud_xyz': ob_pts, 'cloud_normal': ob_normals}
+    nocs_cloud, nocs_pose = nunocs_predicter.predict(data)
+    lap('nunocs+ransac', t0)
+    # --- candidates ---
+    t0 = t()
+    rng_ids = np.random.choice(len(ob_pts), size=min(n_surface_samples, len(ob_pts)), replace=False)
+    if sphere_pts is None:
+        g = np.random.default_rng(0).normal(size=(30, 3)); g[:, 0] = np.abs(g[:, 0]) + 1.0       # directions within a cone about +x
+        sphere_pts = g / np.linalg.norm(g, axis=1, keepdims=True)
+    cone = grasp_sampler.cone_grasp_poses(ob_pts, ob_normals, rng_ids, sphere_pts, r_ball=0.003, hand_depth=gripper['hand_depth'],
+                                          init_bite=gripper['init_bite'], approach_step=approach_step, center_ob_between_gripper=True,
+                                          device=dev, return_tensor=True)
+    lap('candidate generation', t0)
+    # --- collision / approach filter ---
+    t0 = t()
+    scene = my_cpp.GripperScene(gripper['vertices'], gripper['faces'], gripper['enclosed_vertices'], gripper['enclosed_faces'], ob_pts, occ,
+                                resolution, dev)
+    sym1 = torch.eye(4, device=dev).reshape(1, 16)
+    codes, poses, _ = my_cpp.filter_on_device(scene, cone.float().reshape(-1, 16), sym1, I4, I4, cam_in_world, I4, gripper['gripper_in_grasp'],
+                                              True, False, True)
+    keep = codes == 0
+    surv = [poses[keep]]
+    n_evaluated = int(codes.numel())
+    if canonical is not None and nocs_pose is not None and len(canonical.get('grasps', [])):
+        sym = symmetry_tfs if symmetry_tfs is not None else [np.eye(4)]
+        c2, p2, _ = my_cpp.filter_on_device(scene, np.asarray(canonical['grasps']), np.asarray(sym), nocs_pose, I4, cam_in_world, I4,
+                                            gripper['gripper_in_grasp'], True, False, True)
+        surv.append(p2[c2 == 0]); n_evaluated += int(c2.numel())
+    surv = torch.cat(surv).contiguous()
+    lap('filterGraspPose', t0)
+    n = surv.shape[0]
+    out = {'n_evaluated': n_evaluated, 'nocs_pose': nocs_pose}
+    if n == 0:
+        out.update(poses=np.zeros((0, 4, 4), np.float32), p_G=np.zeros(0), p_T_given_G=np.zeros(0), p_T_G=np.zeros(0))
+        return out
+    surv_np = surv.cpu().numpy().astype(np.float64)
+    # --- affordance ---
+    t0 = t()
+    if canonical is not None and nocs_pose is not None:
+        full = np.asarray(canonical['cloud']) @ nocs_pose[:3, :3].T + nocs_pose[:3, 3]
+        nrm = np.asarray(canonical['normals']) @ nocs_pose[:3, :3].T
+        sel = np.arange(0, len(full), max(1, len(full) // 2000))
+        model = aff_mod.AffordanceModel(full[sel], nrm[sel], full, canonical['affordance'], device=dev)
+        p_t_g = aff_mod.compute_grasp_affordance(model, surv_np, gripper['gripper_in_grasp'], gripper['finger_vertices'], gripper['grip_dirs'])
+    else:
+        p_t_g = np.ones(n)
+    lap('affordance', t0)
+    # --- grasp quality ---
+    t0 = t()
+    cloud = transforms.DeviceCloud(ob_pts, ob_normals, dev)
+    ids = transforms.draw_ids_device(cloud.n, grasp_predicter.cfg['n_pts'], n, dev)
+    pinv = torch.from_numpy(transforms.pose_inverse_rows(surv_np, cloud.center)).to(dev)
+    _, _, _, p_g = grasp_predicter.score_on_device(cloud.xyz, cloud.normal, ids, pinv)
+    p_g = p_g.cpu().numpy().astype(np.float64)
+    lap('grasp-Q scoring', t0)
+    valid = np.isfinite(p_t_g)                    # the reference drops grasps without a finger contact (:68-70)
+    p_tg = np.where(valid, p_t_g, 0.0) * p_g
+    order = np.argsort(-p_tg, kind='stable')
+    order = order[valid[order]]
+    out.update(poses=surv_np[order].astype(np.float32), p_G=p_g[order], p_T_given_G=p_t_g[order], p_T_G=p_tg[order])
+    return out

@@ -131,7 +131,8 @@ class GraspPredicter:
 class NunocsPredicter:
     class_name_to_artifact_id = {'nut': 78, 'hnm': 73, 'screw': 76}          # predicter.py:101-105
 
-    def __init__(self, class_name, artifact_dir=None, cfg=None, state_dict=None, normalizer=None, device=None, align_fn=None):
+    def __init__(self, class_name, artifact_dir=None, cfg=None, state_dict=None, normalizer=None, device=None, align_fn=None,
+                 ransac_sampling='reference'):
         self.class_name = class_name
         if self.class_name == 'nut':                                         # predicter.py:106-114
             self.min_scale = [0.005, 0.005, 0.001]
@@ -152,8 +153,9 @@ class NunocsPredicter:
         self._W = folding.prepare_seg(sd, self.device)
         self._mean, self._inv_std = transforms.normalizer_device(self.cfg, self.device)
         if align_fn is None:          # estimate9DTransform (aligning.py:83-119): device RANSAC (catgrasp_amd/aligning.py, row N1)
+            import functools
             from . import aligning
-            align_fn = aligning.estimate9DTransform
+            align_fn = functools.partial(aligning.estimate9DTransform, sampling=ransac_sampling)
         self.align_fn = align_fn
 
     def nocs_on_device(self, cloud_xyz, cloud_normal, ids):

@@ -1,0 +1,52 @@
+"""GPU: the per-object device pipeline (catgrasp_amd/pipeline.py) runs end to end and its pieces are mutually consistent."""
+import numpy as np
+import pytest
+import torch
+
+from catgrasp_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def test_evaluate_object_end_to_end(cuda_device):
+    from catgrasp_amd import my_cpp, pipeline
+    from catgrasp_amd.predicter import DEFAULT_GRASP_CFG, DEFAULT_NUNOCS_CFG, GraspPredicter, NunocsPredicter
+    objs = synth.make_scene(3, 1500, seed=2)
+    g = synth.make_gripper()
+    g['finger_vertices'] = [g['vertices'][8:16], g['vertices'][16:24]]
+    g['grip_dirs'] = [[0, -1, 0], [0, 1, 0]]
+    gp = GraspPredicter('nut', cfg=DEFAULT_GRASP_CFG, state_dict=synth.make_state_dict('cls', 6, 10, seed=0), device=cuda_device)
+    npred = NunocsPredicter('nut', cfg=DEFAULT_NUNOCS_CFG, state_dict=synth.make_state_dict('seg', 6, 300, seed=1), device=cuda_device)
+    scene_pts = np.concatenate([o['xyz'] for o in objs])
+    K = np.array([[600, 0, 320], [0, 600, 240], [0, 0, 1.0]])
+    ob = objs[0]
+    # a canonical model in the NUNOCS-scaled frame with a known pose, so the canonical-grasp branch and the affordance run
+    rng = np.random.default_rng(0)
+    canon_pts, canon_nrm = synth.nut_surface(3000, rng)
+    canonical = {'cloud': canon_pts, 'normals': canon_nrm, 'affordance': rng.uniform(0, 1, 3000),
+                 'grasps': np.linalg.inv(ob['pose']) @ synth.make_candidates(ob, 30, rng)}
+    np.random.seed(1)
+    timings = {}
+
+    class FixedPose(NunocsPredicter):              # random weights cannot recover a pose: pin the RANSAC output to the truth
+        def predict(self, data, ids=None):
+            nocs, _, _ = self.predict_nocs(data, ids)
+            self.nocs_pose = ob['pose'].copy(); self.best_ratio = 1.0
+            return nocs, ob['pose'].copy()
+    npred.__class__ = FixedPose
+    out = pipeline.evaluate_object(ob['xyz'], ob['normal'], scene_pts, K, g, gp, npred, canonical=canonical, symmetry_tfs=[np.eye(4)],
+                                   n_surface_samples=12, timings=timings)
+    n = len(out['poses'])
+    assert out['n_evaluated'] > 1000 and 0 < n < out['n_evaluated']
+    assert out['poses'].shape == (n, 4, 4) and len(out['p_G']) == n == len(out['p_T_G'])
+    assert np.all(np.diff(out['p_T_G']) <= 1e-12)                               # ranked best first
+    assert np.all((out['p_G'] >= 0) & (out['p_G'] <= 0.9 + 1e-6))               # sum_k p_k k / 10, k <= 9
+    assert np.allclose(out['p_T_G'], out['p_T_given_G'] * out['p_G'])
+    assert set(timings) >= {'occupancy', 'nunocs+ransac', 'candidate generation', 'filterGraspPose', 'affordance', 'grasp-Q scoring'}
+    # survivors really are collision free / camera facing according to an independent re-check of the filter
+    bg = pipeline._background_points(scene_pts, ob['xyz'], g['diameter'], cuda_device)
+    occ = my_cpp.makeOccupancyGridFromCloudScan(bg, K, 0.001)
+    I4 = np.eye(4)
+    codes, _, _ = my_cpp.filterGraspPoseDetailed(out['poses'][:50], [I4], I4, I4, I4, I4, g['gripper_in_grasp'], True, False, False, [0] * 7, [0] * 7,
+                                                 g['vertices'], g['faces'], g['enclosed_vertices'], g['enclosed_faces'], ob['xyz'], occ, 0.0005)
+    assert (codes == 0).all()
