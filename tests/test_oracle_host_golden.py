@@ -1,0 +1,119 @@
+"""CPU tests (no GPU): pin the HOST-side oracle restatements to the reference's own python code.
+tests/golden/host_golden.npz was produced by tests/golden/make_golden_host.py, which imports the real reference modules
+(dataset_grasp, dataset_nunocs, augmentations, Utils, meshpy.sdf / sdf_file, aligning, dexnet grasp_sampler) with inert
+stubs for the uninstallable packages they merely import, and runs their functions unmodified."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import aligning_ref, grasp_sampler_ref, sdf_ref
+from oracle import transforms_ref as tref
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'host_golden.npz')
+
+
+@pytest.fixture(scope='module')
+def g():
+    return np.load(GOLD)
+
+
+def test_grasp_dataset_transform(g):
+    """dataset_grasp.py:63-91, including the z>=0.1 mask, the numpy-global-RNG resample and the (x-mean)/(std+1e-15) step."""
+    xyz, nrm = g['grasp_xyz'], g['grasp_normal']
+    n_valid = int((xyz[:, 2] >= 0.1).sum())
+    assert n_valid == len(xyz) - 5
+    np.random.seed(3)
+    for i, pose in enumerate(g['grasp_poses']):
+        ids = tref.draw_ids(n_valid, 256)
+        out = tref.grasp_transform(xyz.copy(), nrm.copy(), pose, ids, g['grasp_mean'], g['grasp_std'])['input']
+        assert np.array_equal(out, g['grasp_input'][i])
+    np.random.seed(4)
+    ids = tref.draw_ids(n_valid, 2048)                       # fewer points than n_pts -> with replacement
+    out = tref.grasp_transform(xyz.copy(), nrm.copy(), g['grasp_poses'][0], ids)['input']
+    assert np.array_equal(out, g['grasp_input_replace'])
+
+
+def test_nunocs_dataset_transform_and_normalize_cloud(g):
+    """dataset_nunocs.py:38-65 + augmentations.py:66-75."""
+    xyz, nrm = g['grasp_xyz'], g['grasp_normal']
+    np.random.seed(5)
+    ids = tref.draw_ids(int((xyz[:, 2] >= 0.1).sum()), 512)
+    out = tref.nunocs_transform(xyz.copy(), nrm.copy(), ids)
+    assert np.array_equal(out['input'], g['nunocs_input'])
+    assert np.array_equal(out['keep_ids'], g['nunocs_keep_ids']) and np.array_equal(out['cloud_xyz_original'], g['nunocs_xyz_original'])
+    assert np.array_equal(tref.normalize_cloud(xyz[:50].copy()), g['normalize_cloud'])
+    assert np.array_equal(tref.to_homo(xyz[:4]), g['to_homo'])
+
+
+def test_utils_rotation_helpers(g):
+    """Utils.directionVecToRotation (Utils.py:262-290) and normalizeRotation (:172-178)."""
+    for v, R in zip(g['dir2rot_dirs'], g['dir2rot']):
+        assert np.allclose(grasp_sampler_ref.direction_vec_to_rotation(v.copy(), np.array([1., 0, 0])), R, atol=1e-15)
+    M = g['normrot_in']
+    ref = g['normrot']
+    mine = M.copy(); mine[:3, :3] = grasp_sampler_ref.normalize_rotation(M[:3, :3])
+    assert np.allclose(mine, ref, atol=1e-15)
+
+
+def test_sdf_lookups_and_file_reader(g, tmp_path):
+    """meshpy Sdf3D._signed_distance / _signed_distance_batch / is_any_points_inside (sdf.py:312-389), SdfFile._read_3d."""
+    data = g['sdf_data'].astype(np.float64)
+    coords = g['sdf_coords']
+    data64, _, _ = sdf_ref.box_sdf_grid([-0.01, -0.004, -0.007], [0.012, 0.006, 0.003], 0.001, 5)
+    assert np.allclose(sdf_ref.signed_distance(data64, coords.copy()), g['sdf_trilinear'], atol=1e-15)
+    assert np.array_equal(sdf_ref.signed_distance(data64, coords.copy(), fast=True), g['sdf_fast'])
+    assert np.array_equal(sdf_ref.signed_distance_batch(data.astype(np.float32), coords[None].astype(np.float32)), g['sdf_batch'])
+    for c, r in zip(g['sdf_inside_coords'], g['sdf_inside']):
+        assert sdf_ref.is_any_points_inside(data64, c) == bool(r)
+    p = os.path.join(tmp_path, 'box.sdf')
+    with open(p, 'wb') as f:
+        f.write(g['sdffile_text'].tobytes())
+    d, o, r = sdf_ref.read_sdf_file(p)
+    assert np.array_equal(d, g['sdffile_data']) and np.array_equal(o, g['sdffile_origin']) and r == g['sdffile_res'][0]
+
+
+def test_ransac_worker(g):
+    """aligning.estimate9DTransform_worker (aligning.py:33-81) with the exact 4-point affine standing in for OpenCV."""
+    src, dst, ids = g['ransac_src'], g['ransac_dst'], g['ransac_ids']
+    n_ok = 0
+    for k in range(len(ids)):
+        o = aligning_ref.worker(src[ids[k]], dst[ids[k]], src, dst, 0.003, np.array([0.05] * 3), np.array([0.005, 0.005, 0.001]), np.array([1.2] * 3))
+        if g['ransac_ratio'][k] < 0:
+            assert o is None
+        else:
+            assert o is not None and abs(o[0] / len(src) - g['ransac_ratio'][k]) < 1e-12
+            assert np.allclose(o[1], g['ransac_tf'][k], atol=1e-9)
+            n_ok += 1
+    assert n_ok > 5
+
+
+def test_cone_sampler(g):
+    """PointConeGraspSampler.sample_one_surface_point (grasp_sampler.py:225-298): same LAPACK eigenvectors here, so exact."""
+    s = grasp_sampler_ref.ConeSampler(r_ball=0.003, hand_depth=0.02, init_bite=0.005, approach_step=0.004)
+    pts, nrm = g['cone_pts'], g['cone_nrm']
+    for sid, blk in zip(g['cone_ids'], g['cone_poses']):
+        mine = s.sample_one_surface_point(pts[sid], nrm[sid], pts, nrm, g['cone_sphere'])
+        assert mine.shape == blk.shape
+        assert np.allclose(mine, blk, atol=1e-12)
+
+
+def test_finger_contact_area():
+    """pybullet_env/env_grasp.py:243-283 get_finger_contact_area (the real function, run through a functional open3d
+    stand-in) vs oracle/affordance_ref.py."""
+    from oracle import affordance_ref
+    a = np.load(os.path.join(os.path.dirname(GOLD), 'affordance_golden.npz'))
+    fingers = [a['finger0'], a['finger1']]
+    grip_dirs = [[0, -1, 0], [0, 1, 0]]
+    n_contact = 0
+    for k, P in enumerate(a['poses']):
+        cam_in_finger = np.linalg.inv(a['finger_mesh_in_grasp']) @ np.linalg.inv(P)
+        for i in range(2):
+            sp = affordance_ref.get_finger_contact_area(fingers[i], cam_in_finger, a['xyz'], grip_dirs[i], a['normal'], 0.005)
+            if a['counts'][k, i] < 0:
+                assert sp is None
+            else:
+                assert sp is not None and len(sp) == a['counts'][k, i]
+                assert np.allclose(sp.mean(axis=0), a['centroid'][k, i], atol=1e-12)
+                n_contact += 1
+    assert n_contact > 10
