@@ -117,3 +117,34 @@ def test_finger_contact_area():
                 assert np.allclose(sp.mean(axis=0), a['centroid'][k, i], atol=1e-12)
                 n_contact += 1
     assert n_contact > 10
+
+
+def test_predicter_glue_against_real_predict_batch():
+    """tests/golden/predicter_golden.npz holds the output of the REAL predicter.GraspPredicter.predict_batch (predicter.py:67-94)
+    and of the network + decode lines of NunocsPredicter.predict (:135-150) run on the CPU; the oracle chain
+    (transform restatement -> pointnet restatement -> softmax / argmax glue) must reproduce them."""
+    import torch
+    from catgrasp_amd import synth
+    from oracle import pointnet_ref as oref
+    p = np.load(os.path.join(os.path.dirname(GOLD), 'predicter_golden.npz'))
+    sd = synth.make_state_dict('cls', 6, 10, seed=77)
+    np.random.seed(123)
+    xs = []
+    for pose in p['poses']:
+        ids = tref.draw_ids(len(p['xyz']), 2048)
+        xs.append(tref.grasp_transform(p['xyz'].copy(), p['normal'].copy(), pose, ids, p['mean'], p['std'])['input'])
+    logits, _ = oref.pointnet_cls_forward(sd, torch.from_numpy(np.stack(xs)).float())
+    post = tref.predict_batch_post(logits.numpy())
+    assert np.abs(np.array([r[2] for r in post]) - p['grasp_probs']).max() < 2e-6
+    assert np.array_equal(np.array([r[0] for r in post]), p['grasp_labels'])
+    assert np.abs(np.array([r[1] for r in post]) - p['grasp_conf']).max() < 2e-6
+    sds = synth.make_state_dict('seg', 6, 300, seed=78)
+    np.random.seed(321)
+    ids = tref.draw_ids(len(p['xyz']), 8192)
+    tr = tref.nunocs_transform(p['xyz'].copy(), p['normal'].copy(), ids)
+    assert np.array_equal(tr['keep_ids'], p['nocs_keep_ids'])
+    lg, _ = oref.pointnet_seg_forward(sds, torch.from_numpy(tr['input'][None]).float())
+    coords, conf = tref.nunocs_decode(lg[0].numpy(), 100)
+    clear = p['nocs_top2_gap'] > 1e-4
+    assert clear.mean() > 0.99 and np.array_equal(coords[clear], p['nocs_cloud'][clear])
+    assert np.abs(conf[clear[:, 2]] - p['nocs_conf_z'][clear[:, 2]]).max() < 1e-5
