@@ -20,12 +20,14 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 // row of accumulator register r for lane l in a 32x32 MFMA tile
 __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
+// max over the 16 accumulator registers of a lane.  Written as max(max(m, a), b) chains so that every pair folds into one
+// v_max3_f32 (8 VALU ops per tile); the pointmlp files are compiled with -fno-honor-nans, which removes the per-operand
+// canonicalisation (v_max x, x) the IEEE maxnum lowering would otherwise insert for MFMA results.
 __device__ __forceinline__ float max16(const f32x16& c) {
-  float m0 = fmaxf(fmaxf(c[0], c[1]), fmaxf(c[2], c[3]));
-  float m1 = fmaxf(fmaxf(c[4], c[5]), fmaxf(c[6], c[7]));
-  float m2 = fmaxf(fmaxf(c[8], c[9]), fmaxf(c[10], c[11]));
-  float m3 = fmaxf(fmaxf(c[12], c[13]), fmaxf(c[14], c[15]));
-  return fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+  float m = fmaxf(fmaxf(c[0], c[1]), c[2]);
+#pragma unroll
+  for (int i = 3; i < 15; i += 2) m = fmaxf(fmaxf(m, c[i]), c[i + 1]);
+  return fmaxf(m, c[15]);
 }
 
 // float atomic max valid for any sign (buffer pre-filled with -inf)

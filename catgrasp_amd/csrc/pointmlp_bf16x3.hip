@@ -1,40 +1,47 @@
 // Split-precision variant of the fused per-point MLP chain + max-pool (see pointmlp.hip for the op sequence it
 // replaces: pointnet2.py:172-176, :210-214, :243-266).
 //
-// Every K>=64 contraction is evaluated as three bf16 MFMAs with f32 accumulation ("bf16x3"):
+// Every contraction is evaluated as three bf16 MFMAs with f32 accumulation ("bf16x3"):
 //     x = x_hi + x_lo,  w = w_hi + w_lo  (bf16 each, round-to-nearest-even; lo = bf16(x - x_hi))
-//     x.w ~= x_hi.w_hi + x_lo.w_hi + x_hi.w_lo          (dropped term x_lo.w_lo <= 2^-16 |x.w|)
+//     x.w ~= x_lo.w_hi + x_hi.w_lo + x_hi.w_hi          (dropped term x_lo.w_lo <= 2^-16 |x.w|)
 // on v_mfma_f32_32x32x16_bf16 (16x the f32-MFMA rate, so 16/3 = 5.3x per contraction).  Measured end-to-end
 // error on the grasp-Q logits is ~1e-5 (tests/test_pointnet_gpu.py), inside the 1e-4 parity bar.
 //
-// Layout: one workgroup = 8 waves owns one sample (or a slice of its point tiles).  A tile of 256 points is
-// carried through 6->64 (f32 VALU) -> [64->64] -> 64->128 -> 128->1024 inside LDS (148 KB, one workgroup per CU;
-// a 128-point / 4-wave geometry with two workgroups per CU is also instantiated).
-//  * Front layers are WAVE-PRIVATE: wave w takes rows [32w, 32w+32) of the tile through the whole chain with no
-//    workgroup barrier.  Its f32 scratch ([32][68] floats twice) aliases exactly its own 32 rows of the two
-//    bf16 images of the 128-wide activation (32 rows x 272 B == 32 x 68 floats), which it overwrites last.
-//  * The 128-wide activation lives in LDS split into bf16 hi / lo images ([256][136] each; row stride 272 B makes
-//    the ds_read_b128 fragment reads conflict-free).
-//  * In the 128->1024 layer wave w owns channel blocks [4w,4w+4) and ALL 8 row tiles, so each packed weight
-//    fragment is fetched from L2 exactly once per workgroup tile (10.7 B/clk/CU at full MFMA rate), and the max
-//    over points is a per-lane reduction over accumulator registers + one lane^32 swap.
+// Layout: one workgroup = 8 waves owns one sample (or a slice of its point tiles); a tile is 256 points; 160 KB LDS,
+// one workgroup per CU.
+//  * FRONT LAYERS (6->64 -> [64->64] -> 64->128) ARE WAVE-PRIVATE AND REGISTER-RESIDENT.  Wave w carries points
+//    [32w, 32w+32) of the tile through the chain TRANSPOSED: out^T = W . in^T, i.e. the weights are the MFMA A operand
+//    and the activations the B operand.  In the 32x32 accumulator layout a lane then holds ONE point (column) and 16
+//    channels (rows 8q + 4*(lane>>5) + 0..3), and the next layer's B fragment (8 consecutive channels of that point)
+//    is assembled from the lane's own registers plus one v_permlane32_swap with its partner lane (lane^32) per dword:
+//    no LDS round trip and no barrier between layers.  The first layer's K (6 inputs + a constant-1 bias row, padded to
+//    16) rides the same MFMA.
+//  * The 128-wide activation is written to LDS already split into bf16 hi / lo images ([256][136] each; row stride
+//    272 B makes the ds_read_b128 fragment reads of the next layer conflict-free), 8 bytes per store.
+//  * In the 128->1024 layer (points = A operand again) wave w owns channel blocks [4w,4w+4) and ALL 8 row tiles, so
+//    each packed weight fragment is fetched from L2 exactly once per workgroup tile (10.7 B/clk/CU at full MFMA rate),
+//    and the max over points is a per-lane reduction over accumulator registers + one lane^32 swap.
+//  * The operand fragments of the first layer and of the 64->64 layer (shared weights, or the per-sample feature
+//    transform split on the fly) are staged once per workgroup in the remaining 20 KB of LDS.
 #include "cg_common.hpp"
 #include "../../include/catgrasp_amd.h"
+#include "l3_asm.inc"
 
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int SH = 136;        // bf16 elements per row of the h2 hi / lo images
-constexpr int S64 = 68;        // floats per row of the f32 scratch tiles
-constexpr int XS = 8;
-// Two geometries: RT = 8 row tiles (256 points, 8 waves, 148 KB LDS, one workgroup per CU; the default) and RT = 4
-// (128 points, 4 waves, 78 KB, two workgroups per CU; measured 7 % slower: twice the weight traffic).  One wave per 32-row tile.
 template <int RT> struct Geo {
-  static constexpr int TP = 32 * RT;
+  static constexpr int TP = 32 * RT;        // points per tile, one wave per 32-point row tile
   static constexpr int NT = 64 * RT;
   static constexpr int NBW = 32 / RT;       // 32-channel blocks of the 1024-wide layer owned by each wave
-  static constexpr size_t LDS_BYTES = (size_t)2 * TP * SH * 2 + 1024 * 4 + (size_t)TP * XS * 4;
+  // h2 hi/lo images + running max + first-layer fragments [2][2][64] + mid-layer fragments [2][4][2][64] (16 B each)
+  static constexpr size_t LDS_BYTES = (size_t)2 * TP * SH * 2 + 1024 * 4 + 256 * 16 + 1024 * 16;
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
 
 struct ArgsB {
@@ -52,6 +59,12 @@ struct ArgsB {
 __device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
+// bf16x3 product block: c += A.B with A = ah + al, B = bh + bl (small terms first)
+__device__ __forceinline__ f32x16 mfma3(bf16x8 ah, bf16x8 al, bf16x8 bh, bf16x8 bl, f32x16 c) {
+  c = mfma_bf16(ah, bl, c);
+  c = mfma_bf16(al, bh, c);
+  return mfma_bf16(ah, bh, c);
+}
 
 __device__ __forceinline__ void split8(const f32x4& v0, const f32x4& v1, bf16x8& hi, bf16x8& lo) {
 #pragma unroll
@@ -61,18 +74,67 @@ __device__ __forceinline__ void split8(const f32x4& v0, const f32x4& v1, bf16x8&
   }
 }
 
+// two floats -> packed bf16 pair of the high parts and packed pair of the residuals (v_cvt_pk_bf16_f32 x2)
+__device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
+  const bf16x2 h = {(__bf16)a, (__bf16)b};
+  hi = __builtin_bit_cast(unsigned, h);
+  const float ha = __uint_as_float(hi << 16), hb = __uint_as_float(hi & 0xffff0000u);
+  const bf16x2 l = {(__bf16)(a - ha), (__bf16)(b - hb)};
+  lo = __builtin_bit_cast(unsigned, l);
+}
+
+// One 32-channel x 32-point accumulator tile (lane = point l&31; register r = channel 8*(r>>2) + 4*(l>>5) + (r&3)) ->
+// the two 16-deep B fragments (hi and lo images) the next layer consumes: lane (p, h) needs channels 16*kc + 8*h + 0..7.
+// Quads (0,1) feed kc = 0 and (2,3) feed kc = 1; v_permlane32_swap exchanges the upper half of the even quad with the
+// lower half of the odd quad, which lands exactly the partner lane's four channels next to the lane's own four.
+__device__ __forceinline__ void acts_to_frags(const f32x16& c, bf16x8& h0, bf16x8& l0, bf16x8& h1, bf16x8& l1) {
+  unsigned H[4][2], L[4][2];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    split2(c[4 * q], c[4 * q + 1], H[q][0], L[q][0]);
+    split2(c[4 * q + 2], c[4 * q + 3], H[q][1], L[q][1]);
+  }
+#pragma unroll
+  for (int q = 0; q < 4; q += 2) {
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+      u32x2 r = __builtin_amdgcn_permlane32_swap(H[q][d], H[q + 1][d], false, false);
+      H[q][d] = r[0]; H[q + 1][d] = r[1];
+      r = __builtin_amdgcn_permlane32_swap(L[q][d], L[q + 1][d], false, false);
+      L[q][d] = r[0]; L[q + 1][d] = r[1];
+    }
+  }
+  h0 = __builtin_bit_cast(bf16x8, (u32x4){H[0][0], H[0][1], H[1][0], H[1][1]});
+  l0 = __builtin_bit_cast(bf16x8, (u32x4){L[0][0], L[0][1], L[1][0], L[1][1]});
+  h1 = __builtin_bit_cast(bf16x8, (u32x4){H[2][0], H[2][1], H[3][0], H[3][1]});
+  l1 = __builtin_bit_cast(bf16x8, (u32x4){L[2][0], L[2][1], L[3][0], L[3][1]});
+}
+
+// accumulator tile initialised with the per-channel bias of channel block nb (channels = accumulator rows)
+__device__ __forceinline__ f32x16 bias_tile(const float* bias, int nb, int lhi) {
+  f32x16 c;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const f32x4 v = *(const f32x4*)(bias + nb * 32 + 8 * q + 4 * lhi);
+    c[4 * q] = v[0]; c[4 * q + 1] = v[1]; c[4 * q + 2] = v[2]; c[4 * q + 3] = v[3];
+  }
+  return c;
+}
+
+__device__ __forceinline__ f32x16 relu16(f32x16 c) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) c[r] = fmaxf(c[r], 0.f);
+  return c;
+}
+
 // packed split weights: Wp[nb][kc][2 (hi,lo)][lane][8] bf16
 __device__ __forceinline__ void load_b(const unsigned short* wp, int nb, int kc, int nkc, int lane, bf16x8& bhi, bf16x8& blo) {
   const bf16x8* p = (const bf16x8*)wp + ((size_t)(nb * nkc + kc) * 2) * 64 + lane;
   bhi = p[0]; blo = p[64];
 }
 
-// LDS accesses of one wave execute in order; this only stops the COMPILER from reordering the aliased
-// (float scratch vs bf16 image) accesses across a phase boundary.
-__device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-
 // An opaque zero: added to the (tile-invariant) front-layer weight pointers inside the tile loop so the compiler
-// does not hoist 48 KB of weight-fragment loads out of the loop and spill them.
+// does not hoist 32 KB of weight-fragment loads out of the loop and spill them.
 __device__ __forceinline__ int opaque_zero() { int z; asm volatile("s_mov_b32 %0, 0" : "=s"(z)); return z; }
 
 template <int MID, int RT>
@@ -82,7 +144,8 @@ __global__ __launch_bounds__(64 * RT, 2) void pointmlp_max_bf16x3_kernel(ArgsB a
   __bf16* h2hi = (__bf16*)smem_raw;
   __bf16* h2lo = h2hi + TP * SH;
   float* rmax = (float*)(h2lo + TP * SH);
-  float* xs = rmax + 1024;
+  bf16x8* w1f = (bf16x8*)(rmax + 1024);     // [nb 2][hi|lo][lane]
+  bf16x8* wmf = w1f + 256;                  // [nb 2][kc 4][hi|lo][lane]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -94,40 +157,61 @@ __global__ __launch_bounds__(64 * RT, 2) void pointmlp_max_bf16x3_kernel(ArgsB a
   const int t_begin = (int)(((long)ntiles * split) / a.nsplit);
   const int t_end = (int)(((long)ntiles * (split + 1)) / a.nsplit);
 
-  // wave-private views: f32 scratch aliasing this wave's 32 rows of the hi / lo images, and its staged points
-  float* hA = (float*)(h2hi + w * 32 * SH);
-  float* hB = (float*)(h2lo + w * 32 * SH);
-  float* xw = xs + w * 32 * XS;
-
+  // ---- once per workgroup: running max, first-layer fragments (W1 | b1 as the k = 6 column), mid-layer fragments
   for (int i = tid; i < 1024; i += NT) rmax[i] = -INFINITY;
-
-  float w1r[6], b1r;     // first layer: lane = output channel
-#pragma unroll
-  for (int j = 0; j < 6; ++j) w1r[j] = a.w1[lane * 6 + j];
-  b1r = a.b1[lane];
+  for (int i = tid; i < 128; i += NT) {
+    const int nb = i >> 6, ln = i & 63, row = nb * 32 + (ln & 31);
+    f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
+    if ((ln >> 5) == 0) {
+      const float* wr = a.w1 + row * 6;
+      v0 = f32x4{wr[0], wr[1], wr[2], wr[3]};
+      v1 = f32x4{wr[4], wr[5], a.b1[row], 0.f};
+    }
+    bf16x8 hi, lo;
+    split8(v0, v1, hi, lo);
+    w1f[(nb * 2) * 64 + ln] = hi;
+    w1f[(nb * 2 + 1) * 64 + ln] = lo;
+  }
+  if (MID == 1) {
+    for (int i = tid; i < 1024; i += NT) wmf[i] = ((const bf16x8*)a.wm)[i];
+  }
+  if (MID == 2) {   // t64 is stored TRANSPOSED (Tt[n][k] = T[k][n]): a lane's 8 consecutive k are two 16-byte loads
+    for (int i = tid; i < 512; i += NT) {
+      const int ln = i & 63, kc = (i >> 6) & 3, nb = i >> 8;
+      const float* tp = a.t64 + (size_t)b * 4096 + (nb * 32 + (ln & 31)) * 64 + kc * 16 + (ln >> 5) * 8;
+      bf16x8 hi, lo;
+      split8(*(const f32x4*)tp, *(const f32x4*)(tp + 4), hi, lo);
+      wmf[((nb * 4 + kc) * 2) * 64 + ln] = hi;
+      wmf[((nb * 4 + kc) * 2 + 1) * 64 + ln] = lo;
+    }
+  }
   float t3r[9];
   if (a.t3) {
 #pragma unroll
     for (int j = 0; j < 9; ++j) t3r[j] = a.t3[b * 9 + j];
   }
   const float* xb = a.x + (size_t)b * a.N * 6;
+  // LDS byte addresses of this lane's A-fragment row in the hi / lo images (generic -> LDS address = low 32 bits)
+  const unsigned ahi_addr = (unsigned)(uintptr_t)(h2hi + l31 * SH + lhi * 8);
+  const unsigned alo_addr = (unsigned)(uintptr_t)(h2lo + l31 * SH + lhi * 8);
+  u32x4 wxh, wxl;          // weight fragments (hi / lo) of the wave's next channel block, k chunk 0
+  {
+    const u32x4* p = (const u32x4*)a.w3 + (size_t)((w * NBW * 8) * 2) * 64 + lane;
+    wxh = p[0]; wxl = p[64];
+  }
+  __syncthreads();
 
   for (int tile = t_begin; tile < t_end; ++tile) {
-    __syncthreads();   // the previous tile's L3 reads of the h2 images (and the rmax init) are complete
-#ifdef ABL_NO_FRONT
-    if (tile == t_begin)
-#endif
-    {
-    // ================= front layers, wave-private: rows [32w, 32w+32) =================
+    // ================= front layers, wave-private and register-resident: points [32w, 32w+32) =================
     const int oz = opaque_zero();
-    const unsigned short* wm_t = a.wm + oz;
     const unsigned short* w2_t = a.w2 + oz;
-    const float* t64_t = a.t64 + oz;
-    if (lane < 32) {
-      int p = tile * TP + w * 32 + lane;
-      if (p >= a.N) p = a.N - 1;          // replicate the last point: max-pool is idempotent
+    const float* b2_t = a.b2 + oz;
+    const int pt = tile * TP + w * 32 + l31;
+    bf16x8 fh[4], fl[4];          // the activation as B fragments (hi / lo), 4 chunks of 16 channels
+    {
+      const int p = pt < a.N ? pt : a.N - 1;       // replicate the last point: max-pool is idempotent
       const f32x2* src = (const f32x2*)(xb + (size_t)p * 6);
-      f32x2 v0 = src[0], v1 = src[1], v2 = src[2];
+      const f32x2 v0 = src[0], v1 = src[1], v2 = src[2];
       float px = v0[0], py = v0[1], pz = v1[0];
       if (a.t3) {
         const float qx = px * t3r[0] + py * t3r[3] + pz * t3r[6];
@@ -135,163 +219,103 @@ __global__ __launch_bounds__(64 * RT, 2) void pointmlp_max_bf16x3_kernel(ArgsB a
         const float qz = px * t3r[2] + py * t3r[5] + pz * t3r[8];
         px = qx; py = qy; pz = qz;
       }
-      *(f32x4*)(xw + lane * XS) = f32x4{px, py, pz, v1[1]};
-      *(f32x4*)(xw + lane * XS + 4) = f32x4{v2[0], v2[1], 0.f, 0.f};
+      f32x4 q0 = {px, py, pz, v1[1]}, q1 = {v2[0], v2[1], 1.f, 0.f};     // k = 6 carries the bias
+      if (lhi) { q0 = f32x4{0.f, 0.f, 0.f, 0.f}; q1 = q0; }              // k = 8..15: padding
+      bf16x8 xh, xl;
+      split8(q0, q1, xh, xl);
+      // L0: 6(+1) -> 64
+      const f32x16 z = {0};
+      f32x16 c0 = mfma3(w1f[lane], w1f[64 + lane], xh, xl, z);
+      f32x16 c1 = mfma3(w1f[128 + lane], w1f[192 + lane], xh, xl, z);
+      acts_to_frags(relu16(c0), fh[0], fl[0], fh[1], fl[1]);
+      acts_to_frags(relu16(c1), fh[2], fl[2], fh[3], fl[3]);
     }
-    wave_lds_fence();
-    {  // L0: 6 -> 64 on the VALU, lane = channel, loop over the wave's 32 points (broadcast LDS reads)
-      float* dst = (MID == 0) ? hB : hA;
-#pragma unroll 8
-      for (int p = 0; p < 32; ++p) {
-        const f32x4 q0 = *(const f32x4*)(xw + p * XS);
-        const f32x2 q1 = *(const f32x2*)(xw + p * XS + 4);
-        float v = b1r;
-        v = fmaf(w1r[0], q0[0], v); v = fmaf(w1r[1], q0[1], v); v = fmaf(w1r[2], q0[2], v);
-        v = fmaf(w1r[3], q0[3], v); v = fmaf(w1r[4], q1[0], v); v = fmaf(w1r[5], q1[1], v);
-        dst[p * S64 + lane] = fmaxf(v, 0.f);
-      }
-    }
-    wave_lds_fence();
     if (MID != 0) {  // mid: 64 -> 64 (shared conv+BN+ReLU, or the per-sample 64x64 feature transform)
-      f32x16 c0 = {0}, c1 = {0};
-      const float* arow = hA + l31 * S64 + lhi * 8;
+      f32x16 c0, c1;
+      if (MID == 1) { c0 = bias_tile(a.bm + oz, 0, lhi); c1 = bias_tile(a.bm + oz, 1, lhi); }
+      else { c0 = f32x16{0}; c1 = f32x16{0}; }
 #pragma unroll
       for (int kc = 0; kc < 4; ++kc) {
-        bf16x8 ahi, alo, b0h, b0l, b1h, b1l;
-        split8(*(const f32x4*)(arow + kc * 16), *(const f32x4*)(arow + kc * 16 + 4), ahi, alo);
-        if (MID == 1) {
-          load_b(wm_t, 0, kc, 4, lane, b0h, b0l);
-          load_b(wm_t, 1, kc, 4, lane, b1h, b1l);
-        } else {
-          // t64 is stored TRANSPOSED (Tt[n][k] = T[k][n]): a lane's 8 consecutive k are two 16-byte loads
-          const float* tp = t64_t + (size_t)b * 4096 + l31 * 64 + kc * 16 + lhi * 8;
-          split8(*(const f32x4*)tp, *(const f32x4*)(tp + 4), b0h, b0l);
-          tp += 32 * 64;
-          split8(*(const f32x4*)tp, *(const f32x4*)(tp + 4), b1h, b1l);
-        }
-        c0 = mfma_bf16(alo, b0h, c0); c1 = mfma_bf16(alo, b1h, c1);
-        c0 = mfma_bf16(ahi, b0l, c0); c1 = mfma_bf16(ahi, b1l, c1);
-        c0 = mfma_bf16(ahi, b0h, c0); c1 = mfma_bf16(ahi, b1h, c1);
+        const bf16x8* f0 = wmf + (kc * 2) * 64 + lane;
+        const bf16x8* f1 = wmf + ((4 + kc) * 2) * 64 + lane;
+        const bf16x8 a0h = f0[0], a0l = f0[64], a1h = f1[0], a1l = f1[64];
+        c0 = mfma_bf16(a0h, fl[kc], c0); c1 = mfma_bf16(a1h, fl[kc], c1);
+        c0 = mfma_bf16(a0l, fh[kc], c0); c1 = mfma_bf16(a1l, fh[kc], c1);
+        c0 = mfma_bf16(a0h, fh[kc], c0); c1 = mfma_bf16(a1h, fh[kc], c1);
       }
+      if (MID == 1) { c0 = relu16(c0); c1 = relu16(c1); }
+      if (MID == 2 && a.pointfeat && pt < a.N) {
+        float* pf = a.pointfeat + ((size_t)b * a.N + pt) * 64 + 4 * lhi;
 #pragma unroll
-      for (int nb = 0; nb < 2; ++nb) {
-        const int col = nb * 32 + l31;
-        const float bias = (MID == 1) ? a.bm[col] : 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = acc_row(r, lane);
-          float v = (nb ? c1[r] : c0[r]) + bias;
-          if (MID == 1) v = fmaxf(v, 0.f);
-          hB[row * S64 + col] = v;
-          if (MID == 2 && a.pointfeat) {
-            const int p = tile * TP + w * 32 + row;
-            if (p < a.N) a.pointfeat[((size_t)b * a.N + p) * 64 + col] = v;
-          }
+        for (int q = 0; q < 4; ++q) {
+          *(f32x4*)(pf + 8 * q) = f32x4{c0[4 * q], c0[4 * q + 1], c0[4 * q + 2], c0[4 * q + 3]};
+          *(f32x4*)(pf + 32 + 8 * q) = f32x4{c1[4 * q], c1[4 * q + 1], c1[4 * q + 2], c1[4 * q + 3]};
         }
       }
-      wave_lds_fence();
+      acts_to_frags(c0, fh[0], fl[0], fh[1], fl[1]);
+      acts_to_frags(c1, fh[2], fl[2], fh[3], fl[3]);
     }
-    {  // L2: 64 -> 128.  All A fragments are pulled into registers first: the result overwrites the scratch rows.
-      bf16x8 ah[4], al[4];
-      const float* arow = hB + l31 * S64 + lhi * 8;
+    __syncthreads();   // the previous tile's L3 reads of the h2 images are complete
+    {  // L2: 64 -> 128, two channel blocks at a time, written split into the hi / lo images
+      const int row = w * 32 + l31;
 #pragma unroll
-      for (int kc = 0; kc < 4; ++kc) split8(*(const f32x4*)(arow + kc * 16), *(const f32x4*)(arow + kc * 16 + 4), ah[kc], al[kc]);
-      wave_lds_fence();
-#pragma unroll
-      for (int np = 0; np < 2; ++np) {       // two channel blocks at a time
-        f32x16 c0 = {0}, c1 = {0};
+      for (int np = 0; np < 2; ++np) {
+        f32x16 c0 = bias_tile(b2_t, np * 2, lhi), c1 = bias_tile(b2_t, np * 2 + 1, lhi);
 #pragma unroll
         for (int kc = 0; kc < 4; ++kc) {
-          bf16x8 b0h, b0l, b1h, b1l;
-          load_b(w2_t, np * 2, kc, 4, lane, b0h, b0l);
-          load_b(w2_t, np * 2 + 1, kc, 4, lane, b1h, b1l);
-          c0 = mfma_bf16(al[kc], b0h, c0); c1 = mfma_bf16(al[kc], b1h, c1);
-          c0 = mfma_bf16(ah[kc], b0l, c0); c1 = mfma_bf16(ah[kc], b1l, c1);
-          c0 = mfma_bf16(ah[kc], b0h, c0); c1 = mfma_bf16(ah[kc], b1h, c1);
+          bf16x8 a0h, a0l, a1h, a1l;
+          load_b(w2_t, np * 2, kc, 4, lane, a0h, a0l);
+          load_b(w2_t, np * 2 + 1, kc, 4, lane, a1h, a1l);
+          c0 = mfma_bf16(a0h, fl[kc], c0); c1 = mfma_bf16(a1h, fl[kc], c1);
+          c0 = mfma_bf16(a0l, fh[kc], c0); c1 = mfma_bf16(a1l, fh[kc], c1);
+          c0 = mfma_bf16(a0h, fh[kc], c0); c1 = mfma_bf16(a1h, fh[kc], c1);
         }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          const int col = (np * 2 + h) * 32 + l31;
-          const float bias = a.b2[col];
+          const f32x16 c = relu16(h ? c1 : c0);
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int row = w * 32 + acc_row(r, lane);
-            const float v = fmaxf((h ? c1[r] : c0[r]) + bias, 0.f);
-            const __bf16 hv = (__bf16)v;
-            h2hi[row * SH + col] = hv;
-            h2lo[row * SH + col] = (__bf16)(v - (float)hv);
+          for (int q = 0; q < 4; ++q) {
+            unsigned h0, l0, h1, l1;
+            split2(c[4 * q], c[4 * q + 1], h0, l0);
+            split2(c[4 * q + 2], c[4 * q + 3], h1, l1);
+            const int off = row * SH + (np * 2 + h) * 32 + 8 * q + 4 * lhi;
+            *(u32x2*)(h2hi + off) = u32x2{h0, h1};
+            *(u32x2*)(h2lo + off) = u32x2{l0, l1};
           }
         }
       }
-    }
     }
     __syncthreads();
-#ifndef ABL_NO_L3
     // ================= L3: 128 -> 1024 + running max.  wave w owns channel blocks [4w, 4w+4) =================
-    // Two-stage software pipeline per 16-deep k chunk: while the 12 MFMAs of one half of the row tiles run, the LDS
-    // reads of the other half (and the L2 weight fetch of the next chunk) are in flight.
-    {
-      constexpr int G = 2;                 // row tiles per pipeline stage
-      constexpr int NST = RT / G;          // stages per k chunk
-      const __bf16* ahi_base = h2hi + l31 * SH + lhi * 8;
-      const __bf16* alo_base = h2lo + l31 * SH + lhi * 8;
-      for (int q = 0; q < NBW; ++q) {
-        const int nb = w * NBW + q;
-        f32x16 c[RT];
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) c[rt] = f32x16{0};
-        bf16x8 bh[2], bl[2], sh[2][G], sl[2][G];
-        load_b(a.w3, nb, 0, 8, lane, bh[0], bl[0]);
-#pragma unroll
-        for (int r = 0; r < G; ++r) {
-          sh[0][r] = *(const bf16x8*)(ahi_base + r * 32 * SH);
-          sl[0][r] = *(const bf16x8*)(alo_base + r * 32 * SH);
-        }
-#pragma unroll
-        for (int kc = 0; kc < 8; ++kc) {
-          const int cur = kc & 1, nxt = cur ^ 1;
-          if (kc < 7) load_b(a.w3, nb, kc + 1, 8, lane, bh[nxt], bl[nxt]);
-#pragma unroll
-          for (int st = 0; st < NST; ++st) {
-            const int sc = st & 1, sn = sc ^ 1;
-            // prefetch the next stage's A fragments (next row-tile group, or the first group of the next k chunk)
-            const int nst = (st + 1) % NST, nkc = (st + 1 == NST) ? kc + 1 : kc;
-            if (nkc < 8) {
-#pragma unroll
-              for (int r = 0; r < G; ++r) {
-                sh[sn][r] = *(const bf16x8*)(ahi_base + (nst * G + r) * 32 * SH + nkc * 16);
-                sl[sn][r] = *(const bf16x8*)(alo_base + (nst * G + r) * 32 * SH + nkc * 16);
-              }
-            }
-#pragma unroll
-            for (int r = 0; r < G; ++r) c[st * G + r] = mfma_bf16(sl[sc][r], bh[cur], c[st * G + r]);
-#pragma unroll
-            for (int r = 0; r < G; ++r) c[st * G + r] = mfma_bf16(sh[sc][r], bl[cur], c[st * G + r]);
-#pragma unroll
-            for (int r = 0; r < G; ++r) c[st * G + r] = mfma_bf16(sh[sc][r], bh[cur], c[st * G + r]);
-            // interleave: M M D M D M D M D M  (6 MFMAs of this stage, 4 LDS fragment reads of the next)
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          }
-        }
-        float m = max16(c[0]);
-#pragma unroll
-        for (int rt = 1; rt < RT; ++rt) m = fmaxf(m, max16(c[rt]));
-        m = fmaxf(m, __shfl_xor(m, 32));
-        if (lane < 32) {
-          const int ch = nb * 32 + lane;
-          rmax[ch] = fmaxf(rmax[ch], m);
-        }
+    // The 192-MFMA stream of one channel block is hand-scheduled assembly (gen_l3_asm.py -> l3_asm.inc): exact wait
+    // counts, A fragments through a 3-deep register ring, weight fragments double buffered with the next block's first
+    // fragments (wxh / wxl) already in flight when the block ends.
+#pragma unroll 1
+    for (int q = 0; q < NBW; ++q) {
+      const int nb = w * NBW + q;
+      const int nb_next = (q + 1 < NBW) ? nb + 1 : w * NBW;
+      unsigned voff = (unsigned)((nb * 8 * 2) * 64 + lane) * 16u;
+      const unsigned vnext = (unsigned)((nb_next * 8 * 2) * 64 + lane) * 16u;
+      f32x16 c0, c1, c2, c3, c4, c5, c6, c7;
+      u32x4 r0ah, r0al, r0bh, r0bl, r1ah, r1al, r1bh, r1bl, r2ah, r2al, r2bh, r2bl, wyh, wyl;
+      asm volatile(CG_L3_BLOCK_ASM
+                   : [c0] "=&v"(c0), [c1] "=&v"(c1), [c2] "=&v"(c2), [c3] "=&v"(c3), [c4] "=&v"(c4), [c5] "=&v"(c5),
+                     [c6] "=&v"(c6), [c7] "=&v"(c7), [r0ah] "=&v"(r0ah), [r0al] "=&v"(r0al), [r0bh] "=&v"(r0bh),
+                     [r0bl] "=&v"(r0bl), [r1ah] "=&v"(r1ah), [r1al] "=&v"(r1al), [r1bh] "=&v"(r1bh), [r1bl] "=&v"(r1bl),
+                     [r2ah] "=&v"(r2ah), [r2al] "=&v"(r2al), [r2bh] "=&v"(r2bh), [r2bl] "=&v"(r2bl), [yh] "=&v"(wyh),
+                     [yl] "=&v"(wyl), [xh] "+v"(wxh), [xl] "+v"(wxl), [voff] "+v"(voff)
+                   : [vnext] "v"(vnext), [ahi] "v"(ahi_addr), [alo] "v"(alo_addr), [wbase] "s"(a.w3)
+                   : "memory");
+      float m = fmaxf(fmaxf(max16(c0), max16(c1)), max16(c2));
+      m = fmaxf(fmaxf(m, max16(c3)), max16(c4));
+      m = fmaxf(fmaxf(m, max16(c5)), max16(c6));
+      m = fmaxf(m, max16(c7));
+      m = fmaxf(m, __shfl_xor(m, 32));
+      if (lane < 32) {
+        const int ch = nb * 32 + lane;
+        rmax[ch] = fmaxf(rmax[ch], m);
       }
     }
-#endif
   }
   __syncthreads();
   if (t_end > t_begin) {
@@ -331,7 +355,8 @@ extern "C" int cg_pointmlp_max_bf16x3(const float* x, int B, int N, const float*
                                       const unsigned short* w2_split, const float* b2, const unsigned short* w3_split,
                                       const float* b3, int relu3, int nsplit, int tile_points, float* out, float* pointfeat,
                                       void* stream) {
-  if (B < 0 || N <= 0 || mid_mode < 0 || mid_mode > 2 || (tile_points != 128 && tile_points != 256)) return CG_ERR_ARG;
+  if (B < 0 || N <= 0 || mid_mode < 0 || mid_mode > 2) return CG_ERR_ARG;
+  if (tile_points != 256) return CG_ERR_UNSUPPORTED;      // one geometry: 256-point tiles, 8 waves, one workgroup per CU
   if (B == 0) return CG_OK;
   if (!x || !w1 || !b1 || !w2_split || !b2 || !w3_split || !b3 || !out) return CG_ERR_ARG;
   if (mid_mode == 1 && (!wm_split || !bm)) return CG_ERR_ARG;
@@ -346,12 +371,7 @@ extern "C" int cg_pointmlp_max_bf16x3(const float* x, int B, int N, const float*
     hipLaunchKernelGGL(fill_kernel_b, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, out, n, -INFINITY);
   }
   ArgsB a{x, B, N, t3, w1, b1, wm_split, bm, t64, w2_split, b2, w3_split, b3, relu3, nsplit, out, pointfeat};
-  if (tile_points == 256) {
-    if (mid_mode == 0) return launch<0, 8>(a, s);
-    if (mid_mode == 1) return launch<1, 8>(a, s);
-    return launch<2, 8>(a, s);
-  }
-  if (mid_mode == 0) return launch<0, 4>(a, s);
-  if (mid_mode == 1) return launch<1, 4>(a, s);
-  return launch<2, 4>(a, s);
+  if (mid_mode == 0) return launch<0, 8>(a, s);
+  if (mid_mode == 1) return launch<1, 8>(a, s);
+  return launch<2, 8>(a, s);
 }

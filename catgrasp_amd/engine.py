@@ -17,7 +17,7 @@ from . import ops
 # 'f32'   : exact-f32 MFMA kernels (default; bitwise an fmaf chain per dot product)
 # 'bf16x3': split-bf16 MFMA kernels for the per-point MLP chain (3 bf16 MFMAs per product block, f32 accumulate)
 PRECISION = os.environ.get('CATGRASP_AMD_PRECISION', 'f32')
-TILE_POINTS = int(os.environ.get('CATGRASP_AMD_TILE_POINTS', '256'))   # bf16x3 kernel geometry: 256 or 128 points per workgroup tile
+TILE_POINTS = 256   # bf16x3 kernel geometry: points per workgroup tile (8 waves, one workgroup per CU)
 
 
 def set_precision(p):

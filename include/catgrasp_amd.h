@@ -44,11 +44,12 @@ int cg_pointmlp_max(const float* x, int B, int N, const float* t3, const float* 
                     const float* w2_packed, const float* b2, const float* w3_packed, const float* b3,
                     int relu3, int nsplit, float* out, float* pointfeat, void* stream);
 
-/* Split-precision ("bf16x3") variant of cg_pointmlp_max: every K>=64 contraction is three bf16 MFMAs with f32
- * accumulation (x_hi.w_hi + x_lo.w_hi + x_hi.w_lo); logits agree with the exact-f32 path to ~1e-5.
+/* Split-precision ("bf16x3") variant of cg_pointmlp_max: every contraction is three bf16 MFMAs with f32
+ * accumulation (x_lo.w_hi + x_hi.w_lo + x_hi.w_hi); logits agree with the exact-f32 path to ~1e-5.
  * Weights are split on the host (folding.pack_b_bf16x3): Wp[nb][kc][2 (hi,lo)][lane][8] bf16 with
- * element e of lane l = W[nb*32 + (l&31)][kc*16 + (l>>5)*8 + e].  tile_points: 256 (8 waves, one workgroup per CU)
- * or 128 (4 waves, two workgroups per CU whose phases overlap).  Other arguments as cg_pointmlp_max. */
+ * element e of lane l = W[nb*32 + (l&31)][kc*16 + (l>>5)*8 + e].  tile_points: points per workgroup tile; must be 256
+ * (8 waves, one workgroup per CU; other values return CG_ERR_UNSUPPORTED).  w1 / b1 stay plain f32 (split in the
+ * kernel).  Other arguments as cg_pointmlp_max. */
 int cg_pointmlp_max_bf16x3(const float* x, int B, int N, const float* t3, const float* w1, const float* b1,
                            int mid_mode, const unsigned short* wm_split, const float* bm, const float* t64,
                            const unsigned short* w2_split, const float* b2, const unsigned short* w3_split,

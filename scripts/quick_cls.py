@@ -11,8 +11,6 @@ W = folding.prepare_cls(sd, dev)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 if len(sys.argv) > 2:
     engine.PRECISION = sys.argv[2]
-if len(sys.argv) > 3:
-    engine.TILE_POINTS = int(sys.argv[3])
 x = (torch.randn(B, 2048, 6) * 0.5).to(dev)
 for _ in range(2):
     engine.cls_forward(W, x)
