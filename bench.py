@@ -31,8 +31,8 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0                          # MI355X_MICROARCH.md: b
 # HBM bytes per candidate of the encoder-pass kernel from the PMC passes in profiles/r1_pmc_pointmlp.csv
 # (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate runs, B=4096): 2*FETCH_SIZE (gfx950 correction for wide
 # coalesced reads, MI355X_MICROARCH.md §HBM) + WRITE_SIZE, divided by 4096.  Algorithmic: 49152 B x + 16384 B transform
-# + 4096 B out = 69632 B/candidate; the excess is the kernel's scratch (register-spill) footprint being written once.
-PMC_HBM_BYTES_PER_CANDIDATE = {'bf16x3': (2 * 149842.4 + 211313.8) * 1024 / 4096, 'f32': (2 * 133763.3 + 16384.0) * 1024 / 4096}
+# + 4096 B out = 69632 B/candidate; both kernels move the algorithmic bytes and nothing else (no scratch).
+PMC_HBM_BYTES_PER_CANDIDATE = {'bf16x3': (2 * 133760.3 + 16384.0) * 1024 / 4096, 'f32': (2 * 133763.3 + 16384.0) * 1024 / 4096}
 
 
 def build_workload(device, G, seed, n_objects=8, pts_per_object=2500):
