@@ -27,7 +27,10 @@ def _stale(target, deps):
 
 def build(force=False, verbose=True):
     srcs = sources()
-    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.hpp')]
+    gen, inc = os.path.join(CSRC, 'gen_l3_asm.py'), os.path.join(CSRC, 'l3_asm.inc')
+    if _stale(inc, [gen]):      # the hand-scheduled instruction stream of pointmlp_bf16x3.hip is generated text
+        subprocess.check_call([sys.executable, gen])
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(('.hpp', '.inc'))]
     hdrs.append(os.path.join(PKG_DIR, '..', 'include', 'catgrasp_amd.h'))
     objs = []
     jobs = []
