@@ -18,3 +18,25 @@ def cuda_device():
     if not torch.cuda.is_available():
         pytest.fail('this test is marked gpu but no HIP device is visible')
     return torch.device('cuda:0')
+
+
+# Every GPU test module that runs the PointNet kernels is executed under BOTH arithmetic modes of the per-point MLP chain
+# (exact-f32 MFMA and the split-bf16 "bf16x3" MFMA path that bench.py times), against the same oracle and the same bar.
+_NET_MODULES = ('test_pointnet_gpu', 'test_predicter_gpu', 'test_pipeline_gpu')
+
+
+def pytest_generate_tests(metafunc):
+    if metafunc.module.__name__.split('.')[-1] in _NET_MODULES and 'mlp_precision' in metafunc.fixturenames:
+        metafunc.parametrize('mlp_precision', ['f32', 'bf16x3'], indirect=True)
+
+
+@pytest.fixture(autouse=True)
+def mlp_precision(request):
+    if request.module.__name__.split('.')[-1] not in _NET_MODULES:
+        yield None
+        return
+    from catgrasp_amd import engine
+    old = engine.PRECISION
+    engine.set_precision(getattr(request, 'param', old))
+    yield engine.PRECISION
+    engine.set_precision(old)

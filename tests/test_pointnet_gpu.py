@@ -24,8 +24,8 @@ def _inputs(B, N, seed, scale=0.5):
     return torch.from_numpy(x)
 
 
-@pytest.mark.parametrize('B,N,gain', [(3, 256, 1.6), (2, 2048, 1.6), (5, 100, 1.0), (1, 64, 1.6), (70, 130, 1.7)])
-def test_cls_forward_matches_oracle(cuda_device, B, N, gain):
+@pytest.mark.parametrize('B,N,gain', [(3, 256, 1.6), (2, 2048, 1.6), (5, 100, 1.0), (1, 64, 1.6), (70, 130, 1.7), (3, 700, 1.7), (1, 31, 1.6), (2, 257, 1.6)])
+def test_cls_forward_matches_oracle(cuda_device, mlp_precision, B, N, gain):
     from catgrasp_amd import engine, folding
     sd = synth.make_state_dict('cls', 6, 10, seed=11, gain=gain)
     x = _inputs(B, N, 5)
@@ -39,11 +39,12 @@ def test_cls_forward_matches_oracle(cuda_device, B, N, gain):
     # the grasp-Q *scores* (softmax probabilities, predicter.py:86) within 1e-4 absolute
     perr = (torch.softmax(logits.cpu(), 1) - torch.softmax(ref_logits, 1)).abs().max().item()
     assert perr <= TOL, f'probs max abs err {perr}'
-    # against the float64 evaluation: the HIP path is as close to the truth as the reference dtype
+    # against the float64 evaluation: the exact-f32 HIP path is as close to the truth as the reference dtype; the split-bf16
+    # path (2^-16 relative per product block) stays within a small multiple of it
     y64, _ = oref.pointnet_cls_forward(sd, x, torch.float64)
-    e_hip = (logits.cpu().double() - y64).abs().max().item()
-    e_ref = (ref_logits.double() - y64).abs().max().item()
-    assert e_hip <= max(4 * e_ref, 1e-5), (e_hip, e_ref)
+    e_hip = ((logits.cpu().double() - y64).abs() / y64.abs().clamp(min=1)).max().item()
+    e_ref = ((ref_logits.double() - y64).abs() / y64.abs().clamp(min=1)).max().item()
+    assert e_hip <= (max(4 * e_ref, 1e-5) if mlp_precision == 'f32' else 5e-5), (e_hip, e_ref)
 
 
 @pytest.mark.parametrize('B,N', [(1, 512), (2, 1000), (1, 8192)])
@@ -58,42 +59,3 @@ def test_seg_forward_matches_oracle(cuda_device, B, N):
     assert y.shape == (B, N, 300)
     _close(y.cpu(), ref_y, 'seg logits')
     _close(tf.cpu(), ref_tf, 'trans_feat')
-
-
-@pytest.mark.parametrize('B,N,gain', [(3, 256, 1.6), (2, 2048, 1.6), (5, 100, 1.0), (3, 700, 1.7), (1, 31, 1.6), (2, 257, 1.6)])
-def test_cls_forward_bf16x3_within_parity_bar(cuda_device, B, N, gain):
-    """The split-bf16 (bf16x3) kernels: same 1e-4 bar against the f32 oracle; error is ~1e-5."""
-    from catgrasp_amd import engine, folding
-    sd = synth.make_state_dict('cls', 6, 10, seed=21, gain=gain)
-    x = _inputs(B, N, 7)
-    ref_logits, ref_tf = oref.pointnet_cls_forward(sd, x)
-    W = folding.prepare_cls(sd, cuda_device)
-    old = engine.PRECISION
-    try:
-        engine.PRECISION = 'bf16x3'
-        logits, tf = engine.cls_forward(W, x.to(cuda_device))
-        torch.cuda.synchronize()
-    finally:
-        engine.PRECISION = old
-    _close(logits.cpu(), ref_logits, 'logits (bf16x3)')
-    _close(tf.cpu(), ref_tf, 'trans_feat (bf16x3)')
-    perr = (torch.softmax(logits.cpu(), 1) - torch.softmax(ref_logits, 1)).abs().max().item()
-    assert perr <= TOL, f'probs max abs err {perr}'
-    print(f'bf16x3 B={B} N={N}: logits err {(logits.cpu() - ref_logits).abs().max().item():.2e} probs err {perr:.2e}')
-
-
-def test_seg_forward_bf16x3(cuda_device):
-    from catgrasp_amd import engine, folding
-    sd = synth.make_state_dict('seg', 6, 300, seed=22)
-    x = _inputs(2, 1500, 8)
-    ref_y, ref_tf = oref.pointnet_seg_forward(sd, x)
-    W = folding.prepare_seg(sd, cuda_device)
-    old = engine.PRECISION
-    try:
-        engine.PRECISION = 'bf16x3'
-        y, tf = engine.seg_forward(W, x.to(cuda_device))
-        torch.cuda.synchronize()
-    finally:
-        engine.PRECISION = old
-    _close(y.cpu(), ref_y, 'seg logits (bf16x3)')
-    _close(tf.cpu(), ref_tf, 'trans_feat (bf16x3)')

@@ -127,27 +127,21 @@ def test_pointnet2_modules_dropin(cuda_device):
     assert ((ys.cpu() - rs).abs() / rs.abs().clamp(min=1)).max().item() <= 1e-4
 
 
-@pytest.mark.parametrize('precision', ['f32', 'bf16x3'])
-def test_dropin_predicters_against_the_real_reference_outputs(cuda_device, precision):
+def test_dropin_predicters_against_the_real_reference_outputs(cuda_device, mlp_precision):
     """The headline parity test: catgrasp_amd.predicter run with the same numpy seed, weights and normaliser as the REAL
     reference predicter (outputs committed in tests/golden/predicter_golden.npz by make_golden_predicter.py) must return the
     same [label, confidence, probs] lists (1e-4) and the same NUNOCS cloud (away from arg-max ties)."""
     import os
-    from catgrasp_amd import engine
     from catgrasp_amd.predicter import DEFAULT_GRASP_CFG, DEFAULT_NUNOCS_CFG, GraspPredicter, NunocsPredicter
     p = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'predicter_golden.npz'))
-    old = engine.PRECISION
-    try:
-        engine.set_precision(precision)
-        gp = GraspPredicter('nut', cfg=DEFAULT_GRASP_CFG, state_dict=synth.make_state_dict('cls', 6, 10, seed=77),
-                            normalizer={'mean': p['mean'], 'std': p['std']}, device=cuda_device)
-        np.random.seed(123)
-        ret = gp.predict_batch({'cloud_xyz': p['xyz'], 'cloud_normal': p['normal']}, list(p['poses']))
-        npred = NunocsPredicter('nut', cfg=DEFAULT_NUNOCS_CFG, state_dict=synth.make_state_dict('seg', 6, 300, seed=78), device=cuda_device)
-        np.random.seed(321)
-        nocs, conf, dt = npred.predict_nocs({'cloud_xyz': p['xyz'], 'cloud_normal': p['normal']})
-    finally:
-        engine.set_precision(old)
+    precision = mlp_precision
+    gp = GraspPredicter('nut', cfg=DEFAULT_GRASP_CFG, state_dict=synth.make_state_dict('cls', 6, 10, seed=77),
+                        normalizer={'mean': p['mean'], 'std': p['std']}, device=cuda_device)
+    np.random.seed(123)
+    ret = gp.predict_batch({'cloud_xyz': p['xyz'], 'cloud_normal': p['normal']}, list(p['poses']))
+    npred = NunocsPredicter('nut', cfg=DEFAULT_NUNOCS_CFG, state_dict=synth.make_state_dict('seg', 6, 300, seed=78), device=cuda_device)
+    np.random.seed(321)
+    nocs, conf, dt = npred.predict_nocs({'cloud_xyz': p['xyz'], 'cloud_normal': p['normal']})
     assert len(ret) == len(p['poses'])
     assert np.abs(np.array([r[2] for r in ret]) - p['grasp_probs']).max() <= 1e-4
     assert np.abs(np.array([float(r[1]) for r in ret]) - p['grasp_conf']).max() <= 1e-4
