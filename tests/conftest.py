@@ -22,7 +22,7 @@ def cuda_device():
 
 # Every GPU test module that runs the PointNet kernels is executed under BOTH arithmetic modes of the per-point MLP chain
 # (exact-f32 MFMA and the split-bf16 "bf16x3" MFMA path that bench.py times), against the same oracle and the same bar.
-_NET_MODULES = ('test_pointnet_gpu', 'test_predicter_gpu', 'test_pipeline_gpu')
+_NET_MODULES = ('test_pointnet_gpu', 'test_predicter_gpu', 'test_pipeline_gpu', 'test_fullsize_properties_gpu')
 
 
 def pytest_generate_tests(metafunc):

@@ -1,0 +1,136 @@
+"""Parity at BASELINE.json's full sizes through size-independent properties (the oracle cannot finish 10^4..10^5 candidates in
+seconds): candidate-permutation equivariance, point-order invariance (PointNet symmetry), shard-union == whole,
+reduction identities, batch-composition independence of the collision codes, broad phase == exhaustive -- all BIT-EXACT --
+plus an oracle spot check of a random sample of the same batch.
+
+Sizes: C2 = 20k-pt scene (8 x 2500), 10k candidates; C3 = same scene, 50k candidates through NUNOCS + grasp-Q + collision;
+C4 = 40k-pt scene (16 x 2500), 200k candidates (the 8-GPU configuration, run here on one device in 8 shards)."""
+import numpy as np
+import pytest
+import torch
+
+import bench
+from catgrasp_amd import distributed, my_cpp, synth
+from catgrasp_amd.predicter import DEFAULT_GRASP_CFG, DEFAULT_NUNOCS_CFG, GraspPredicter, NunocsPredicter
+from oracle import collision_oracle as co
+from oracle import pointnet_ref as oref
+from oracle import transforms_ref as tref
+
+pytestmark = pytest.mark.gpu
+
+
+def _candidate_owner(wl):
+    """global candidate index -> (object k, local index j), following bench.build_workload's per-object blocks"""
+    start = np.concatenate([[0], np.cumsum(wl['per'])])
+    return start
+
+
+@pytest.mark.parametrize('n_obj,G', [(8, 10000), (16, 200000)])
+def test_scoring_properties_at_baseline_sizes(cuda_device, n_obj, G):
+    wl = bench.build_workload(cuda_device, G, seed=0, n_objects=n_obj, pts_per_object=2500)
+    assert wl['cloud_xyz'].shape[0] == n_obj * 2500 and wl['ids'].shape == (G, 2048)
+    sd = synth.make_state_dict('cls', 6, 10, seed=0)
+    gp = GraspPredicter('nut', cfg=DEFAULT_GRASP_CFG, state_dict=sd, device=cuda_device)
+    xyz, nrm, ids, pinv = wl['cloud_xyz'], wl['cloud_normal'], wl['ids'], wl['pose_inv']
+    with torch.no_grad():
+        probs, label, conf, pg = gp.score_on_device(xyz, nrm, ids, pinv)
+        # reduction identities (predicter.py:86-91, run_grasp_simulation.py:311-319)
+        assert (probs.sum(1) - 1).abs().max().item() < 1e-5
+        assert torch.equal(label.long(), probs.argmax(1)) and torch.equal(conf, probs.max(1).values)
+        k = torch.arange(10, device=cuda_device, dtype=torch.float32)
+        assert ((probs * k).sum(1) / 10 - pg).abs().max().item() < 1e-6
+        assert torch.isfinite(probs).all()
+        # candidate-permutation equivariance: a candidate's score does not depend on where it sits in the batch
+        gen = torch.Generator(device='cpu'); gen.manual_seed(5)
+        perm = torch.randperm(G, generator=gen).to(cuda_device)
+        probs_p = gp.score_on_device(xyz, nrm, ids[perm].contiguous(), pinv[perm].contiguous())[0]
+        assert torch.equal(probs_p, probs[perm])
+        # point-order invariance: the max-pool makes the network a set function of the 2048 resampled points
+        probs_r = gp.score_on_device(xyz, nrm, ids.flip(1).contiguous(), pinv)[0]
+        assert torch.equal(probs_r, probs)
+        # shard union == whole (the multi-GPU partition of SURVEY 8(e), 8 ranks, evaluated on one device)
+        per, bounds = distributed.shard_bounds(G, 8)
+        parts = [gp.score_on_device(xyz, nrm, ids[lo:hi], pinv[lo:hi])[0] for lo, hi in bounds if hi > lo]
+        assert torch.equal(torch.cat(parts), probs)
+    # oracle spot check on a random sample of the same batch
+    rng = np.random.default_rng(3)
+    pick = np.sort(rng.choice(G, 32, replace=False))
+    start = _candidate_owner(wl)
+    ids_h = ids[torch.from_numpy(pick).to(cuda_device)].cpu().numpy()
+    xs = []
+    for g, row in zip(pick, ids_h):
+        kob = int(np.searchsorted(start, g, side='right') - 1)
+        ob = wl['objs'][kob]
+        P = wl['poses_dev'][kob][g - start[kob]].cpu().numpy().reshape(4, 4).astype(np.float64)
+        xs.append(tref.grasp_transform(ob['xyz'].copy(), ob['normal'].copy(), P, row - kob * 2500)['input'])
+    ref_logits, _ = oref.pointnet_cls_forward(sd, torch.from_numpy(np.stack(xs)).float())
+    ref_probs = torch.softmax(ref_logits, 1).numpy()
+    assert np.abs(probs[torch.from_numpy(pick).to(cuda_device)].cpu().numpy() - ref_probs).max() <= 1e-4
+
+
+def test_collision_and_nunocs_properties_at_c3_size(cuda_device):
+    G = 50000
+    wl = bench.build_workload(cuda_device, G, seed=1, n_objects=8, pts_per_object=2500)
+    g = wl['gripper']
+    I4 = np.eye(4)
+    sym_h = np.stack([nut_symmetry(i) for i in range(12)])      # nut: 12 symmetry transforms (Utils.py:79-94)
+    sym = torch.from_numpy(sym_h.astype(np.float32)).to(cuda_device)
+    total = 0
+    for kob in (0, 5):
+        ob, sc = wl['objs'][kob], wl['scenes'][kob]
+        # grasp_sampler.py:345 call shape: canonical-frame grasps, 9-D nocs_pose (anisotropic scale), symmetry expansion, nudging
+        nocs_pose = ob['pose'] @ np.diag([0.016, 0.016, 0.006, 1.0])
+        P_cam = wl['poses_dev'][kob].cpu().numpy().reshape(-1, 4, 4).astype(np.float64)
+        P_can = np.linalg.inv(nocs_pose) @ P_cam
+        P = torch.from_numpy(P_can.astype(np.float32).reshape(-1, 16)).to(cuda_device)
+        n = P.shape[0]
+        args = (nocs_pose, I4, I4, I4, g['gripper_in_grasp'], False, False, True)
+        codes, poses, nudge = my_cpp.filter_on_device(sc, P, sym, *args)
+        E = n * 12
+        total += E
+        hist = np.bincount(codes.cpu().numpy(), minlength=5)
+        assert codes.shape == (E,) and hist[0] > 0 and hist[3] + hist[4] > 0 and hist[1] == hist[2] == 0, hist
+        # batch-composition independence, bit-exact: a random subset filtered alone gives the same codes / poses / nudges
+        rng = np.random.default_rng(10 + kob)
+        sub = np.sort(rng.choice(n, 384, replace=False))
+        sub_t = torch.from_numpy(sub).to(cuda_device)
+        c2, p2, n2 = my_cpp.filter_on_device(sc, P[sub_t].contiguous(), sym, *args)
+        e_idx = (sub_t[:, None] * 12 + torch.arange(12, device=cuda_device)[None]).reshape(-1)
+        assert torch.equal(c2, codes[e_idx]) and torch.equal(n2, nudge[e_idx])
+        keep = c2 == 0
+        assert torch.equal(p2[keep], poses[e_idx][keep])
+        # broad phase == exhaustive kernel at full size
+        bg = synth.background_points(wl['objs'], kob, g['diameter'])
+        sc_ex = my_cpp.GripperScene(g['vertices'], g['faces'], g['enclosed_vertices'], g['enclosed_faces'], ob['xyz'], bg, 0.0005,
+                                    cuda_device, accel=False)
+        c3, p3, n3 = my_cpp.filter_on_device(sc_ex, P, sym, *args)
+        assert torch.equal(c3, codes) and torch.equal(n3, nudge) and torch.equal(p3[codes == 0], poses[codes == 0])
+        # the C oracle on the subset (bit-exact codes and nudge indices, poses of the survivors)
+        oc, op, on = co.filter_grasp_pose(P[sub_t].cpu().numpy().reshape(-1, 4, 4), list(sym_h), nocs_pose, I4, I4, I4,
+                                          g['gripper_in_grasp'], 0, 0, 1, g['vertices'], g['faces'], g['enclosed_vertices'],
+                                          g['enclosed_faces'], ob['xyz'], bg, 0.0005)
+        assert np.array_equal(oc, c2.cpu().numpy()) and np.array_equal(on, n2.cpu().numpy())
+        assert np.array_equal(op[oc == 0], p2.cpu().numpy()[oc == 0])
+    assert total == 2 * 6250 * 12
+    # NUNOCS over the 8 object clouds of the scene: every decoded coordinate is a bin centre in [-0.5, 0.5), and the batch of 8
+    # equals 8 single-cloud calls bit for bit
+    npred = NunocsPredicter('nut', cfg=DEFAULT_NUNOCS_CFG, state_dict=synth.make_state_dict('seg', 6, 300, seed=1), device=cuda_device)
+    with torch.no_grad():
+        coords, conf, _ = npred.nocs_on_device(wl['cloud_xyz'], wl['cloud_normal'], wl['nunocs_ids'])
+        assert coords.shape == (8, 8192, 3)
+        binned = (coords + 0.5) * 100
+        assert (binned - binned.round()).abs().max().item() < 1e-4 and coords.min().item() >= -0.5 and coords.max().item() < 0.5
+        for k in (0, 7):
+            ck, fk, _ = npred.nocs_on_device(wl['cloud_xyz'], wl['cloud_normal'], wl['nunocs_ids'][k:k + 1].contiguous())
+            assert torch.equal(ck[0], coords[k]) and torch.equal(fk[0], conf[k])
+
+
+def nut_symmetry(i):
+    """nut symmetry set: 6 rotations about z (60 degree steps) x flip about x (Utils.py:79-94 builds the same group)"""
+    a = (i % 6) * np.pi / 3
+    R = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]])
+    if i >= 6:
+        R = R @ np.diag([1.0, -1.0, -1.0])
+    T = np.eye(4)
+    T[:3, :3] = R
+    return T
