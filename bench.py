@@ -35,9 +35,9 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0                          # MI355X_MICROARCH.md: b
 PMC_HBM_BYTES_PER_CANDIDATE = {'bf16x3': (2 * 133760.3 + 16384.0) * 1024 / 4096, 'f32': (2 * 133763.3 + 16384.0) * 1024 / 4096}
 
 
-def build_workload(device, G, seed, n_objects=8, pts_per_object=2500):
+def build_workload(device, G, seed, n_objects=8, pts_per_object=2500, kind='nut'):
     from catgrasp_amd import my_cpp, synth, transforms
-    objs = synth.make_scene(n_objects, pts_per_object, seed=0)           # same scene on every rank
+    objs = synth.make_scene(n_objects, pts_per_object, seed=0, kind=kind)           # same scene on every rank
     gripper = synth.make_gripper()
     rng = np.random.default_rng(1000 + seed)
     per = [G // n_objects + (1 if k < G % n_objects else 0) for k in range(n_objects)]

@@ -4,7 +4,8 @@ reduction identities, batch-composition independence of the collision codes, bro
 plus an oracle spot check of a random sample of the same batch.
 
 Sizes: C2 = 20k-pt scene (8 x 2500), 10k candidates; C3 = same scene, 50k candidates through NUNOCS + grasp-Q + collision;
-C4 = 40k-pt scene (16 x 2500), 200k candidates (the 8-GPU configuration, run here on one device in 8 shards)."""
+C4 = screw category, 40k-pt scene (16 x 2500), 200k candidates (the 8-GPU configuration, run here on one device in 8 shards);
+C5 = mixed-category bin (nut + screw + screw per triple, 24 objects = 60k points), 500k candidates, split-bf16 MFMA path."""
 import numpy as np
 import pytest
 import torch
@@ -25,12 +26,12 @@ def _candidate_owner(wl):
     return start
 
 
-@pytest.mark.parametrize('n_obj,G', [(8, 10000), (16, 200000)])
-def test_scoring_properties_at_baseline_sizes(cuda_device, n_obj, G):
-    wl = bench.build_workload(cuda_device, G, seed=0, n_objects=n_obj, pts_per_object=2500)
+@pytest.mark.parametrize('n_obj,G,kind', [(8, 10000, 'nut'), (16, 200000, 'screw')])
+def test_scoring_properties_at_baseline_sizes(cuda_device, n_obj, G, kind):
+    wl = bench.build_workload(cuda_device, G, seed=0, n_objects=n_obj, pts_per_object=2500, kind=kind)
     assert wl['cloud_xyz'].shape[0] == n_obj * 2500 and wl['ids'].shape == (G, 2048)
     sd = synth.make_state_dict('cls', 6, 10, seed=0)
-    gp = GraspPredicter('nut', cfg=DEFAULT_GRASP_CFG, state_dict=sd, device=cuda_device)
+    gp = GraspPredicter(kind, cfg=DEFAULT_GRASP_CFG, state_dict=sd, device=cuda_device)
     xyz, nrm, ids, pinv = wl['cloud_xyz'], wl['cloud_normal'], wl['ids'], wl['pose_inv']
     with torch.no_grad():
         probs, label, conf, pg = gp.score_on_device(xyz, nrm, ids, pinv)
@@ -66,6 +67,43 @@ def test_scoring_properties_at_baseline_sizes(cuda_device, n_obj, G):
     ref_logits, _ = oref.pointnet_cls_forward(sd, torch.from_numpy(np.stack(xs)).float())
     ref_probs = torch.softmax(ref_logits, 1).numpy()
     assert np.abs(probs[torch.from_numpy(pick).to(cuda_device)].cpu().numpy() - ref_probs).max() <= 1e-4
+
+
+def test_mixed_category_bin_at_c5_size(cuda_device, mlp_precision):
+    """configs[4]: every object is scored by its own category's predicter (run_grasp_simulation.py keeps one GraspPredicter per
+    class); shard-union == whole per category and an oracle spot check per category."""
+    if mlp_precision != 'bf16x3':
+        pytest.skip('configs[4] names the bf16 MFMA path')
+    G = 500000
+    wl = bench.build_workload(cuda_device, G, seed=2, n_objects=24, pts_per_object=2500, kind='mixed')
+    kinds = [ob['kind'] for ob in wl['objs']]
+    assert set(kinds) == {'nut', 'screw'} and wl['cloud_xyz'].shape[0] == 60000
+    start = _candidate_owner(wl)
+    owner = torch.from_numpy(np.repeat(np.arange(24), wl['per'])).to(cuda_device)
+    is_nut = torch.tensor([k == 'nut' for k in kinds], device=cuda_device)[owner]
+    sds = {'nut': synth.make_state_dict('cls', 6, 10, seed=40), 'screw': synth.make_state_dict('cls', 6, 10, seed=41)}
+    rng = np.random.default_rng(9)
+    scored = 0
+    with torch.no_grad():
+        for cat in ('nut', 'screw'):
+            gp = GraspPredicter(cat, cfg=DEFAULT_GRASP_CFG, state_dict=sds[cat], device=cuda_device)
+            sel = torch.nonzero(is_nut if cat == 'nut' else ~is_nut)[:, 0]
+            ids, pinv = wl['ids'][sel].contiguous(), wl['pose_inv'][sel].contiguous()
+            probs = gp.score_on_device(wl['cloud_xyz'], wl['cloud_normal'], ids, pinv)[0]
+            scored += probs.shape[0]
+            per, bounds = distributed.shard_bounds(len(sel), 8)
+            parts = [gp.score_on_device(wl['cloud_xyz'], wl['cloud_normal'], ids[lo:hi], pinv[lo:hi])[0] for lo, hi in bounds if hi > lo]
+            assert torch.equal(torch.cat(parts), probs)
+            pick = np.sort(rng.choice(len(sel), 16, replace=False))
+            xs = []
+            for j in pick:
+                g = int(sel[j]); kob = int(np.searchsorted(start, g, side='right') - 1)
+                ob = wl['objs'][kob]
+                P = wl['poses_dev'][kob][g - start[kob]].cpu().numpy().reshape(4, 4).astype(np.float64)
+                xs.append(tref.grasp_transform(ob['xyz'].copy(), ob['normal'].copy(), P, ids[j].cpu().numpy() - kob * 2500)['input'])
+            ref = torch.softmax(oref.pointnet_cls_forward(sds[cat], torch.from_numpy(np.stack(xs)).float())[0], 1).numpy()
+            assert np.abs(probs[torch.from_numpy(pick).to(cuda_device)].cpu().numpy() - ref).max() <= 1e-4
+    assert scored == G
 
 
 def test_collision_and_nunocs_properties_at_c3_size(cuda_device):
