@@ -69,7 +69,7 @@ int cg_softmax_pg(const float* logits, int B, int C, float* probs, int* label, f
                   void* stream);
 
 /* NUNOCS bin decode (predicter.py:144-150): logits (P, 3*nbins) -> coords (P,3) = argmax/nbins - 0.5,
- * conf_z (P) = softmax probability of the arg-max z bin. */
+ * conf_z (P) = softmax probability of the arg-max z bin.  nbins <= 128 (config_nunocs.yml: 100). */
 int cg_nunocs_decode(const float* logits, long P, int nbins, float* coords, float* conf_z, void* stream);
 
 /* ---------------------------------------------------------------------------------------------

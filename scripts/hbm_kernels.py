@@ -1,0 +1,97 @@
+"""HBM-roofline table of the scan / gather / write kernels around the two networks ("fraction of HBM roofline is
+meaningful only for the scan/gather kernels").  For each kernel: ALGORITHMIC bytes per launch (stated below) / the launch
+time measured with HIP events on the launch stream, against the 8 TB/s HBM3E peak (MI355X_MICROARCH.md).  Latency-bound
+kernels (FPS: sequential dependency over npoint; the collision filter: L2/LDS gathers) are reported with their own unit.
+
+    python scripts/hbm_kernels.py > profiles/r1_hbm_kernels.json          (on the GPU box)
+"""
+import json
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, '.')
+from catgrasp_amd import my_cpp, ops, primitives, synth   # noqa: E402
+
+PEAK = 8000.0   # GB/s
+dev = torch.device('cuda:0')
+
+
+def timed(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters * 1e-3
+
+
+rows = []
+
+
+def row(name, secs, nbytes, what, bound='hbm', extra=None):
+    r = {'kernel': name, 'bound': bound, 'avg_launch_us': round(secs * 1e6, 2), 'algorithmic_bytes': int(nbytes),
+         'achieved_GBps': round(nbytes / secs / 1e9, 1), 'frac_of_8TBps': round(nbytes / secs / 1e9 / PEAK, 4), 'bytes_are': what}
+    if extra:
+        r.update(extra)
+    rows.append(r)
+
+
+g = torch.Generator(device=dev); g.manual_seed(0)
+# --- candidate input build (dataset_grasp.py:63-91 on the device): 20k-pt scene, 10k candidates x 2048 points
+M, G, NP = 20000, 10000, 2048
+xyz = torch.randn(M, 3, device=dev, generator=g) * 0.05
+nrm = torch.nn.functional.normalize(torch.randn(M, 3, device=dev, generator=g), dim=1)
+obj = (torch.arange(G, device=dev) * 8 // G)[:, None]                       # candidates grouped per object, as bench.py / pipeline.py issue them
+ids = (obj * 2500 + torch.randint(0, 2500, (G, NP), device=dev, generator=g)).int().contiguous()      # each candidate resamples its object's cloud
+pinv = torch.randn(G, 12, device=dev, generator=g)
+out = torch.empty(G, NP, 6, device=dev)
+row('build_grasp_input_kernel', timed(lambda: ops.build_grasp_input(xyz, nrm, ids, pinv, out=out)),
+    G * (NP * 4 + 48 + NP * 24) + M * 24, 'ids 4 B/pt + pose 48 B + 24 B/pt written + the 480 KB cloud once (object slices are staged in LDS from L2)')
+# --- NUNOCS decode: 8 clouds x 8192 points x 300 logits
+P = 8 * 8192
+lg = torch.randn(P, 300, device=dev, generator=g)
+row('nunocs_decode_kernel', timed(lambda: ops.nunocs_decode(lg, 100)), P * (1200 + 16), '1200 B logits in + 16 B out per point')
+# --- softmax / p_G over 10k candidates
+l10 = torch.randn(G, 10, device=dev, generator=g)
+row('softmax_pg_kernel', timed(lambda: ops.softmax_pg(l10)), G * (40 + 52), '40 B in + 52 B out per candidate (launch-latency bound at this size)')
+# --- NUNOCS input build: 8 clouds x 8192
+ids8 = torch.randint(0, 2500, (8, 8192), device=dev, generator=g).int() + (torch.arange(8, device=dev) * 2500).int()[:, None]
+row('build_nunocs_input_kernel', timed(lambda: ops.build_nunocs_input(xyz, nrm, ids8.contiguous())), 8 * 8192 * (4 + 24),
+    '4 B id + 24 B out per point; 8 workgroups (one per cloud: min/max reduction) -> latency bound')
+# --- PointNet++ primitives at the SURVEY 8(a) sizes: N = 20000, S = 1024, nsample = 32
+N, S, K = 20000, 1024, 32
+pts = (torch.rand(1, N, 3, device=dev, generator=g) * 0.1).contiguous()
+feat = torch.randn(1, N, 6, device=dev, generator=g)
+new = pts[:, :S].contiguous()
+row('square_distance_kernel', timed(lambda: primitives.square_distance(new, pts)), S * N * 4 + (S + N) * 12, 'S x N x 4 B written')
+idx = torch.randint(0, N, (1, S, K), device=dev, generator=g)
+row('index_points (group) kernel', timed(lambda: primitives.index_points(feat, idx)), S * K * (8 + 24), '8 B index + 24 B row written per neighbour (gathers are L2 hits)')
+t_fps = timed(lambda: primitives.farthest_point_sample(pts, S, start=torch.zeros(1, dtype=torch.long, device=dev)), iters=5, warm=1)
+row('farthest_point_sample_kernel', t_fps, N * 12 + S * 8, 'N x 12 B read once + S x 8 B out', bound='latency (sequential over npoint)',
+    extra={'rounds_per_s': round(S / t_fps), 'note': 'one 1024-thread workgroup, points in VGPRs; reference CPU: 0.24 s'})
+t_bq = timed(lambda: primitives.query_ball_point(0.02, K, pts, new), iters=10)
+row('query_ball_point_kernel', t_bq, (N + S) * 12 + S * K * 8, '(N+S) x 12 B read + S x nsample x 8 B written (HBM level)', bound='L2 scan',
+    extra={'cache_level_GBps': round(S * N * 12 / t_bq / 1e9, 1), 'cache_level_bytes': 'S x N x 12 B distance tests'})
+# --- voxelisation + collision filter on the bench scene
+objs = synth.make_scene(8, 2500, seed=0)
+gr = synth.make_gripper()
+cloud = np.concatenate([o['xyz'] for o in objs]).astype(np.float32)
+cl_d = torch.from_numpy(cloud).to(dev)
+row('voxel_keys + sort/unique (voxelize)', timed(lambda: my_cpp.voxelize(cl_d, 0.0005, dev), iters=10), len(cloud) * (12 + 8),
+    '12 B point in + 8 B key out', bound='launch latency (20k points)')
+bg = synth.background_points(objs, 0, gr['diameter'])
+sc = my_cpp.GripperScene(gr['vertices'], gr['faces'], gr['enclosed_vertices'], gr['enclosed_faces'], objs[0]['xyz'], bg, 0.0005, dev)
+Pn = 50000
+Pc = torch.from_numpy(synth.make_candidates(objs[0], Pn, np.random.default_rng(0), gr['hand_depth'], gr['init_bite']).astype(np.float32).reshape(-1, 16)).to(dev)
+sym = torch.eye(4, device=dev).reshape(1, 16)
+I4 = np.eye(4, dtype=np.float32)
+t_f = timed(lambda: my_cpp.filter_on_device(sc, Pc, sym, I4, I4, I4, I4, gr['gripper_in_grasp'], True, False, False), iters=10)
+row('filter_grasp_pose_kernel (broad-phase grid)', t_f, Pn * (64 + 66), '64 B pose in + 66 B code/pose/nudge out per evaluation (HBM level)',
+    bound='L2/LDS gather latency', extra={'evaluations_per_s': round(Pn / t_f), 'voxels_open': int(sc.keys_open.shape[0]), 'voxels_background': int(sc.keys_bg.shape[0])})
+print(json.dumps({'device': torch.cuda.get_device_name(0), 'hbm_peak_GBps': PEAK, 'kernels': rows}, indent=1))
