@@ -1,0 +1,125 @@
+// Split-precision variant of gemm.hip:  Y = act(X . W^T + bias [+ row_bias[row / rows_per_group]]) [+ I_k]
+// with every product block evaluated as three bf16 MFMAs with f32 accumulation (see pointmlp_bf16x3.hip):
+//     x.w ~= x_lo.w_hi + x_hi.w_lo + x_hi.w_hi      on v_mfma_f32_32x32x16_bf16.
+// Used for the per-point segmentation head of PointNetSeg (pointnet2.py:324-328) when the engine runs in 'bf16x3' mode; the
+// per-candidate FC tails stay on the exact-f32 kernel (their share of the step is 2 %, their share of the error budget is not).
+// X (f32) is split while it is staged: 128 rows x 64 columns per workgroup as two bf16 images (144-byte rows: conflict-free
+// ds_read_b128 fragment reads).  W is split and packed on the host (folding.pack_b_bf16x3):
+// Wp[nb][kc][2 (hi,lo)][lane][8], element e of lane l = W[nb*32 + (l&31)][kc*16 + (l>>5)*8 + e].
+#include "cg_common.hpp"
+#include "../../include/catgrasp_amd.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int BM = 128;      // rows per workgroup (4 row tiles per wave: each weight fragment feeds 12 MFMAs)
+constexpr int BK = 64;       // K chunk staged in LDS
+constexpr int SR = BK + 8;   // bf16 elements per LDS row
+
+struct GemmArgsB {
+  const float* x; int M; int K; int ldx;
+  const unsigned short* wp; int N; int nblocks;
+  const float* bias;
+  const float* row_bias; int rows_per_group; int ld_rb;
+  int relu; int eye_k;
+  float* y; int ldy;
+};
+
+__device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
+  const bf16x2 h = {(__bf16)a, (__bf16)b};
+  hi = __builtin_bit_cast(unsigned, h);
+  const float ha = __uint_as_float(hi << 16), hb = __uint_as_float(hi & 0xffff0000u);
+  const bf16x2 l = {(__bf16)(a - ha), (__bf16)(b - hb)};
+  lo = __builtin_bit_cast(unsigned, l);
+}
+
+__global__ __launch_bounds__(256) void gemm_bias_act_bf16x3_kernel(GemmArgsB a) {
+  __shared__ __attribute__((aligned(16))) __bf16 xh[BM * SR];
+  __shared__ __attribute__((aligned(16))) __bf16 xl[BM * SR];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int row0 = blockIdx.x * BM;
+  const int nb = blockIdx.y * 4 + w;            // this wave's 32-channel block
+  const bool active = nb < a.nblocks;
+  const int nkc_total = a.K / 16;               // K is a multiple of 16 (checked by the launcher)
+  f32x16 c[4];
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) c[rt] = f32x16{0};
+  for (int k0 = 0; k0 < a.K; k0 += BK) {
+    const int kc = min(BK, a.K - k0);
+    __syncthreads();
+    for (int i = tid; i < BM * (BK / 4); i += 256) {
+      const int r = i / (BK / 4), cq = i - r * (BK / 4);
+      if (cq * 4 < kc) {
+        int row = row0 + r; if (row >= a.M) row = a.M - 1;
+        const f32x4 v = *(const f32x4*)(a.x + (size_t)row * a.ldx + k0 + cq * 4);
+        unsigned h0, l0, h1, l1;
+        split2(v[0], v[1], h0, l0); split2(v[2], v[3], h1, l1);
+        *(u32x2*)(xh + r * SR + cq * 4) = u32x2{h0, h1};
+        *(u32x2*)(xl + r * SR + cq * 4) = u32x2{l0, l1};
+      }
+    }
+    __syncthreads();
+    if (active) {
+      const bf16x8* bp = (const bf16x8*)a.wp + ((size_t)(nb * nkc_total + k0 / 16) * 2) * 64 + lane;
+      const __bf16* ah0 = xh + l31 * SR + lhi * 8;
+      const __bf16* al0 = xl + l31 * SR + lhi * 8;
+      const int ns = kc / 16;
+#pragma unroll 2
+      for (int s = 0; s < ns; ++s) {
+        const bf16x8 bh = bp[s * 128], bl = bp[s * 128 + 64];
+        bf16x8 ah[4], al[4];
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) {
+          ah[rt] = *(const bf16x8*)(ah0 + rt * 32 * SR + s * 16);
+          al[rt] = *(const bf16x8*)(al0 + rt * 32 * SR + s * 16);
+        }
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) c[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[rt], bh, c[rt], 0, 0, 0);
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) c[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[rt], bl, c[rt], 0, 0, 0);
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) c[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[rt], bh, c[rt], 0, 0, 0);
+      }
+    }
+  }
+  if (!active) return;
+  const int col = nb * 32 + l31;
+  if (col >= a.N) return;
+  float bias = a.bias ? a.bias[col] : 0.f;
+  if (a.eye_k > 0 && (col % (a.eye_k + 1)) == 0) bias += 1.f;   // flattened identity: col = i*k + i
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = row0 + rt * 32 + acc_row(r, lane);
+      if (row < a.M) {
+        float v = c[rt][r] + bias;
+        if (a.row_bias) v += a.row_bias[(size_t)(row / a.rows_per_group) * a.ld_rb + col];
+        if (a.relu) v = fmaxf(v, 0.f);
+        a.y[(size_t)row * a.ldy + col] = v;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int cg_gemm_bias_act_bf16x3(const float* x, int M, int K, int ldx, const unsigned short* w_split, int N,
+                                       const float* bias, const float* row_bias, int rows_per_group, int ld_rb,
+                                       int relu, int eye_k, float* y, int ldy, void* stream) {
+  if (!x || !w_split || !y) return CG_ERR_ARG;
+  if (M < 0 || N <= 0 || K <= 0 || (K % 16) != 0 || (ldx % 4) != 0 || ldx < K || ldy < N) return CG_ERR_ARG;
+  if (((uintptr_t)x & 15) != 0) return CG_ERR_ARG;
+  if (row_bias && (rows_per_group <= 0 || ld_rb < N)) return CG_ERR_ARG;
+  if (M == 0) return CG_OK;
+  GemmArgsB a{x, M, K, ldx, w_split, N, (N + 31) / 32, bias, row_bias, rows_per_group, ld_rb, relu, eye_k, y, ldy};
+  dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((a.nblocks + 3) / 4)), block(256);
+  hipLaunchKernelGGL(gemm_bias_act_bf16x3_kernel, grid, block, 0, (hipStream_t)stream, a);
+  return cg_hip_status(hipGetLastError());
+}

@@ -36,6 +36,15 @@ def _nsplit(B, N, tp=64):
     return max(1, min(ntiles, (1024 + B - 1) // B))
 
 
+def _dense(W, name, x, n_out, bias, **kw):
+    """One folded Linear/Conv1d(k=1) layer.  In 'bf16x3' mode layers that have a split image run on the split-bf16 MFMA GEMM:
+    the per-point segmentation head (folding.prepare_seg).  The per-candidate FC tails stay on the exact-f32 kernel -- measured,
+    splitting them too buys 3 % of the step and raises the logits error from ~2e-5 to ~6e-5 of the 1e-4 bar."""
+    if PRECISION == 'bf16x3' and (name + '.s') in W:
+        return ops.gemm_bias_act(x, W[name + '.s'], n_out, bias, split=True, **kw)
+    return ops.gemm_bias_act(x, W[name], n_out, bias, **kw)
+
+
 def encoder_forward(W, x, want_pointfeat=False):
     """x:(B,N,6) cuda f32 -> global feature (B,1024), trans (B,9), trans_feat TRANSPOSED (B,4096) [, pointfeat]."""
     if PRECISION == 'bf16x3':
@@ -44,14 +53,14 @@ def encoder_forward(W, x, want_pointfeat=False):
     ns = _nsplit(B, N)
     g = ops.pointmlp_max(x, W['stn.w1'], W['stn.b1'], W['stn.w2'], W['stn.b2'], W['stn.w3'], W['stn.b3'], True,
                          nsplit=ns)
-    h = ops.gemm_bias_act(g, W['stn.fc1'], 512, W['stn.fc1b'], relu=True)
-    h = ops.gemm_bias_act(h, W['stn.fc2'], 256, W['stn.fc2b'], relu=True)
-    t3 = ops.gemm_bias_act(h, W['stn.fc3'], 9, W['stn.fc3b'], eye_k=3)
+    h = _dense(W, 'stn.fc1', g, 512, W['stn.fc1b'], relu=True)
+    h = _dense(W, 'stn.fc2', h, 256, W['stn.fc2b'], relu=True)
+    t3 = _dense(W, 'stn.fc3', h, 9, W['stn.fc3b'], eye_k=3)
     g = ops.pointmlp_max(x, W['enc.w1'], W['enc.b1'], W['fstn.w2'], W['fstn.b2'], W['fstn.w3'], W['fstn.b3'], True,
                          t3=t3, mid_mode=1, wm=W['fstn.wm'], bm=W['fstn.bm'], nsplit=ns)
-    h = ops.gemm_bias_act(g, W['fstn.fc1'], 512, W['fstn.fc1b'], relu=True)
-    h = ops.gemm_bias_act(h, W['fstn.fc2'], 256, W['fstn.fc2b'], relu=True)
-    t64 = ops.gemm_bias_act(h, W['fstn.fc3'], 4096, W['fstn.fc3b'], eye_k=64)
+    h = _dense(W, 'fstn.fc1', g, 512, W['fstn.fc1b'], relu=True)
+    h = _dense(W, 'fstn.fc2', h, 256, W['fstn.fc2b'], relu=True)
+    t64 = _dense(W, 'fstn.fc3', h, 4096, W['fstn.fc3b'], eye_k=64)
     r = ops.pointmlp_max(x, W['enc.w1'], W['enc.b1'], W['enc.w2'], W['enc.b2'], W['enc.w3'], W['enc.b3'], False,
                          t3=t3, mid_mode=2, t64=t64, nsplit=ns, pointfeat=want_pointfeat)
     if want_pointfeat:
@@ -65,14 +74,14 @@ def _encoder_forward_split(W, x, want_pointfeat=False):
     ns = _nsplit(B, N, TILE_POINTS)
     kw = dict(nsplit=ns, split=True, tile_points=TILE_POINTS)
     g = ops.pointmlp_max(x, W['stn.w1'], W['stn.b1'], W['stn.w2.s'], W['stn.b2'], W['stn.w3.s'], W['stn.b3'], True, **kw)
-    h = ops.gemm_bias_act(g, W['stn.fc1'], 512, W['stn.fc1b'], relu=True)
-    h = ops.gemm_bias_act(h, W['stn.fc2'], 256, W['stn.fc2b'], relu=True)
-    t3 = ops.gemm_bias_act(h, W['stn.fc3'], 9, W['stn.fc3b'], eye_k=3)
+    h = _dense(W, 'stn.fc1', g, 512, W['stn.fc1b'], relu=True)
+    h = _dense(W, 'stn.fc2', h, 256, W['stn.fc2b'], relu=True)
+    t3 = _dense(W, 'stn.fc3', h, 9, W['stn.fc3b'], eye_k=3)
     g = ops.pointmlp_max(x, W['enc.w1'], W['enc.b1'], W['fstn.w2.s'], W['fstn.b2'], W['fstn.w3.s'], W['fstn.b3'], True,
                          t3=t3, mid_mode=1, wm=W['fstn.wm.s'], bm=W['fstn.bm'], **kw)
-    h = ops.gemm_bias_act(g, W['fstn.fc1'], 512, W['fstn.fc1b'], relu=True)
-    h = ops.gemm_bias_act(h, W['fstn.fc2'], 256, W['fstn.fc2b'], relu=True)
-    t64 = ops.gemm_bias_act(h, W['fstn.fc3'], 4096, W['fstn.fc3b'], eye_k=64)
+    h = _dense(W, 'fstn.fc1', g, 512, W['fstn.fc1b'], relu=True)
+    h = _dense(W, 'fstn.fc2', h, 256, W['fstn.fc2b'], relu=True)
+    t64 = _dense(W, 'fstn.fc3', h, 4096, W['fstn.fc3b'], eye_k=64)
     r = ops.pointmlp_max(x, W['enc.w1'], W['enc.b1'], W['enc.w2.s'], W['enc.b2'], W['enc.w3.s'], W['enc.b3'], False,
                          t3=t3, mid_mode=2, t64=t64, pointfeat=want_pointfeat, **kw)
     if want_pointfeat:
@@ -84,9 +93,9 @@ def cls_forward(W, x):
     """PointNetCls.forward in eval mode.  x:(B,N,6) -> logits (B,n_out), trans_feat (B,64,64)."""
     B = x.shape[0]
     g, t3, t64 = encoder_forward(W, x)
-    h = ops.gemm_bias_act(g, W['head.fc1'], 512, W['head.fc1b'], relu=True)
-    h = ops.gemm_bias_act(h, W['head.fc2'], 256, W['head.fc2b'], relu=True)
-    logits = ops.gemm_bias_act(h, W['head.fc3'], W.n_out, W['head.fc3b'])
+    h = _dense(W, 'head.fc1', g, 512, W['head.fc1b'], relu=True)
+    h = _dense(W, 'head.fc2', h, 256, W['head.fc2b'], relu=True)
+    logits = _dense(W, 'head.fc3', h, W.n_out, W['head.fc3b'])
     return logits, t64.view(B, 64, 64).transpose(1, 2)      # the FC kernel emits the transform transposed
 
 
@@ -95,9 +104,9 @@ def seg_forward(W, x):
     B, N, _ = x.shape
     g, t3, t64, pf = encoder_forward(W, x, want_pointfeat=True)
     # conv1 over cat([global(1024) repeated, pointfeat(64)]) = Wg.g (per cloud) + Wp.pointfeat (per point)
-    gb = ops.gemm_bias_act(g, W['seg.c1g'], 512, W['seg.c1b'])
-    h = ops.gemm_bias_act(pf.view(B * N, 64), W['seg.c1p'], 512, None, relu=True, row_bias=gb, rows_per_group=N)
-    h = ops.gemm_bias_act(h, W['seg.c2'], 256, W['seg.c2b'], relu=True)
-    h = ops.gemm_bias_act(h, W['seg.c3'], 128, W['seg.c3b'], relu=True)
-    y = ops.gemm_bias_act(h, W['seg.c4'], W.n_out, W['seg.c4b'])
+    gb = _dense(W, 'seg.c1g', g, 512, W['seg.c1b'])
+    h = _dense(W, 'seg.c1p', pf.view(B * N, 64), 512, None, relu=True, row_bias=gb, rows_per_group=N)
+    h = _dense(W, 'seg.c2', h, 256, W['seg.c2b'], relu=True)
+    h = _dense(W, 'seg.c3', h, 128, W['seg.c3b'], relu=True)
+    y = _dense(W, 'seg.c4', h, W.n_out, W['seg.c4b'])
     return y.view(B, N, W.n_out), t64.view(B, 64, 64).transpose(1, 2)

@@ -157,13 +157,13 @@ def prepare_seg(sd, device):
     sd = {k.replace('module.', ''): v for k, v in sd.items()}
     W = prepare_encoder(sd, 'feat.', device)
     w, b = fold_bn(*_conv(sd, 'conv1'), _bn(sd, 'bn1'))
-    W.put('seg.c1g', pack_b(w[:, :1024])); W.put('seg.c1b', b)
-    W.put('seg.c1p', pack_b(w[:, 1024:]))
+    W.put('seg.c1g', pack_b(w[:, :1024])); W.put('seg.c1b', b); W.put_split('seg.c1g.s', w[:, :1024])
+    W.put('seg.c1p', pack_b(w[:, 1024:])); W.put_split('seg.c1p.s', w[:, 1024:])
     w, b = fold_bn(*_conv(sd, 'conv2'), _bn(sd, 'bn2'))
-    W.put('seg.c2', pack_b(w)); W.put('seg.c2b', b)
+    W.put('seg.c2', pack_b(w)); W.put_split('seg.c2.s', w); W.put('seg.c2b', b)
     w, b = fold_bn(*_conv(sd, 'conv3'), _bn(sd, 'bn3'))
-    W.put('seg.c3', pack_b(w)); W.put('seg.c3b', b)
+    W.put('seg.c3', pack_b(w)); W.put_split('seg.c3.s', w); W.put('seg.c3b', b)
     w, b = _conv(sd, 'conv4')
-    W.put('seg.c4', pack_b(w)); W.put('seg.c4b', b)
+    W.put('seg.c4', pack_b(w)); W.put_split('seg.c4.s', w); W.put('seg.c4b', b)
     W.n_out = w.shape[0]
     return W

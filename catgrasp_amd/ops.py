@@ -52,17 +52,19 @@ def pointmlp_max(x, w1, b1, w2p, b2, w3p, b3, relu3, t3=None, mid_mode=0, wm=Non
     return (out, pf) if pointfeat else out
 
 
-def gemm_bias_act(x, wp, n_out, bias=None, relu=False, eye_k=0, row_bias=None, rows_per_group=1):
-    """act(x @ W^T + bias [+ row_bias[row // rows_per_group]]) with packed W.  x:(M,K)."""
+def gemm_bias_act(x, wp, n_out, bias=None, relu=False, eye_k=0, row_bias=None, rows_per_group=1, split=False):
+    """act(x @ W^T + bias [+ row_bias[row // rows_per_group]]) with packed W.  x:(M,K).
+    split=True: wp is the bf16x3 split-packed image and the product runs on the split-bf16 MFMA kernel."""
     require_cuda(x)
     f32c(x)
     M, K = x.shape
     y = torch.empty((M, n_out), dtype=torch.float32, device=x.device)
     ld_rb = row_bias.shape[1] if row_bias is not None else 0
-    st = L.lib().cg_gemm_bias_act(_p(x), _c_int(M), _c_int(K), _c_int(K), _p(wp), _c_int(n_out), _p(bias),
-                                  _p(row_bias), _c_int(rows_per_group), _c_int(ld_rb), _c_int(int(relu)),
-                                  _c_int(eye_k), _p(y), _c_int(n_out), _stream())
-    check(st, 'cg_gemm_bias_act')
+    fn = L.lib().cg_gemm_bias_act_bf16x3 if split else L.lib().cg_gemm_bias_act
+    st = fn(_p(x), _c_int(M), _c_int(K), _c_int(K), _p(wp), _c_int(n_out), _p(bias),
+            _p(row_bias), _c_int(rows_per_group), _c_int(ld_rb), _c_int(int(relu)),
+            _c_int(eye_k), _p(y), _c_int(n_out), _stream())
+    check(st, 'cg_gemm_bias_act_bf16x3' if split else 'cg_gemm_bias_act')
     return y
 
 

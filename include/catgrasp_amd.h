@@ -63,6 +63,13 @@ int cg_gemm_bias_act(const float* x, int M, int K, int ldx, const float* w_packe
                      const float* bias, const float* row_bias, int rows_per_group, int ld_rb,
                      int relu, int eye_k, float* y, int ldy, void* stream);
 
+/* Split-precision ("bf16x3") variant of cg_gemm_bias_act for the wide FC tails / segmentation head: every product block
+ * is three bf16 MFMAs with f32 accumulation, X is split on the fly, W is split-packed on the host
+ * (folding.pack_b_bf16x3, same layout as cg_pointmlp_max_bf16x3).  K % 16 == 0; other arguments as cg_gemm_bias_act. */
+int cg_gemm_bias_act_bf16x3(const float* x, int M, int K, int ldx, const unsigned short* w_split, int N,
+                            const float* bias, const float* row_bias, int rows_per_group, int ld_rb,
+                            int relu, int eye_k, float* y, int ldy, void* stream);
+
 /* softmax / argmax / confidence (predicter.py:86-91) and p_G = sum_k p_k * k / C
  * (run_grasp_simulation.py:313).  logits (B,C) -> probs (B,C), label (B) i32, conf (B), p_g (B). */
 int cg_softmax_pg(const float* logits, int B, int C, float* probs, int* label, float* conf, float* p_g,
