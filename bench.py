@@ -222,7 +222,7 @@ def main():
                     'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': traffic('f32'), 'traffic_unit': 'HBM bytes per launch (PMC)',
                     'avg_launch_ms': round(avg_ms, 4),
                     'launches': n, 'flop_per_candidate_launch': 2 * MAC_PER_POINT_ENC * 2048}
-        return {'bound': 'mfma', 'kernel': 'pointmlp_max_bf16x3_kernel<2> (encoder pass; 3 bf16 MFMAs per algorithmic product block)',
+        return {'bound': 'mfma', 'kernel': 'pointmlp_max_bf16x3_kernel<2, 8> (encoder pass; 3 bf16 MFMAs per algorithmic product block)',
                 'achieved': round(achieved, 2), 'peak': PEAK_BF16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': round(achieved / PEAK_BF16_MFMA_TFLOPS, 4), 'traffic': traffic('bf16x3'), 'traffic_unit': 'HBM bytes per launch (PMC)',
                 'avg_launch_ms': round(avg_ms, 4),
