@@ -76,3 +76,25 @@ def test_batched_candidate_inside_check(cuda_device, box):
     # neighbouring voxel, which can flip a candidate whose only inside point sits on the surface: allow <= 2 of 64
     assert (got != exp).sum() <= 2
     assert 0 < exp.sum() < len(exp)
+
+
+def test_robot_gripper_loads_sdf_grids_onto_the_device(cuda_device, box, tmp_path):
+    """RobotGripper.load (dexnet/grasping/gripper.py:119-129): the optional .sdf files next to the meshes become device Sdf3D grids."""
+    from catgrasp_amd import gripper as G
+    from catgrasp_amd import synth
+    from catgrasp_amd.sdf import SdfFile
+    data, origin, res = box
+    g = synth.make_gripper()
+    d = str(tmp_path)
+    G.save_obj(f'{d}/gripper_air_tight.obj', g['vertices'], g['faces'])
+    G.save_obj(f'{d}/gripper_enclosed_air_tight.obj', g['enclosed_vertices'], g['enclosed_faces'])
+    G.save_obj(f'{d}/finger1.obj', *synth.box_mesh([0.0, 0.02, -0.01], [0.04, 0.03, 0.01]))
+    open(f'{d}/params.json', 'w').write('{"hand_depth": 0.04}')
+    G.save_rigid_transform(f'{d}/T_grasp_gripper.tf', np.linalg.inv(g['gripper_in_grasp']), 'gripper', 'grasp')
+    small = data[:9, :8, :7]
+    SdfFile.write(f'{d}/gripper_air_tight.sdf', small, origin, res)
+    rg = G.RobotGripper.load(d, device=cuda_device)
+    assert rg.sdf is not None and rg.sdf_enclosed is None
+    assert np.array_equal(rg.sdf.data_torch.cpu().numpy(), small.astype(np.float32)) and rg.sdf.data_torch.is_cuda
+    c = np.array([[1.5], [2.25], [3.0]])
+    assert abs(float(rg.sdf._signed_distance(c).cpu()[0]) - sdf_ref.signed_distance(small, c)[0]) < 1e-6
