@@ -30,12 +30,24 @@ _ik_solver = None
 
 
 def set_ik_solver(fn):
-    """Register the host IK feasibility callback used when filter_ik=True:
-    fn(ee_in_base: (E,4,4) float32, upper: list[7], lower: list[7]) -> bool array (E,).
-    (The reference links a generated IKFast solver for the KUKA iiwa14, my_cpp/common.cpp:9-72; it is a
-    robot-specific fp64 host routine and is not part of this library.)"""
+    """Replace the IK feasibility test used when filter_ik=True by a host callback
+    fn(ee_in_base: (E,4,4) float32, upper: list[7], lower: list[7]) -> bool array (E,)  -- e.g. a wrapper over ikfast_pybind for
+    another robot.  `set_ik_solver(None)` restores the default: the device closed-form solver of the KUKA iiwa14 with the
+    redundancy joint fixed at 0 (csrc/iiwa_ik.hip), which is what the reference's generated IKFast file solves
+    (my_cpp/common.cpp:9-72)."""
     global _ik_solver
     _ik_solver = fn
+
+
+def ik_within_limits_device(ee, upper, lower):
+    """ee (E,16)/(E,4,4) float32 cuda tensor -> (E,) uint8 cuda tensor: get_ik_within_limits(...).size() > 0 per pose."""
+    ee = ee.reshape(-1, 16).contiguous()
+    E = ee.shape[0]
+    up = (ctypes.c_double * 7)(*[float(v) for v in upper])
+    lo = (ctypes.c_double * 7)(*[float(v) for v in lower])
+    ok = torch.empty((E,), dtype=torch.uint8, device=ee.device)
+    check(L.lib().cg_iiwa_ik_within_limits(_p(ee), ctypes.c_long(E), up, lo, _p(ok), _stream()), 'cg_iiwa_ik_within_limits')
+    return ok
 
 
 def _device():
@@ -241,12 +253,15 @@ def filter_on_device(scene, grasp_poses, symmetry_tfs, nocs_pose, canonical_to_n
 
     ik_ok = None
     if filter_ik and E > 0:
-        if _ik_solver is None:
-            raise NotImplementedError('filter_ik=True needs a host IK callback: catgrasp_amd.my_cpp.set_ik_solver(fn)')
+        if upper is None or lower is None or len(upper) != 7 or len(lower) != 7:
+            raise ValueError('filter_ik=True needs the 7 upper and 7 lower joint limits')
         ee = torch.empty((E, 16), dtype=torch.float32, device=dev)
         launch(None, ee)
-        ok = np.asarray(_ik_solver(ee.cpu().numpy().reshape(E, 4, 4), list(upper), list(lower))).astype(np.uint8).reshape(E)
-        ik_ok = torch.from_numpy(ok).to(dev)
+        if _ik_solver is None:       # default: iiwa14 closed form on the device, no host round trip
+            ik_ok = ik_within_limits_device(ee, upper, lower)
+        else:
+            ok = np.asarray(_ik_solver(ee.cpu().numpy().reshape(E, 4, 4), list(upper), list(lower))).astype(np.uint8).reshape(E)
+            ik_ok = torch.from_numpy(ok).to(dev)
     if E > 0:
         launch(ik_ok, None)
     return codes, poses.view(E, 4, 4), nudge

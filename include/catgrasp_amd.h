@@ -306,6 +306,13 @@ int cg_pg_get_iou(const int* proposals_idx, const int* proposals_offset, const l
 int cg_pg_voxelize_fp(const float* feats, const int* rules, int n_rows, int max_active, int C, int average, float* out,
                       void* stream);
 
+/* get_ik_within_limits(...).size() > 0 (my_cpp/common.cpp:9-72, called at :230-236 of filterGraspPose): closed-form IK of the
+ * KUKA LBR iiwa14 with the redundancy joint (index 2) at 0 -- what the reference's generated IKFast file solves -- one thread
+ * per pose, float64.  ee_in_base (E,16) float32 row-major 4x4 on the device, h_upper7 / h_lower7 HOST joint limits,
+ * ok[e] = 1 iff some solution lies inside the limits. */
+int cg_iiwa_ik_within_limits(const float* ee_in_base, long E, const double* h_upper7, const double* h_lower7,
+                             unsigned char* ok, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

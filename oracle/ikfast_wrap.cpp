@@ -31,3 +31,22 @@ extern "C" int ik_within_limits(const float* ee16, const double* upper, const do
 }
 
 extern "C" void ik_fk(const double* joints, double* eetrans, double* eerot) { ComputeFk(joints, eetrans, eerot); }
+
+// all solutions (free values = 0 as in common.cpp:46-49): writes up to max_solutions x 7 joint values, returns their number
+extern "C" int ik_solutions(const float* ee16, double* out, int max_solutions) {
+  IkSolutionList<double> solutions;
+  std::vector<double> vfree(GetNumFreeParameters());
+  double eerot[9], eetrans[3];
+  for (int i = 0; i < 3; ++i) eetrans[i] = ee16[i * 4 + 3];
+  for (int h = 0; h < 3; ++h) for (int w = 0; w < 3; ++w) eerot[h * 3 + w] = ee16[h * 4 + w];
+  if (!ComputeIk(eetrans, eerot, &vfree[0], solutions)) return 0;
+  std::vector<double> sol(GetNumJoints());
+  int n = 0;
+  for (std::size_t i = 0; i < solutions.GetNumSolutions() && n < max_solutions; ++i, ++n) {
+    const IkSolutionBase<double>& s = solutions.GetSolution(i);
+    std::vector<double> vsolfree(s.GetFree().size());
+    s.GetSolution(&sol[0], vsolfree.size() > 0 ? &vsolfree[0] : NULL);
+    for (int j = 0; j < 7; ++j) out[n * 7 + j] = sol[j];
+  }
+  return n;
+}

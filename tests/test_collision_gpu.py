@@ -254,8 +254,12 @@ def test_filter_with_ik_stage(cuda_device):
                                g['enclosed_vertices'], g['enclosed_faces'], objs[0]['xyz'], bg, 0.0005, ik_fn=ik_cb)
     _check(dev, ora)
     assert (ora[0] == 2).sum() > 0 and (ora[0] == 0).sum() > 0
-    with pytest.raises(NotImplementedError):       # no silent skipping of the IK test
-        my_cpp.filterGraspPoseDetailed(*_args(P, [I4], I4, g, objs[0]['xyz'], bg, True, False)[:8], True, False, upper, lower,
+    # default solver (no callback registered): the device closed-form iiwa14 IK must reproduce the IKFast-driven result
+    dev2 = my_cpp.filterGraspPoseDetailed(P, [I4], I4, I4, cam_in_world, ee_in_grasp, g['gripper_in_grasp'], True, True, False, upper, lower,
+                                          g['vertices'], g['faces'], g['enclosed_vertices'], g['enclosed_faces'], objs[0]['xyz'], bg, 0.0005)
+    _check(dev2, ora)
+    with pytest.raises(ValueError):                # limits are mandatory with filter_ik
+        my_cpp.filterGraspPoseDetailed(P, [I4], I4, I4, cam_in_world, ee_in_grasp, g['gripper_in_grasp'], True, True, False, None, None,
                                        g['vertices'], g['faces'], g['enclosed_vertices'], g['enclosed_faces'], objs[0]['xyz'], bg, 0.0005)
 
 
