@@ -36,11 +36,13 @@ def _background_points(scene_pts, ob_pts, gripper_diameter, device):
 
 
 def evaluate_object(ob_pts, ob_normals, scene_pts, K, gripper, grasp_predicter, nunocs_predicter, canonical=None, symmetry_tfs=None,
-                    n_surface_samples=50, sphere_pts=None, approach_step=0.004, resolution=0.0005, cam_in_world=None, timings=None):
+                    n_surface_samples=50, sphere_pts=None, approach_step=0.004, resolution=0.0005, cam_in_world=None, timings=None, ik=None):
     """Returns dict(poses (n,4,4) f32, p_G, p_T_given_G, p_T_G, order) for the surviving candidates, best first.
     `gripper`: dict with vertices/faces/enclosed_vertices/enclosed_faces/gripper_in_grasp/hand_depth/init_bite/diameter and
     finger_vertices (list of 2 arrays), grip_dirs.  `canonical`: optional dict(cloud, normals, affordance, grasps (m,4,4))
-    in the canonical (NUNOCS-scaled) frame; without it P(T|G) = 1 and only cone-sampled candidates are produced."""
+    in the canonical (NUNOCS-scaled) frame; without it P(T|G) = 1 and only cone-sampled candidates are produced.
+    `ik`: optional dict(ee_in_grasp 4x4, upper[7], lower[7]) -> filter_ik=True with the device iiwa14 solver (cam_in_world must
+    then be the camera pose in the robot base frame, common.cpp:214-226)."""
     dev = grasp_predicter.device
     t = time.perf_counter
 
@@ -76,15 +78,17 @@ def evaluate_object(ob_pts, ob_normals, scene_pts, K, gripper, grasp_predicter, 
     scene = my_cpp.GripperScene(gripper['vertices'], gripper['faces'], gripper['enclosed_vertices'], gripper['enclosed_faces'], ob_pts, occ,
                                 resolution, dev)
     sym1 = torch.eye(4, device=dev).reshape(1, 16)
-    codes, poses, _ = my_cpp.filter_on_device(scene, cone.float().reshape(-1, 16), sym1, I4, I4, cam_in_world, I4, gripper['gripper_in_grasp'],
-                                              True, False, True)
+    ee_in_grasp = I4 if ik is None else np.asarray(ik['ee_in_grasp'])
+    ik_kw = {} if ik is None else dict(upper=list(ik['upper']), lower=list(ik['lower']))
+    codes, poses, _ = my_cpp.filter_on_device(scene, cone.float().reshape(-1, 16), sym1, I4, I4, cam_in_world, ee_in_grasp,
+                                              gripper['gripper_in_grasp'], True, ik is not None, True, **ik_kw)
     keep = codes == 0
     surv = [poses[keep]]
     n_evaluated = int(codes.numel())
     if canonical is not None and nocs_pose is not None and len(canonical.get('grasps', [])):
         sym = symmetry_tfs if symmetry_tfs is not None else [np.eye(4)]
-        c2, p2, _ = my_cpp.filter_on_device(scene, np.asarray(canonical['grasps']), np.asarray(sym), nocs_pose, I4, cam_in_world, I4,
-                                            gripper['gripper_in_grasp'], True, False, True)
+        c2, p2, _ = my_cpp.filter_on_device(scene, np.asarray(canonical['grasps']), np.asarray(sym), nocs_pose, I4, cam_in_world, ee_in_grasp,
+                                            gripper['gripper_in_grasp'], True, ik is not None, True, **ik_kw)
         surv.append(p2[c2 == 0]); n_evaluated += int(c2.numel())
     surv = torch.cat(surv).contiguous()
     lap('filterGraspPose', t0)

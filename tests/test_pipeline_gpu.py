@@ -50,3 +50,14 @@ def test_evaluate_object_end_to_end(cuda_device):
     codes, _, _ = my_cpp.filterGraspPoseDetailed(out['poses'][:50], [I4], I4, I4, I4, I4, g['gripper_in_grasp'], True, False, False, [0] * 7, [0] * 7,
                                                  g['vertices'], g['faces'], g['enclosed_vertices'], g['enclosed_faces'], ob['xyz'], occ, 0.0005)
     assert (codes == 0).all()
+    # with the IK stage (device iiwa14 solver): survivors are a subset, and each of them passes the host statement of the solver
+    from catgrasp_amd import iiwa_ik
+    cam_in_world = np.eye(4); cam_in_world[:3, :3] = [[0, -1, 0], [-1, 0, 0], [0, 0, -1]]; cam_in_world[:3, 3] = [0.55, 0.0, 0.95]
+    ee_in_grasp = np.eye(4); ee_in_grasp[0, 3] = -0.15
+    upper = [2.96, 2.09, 2.96, 2.09, 2.96, 2.09, 3.05]; lower = [-u for u in upper]
+    np.random.seed(1)
+    out_ik = pipeline.evaluate_object(ob['xyz'], ob['normal'], scene_pts, K, g, gp, npred, canonical=canonical, symmetry_tfs=[np.eye(4)],
+                                      n_surface_samples=12, cam_in_world=cam_in_world, ik={'ee_in_grasp': ee_in_grasp, 'upper': upper, 'lower': lower})
+    assert 0 < len(out_ik['poses']) and out_ik['n_evaluated'] == out['n_evaluated']
+    ee = cam_in_world[None] @ out_ik['poses'].astype(np.float64) @ ee_in_grasp[None]
+    assert iiwa_ik.ik_within_limits(ee.astype(np.float32).astype(np.float64), upper, lower).mean() > 0.999
