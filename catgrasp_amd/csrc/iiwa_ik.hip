@@ -1,7 +1,8 @@
 // get_ik_within_limits (my_cpp/common.cpp:9-72) on the device: closed-form IK of the KUKA LBR iiwa14 with the redundancy
 // joint (index 2) fixed at 0, one thread per end-effector pose, float64.  The algorithm, its derivation from the arm's DH
 // table and the degeneracy windows of the reference's generated solver that it reproduces are stated in
-// catgrasp_amd/iiwa_ik.py (the host statement of the same arithmetic, checked against the real solver).
+// oracle/iiwa_ik_ref.py (the host restatement of the same arithmetic used by the tests, itself pinned to the real solver's
+// answers in tests/golden/iiwa_ik_golden.npz).
 #include "cg_common.hpp"
 #include "../../include/catgrasp_amd.h"
 

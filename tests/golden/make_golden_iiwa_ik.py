@@ -1,4 +1,4 @@
-"""Golden vectors for the iiwa14 closed-form IK (catgrasp_amd/iiwa_ik.py, csrc/iiwa_ik.hip) from the REFERENCE's own solver:
+"""Golden vectors for the iiwa14 closed-form IK (csrc/iiwa_ik.hip; host restatement oracle/iiwa_ik_ref.py) from the REFERENCE's own solver:
 the vendored IKFast file compiled where it lies (oracle/build_ref.py -> oracle/_ref/libikfast_ref.so) and driven exactly like
 get_ik_within_limits (my_cpp/common.cpp:9-72).  Run in the build container (needs /root/reference):
 

@@ -1,11 +1,11 @@
-"""The iiwa14 closed-form IK (catgrasp_amd/iiwa_ik.py on the host, csrc/iiwa_ik.hip on the device) against golden vectors produced
+"""The iiwa14 closed-form IK (csrc/iiwa_ik.hip on the device; oracle/iiwa_ik_ref.py is its host restatement) against golden vectors produced
 by the REFERENCE's own generated IKFast solver (tests/golden/make_golden_iiwa_ik.py; my_cpp/common.cpp:9-72)."""
 import os
 
 import numpy as np
 import pytest
 
-from catgrasp_amd import iiwa_ik as K
+from oracle import iiwa_ik_ref as K
 
 GOLD = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'iiwa_ik_golden.npz'))
 

@@ -51,7 +51,7 @@ def test_evaluate_object_end_to_end(cuda_device):
                                                  g['vertices'], g['faces'], g['enclosed_vertices'], g['enclosed_faces'], ob['xyz'], occ, 0.0005)
     assert (codes == 0).all()
     # with the IK stage (device iiwa14 solver): survivors are a subset, and each of them passes the host statement of the solver
-    from catgrasp_amd import iiwa_ik
+    from oracle import iiwa_ik_ref as iiwa_ik
     cam_in_world = np.eye(4); cam_in_world[:3, :3] = [[0, -1, 0], [-1, 0, 0], [0, 0, -1]]; cam_in_world[:3, 3] = [0.55, 0.0, 0.95]
     ee_in_grasp = np.eye(4); ee_in_grasp[0, 3] = -0.15
     upper = [2.96, 2.09, 2.96, 2.09, 2.96, 2.09, 3.05]; lower = [-u for u in upper]
