@@ -93,5 +93,7 @@ sym = torch.eye(4, device=dev).reshape(1, 16)
 I4 = np.eye(4, dtype=np.float32)
 t_f = timed(lambda: my_cpp.filter_on_device(sc, Pc, sym, I4, I4, I4, I4, gr['gripper_in_grasp'], True, False, False), iters=10)
 row('filter_grasp_pose_kernel (broad-phase grid)', t_f, Pn * (64 + 66), '64 B pose in + 66 B code/pose/nudge out per evaluation (HBM level)',
-    bound='L2/LDS gather latency', extra={'evaluations_per_s': round(Pn / t_f), 'voxels_open': int(sc.keys_open.shape[0]), 'voxels_background': int(sc.keys_bg.shape[0])})
+    bound='L2/LDS gather latency', extra={'evaluations_per_s': round(Pn / t_f), 'voxels_open': int(sc.keys_open.shape[0]), 'voxels_background': int(sc.keys_bg.shape[0]),
+                                         'cache_level_bytes': 'every evaluation scans the 8-byte keys of both voxel sets (L2-resident): evaluations x (voxels_open + voxels_background) x 8 B',
+                                         'cache_level_GBps': round(Pn / t_f * (int(sc.keys_open.shape[0]) + int(sc.keys_bg.shape[0])) * 8 / 1e9, 1)})
 print(json.dumps({'device': torch.cuda.get_device_name(0), 'hbm_peak_GBps': PEAK, 'kernels': rows}, indent=1))
