@@ -95,7 +95,12 @@ def run_step(wl, gp, npred, gather_buf=None, world=1):
     # (4) packed per-candidate record: p_G (f32) + code (as f32 lane) -> one all_gather over xGMI
     rec = torch.stack([p_g, codes.float()], dim=1).contiguous()
     if world > 1:
-        torch.distributed.all_gather_into_tensor(gather_buf, rec)
+        if torch.distributed.get_backend() == 'nccl':
+            torch.distributed.all_gather_into_tensor(gather_buf, rec)
+        else:           # dev only (CATGRASP_BENCH_BACKEND=gloo): exercise the multi-rank control flow on a 1-GPU box
+            parts = [torch.empty(rec.shape, dtype=rec.dtype) for _ in range(world)]
+            torch.distributed.all_gather(parts, rec.cpu())
+            gather_buf.copy_(torch.cat(parts))
         return gather_buf
     return rec
 
@@ -163,11 +168,17 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a HIP device')
+    # dev only: CATGRASP_BENCH_BACKEND=gloo CATGRASP_BENCH_DEVICE=0 runs N ranks on ONE GPU to check the multi-rank control flow
+    backend = os.environ.get('CATGRASP_BENCH_BACKEND', 'nccl')
+    local_rank = int(os.environ.get('CATGRASP_BENCH_DEVICE', local_rank))
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        torch.distributed.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+        if backend == 'nccl':
+            torch.distributed.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+        else:
+            torch.distributed.init_process_group(backend, rank=rank, world_size=world)
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
 
     from catgrasp_amd import ops, synth
@@ -200,7 +211,7 @@ def main():
             barrier()
             dt = time.perf_counter() - t0
             timer, ops.KERNEL_TIMER = ops.KERNEL_TIMER, None
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        t = torch.tensor([dt], dtype=torch.float64, device=device if backend == 'nccl' else 'cpu')
         if world > 1:
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
