@@ -75,3 +75,22 @@ def normalizer_device(cfg, device):
     std = np.asarray(cfg['std'], dtype=np.float64).reshape(-1)
     return (torch.from_numpy(mean.astype(np.float32)).to(device),
             torch.from_numpy((1.0 / (std + 1e-15)).astype(np.float32)).to(device))
+
+
+def get_symmetry_tfs(class_name):
+    """Symmetry transforms of an object category in its canonical frame (Utils.py:79-94 with allow_reflection=True; the
+    reference builds them with transformations.euler_matrix(x, 0, z, 'sxyz') = Rz(z) Rx(x)): nut 2 x 6 = 12, hnm 2, screw 72."""
+    def rz(a):
+        c, s = np.cos(a), np.sin(a)
+        return np.array([[c, -s, 0, 0], [s, c, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1.0]])
+
+    def rx(a):
+        c, s = np.cos(a), np.sin(a)
+        return np.array([[1, 0, 0, 0], [0, c, -s, 0], [0, s, c, 0], [0, 0, 0, 1.0]])
+    if class_name == 'nut':
+        return [rz(z) @ rx(x) for x in np.arange(0, 360, 180) / 180 * np.pi for z in np.arange(0, 360, 60) / 180 * np.pi]
+    if class_name == 'hnm':
+        return [rz(z) for z in (0, np.pi)]
+    if class_name == 'screw':
+        return [rz(z) for z in np.arange(0, 360, 5) / 180.0 * np.pi]
+    raise RuntimeError(f'{class_name} not found')

@@ -205,3 +205,16 @@ def test_robot_gripper_directory_loader(tmp_path):
         f.write('v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nvn 0 0 1\nf 1//1 2//1 3//1 4//1\n')
     Vq, Fq = G.load_obj(f'{d}/q.obj')
     assert Vq.shape == (4, 3) and Fq.tolist() == [[0, 1, 2], [0, 2, 3]]
+
+
+def test_symmetry_sets_form_groups():
+    """get_symmetry_tfs (Utils.py:79-94): sizes, identity first, closed under composition."""
+    for cls, n in (('nut', 12), ('hnm', 2), ('screw', 72)):
+        tfs = transforms.get_symmetry_tfs(cls)
+        assert len(tfs) == n and np.allclose(tfs[0], np.eye(4))
+        S = np.stack(tfs)
+        prod = (S[:, None] @ S[None]).reshape(-1, 4, 4)
+        d = np.abs(prod[:, None] - S[None]).max((-1, -2)).min(-1)
+        assert d.max() < 1e-12
+    with pytest.raises(RuntimeError):
+        transforms.get_symmetry_tfs('bolt')

@@ -95,6 +95,24 @@ def test_filter_nocs_transfer_path_symmetry_and_scale(cuda_device):
     _check(dev, ora)
 
 
+@pytest.mark.parametrize('cls,kind,n_sym', [('hnm', 'screw', 2), ('screw', 'screw', 72), ('nut', 'nut', 12)])
+def test_filter_category_symmetry_sets(cuda_device, cls, kind, n_sym):
+    """The per-category symmetry expansion of the NOCS-transfer sampler (Utils.py:79-94 -> grasp_sampler.py:345)."""
+    from catgrasp_amd import my_cpp, transforms
+    objs = synth.make_scene(4, 2000, seed=11, kind=kind)
+    g = synth.make_gripper()
+    bg = synth.background_points(objs, 1, g['diameter'])
+    obj = objs[1]
+    sym = transforms.get_symmetry_tfs(cls)
+    assert len(sym) == n_sym and all(np.allclose(S[:3, :3] @ S[:3, :3].T, np.eye(3)) for S in sym)
+    nocs_pose = obj['pose'] @ np.diag([0.01, 0.01, 0.05, 1.0])
+    P_can = np.linalg.inv(nocs_pose) @ synth.make_candidates(obj, 24, np.random.default_rng(3))
+    dev = my_cpp.filterGraspPoseDetailed(*_args(P_can, sym, nocs_pose, g, obj['xyz'], bg, True, True))
+    ora = _oracle(P_can, sym, nocs_pose, g, obj['xyz'], bg, 1, 1)
+    assert len(dev[0]) == 24 * n_sym
+    _check(dev, ora)
+
+
 def test_filter_edge_cases(cuda_device):
     from catgrasp_amd import my_cpp
     objs, g, bg = _scene(4, n_obj=3, pts=800)
