@@ -1,0 +1,101 @@
+"""Class-level sampler mirrors (catgrasp_amd/grasp_sampler.py) against the REAL reference PointConeGraspSampler.sample_grasps run
+under the same numpy seed (tests/golden/make_golden_sampler.py -> sampler_golden.npz)."""
+import os
+import types
+
+import numpy as np
+import pytest
+
+from catgrasp_amd import grasp_sampler as gs
+
+GOLD = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'sampler_golden.npz'))
+
+
+def _gripper():
+    return types.SimpleNamespace(hand_depth=0.04, init_bite=0.005, get_grasp_pose_in_gripper_base=lambda: np.eye(4))
+
+
+def test_hinter_sampling_enumeration():
+    pts, level = gs.hinter_sampling(1000)
+    assert np.array_equal(pts, GOLD['hinter_1000']) and len(level) == len(pts) == 2562
+
+
+def test_transfer_sampler_selection_and_centring():
+    """NocsTransferGraspSampler.__init__ (grasp_sampler.py:302-327): score threshold, best-n, y-centring of the object in the grasp."""
+    rng = np.random.default_rng(0)
+    grasps = []
+    for i in range(10):
+        T = np.eye(4); T[:3, 3] = rng.normal(0, 0.01, 3)
+        grasps.append(gs.ParallelJawPtGrasp3D(T, perturbation_score=i / 10))
+    s = gs.NocsTransferGraspSampler(_gripper(), None, {'canonical_grasps': grasps}, 'nut', score_larger_than=0.35, max_n_grasp=4,
+                                    center_ob_between_gripper=True)
+    kept = s.canonical['canonical_grasps']
+    assert [round(g.perturbation_score, 1) for g in kept] == [0.9, 0.8, 0.7, 0.6]
+    assert all(abs(np.linalg.inv(g.get_grasp_pose_matrix())[1, 3]) < 1e-15 for g in kept)
+    assert len(grasps) == 10 and abs(np.linalg.inv(grasps[9].grasp_pose)[1, 3]) > 0        # the caller's list is not modified
+
+
+def _surface_point(group):
+    return group[0, :3, 3] - 0.005 * group[0, :3, 0]          # first pose: depth 0 -> surface + init_bite * approach
+
+
+def _match_groups(mine, gold, n_per_point):
+    """Compare the per-surface-point groups.  Two LAPACK artefacts of the reference's `np.linalg.eig(M)` are tolerated and
+    counted: (a) the arbitrary sign of the minor axis (group differs by R0 -> R0 diag(1,-1,-1)); (b) a complex eigen-decomposition
+    of a symmetric matrix with (near-)repeated eigenvalues, which makes the reference skip every rotation of that point
+    (`np.iscomplex(R).any()`, grasp_sampler.py:277) -- the device solver is symmetric and always real, so the group exists here."""
+    F = np.diag([1.0, -1.0, -1.0])
+    gold_groups = {tuple(np.round(_surface_point(gold[k:k + n_per_point]), 9)): gold[k:k + n_per_point] for k in range(0, len(gold), n_per_point)}
+    flips, extra, degenerate = 0, [], []
+    for k in range(0, len(mine), n_per_point):
+        m = mine[k:k + n_per_point]
+        g = gold_groups.pop(tuple(np.round(_surface_point(m), 9)), None)
+        if g is None:
+            extra.append(_surface_point(m))
+            continue
+        if np.abs(g - m).max() < 1e-9:
+            continue
+        R0g = g[0, :3, :3]
+        A = np.swapaxes(R0g, 0, 1)[None] @ g[:, :3, :3]                      # R = R0 . A
+        R_exp = (R0g @ F)[None] @ A
+        if np.abs(R_exp - m[:, :3, :3]).max() >= 1e-9:                       # neither the same frame nor the flipped one:
+            assert np.abs(R0g[:, 0] - m[0, :3, 0]).max() < 1e-9             # same approach axis, and ...
+            degenerate.append(_surface_point(m))                             # ... the caller checks that the minor axis is ill-defined there
+            continue
+        surf = _surface_point(g)
+        depth = np.linalg.norm(g[:, :3, 3] - surf, axis=1)
+        assert np.abs(surf + depth[:, None] * R_exp[:, :, 0] - m[:, :3, 3]).max() < 1e-9
+        flips += 1
+    assert not gold_groups, 'a group of the reference has no counterpart'
+    return flips, extra, degenerate
+
+
+@pytest.mark.gpu
+def test_point_cone_sampler_reproduces_the_reference_candidate_list(cuda_device):
+    pts, nrm = GOLD['pts'], GOLD['nrm']
+    np.random.seed(99)
+    assert abs(gs.compute_cloud_resolution(pts) - float(GOLD['resolution_seed99'])) < 1e-12
+    s = gs.PointConeGraspSampler(_gripper(), None)
+    np.random.seed(4242)
+    mine = s.candidate_poses(pts.copy(), nrm.copy(), max_num_samples=8, n_sphere_dir=5, approach_step=0.01)
+    gold = GOLD['poses_plain']
+    assert abs(float(GOLD['r_ball_plain']) - s.params['r_ball']) < 1e-12     # incl. the doublings made while sampling (:243-247)
+    radii = s.info['radii']
+    n_per_point = (1 + 5 * 6) * 4
+    assert len(mine) == 8 * n_per_point and len(gold) % n_per_point == 0
+    flips, extra, degenerate = _match_groups(mine, gold, n_per_point)
+    print('groups:', len(mine) // n_per_point, 'sign flips:', flips, 'dropped by the reference (complex eig):', len(extra), 'degenerate:', len(degenerate))
+    assert len(mine) // n_per_point - len(extra) - len(degenerate) >= 3        # flat nut faces have identical normals: rank-1 scatter, minor axis arbitrary
+    for surf in extra + degenerate:   # such a point must indeed have a degenerate normal scatter: (near-)repeated smallest eigenvalues
+        d = np.linalg.norm(pts - surf, axis=1)
+        k = [i for i in range(0, len(mine), n_per_point) if np.abs(_surface_point(mine[i:i + n_per_point]) - surf).max() < 1e-9][0] // n_per_point
+        nb = nrm[(d <= radii[k]) & (d > 0)]
+        w = np.linalg.eigvalsh(nb.T @ nb)
+        assert (w[1] - w[0]) < 1e-6 * max(w[2], 1e-30), w
+    # centred variant: same rotations, y-offset so the object sits between the fingers (grasp_sampler.py:189-196)
+    np.random.seed(4242)
+    mine_c = s.candidate_poses(pts.copy(), nrm.copy(), max_num_samples=8, n_sphere_dir=5, approach_step=0.01, center_ob_between_gripper=True)
+    gold_c = GOLD['poses_centred']
+    assert not extra and mine.shape == gold.shape               # same groups in the same order on this fixture
+    same = np.abs(mine - gold).max((1, 2)) < 1e-9                # poses whose un-centred version is identical
+    assert same.sum() >= n_per_point and np.abs(mine_c[same] - gold_c[same]).max() < 1e-9
