@@ -1,5 +1,8 @@
 """TEST INFRASTRUCTURE ONLY (oracle) -- numpy/scipy restatement of compute_grasp_affordance_worker
-(run_grasp_simulation.py:50-75) and get_finger_contact_area (pybullet_env/env_grasp.py:243-283)."""
+(run_grasp_simulation.py:50-75) and get_finger_contact_area (pybullet_env/env_grasp.py:243-283).
+
+Pinned against the reference itself: tests/golden/make_golden_affordance.py runs the REAL get_finger_contact_area (open3d
+replaced by a small functional stand-in) -> affordance_golden.npz, checked in tests/test_oracle_host_golden.py."""
 import numpy as np
 from scipy.spatial import cKDTree
 

@@ -1,5 +1,9 @@
 """TEST INFRASTRUCTURE ONLY (oracle) -- numpy restatement of my_cpp directionVecToRotation / augmentGraspPoses
-(my_cpp/common.cpp:75-153), float32 loop counters, SVD orthonormalisation (R = U V^T) like Eigen::JacobiSVD."""
+(my_cpp/common.cpp:75-153), float32 loop counters, SVD orthonormalisation (R = U V^T) like Eigen::JacobiSVD.
+
+PARITY UNPINNED for augmentGraspPoses itself (my_cpp cannot be built here and nothing in the reference calls or tests it);
+its building block has a python twin, Utils.directionVecToRotation, whose REAL outputs pin `direction_vec_to_rotation` in
+tests/golden/host_golden.npz (tests/test_oracle_host_golden.py)."""
 import numpy as np
 
 

@@ -1,6 +1,10 @@
 """TEST INFRASTRUCTURE ONLY (oracle) -- numpy/scipy restatement of PointConeGraspSampler.sample_one_surface_point and
 the centring loop of sample_grasps (dexnet/grasping/grasp_sampler.py:189-198,225-298), Utils.directionVecToRotation /
-normalizeRotation (Utils.py:172-178,262-290)."""
+normalizeRotation (Utils.py:172-178,262-290).
+
+Pinned against the reference itself: tests/golden/make_golden_host.py runs the REAL sample_one_surface_point /
+directionVecToRotation / normalizeRotation under import stubs (host_golden.npz, tests/test_oracle_host_golden.py), and
+make_golden_sampler.py the REAL class-level sample_grasps (sampler_golden.npz, tests/test_sampler_classes.py)."""
 import numpy as np
 from scipy.spatial import cKDTree
 

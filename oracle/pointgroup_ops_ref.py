@@ -1,6 +1,9 @@
 """TEST INFRASTRUCTURE ONLY (oracle) -- numpy float32 restatement of the forward CUDA kernels of
 PointGroup/lib/pointgroup_ops/src (bfs_cluster.cu:15-62, sec_mean.cu:12-85, roipool.cu:12-40, get_iou.cu:12-37,
-voxelize.cu:10-34).  Sequential float32 accumulation in the kernels' loop order."""
+voxelize.cu:10-34).  Sequential float32 accumulation in the kernels' loop order.
+
+PARITY UNPINNED: the originals are CUDA (no nvcc / NVIDIA device here) and the reference holds no test, fixture or golden
+vector for them; the semantics are restated line by line from the .cu sources."""
 import numpy as np
 
 

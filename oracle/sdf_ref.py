@@ -1,6 +1,8 @@
 """TEST INFRASTRUCTURE ONLY (oracle) -- numpy restatement of meshpy Sdf3D lookups
 (meshpy/meshpy/sdf.py:312-343,351-357,377-389) and the SdfFile text reader (sdf_file.py:59-87).
-The originals import open3d / autolab_core and cannot be imported here."""
+The originals import open3d / autolab_core; tests/golden/make_golden_host.py imports them under inert stubs and runs the REAL
+Sdf3D._signed_distance / _signed_distance_batch / is_any_points_inside / SdfFile._read_3d, which pins this restatement
+(host_golden.npz, tests/test_oracle_host_golden.py)."""
 import numpy as np
 
 MIN_X, MAX_X = [0, 2, 3, 5], [1, 4, 6, 7]     # sdf.py:219-224

@@ -5,6 +5,11 @@ not installable here, so they cannot be imported).
 The reference draws resample indices from numpy's global RNG (`np.random.choice`,
 dataset_grasp.py:73, dataset_nunocs.py:44).  Here the indices are an explicit argument so
 the same `ids` feed both the oracle and the HIP path; `draw_ids` reproduces the draw.
+
+Pinned against the reference itself: tests/golden/make_golden_host.py runs the REAL GraspDataset.transform /
+NunocsIsolatedDataset.transform / NormalizeCloud / to_homo under inert import stubs (host_golden.npz), and
+make_golden_predicter.py the REAL GraspPredicter.predict_batch and the NUNOCS decode (predicter_golden.npz);
+tests/test_oracle_host_golden.py checks this file against both.
 """
 import numpy as np
 
