@@ -1,7 +1,9 @@
 """TEST INFRASTRUCTURE ONLY (oracle) -- numpy restatement of aligning.estimate9DTransform (aligning.py:23-119).
 PARITY UNPINNED w.r.t. OpenCV: cv2 is not installable here.  `cv2.estimateAffine3D` on exactly 4 correspondences is
 restated as the exact affine map through them (its RANSAC has a single possible sample and its refit uses the same 4
-points); a degenerate (coplanar) sample yields no model."""
+points); a degenerate (coplanar) sample yields no model.  Everything after that call is pinned against the reference
+itself: tests/golden/make_golden_host.py runs the REAL aligning.estimate9DTransform_worker with that one substitution
+(host_golden.npz, tests/test_oracle_host_golden.py)."""
 import numpy as np
 
 
