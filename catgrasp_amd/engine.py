@@ -10,8 +10,6 @@ Call graph per PointNetCls.forward (pointnet2.py:289-299), B samples of N points
 """
 import os
 
-import torch
-
 from . import ops
 
 # 'bf16x3': split-bf16 MFMA kernels for the per-point MLP chain (3 bf16 MFMAs per product block, f32 accumulate); the default:

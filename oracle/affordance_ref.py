@@ -4,7 +4,6 @@
 Pinned against the reference itself: tests/golden/make_golden_affordance.py runs the REAL get_finger_contact_area (open3d
 replaced by a small functional stand-in) -> affordance_golden.npz, checked in tests/test_oracle_host_golden.py."""
 import numpy as np
-from scipy.spatial import cKDTree
 
 
 def to_homo(p):

@@ -11,7 +11,6 @@ Pinned against the reference itself: ``tests/golden/make_golden.py`` imports the
 seeded inputs and commits the outputs under ``tests/golden/``;
 ``tests/test_oracle_golden.py`` checks this restatement against those vectors.
 """
-import numpy as np
 import torch
 
 BN_EPS = 1e-5  # torch.nn.BatchNorm1d default; pointnet2.py:164-168 constructs BN with no overrides

@@ -1,4 +1,4 @@
-import torch, sys
+import torch
 dev=torch.device('cuda:0')
 def timed(fn, iters=20, warm=3):
     for _ in range(warm): fn()

@@ -1,6 +1,6 @@
-import sys, time, os
+import sys, time
 sys.path.insert(0, '.')
-import torch, numpy as np
+import torch
 from oracle import pointnet_ref as oref
 from catgrasp_amd import synth
 sd = synth.make_state_dict('cls', 6, 10, seed=0)

@@ -1,8 +1,7 @@
 """Quick GPU timing of cls_forward (dev tool)."""
 import sys, time
 sys.path.insert(0, '.')
-import torch, numpy as np
-from oracle import pointnet_ref as oref
+import torch
 from catgrasp_amd import engine, folding
 dev = torch.device('cuda:0')
 from catgrasp_amd import synth

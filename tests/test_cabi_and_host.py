@@ -2,7 +2,6 @@
 (BN folding, fragment packing, pose inversion, RNG semantics, sharding) is correct; the product refuses to
 run without its HIP path instead of falling back."""
 import ctypes
-import os
 
 import numpy as np
 import pytest

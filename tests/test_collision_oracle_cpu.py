@@ -3,7 +3,6 @@ absent, so instead of golden vectors the restatement is checked against independ
 octomap's published key formula in numpy float64, an exact rational-free float64 triangle/box test by
 dense sampling, and control-flow invariants of filterGraspPose (my_cpp/common.cpp:156-321)."""
 import numpy as np
-import pytest
 
 from catgrasp_amd import synth
 from oracle import collision_oracle as co

@@ -1,7 +1,6 @@
 """GPU: the per-object device pipeline (catgrasp_amd/pipeline.py) runs end to end and its pieces are mutually consistent."""
 import numpy as np
 import pytest
-import torch
 
 from catgrasp_amd import synth
 
