@@ -53,6 +53,8 @@ struct ArgsB {
   const unsigned short* w2; const float* b2;     // split-packed 64->128
   const unsigned short* w3; const float* b3;     // split-packed 128->1024
   int relu3; int nsplit;
+  int n_main;            // samples [0, n_main) use `nsplit` workgroups each, samples [n_main, B) `tail_split` (tail balancing)
+  int tail_split;
   float* out; float* pointfeat;
 };
 
@@ -151,11 +153,16 @@ __global__ __launch_bounds__(64 * RT, 2) void pointmlp_max_bf16x3_kernel(ArgsB a
   const int lane = tid & 63;
   const int w = tid >> 6;
   const int l31 = lane & 31, lhi = lane >> 5;
-  const int b = blockIdx.x / a.nsplit;
-  const int split = blockIdx.x - b * a.nsplit;
+  int b, split, nsp;
+  if ((int)blockIdx.x < a.n_main * a.nsplit) {
+    nsp = a.nsplit; b = blockIdx.x / nsp; split = blockIdx.x - b * nsp;
+  } else {                 // the last B % #CU samples of a big batch: one workgroup per tile, so the final round is short
+    const int r = blockIdx.x - a.n_main * a.nsplit;
+    nsp = a.tail_split; b = a.n_main + r / nsp; split = r - (r / nsp) * nsp;
+  }
   const int ntiles = (a.N + TP - 1) / TP;
-  const int t_begin = (int)(((long)ntiles * split) / a.nsplit);
-  const int t_end = (int)(((long)ntiles * (split + 1)) / a.nsplit);
+  const int t_begin = (int)(((long)ntiles * split) / nsp);
+  const int t_end = (int)(((long)ntiles * (split + 1)) / nsp);
 
   // ---- once per workgroup: running max, first-layer fragments (W1 | b1 as the k = 6 column), mid-layer fragments
   for (int i = tid; i < 1024; i += NT) rmax[i] = -INFINITY;
@@ -322,7 +329,7 @@ __global__ __launch_bounds__(64 * RT, 2) void pointmlp_max_bf16x3_kernel(ArgsB a
     for (int ch = tid; ch < 1024; ch += NT) {
       float v = rmax[ch] + a.b3[ch];
       if (a.relu3) v = fmaxf(v, 0.f);
-      if (a.nsplit == 1) a.out[(size_t)b * 1024 + ch] = v;
+      if (nsp == 1) a.out[(size_t)b * 1024 + ch] = v;
       else atomic_max_f32(a.out + (size_t)b * 1024 + ch, v);
     }
   }
@@ -344,7 +351,7 @@ int launch(const ArgsB& a, hipStream_t s) {
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)(a.B * a.nsplit)), dim3(NT), LDS_BYTES, s, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(a.n_main * a.nsplit + (a.B - a.n_main) * a.tail_split)), dim3(NT), LDS_BYTES, s, a);
   return cg_hip_status(hipGetLastError());
 }
 
@@ -366,11 +373,25 @@ extern "C" int cg_pointmlp_max_bf16x3(const float* x, int B, int N, const float*
   if (nsplit < 1) nsplit = 1;
   if (nsplit > ntiles) nsplit = ntiles;
   hipStream_t s = (hipStream_t)stream;
-  if (nsplit > 1) {
-    const size_t n = (size_t)B * 1024;
-    hipLaunchKernelGGL(fill_kernel_b, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, out, n, -INFINITY);
+  // Tail balancing: with one workgroup per sample (nsplit == 1) and B >= #CU, the last B % #CU samples would occupy a few CUs
+  // for a whole sample's duration while the rest of the chip idles; they are split one workgroup per tile instead (atomic max
+  // into a -inf pre-filled row), so the final round lasts one tile, not ntiles.
+  int n_main = B, tail_split = 1;
+  if (nsplit == 1 && ntiles > 1) {
+    static int n_cu = 0;
+    if (n_cu == 0) {
+      int dev = 0; hipDeviceProp_t prop;
+      if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return CG_ERR_UNSUPPORTED;
+      n_cu = prop.multiProcessorCount;
+    }
+    if (B >= n_cu && (B % n_cu) != 0) { n_main = B - B % n_cu; tail_split = ntiles; }
   }
-  ArgsB a{x, B, N, t3, w1, b1, wm_split, bm, t64, w2_split, b2, w3_split, b3, relu3, nsplit, out, pointfeat};
+  if (nsplit > 1 || tail_split > 1) {
+    const int first = (nsplit > 1) ? 0 : n_main;
+    const size_t n = (size_t)(B - first) * 1024;
+    hipLaunchKernelGGL(fill_kernel_b, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, out + (size_t)first * 1024, n, -INFINITY);
+  }
+  ArgsB a{x, B, N, t3, w1, b1, wm_split, bm, t64, w2_split, b2, w3_split, b3, relu3, nsplit, n_main, tail_split, out, pointfeat};
   if (mid_mode == 0) return launch<0, 8>(a, s);
   if (mid_mode == 1) return launch<1, 8>(a, s);
   return launch<2, 8>(a, s);
