@@ -33,6 +33,7 @@ struct Args {
   const float* w3; const float* b3; // packed 128->1024
   int relu3;
   int nsplit;                       // workgroups per sample (point tiles are divided between them)
+  int n_main; int tail_split;       // samples [n_main, B) use tail_split workgroups each (tail balancing, see the launcher)
   float* out;                       // (B,1024); pre-filled with -inf when nsplit>1
   float* pointfeat;                 // optional (B,N,64): output of the mid layer (MID==2 only)
 };
@@ -52,11 +53,16 @@ __global__ __launch_bounds__(256) void pointmlp_max_kernel(Args a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = tid >> 6;
-  const int b = blockIdx.x / a.nsplit;
-  const int split = blockIdx.x - b * a.nsplit;
+  int b, split, nsp;
+  if ((int)blockIdx.x < a.n_main * a.nsplit) {
+    nsp = a.nsplit; b = blockIdx.x / nsp; split = blockIdx.x - b * nsp;
+  } else {
+    const int r = blockIdx.x - a.n_main * a.nsplit;
+    nsp = a.tail_split; b = a.n_main + r / nsp; split = r - (r / nsp) * nsp;
+  }
   const int ntiles = (a.N + TP - 1) / TP;
-  const int t_begin = (int)(((long)ntiles * split) / a.nsplit);
-  const int t_end = (int)(((long)ntiles * (split + 1)) / a.nsplit);
+  const int t_begin = (int)(((long)ntiles * split) / nsp);
+  const int t_end = (int)(((long)ntiles * (split + 1)) / nsp);
 
   for (int i = tid; i < 1024; i += 256) rmax[i] = -INFINITY;
 
@@ -214,7 +220,7 @@ __global__ __launch_bounds__(256) void pointmlp_max_kernel(Args a) {
     for (int ch = tid; ch < 1024; ch += 256) {
       float v = rmax[ch] + a.b3[ch];
       if (a.relu3) v = fmaxf(v, 0.f);
-      if (a.nsplit == 1) a.out[(size_t)b * 1024 + ch] = v;
+      if (nsp == 1) a.out[(size_t)b * 1024 + ch] = v;
       else atomic_max_f32(a.out + (size_t)b * 1024 + ch, v);
     }
   }
@@ -241,13 +247,26 @@ extern "C" int cg_pointmlp_max(const float* x, int B, int N, const float* t3, co
   if (nsplit < 1) nsplit = 1;
   if (nsplit > ntiles) nsplit = ntiles;
   hipStream_t s = (hipStream_t)stream;
-  if (nsplit > 1) {
-    size_t n = (size_t)B * 1024;
-    hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, out, n, -INFINITY);
+  // Tail balancing (as in pointmlp_bf16x3.hip): with one workgroup per sample and B >= the number of resident workgroups
+  // (2 per CU), the samples of the last, partially filled scheduling round are split 8 ways so that round is short.
+  int n_main = B, tail_split = 1;
+  if (nsplit == 1 && ntiles >= 8) {
+    static int slots = 0;
+    if (slots == 0) {
+      int dev = 0; hipDeviceProp_t prop;
+      if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return CG_ERR_UNSUPPORTED;
+      slots = 2 * prop.multiProcessorCount;
+    }
+    if (B >= slots && (B % slots) != 0) { n_main = B - B % slots; tail_split = 8; }
   }
-  Args a{x, B, N, t3, w1, b1, wm_packed, bm, t64, w2_packed, b2, w3_packed, b3, relu3, nsplit, out, pointfeat};
+  if (nsplit > 1 || tail_split > 1) {
+    const int first = (nsplit > 1) ? 0 : n_main;
+    const size_t n = (size_t)(B - first) * 1024;
+    hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, out + (size_t)first * 1024, n, -INFINITY);
+  }
+  Args a{x, B, N, t3, w1, b1, wm_packed, bm, t64, w2_packed, b2, w3_packed, b3, relu3, nsplit, n_main, tail_split, out, pointfeat};
   const size_t lds = LDS_FLOATS * sizeof(float);
-  dim3 grid((unsigned)(B * nsplit)), block(256);
+  dim3 grid((unsigned)(n_main * nsplit + (B - n_main) * tail_split)), block(256);
   if (mid_mode == 0) hipLaunchKernelGGL(pointmlp_max_kernel<0>, grid, block, lds, s, a);
   else if (mid_mode == 1) hipLaunchKernelGGL(pointmlp_max_kernel<1>, grid, block, lds, s, a);
   else hipLaunchKernelGGL(pointmlp_max_kernel<2>, grid, block, lds, s, a);
