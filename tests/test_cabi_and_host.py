@@ -217,3 +217,27 @@ def test_symmetry_sets_form_groups():
         assert d.max() < 1e-12
     with pytest.raises(RuntimeError):
         transforms.get_symmetry_tfs('bolt')
+
+
+def test_committed_bench_line_honours_the_contract():
+    """profiles/r1_bench_line.json is the JSON line bench.py printed on the MI355X for this round: every field of the driver's
+    contract (and the roofline / cpu_baseline objects) must be present and self-consistent."""
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles', 'r1_bench_line.json')
+    d = json.loads(open(path).read())
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype',
+              'data', 'config', 'roofline', 'cpu_baseline'):
+        assert k in d, k
+    assert d['unit'] == 'candidates/s' and d['higher_is_better'] is True and d['scaling'] == 'weak' and d['vs_baseline'] is None
+    assert 'workload' in d['config'] and 'model' not in d['config']
+    per_gpu = d['config']['candidates_per_gpu']
+    assert abs(d['value'] - d['n_gpus'] * per_gpu / (d['ms_per_step'] * 1e-3)) / d['value'] < 1e-3
+    r = d['roofline']
+    for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
+        assert k in r, k
+    assert r['bound'] in ('hbm', 'mfma') and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3
+    c = d['cpu_baseline']
+    for k in ('value', 'unit', 'cores', 'kind', 'sample'):
+        assert k in c, k
+    assert c['kind'] in ('reference', 'port') and c['cores'] >= 1
