@@ -27,12 +27,13 @@ sys.path.insert(0, ROOT)
 
 MAC_PER_POINT_ENC = 9 + 384 + 4096 + 8192 + 131072      # encoder pass (mid_mode 2): T3, conv1, .T64, conv2, conv3
 PEAK_F32_MFMA_TFLOPS = 157.3                            # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
-PEAK_BF16_MFMA_TFLOPS = 2500.0                          # MI355X_MICROARCH.md: bf16 MFMA dense peak (~2.5 PF)
+PEAK_BF16_MFMA_TFLOPS = 2500.0                          # MI355X_MICROARCH.md: BF16/F16 MFMA dense peak (~2.5 PF)
 # HBM bytes per candidate of the encoder-pass kernel from the PMC passes in profiles/r1_pmc_pointmlp.csv
 # (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate runs, B=4096): 2*FETCH_SIZE (gfx950 correction for wide
 # coalesced reads, MI355X_MICROARCH.md §HBM) + WRITE_SIZE, divided by 4096.  Algorithmic: 49152 B x + 16384 B transform
 # + 4096 B out = 69632 B/candidate; both kernels move the algorithmic bytes and nothing else (no scratch).
-PMC_HBM_BYTES_PER_CANDIDATE = {'bf16x3': (2 * 133760.3 + 16384.0) * 1024 / 4096, 'f32': (2 * 133763.3 + 16384.0) * 1024 / 4096}
+PMC_HBM_BYTES_PER_CANDIDATE = {'bf16x3': (2 * 133760.3 + 16384.0) * 1024 / 4096, 'f16x3': (2 * 133760.3 + 16384.0) * 1024 / 4096,
+                               'f32': (2 * 133763.3 + 16384.0) * 1024 / 4096}
 
 
 def build_workload(device, G, seed, n_objects=8, pts_per_object=2500, kind='nut'):
@@ -157,9 +158,9 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--candidates', type=int, default=10000, help='grasp candidates per GPU per step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--precision', choices=['bf16x3', 'f32'], default='bf16x3',
-                    help='per-point MLP arithmetic of the timed path: bf16x3 = split-bf16 MFMA products with f32 accumulation '
-                         '(logits within ~1e-5 of f32; inside the 1e-4 parity bar), f32 = exact-f32 MFMA')
+    ap.add_argument('--precision', choices=['f16x3', 'bf16x3', 'f32'], default='f16x3',
+                    help='arithmetic of the timed path: f16x3 / bf16x3 = split MFMA products (x = hi + lo half / bf16 pieces, 3 MFMAs per '
+                         'product block, f32 accumulation; logits within ~2e-6 / ~2e-5 of the float64 evaluation; bar 1e-4), f32 = exact-f32 MFMA')
     ap.add_argument('--no-secondary', action='store_true', help='skip the second measurement with the other precision')
     args = ap.parse_args()
 
@@ -233,19 +234,20 @@ def main():
                     'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': traffic('f32'), 'traffic_unit': 'HBM bytes per launch (PMC)',
                     'avg_launch_ms': round(avg_ms, 4),
                     'launches': n, 'flop_per_candidate_launch': 2 * MAC_PER_POINT_ENC * 2048}
-        return {'bound': 'mfma', 'kernel': 'pointmlp_max_bf16x3_kernel<2, 8> (encoder pass; 3 bf16 MFMAs per algorithmic product block)',
+        el = 'f16' if precision == 'f16x3' else 'bf16'
+        return {'bound': 'mfma', 'kernel': f'pointmlp_max_split_kernel<2, 8, {"true" if el == "f16" else "false"}> (encoder pass; 3 {el} MFMAs per algorithmic product block)',
                 'achieved': round(achieved, 2), 'peak': PEAK_BF16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': round(achieved / PEAK_BF16_MFMA_TFLOPS, 4), 'traffic': traffic('bf16x3'), 'traffic_unit': 'HBM bytes per launch (PMC)',
+                'frac': round(achieved / PEAK_BF16_MFMA_TFLOPS, 4), 'traffic': traffic(precision), 'traffic_unit': 'HBM bytes per launch (PMC)',
                 'avg_launch_ms': round(avg_ms, 4),
                 'launches': n, 'flop_per_candidate_launch': 2 * MAC_PER_POINT_ENC * 2048,
                 'issued_mfma_tflops': round(3 * achieved, 1), 'issued_frac': round(3 * achieved / PEAK_BF16_MFMA_TFLOPS, 4),
-                'note': 'achieved counts ALGORITHMIC flops; the split issues 3 bf16 MFMA flops per algorithmic flop on the K>=64 layers, '
-                        'so the ceiling for algorithmic flops is peak/3 = 833 TFLOP/s'}
+                'note': 'achieved counts ALGORITHMIC flops; the split issues 3 16-bit MFMA flops per algorithmic flop, '
+                        'so the ceiling for algorithmic flops is peak/3 = 833 TFLOP/s (f16 and bf16 MFMA share the 2.5 PFLOP/s dense peak)'}
 
     dt, avg_ms, achieved, n_launch, out, avg_B = measure(args.precision)
     secondary = None
     if not args.no_secondary:
-        other = 'f32' if args.precision == 'bf16x3' else 'bf16x3'
+        other = 'f32' if args.precision != 'f32' else 'f16x3'
         ref_out = out.clone()
         dt2, avg2, ach2, n2, out2, avg_B2 = measure(other)
         pg_diff = float((out2[:, 0] - ref_out[:, 0]).abs().max().item())
@@ -261,7 +263,8 @@ def main():
             'metric': 'grasp candidates scored+collision-checked /sec, 20k-pt clutter scene',
             'value': round(value, 1), 'unit': 'candidates/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(ms_step, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32' if args.precision == 'f32' else 'f32 in/out/accumulate; per-point MLP products as 3x bf16 MFMA (bf16x3 split)',
+            'dtype': 'f32' if args.precision == 'f32' else
+                     f'f32 in/out/accumulate; wide-layer products as 3x {"f16" if args.precision == "f16x3" else "bf16"} MFMA ({args.precision} split)',
             'data': 'synthetic (seeded clouds/candidates/gripper, random-init weights)',
             'config': {'workload': 'nut clutter pile, 20k-pt scene (8 objects x 2500 pts), '
                                    f'{G} candidates/GPU: NUNOCS(8x8192) + filterGraspPose + grasp-Q PointNetCls(2048x6)',

@@ -13,7 +13,11 @@ namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef u32x4 frag;      // a 128-bit operand fragment; F16 selects IEEE half (true) or bf16 (false) pieces, see pointmlp_bf16x3.hip
 
 constexpr int BM = 128;      // rows per workgroup (4 row tiles per wave: each weight fragment feeds 12 MFMAs)
 constexpr int BK = 64;       // K chunk staged in LDS
@@ -28,17 +32,32 @@ struct GemmArgsB {
   float* y; int ldy;
 };
 
+template <bool F16>
 __device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
-  const bf16x2 h = {(__bf16)a, (__bf16)b};
-  hi = __builtin_bit_cast(unsigned, h);
-  const float ha = __uint_as_float(hi << 16), hb = __uint_as_float(hi & 0xffff0000u);
-  const bf16x2 l = {(__bf16)(a - ha), (__bf16)(b - hb)};
-  lo = __builtin_bit_cast(unsigned, l);
+  if constexpr (F16) {
+    const f16x2 h = {(_Float16)a, (_Float16)b};
+    hi = __builtin_bit_cast(unsigned, h);
+    const f16x2 l = {(_Float16)(a - (float)h[0]), (_Float16)(b - (float)h[1])};
+    lo = __builtin_bit_cast(unsigned, l);
+  } else {
+    const bf16x2 h = {(__bf16)a, (__bf16)b};
+    hi = __builtin_bit_cast(unsigned, h);
+    const float ha = __uint_as_float(hi << 16), hb = __uint_as_float(hi & 0xffff0000u);
+    const bf16x2 l = {(__bf16)(a - ha), (__bf16)(b - hb)};
+    lo = __builtin_bit_cast(unsigned, l);
+  }
 }
 
-__global__ __launch_bounds__(256) void gemm_bias_act_bf16x3_kernel(GemmArgsB a) {
-  __shared__ __attribute__((aligned(16))) __bf16 xh[BM * SR];
-  __shared__ __attribute__((aligned(16))) __bf16 xl[BM * SR];
+template <bool F16>
+__device__ __forceinline__ f32x16 mfma_x(frag a, frag b, f32x16 c) {
+  if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+template <bool F16>
+__global__ __launch_bounds__(256) void gemm_bias_act_split_kernel(GemmArgsB a) {
+  __shared__ __attribute__((aligned(16))) unsigned short xh[BM * SR];
+  __shared__ __attribute__((aligned(16))) unsigned short xl[BM * SR];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = tid >> 6;
@@ -59,32 +78,32 @@ __global__ __launch_bounds__(256) void gemm_bias_act_bf16x3_kernel(GemmArgsB a) 
         int row = row0 + r; if (row >= a.M) row = a.M - 1;
         const f32x4 v = *(const f32x4*)(a.x + (size_t)row * a.ldx + k0 + cq * 4);
         unsigned h0, l0, h1, l1;
-        split2(v[0], v[1], h0, l0); split2(v[2], v[3], h1, l1);
+        split2<F16>(v[0], v[1], h0, l0); split2<F16>(v[2], v[3], h1, l1);
         *(u32x2*)(xh + r * SR + cq * 4) = u32x2{h0, h1};
         *(u32x2*)(xl + r * SR + cq * 4) = u32x2{l0, l1};
       }
     }
     __syncthreads();
     if (active) {
-      const bf16x8* bp = (const bf16x8*)a.wp + ((size_t)(nb * nkc_total + k0 / 16) * 2) * 64 + lane;
-      const __bf16* ah0 = xh + l31 * SR + lhi * 8;
-      const __bf16* al0 = xl + l31 * SR + lhi * 8;
+      const frag* bp = (const frag*)a.wp + ((size_t)(nb * nkc_total + k0 / 16) * 2) * 64 + lane;
+      const unsigned short* ah0 = xh + l31 * SR + lhi * 8;
+      const unsigned short* al0 = xl + l31 * SR + lhi * 8;
       const int ns = kc / 16;
 #pragma unroll 2
       for (int s = 0; s < ns; ++s) {
-        const bf16x8 bh = bp[s * 128], bl = bp[s * 128 + 64];
-        bf16x8 ah[4], al[4];
+        const frag bh = bp[s * 128], bl = bp[s * 128 + 64];
+        frag ah[4], al[4];
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt) {
-          ah[rt] = *(const bf16x8*)(ah0 + rt * 32 * SR + s * 16);
-          al[rt] = *(const bf16x8*)(al0 + rt * 32 * SR + s * 16);
+          ah[rt] = *(const frag*)(ah0 + rt * 32 * SR + s * 16);
+          al[rt] = *(const frag*)(al0 + rt * 32 * SR + s * 16);
         }
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt) c[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[rt], bh, c[rt], 0, 0, 0);
+        for (int rt = 0; rt < 4; ++rt) c[rt] = mfma_x<F16>(al[rt], bh, c[rt]);
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt) c[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[rt], bl, c[rt], 0, 0, 0);
+        for (int rt = 0; rt < 4; ++rt) c[rt] = mfma_x<F16>(ah[rt], bl, c[rt]);
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt) c[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[rt], bh, c[rt], 0, 0, 0);
+        for (int rt = 0; rt < 4; ++rt) c[rt] = mfma_x<F16>(ah[rt], bh, c[rt]);
       }
     }
   }
@@ -110,9 +129,10 @@ __global__ __launch_bounds__(256) void gemm_bias_act_bf16x3_kernel(GemmArgsB a) 
 
 }  // namespace
 
-extern "C" int cg_gemm_bias_act_bf16x3(const float* x, int M, int K, int ldx, const unsigned short* w_split, int N,
-                                       const float* bias, const float* row_bias, int rows_per_group, int ld_rb,
-                                       int relu, int eye_k, float* y, int ldy, void* stream) {
+template <bool F16>
+static int gemm_bias_act_split(const float* x, int M, int K, int ldx, const unsigned short* w_split, int N,
+                                const float* bias, const float* row_bias, int rows_per_group, int ld_rb,
+                                int relu, int eye_k, float* y, int ldy, void* stream) {
   if (!x || !w_split || !y) return CG_ERR_ARG;
   if (M < 0 || N <= 0 || K <= 0 || (K % 16) != 0 || (ldx % 4) != 0 || ldx < K || ldy < N) return CG_ERR_ARG;
   if (((uintptr_t)x & 15) != 0) return CG_ERR_ARG;
@@ -120,6 +140,18 @@ extern "C" int cg_gemm_bias_act_bf16x3(const float* x, int M, int K, int ldx, co
   if (M == 0) return CG_OK;
   GemmArgsB a{x, M, K, ldx, w_split, N, (N + 31) / 32, bias, row_bias, rows_per_group, ld_rb, relu, eye_k, y, ldy};
   dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((a.nblocks + 3) / 4)), block(256);
-  hipLaunchKernelGGL(gemm_bias_act_bf16x3_kernel, grid, block, 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(gemm_bias_act_split_kernel<F16>, grid, block, 0, (hipStream_t)stream, a);
   return cg_hip_status(hipGetLastError());
+}
+
+extern "C" int cg_gemm_bias_act_bf16x3(const float* x, int M, int K, int ldx, const unsigned short* w_split, int N,
+                                       const float* bias, const float* row_bias, int rows_per_group, int ld_rb,
+                                       int relu, int eye_k, float* y, int ldy, void* stream) {
+  return gemm_bias_act_split<false>(x, M, K, ldx, w_split, N, bias, row_bias, rows_per_group, ld_rb, relu, eye_k, y, ldy, stream);
+}
+
+extern "C" int cg_gemm_bias_act_f16x3(const float* x, int M, int K, int ldx, const unsigned short* w_split, int N,
+                                       const float* bias, const float* row_bias, int rows_per_group, int ld_rb,
+                                       int relu, int eye_k, float* y, int ldy, void* stream) {
+  return gemm_bias_act_split<true>(x, M, K, ldx, w_split, N, bias, row_bias, rows_per_group, ld_rb, relu, eye_k, y, ldy, stream);
 }

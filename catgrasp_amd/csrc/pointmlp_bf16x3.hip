@@ -31,6 +31,8 @@ namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
@@ -58,43 +60,60 @@ struct ArgsB {
   float* out; float* pointfeat;
 };
 
-__device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+// Fragments travel as raw 128-bit values; the 16-bit element type (F16 = false: bf16, true: IEEE half) only matters where a
+// float is split into its hi / lo pieces and where the MFMA is issued.  Half pieces carry 11 + 11 significant bits (logits
+// within ~2e-6 of the float64 evaluation -- float32's own distance), bf16 pieces 8 + 8 (~2e-5); both cost 3 MFMAs.
+typedef u32x4 frag;
+
+template <bool F16>
+__device__ __forceinline__ f32x16 mfma_x(frag a, frag b, f32x16 c) {
+  if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
-// bf16x3 product block: c += A.B with A = ah + al, B = bh + bl (small terms first)
-__device__ __forceinline__ f32x16 mfma3(bf16x8 ah, bf16x8 al, bf16x8 bh, bf16x8 bl, f32x16 c) {
-  c = mfma_bf16(ah, bl, c);
-  c = mfma_bf16(al, bh, c);
-  return mfma_bf16(ah, bh, c);
+// split product block: c += A.B with A = ah + al, B = bh + bl (small terms first)
+template <bool F16>
+__device__ __forceinline__ f32x16 mfma3(frag ah, frag al, frag bh, frag bl, f32x16 c) {
+  c = mfma_x<F16>(ah, bl, c);
+  c = mfma_x<F16>(al, bh, c);
+  return mfma_x<F16>(ah, bh, c);
 }
 
-__device__ __forceinline__ void split8(const f32x4& v0, const f32x4& v1, bf16x8& hi, bf16x8& lo) {
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const __bf16 h0 = (__bf16)v0[e]; hi[e] = h0; lo[e] = (__bf16)(v0[e] - (float)h0);
-    const __bf16 h1 = (__bf16)v1[e]; hi[4 + e] = h1; lo[4 + e] = (__bf16)(v1[e] - (float)h1);
+// two floats -> packed pair of the high parts and packed pair of the residuals (v_cvt_pk_{bf16,f16}_f32 x2)
+template <bool F16>
+__device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
+  if constexpr (F16) {
+    const f16x2 h = {(_Float16)a, (_Float16)b};
+    hi = __builtin_bit_cast(unsigned, h);
+    const f16x2 l = {(_Float16)(a - (float)h[0]), (_Float16)(b - (float)h[1])};
+    lo = __builtin_bit_cast(unsigned, l);
+  } else {
+    const bf16x2 h = {(__bf16)a, (__bf16)b};
+    hi = __builtin_bit_cast(unsigned, h);
+    const float ha = __uint_as_float(hi << 16), hb = __uint_as_float(hi & 0xffff0000u);
+    const bf16x2 l = {(__bf16)(a - ha), (__bf16)(b - hb)};
+    lo = __builtin_bit_cast(unsigned, l);
   }
 }
 
-// two floats -> packed bf16 pair of the high parts and packed pair of the residuals (v_cvt_pk_bf16_f32 x2)
-__device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
-  const bf16x2 h = {(__bf16)a, (__bf16)b};
-  hi = __builtin_bit_cast(unsigned, h);
-  const float ha = __uint_as_float(hi << 16), hb = __uint_as_float(hi & 0xffff0000u);
-  const bf16x2 l = {(__bf16)(a - ha), (__bf16)(b - hb)};
-  lo = __builtin_bit_cast(unsigned, l);
+template <bool F16>
+__device__ __forceinline__ void split8(const f32x4& v0, const f32x4& v1, frag& hi, frag& lo) {
+  unsigned h[4], l[4];
+  split2<F16>(v0[0], v0[1], h[0], l[0]); split2<F16>(v0[2], v0[3], h[1], l[1]);
+  split2<F16>(v1[0], v1[1], h[2], l[2]); split2<F16>(v1[2], v1[3], h[3], l[3]);
+  hi = frag{h[0], h[1], h[2], h[3]}; lo = frag{l[0], l[1], l[2], l[3]};
 }
 
 // One 32-channel x 32-point accumulator tile (lane = point l&31; register r = channel 8*(r>>2) + 4*(l>>5) + (r&3)) ->
 // the two 16-deep B fragments (hi and lo images) the next layer consumes: lane (p, h) needs channels 16*kc + 8*h + 0..7.
 // Quads (0,1) feed kc = 0 and (2,3) feed kc = 1; v_permlane32_swap exchanges the upper half of the even quad with the
 // lower half of the odd quad, which lands exactly the partner lane's four channels next to the lane's own four.
-__device__ __forceinline__ void acts_to_frags(const f32x16& c, bf16x8& h0, bf16x8& l0, bf16x8& h1, bf16x8& l1) {
+template <bool F16>
+__device__ __forceinline__ void acts_to_frags(const f32x16& c, frag& h0, frag& l0, frag& h1, frag& l1) {
   unsigned H[4][2], L[4][2];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    split2(c[4 * q], c[4 * q + 1], H[q][0], L[q][0]);
-    split2(c[4 * q + 2], c[4 * q + 3], H[q][1], L[q][1]);
+    split2<F16>(c[4 * q], c[4 * q + 1], H[q][0], L[q][0]);
+    split2<F16>(c[4 * q + 2], c[4 * q + 3], H[q][1], L[q][1]);
   }
 #pragma unroll
   for (int q = 0; q < 4; q += 2) {
@@ -106,10 +125,10 @@ __device__ __forceinline__ void acts_to_frags(const f32x16& c, bf16x8& h0, bf16x
       L[q][d] = r[0]; L[q + 1][d] = r[1];
     }
   }
-  h0 = __builtin_bit_cast(bf16x8, (u32x4){H[0][0], H[0][1], H[1][0], H[1][1]});
-  l0 = __builtin_bit_cast(bf16x8, (u32x4){L[0][0], L[0][1], L[1][0], L[1][1]});
-  h1 = __builtin_bit_cast(bf16x8, (u32x4){H[2][0], H[2][1], H[3][0], H[3][1]});
-  l1 = __builtin_bit_cast(bf16x8, (u32x4){L[2][0], L[2][1], L[3][0], L[3][1]});
+  h0 = frag{H[0][0], H[0][1], H[1][0], H[1][1]};
+  l0 = frag{L[0][0], L[0][1], L[1][0], L[1][1]};
+  h1 = frag{H[2][0], H[2][1], H[3][0], H[3][1]};
+  l1 = frag{L[2][0], L[2][1], L[3][0], L[3][1]};
 }
 
 // accumulator tile initialised with the per-channel bias of channel block nb (channels = accumulator rows)
@@ -130,8 +149,8 @@ __device__ __forceinline__ f32x16 relu16(f32x16 c) {
 }
 
 // packed split weights: Wp[nb][kc][2 (hi,lo)][lane][8] bf16
-__device__ __forceinline__ void load_b(const unsigned short* wp, int nb, int kc, int nkc, int lane, bf16x8& bhi, bf16x8& blo) {
-  const bf16x8* p = (const bf16x8*)wp + ((size_t)(nb * nkc + kc) * 2) * 64 + lane;
+__device__ __forceinline__ void load_b(const unsigned short* wp, int nb, int kc, int nkc, int lane, frag& bhi, frag& blo) {
+  const frag* p = (const frag*)wp + ((size_t)(nb * nkc + kc) * 2) * 64 + lane;
   bhi = p[0]; blo = p[64];
 }
 
@@ -139,15 +158,15 @@ __device__ __forceinline__ void load_b(const unsigned short* wp, int nb, int kc,
 // does not hoist 32 KB of weight-fragment loads out of the loop and spill them.
 __device__ __forceinline__ int opaque_zero() { int z; asm volatile("s_mov_b32 %0, 0" : "=s"(z)); return z; }
 
-template <int MID, int RT>
-__global__ __launch_bounds__(64 * RT, 2) void pointmlp_max_bf16x3_kernel(ArgsB a) {
+template <int MID, int RT, bool F16>
+__global__ __launch_bounds__(64 * RT, 2) void pointmlp_max_split_kernel(ArgsB a) {
   constexpr int TP = Geo<RT>::TP, NT = Geo<RT>::NT, NBW = Geo<RT>::NBW;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  __bf16* h2hi = (__bf16*)smem_raw;
-  __bf16* h2lo = h2hi + TP * SH;
+  unsigned short* h2hi = (unsigned short*)smem_raw;      // 16-bit elements (bf16 or half bit patterns)
+  unsigned short* h2lo = h2hi + TP * SH;
   float* rmax = (float*)(h2lo + TP * SH);
-  bf16x8* w1f = (bf16x8*)(rmax + 1024);     // [nb 2][hi|lo][lane]
-  bf16x8* wmf = w1f + 256;                  // [nb 2][kc 4][hi|lo][lane]
+  frag* w1f = (frag*)(rmax + 1024);     // [nb 2][hi|lo][lane]
+  frag* wmf = w1f + 256;                  // [nb 2][kc 4][hi|lo][lane]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -174,20 +193,20 @@ __global__ __launch_bounds__(64 * RT, 2) void pointmlp_max_bf16x3_kernel(ArgsB a
       v0 = f32x4{wr[0], wr[1], wr[2], wr[3]};
       v1 = f32x4{wr[4], wr[5], a.b1[row], 0.f};
     }
-    bf16x8 hi, lo;
-    split8(v0, v1, hi, lo);
+    frag hi, lo;
+    split8<F16>(v0, v1, hi, lo);
     w1f[(nb * 2) * 64 + ln] = hi;
     w1f[(nb * 2 + 1) * 64 + ln] = lo;
   }
   if (MID == 1) {
-    for (int i = tid; i < 1024; i += NT) wmf[i] = ((const bf16x8*)a.wm)[i];
+    for (int i = tid; i < 1024; i += NT) wmf[i] = ((const frag*)a.wm)[i];
   }
   if (MID == 2) {   // t64 is stored TRANSPOSED (Tt[n][k] = T[k][n]): a lane's 8 consecutive k are two 16-byte loads
     for (int i = tid; i < 512; i += NT) {
       const int ln = i & 63, kc = (i >> 6) & 3, nb = i >> 8;
       const float* tp = a.t64 + (size_t)b * 4096 + (nb * 32 + (ln & 31)) * 64 + kc * 16 + (ln >> 5) * 8;
-      bf16x8 hi, lo;
-      split8(*(const f32x4*)tp, *(const f32x4*)(tp + 4), hi, lo);
+      frag hi, lo;
+      split8<F16>(*(const f32x4*)tp, *(const f32x4*)(tp + 4), hi, lo);
       wmf[((nb * 4 + kc) * 2) * 64 + ln] = hi;
       wmf[((nb * 4 + kc) * 2 + 1) * 64 + ln] = lo;
     }
@@ -214,7 +233,7 @@ __global__ __launch_bounds__(64 * RT, 2) void pointmlp_max_bf16x3_kernel(ArgsB a
     const unsigned short* w2_t = a.w2 + oz;
     const float* b2_t = a.b2 + oz;
     const int pt = tile * TP + w * 32 + l31;
-    bf16x8 fh[4], fl[4];          // the activation as B fragments (hi / lo), 4 chunks of 16 channels
+    frag fh[4], fl[4];          // the activation as B fragments (hi / lo), 4 chunks of 16 channels
     {
       const int p = pt < a.N ? pt : a.N - 1;       // replicate the last point: max-pool is idempotent
       const f32x2* src = (const f32x2*)(xb + (size_t)p * 6);
@@ -228,14 +247,14 @@ __global__ __launch_bounds__(64 * RT, 2) void pointmlp_max_bf16x3_kernel(ArgsB a
       }
       f32x4 q0 = {px, py, pz, v1[1]}, q1 = {v2[0], v2[1], 1.f, 0.f};     // k = 6 carries the bias
       if (lhi) { q0 = f32x4{0.f, 0.f, 0.f, 0.f}; q1 = q0; }              // k = 8..15: padding
-      bf16x8 xh, xl;
-      split8(q0, q1, xh, xl);
+      frag xh, xl;
+      split8<F16>(q0, q1, xh, xl);
       // L0: 6(+1) -> 64
       const f32x16 z = {0};
-      f32x16 c0 = mfma3(w1f[lane], w1f[64 + lane], xh, xl, z);
-      f32x16 c1 = mfma3(w1f[128 + lane], w1f[192 + lane], xh, xl, z);
-      acts_to_frags(relu16(c0), fh[0], fl[0], fh[1], fl[1]);
-      acts_to_frags(relu16(c1), fh[2], fl[2], fh[3], fl[3]);
+      f32x16 c0 = mfma3<F16>(w1f[lane], w1f[64 + lane], xh, xl, z);
+      f32x16 c1 = mfma3<F16>(w1f[128 + lane], w1f[192 + lane], xh, xl, z);
+      acts_to_frags<F16>(relu16(c0), fh[0], fl[0], fh[1], fl[1]);
+      acts_to_frags<F16>(relu16(c1), fh[2], fl[2], fh[3], fl[3]);
     }
     if (MID != 0) {  // mid: 64 -> 64 (shared conv+BN+ReLU, or the per-sample 64x64 feature transform)
       f32x16 c0, c1;
@@ -243,12 +262,12 @@ __global__ __launch_bounds__(64 * RT, 2) void pointmlp_max_bf16x3_kernel(ArgsB a
       else { c0 = f32x16{0}; c1 = f32x16{0}; }
 #pragma unroll
       for (int kc = 0; kc < 4; ++kc) {
-        const bf16x8* f0 = wmf + (kc * 2) * 64 + lane;
-        const bf16x8* f1 = wmf + ((4 + kc) * 2) * 64 + lane;
-        const bf16x8 a0h = f0[0], a0l = f0[64], a1h = f1[0], a1l = f1[64];
-        c0 = mfma_bf16(a0h, fl[kc], c0); c1 = mfma_bf16(a1h, fl[kc], c1);
-        c0 = mfma_bf16(a0l, fh[kc], c0); c1 = mfma_bf16(a1l, fh[kc], c1);
-        c0 = mfma_bf16(a0h, fh[kc], c0); c1 = mfma_bf16(a1h, fh[kc], c1);
+        const frag* f0 = wmf + (kc * 2) * 64 + lane;
+        const frag* f1 = wmf + ((4 + kc) * 2) * 64 + lane;
+        const frag a0h = f0[0], a0l = f0[64], a1h = f1[0], a1l = f1[64];
+        c0 = mfma_x<F16>(a0h, fl[kc], c0); c1 = mfma_x<F16>(a1h, fl[kc], c1);
+        c0 = mfma_x<F16>(a0l, fh[kc], c0); c1 = mfma_x<F16>(a1l, fh[kc], c1);
+        c0 = mfma_x<F16>(a0h, fh[kc], c0); c1 = mfma_x<F16>(a1h, fh[kc], c1);
       }
       if (MID == 1) { c0 = relu16(c0); c1 = relu16(c1); }
       if (MID == 2 && a.pointfeat && pt < a.N) {
@@ -259,8 +278,8 @@ __global__ __launch_bounds__(64 * RT, 2) void pointmlp_max_bf16x3_kernel(ArgsB a
           *(f32x4*)(pf + 32 + 8 * q) = f32x4{c1[4 * q], c1[4 * q + 1], c1[4 * q + 2], c1[4 * q + 3]};
         }
       }
-      acts_to_frags(c0, fh[0], fl[0], fh[1], fl[1]);
-      acts_to_frags(c1, fh[2], fl[2], fh[3], fl[3]);
+      acts_to_frags<F16>(c0, fh[0], fl[0], fh[1], fl[1]);
+      acts_to_frags<F16>(c1, fh[2], fl[2], fh[3], fl[3]);
     }
     __syncthreads();   // the previous tile's L3 reads of the h2 images are complete
     {  // L2: 64 -> 128, two channel blocks at a time, written split into the hi / lo images
@@ -270,12 +289,12 @@ __global__ __launch_bounds__(64 * RT, 2) void pointmlp_max_bf16x3_kernel(ArgsB a
         f32x16 c0 = bias_tile(b2_t, np * 2, lhi), c1 = bias_tile(b2_t, np * 2 + 1, lhi);
 #pragma unroll
         for (int kc = 0; kc < 4; ++kc) {
-          bf16x8 a0h, a0l, a1h, a1l;
+          frag a0h, a0l, a1h, a1l;
           load_b(w2_t, np * 2, kc, 4, lane, a0h, a0l);
           load_b(w2_t, np * 2 + 1, kc, 4, lane, a1h, a1l);
-          c0 = mfma_bf16(a0h, fl[kc], c0); c1 = mfma_bf16(a1h, fl[kc], c1);
-          c0 = mfma_bf16(a0l, fh[kc], c0); c1 = mfma_bf16(a1l, fh[kc], c1);
-          c0 = mfma_bf16(a0h, fh[kc], c0); c1 = mfma_bf16(a1h, fh[kc], c1);
+          c0 = mfma_x<F16>(a0h, fl[kc], c0); c1 = mfma_x<F16>(a1h, fl[kc], c1);
+          c0 = mfma_x<F16>(a0l, fh[kc], c0); c1 = mfma_x<F16>(a1l, fh[kc], c1);
+          c0 = mfma_x<F16>(a0h, fh[kc], c0); c1 = mfma_x<F16>(a1h, fh[kc], c1);
         }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -283,8 +302,8 @@ __global__ __launch_bounds__(64 * RT, 2) void pointmlp_max_bf16x3_kernel(ArgsB a
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             unsigned h0, l0, h1, l1;
-            split2(c[4 * q], c[4 * q + 1], h0, l0);
-            split2(c[4 * q + 2], c[4 * q + 3], h1, l1);
+            split2<F16>(c[4 * q], c[4 * q + 1], h0, l0);
+            split2<F16>(c[4 * q + 2], c[4 * q + 3], h1, l1);
             const int off = row * SH + (np * 2 + h) * 32 + 8 * q + 4 * lhi;
             *(u32x2*)(h2hi + off) = u32x2{h0, h1};
             *(u32x2*)(h2lo + off) = u32x2{l0, l1};
@@ -305,14 +324,17 @@ __global__ __launch_bounds__(64 * RT, 2) void pointmlp_max_bf16x3_kernel(ArgsB a
       const unsigned vnext = (unsigned)((nb_next * 8 * 2) * 64 + lane) * 16u;
       f32x16 c0, c1, c2, c3, c4, c5, c6, c7;
       u32x4 r0ah, r0al, r0bh, r0bl, r1ah, r1al, r1bh, r1bl, r2ah, r2al, r2bh, r2bl, wyh, wyl;
-      asm volatile(CG_L3_BLOCK_ASM
-                   : [c0] "=&v"(c0), [c1] "=&v"(c1), [c2] "=&v"(c2), [c3] "=&v"(c3), [c4] "=&v"(c4), [c5] "=&v"(c5),
-                     [c6] "=&v"(c6), [c7] "=&v"(c7), [r0ah] "=&v"(r0ah), [r0al] "=&v"(r0al), [r0bh] "=&v"(r0bh),
-                     [r0bl] "=&v"(r0bl), [r1ah] "=&v"(r1ah), [r1al] "=&v"(r1al), [r1bh] "=&v"(r1bh), [r1bl] "=&v"(r1bl),
-                     [r2ah] "=&v"(r2ah), [r2al] "=&v"(r2al), [r2bh] "=&v"(r2bh), [r2bl] "=&v"(r2bl), [yh] "=&v"(wyh),
-                     [yl] "=&v"(wyl), [xh] "+v"(wxh), [xl] "+v"(wxl), [voff] "+v"(voff)
-                   : [vnext] "v"(vnext), [ahi] "v"(ahi_addr), [alo] "v"(alo_addr), [wbase] "s"(a.w3)
-                   : "memory");
+#define CG_L3_OPERANDS \
+                   : [c0] "=&v"(c0), [c1] "=&v"(c1), [c2] "=&v"(c2), [c3] "=&v"(c3), [c4] "=&v"(c4), [c5] "=&v"(c5),\
+                     [c6] "=&v"(c6), [c7] "=&v"(c7), [r0ah] "=&v"(r0ah), [r0al] "=&v"(r0al), [r0bh] "=&v"(r0bh),\
+                     [r0bl] "=&v"(r0bl), [r1ah] "=&v"(r1ah), [r1al] "=&v"(r1al), [r1bh] "=&v"(r1bh), [r1bl] "=&v"(r1bl),\
+                     [r2ah] "=&v"(r2ah), [r2al] "=&v"(r2al), [r2bh] "=&v"(r2bh), [r2bl] "=&v"(r2bl), [yh] "=&v"(wyh),\
+                     [yl] "=&v"(wyl), [xh] "+v"(wxh), [xl] "+v"(wxl), [voff] "+v"(voff)\
+                   : [vnext] "v"(vnext), [ahi] "v"(ahi_addr), [alo] "v"(alo_addr), [wbase] "s"(a.w3) \
+                   : "memory"
+      if constexpr (F16) { asm volatile(CG_L3_BLOCK_ASM_F16 CG_L3_OPERANDS); }
+      else { asm volatile(CG_L3_BLOCK_ASM_BF16 CG_L3_OPERANDS); }
+#undef CG_L3_OPERANDS
       float m = fmaxf(fmaxf(max16(c0), max16(c1)), max16(c2));
       m = fmaxf(fmaxf(m, max16(c3)), max16(c4));
       m = fmaxf(fmaxf(m, max16(c5)), max16(c6));
@@ -340,11 +362,11 @@ __global__ void fill_kernel_b(float* p, size_t n, float v) {
   if (i < n) p[i] = v;
 }
 
-template <int MID, int RT>
+template <int MID, int RT, bool F16>
 int launch(const ArgsB& a, hipStream_t s) {
   constexpr int NT = Geo<RT>::NT;
   constexpr size_t LDS_BYTES = Geo<RT>::LDS_BYTES;
-  auto kern = pointmlp_max_bf16x3_kernel<MID, RT>;
+  auto kern = pointmlp_max_split_kernel<MID, RT, F16>;
   static bool attr_set = false;     // per instantiation
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
@@ -357,11 +379,12 @@ int launch(const ArgsB& a, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int cg_pointmlp_max_bf16x3(const float* x, int B, int N, const float* t3, const float* w1, const float* b1,
-                                      int mid_mode, const unsigned short* wm_split, const float* bm, const float* t64,
-                                      const unsigned short* w2_split, const float* b2, const unsigned short* w3_split,
-                                      const float* b3, int relu3, int nsplit, int tile_points, float* out, float* pointfeat,
-                                      void* stream) {
+template <bool F16>
+static int pointmlp_max_split(const float* x, int B, int N, const float* t3, const float* w1, const float* b1,
+                              int mid_mode, const unsigned short* wm_split, const float* bm, const float* t64,
+                              const unsigned short* w2_split, const float* b2, const unsigned short* w3_split,
+                              const float* b3, int relu3, int nsplit, int tile_points, float* out, float* pointfeat,
+                              void* stream) {
   if (B < 0 || N <= 0 || mid_mode < 0 || mid_mode > 2) return CG_ERR_ARG;
   if (tile_points != 256) return CG_ERR_UNSUPPORTED;      // one geometry: 256-point tiles, 8 waves, one workgroup per CU
   if (B == 0) return CG_OK;
@@ -392,7 +415,23 @@ extern "C" int cg_pointmlp_max_bf16x3(const float* x, int B, int N, const float*
     hipLaunchKernelGGL(fill_kernel_b, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, out + (size_t)first * 1024, n, -INFINITY);
   }
   ArgsB a{x, B, N, t3, w1, b1, wm_split, bm, t64, w2_split, b2, w3_split, b3, relu3, nsplit, n_main, tail_split, out, pointfeat};
-  if (mid_mode == 0) return launch<0, 8>(a, s);
-  if (mid_mode == 1) return launch<1, 8>(a, s);
-  return launch<2, 8>(a, s);
+  if (mid_mode == 0) return launch<0, 8, F16>(a, s);
+  if (mid_mode == 1) return launch<1, 8, F16>(a, s);
+  return launch<2, 8, F16>(a, s);
+}
+
+extern "C" int cg_pointmlp_max_bf16x3(const float* x, int B, int N, const float* t3, const float* w1, const float* b1,
+                                      int mid_mode, const unsigned short* wm_split, const float* bm, const float* t64,
+                                      const unsigned short* w2_split, const float* b2, const unsigned short* w3_split,
+                                      const float* b3, int relu3, int nsplit, int tile_points, float* out, float* pointfeat,
+                                      void* stream) {
+  return pointmlp_max_split<false>(x, B, N, t3, w1, b1, mid_mode, wm_split, bm, t64, w2_split, b2, w3_split, b3, relu3, nsplit, tile_points, out, pointfeat, stream);
+}
+
+extern "C" int cg_pointmlp_max_f16x3(const float* x, int B, int N, const float* t3, const float* w1, const float* b1,
+                                      int mid_mode, const unsigned short* wm_split, const float* bm, const float* t64,
+                                      const unsigned short* w2_split, const float* b2, const unsigned short* w3_split,
+                                      const float* b3, int relu3, int nsplit, int tile_points, float* out, float* pointfeat,
+                                      void* stream) {
+  return pointmlp_max_split<true>(x, B, N, t3, w1, b1, mid_mode, wm_split, bm, t64, w2_split, b2, w3_split, b3, relu3, nsplit, tile_points, out, pointfeat, stream);
 }

@@ -12,17 +12,20 @@ import os
 
 from . import ops
 
-# 'bf16x3': split-bf16 MFMA kernels for the per-point MLP chain (3 bf16 MFMAs per product block, f32 accumulate); the default:
-#           logits within ~1e-5 of the fp32 reference (bar: 1e-4), 3.9x the exact-f32 rate.  For scale: the reference's own
-#           GPU path runs its Conv1d layers through cuDNN, where TF32 (10-bit mantissa) is PyTorch's default on Ampere+.
-# 'f32'   : exact-f32 MFMA kernels (bitwise an fmaf chain per dot product)
-PRECISION = os.environ.get('CATGRASP_AMD_PRECISION', 'bf16x3')
+# 'f16x3' : split-half MFMA kernels (x = hi + lo IEEE-half pieces, 3 f16 MFMAs per product block, f32 accumulate) for every
+#           wide layer; the default: logits within ~2e-6 of the float64 evaluation -- float32's own distance -- at 4x the exact-f32
+#           rate.  Half range applies to activations (|x| < 65504); the networks' BN-folded activations are O(1..100).
+# 'bf16x3': the same with bf16 pieces (8 + 8 bits; ~2e-5): no range limit, per-point layers + segmentation head only.
+# 'f32'   : exact-f32 MFMA kernels (bitwise an fmaf chain per dot product).
+# For scale: the reference's own GPU path runs its Conv1d layers through cuDNN, where TF32 (10-bit mantissa) is PyTorch's default
+# on Ampere and later.
+PRECISION = os.environ.get('CATGRASP_AMD_PRECISION', 'f16x3')
 TILE_POINTS = 256   # bf16x3 kernel geometry: points per workgroup tile (8 waves, one workgroup per CU)
 
 
 def set_precision(p):
     global PRECISION
-    assert p in ('f32', 'bf16x3'), p
+    assert p in ('f32', 'bf16x3', 'f16x3'), p
     PRECISION = p
 
 
@@ -35,17 +38,20 @@ def _nsplit(B, N, tp=64):
 
 
 def _dense(W, name, x, n_out, bias, **kw):
-    """One folded Linear/Conv1d(k=1) layer.  In 'bf16x3' mode layers that have a split image run on the split-bf16 MFMA GEMM:
-    the per-point segmentation head (folding.prepare_seg).  The per-candidate FC tails stay on the exact-f32 kernel -- measured,
-    splitting them too buys 3 % of the step and raises the logits error from ~2e-5 to ~6e-5 of the 1e-4 bar."""
+    """One folded Linear/Conv1d(k=1) layer on the GEMM kernel of the active arithmetic.  'f16x3': every wide layer has a half
+    image (FC tails and segmentation head; the 9- and 10-wide output layers stay exact f32).  'bf16x3': only the per-point
+    segmentation head -- measured, splitting the per-candidate FC tails with bf16 pieces buys 3 % of the step and raises the
+    logits error from ~2e-5 to ~6e-5 of the 1e-4 bar."""
+    if PRECISION == 'f16x3' and (name + '.h') in W:
+        return ops.gemm_bias_act(x, W[name + '.h'], n_out, bias, split='f16', **kw)
     if PRECISION == 'bf16x3' and (name + '.s') in W:
-        return ops.gemm_bias_act(x, W[name + '.s'], n_out, bias, split=True, **kw)
+        return ops.gemm_bias_act(x, W[name + '.s'], n_out, bias, split='bf16', **kw)
     return ops.gemm_bias_act(x, W[name], n_out, bias, **kw)
 
 
 def encoder_forward(W, x, want_pointfeat=False):
     """x:(B,N,6) cuda f32 -> global feature (B,1024), trans (B,9), trans_feat TRANSPOSED (B,4096) [, pointfeat]."""
-    if PRECISION == 'bf16x3':
+    if PRECISION != 'f32':
         return _encoder_forward_split(W, x, want_pointfeat)
     B, N, _ = x.shape
     ns = _nsplit(B, N)
@@ -67,20 +73,21 @@ def encoder_forward(W, x, want_pointfeat=False):
 
 
 def _encoder_forward_split(W, x, want_pointfeat=False):
-    """encoder_forward with the bf16x3 per-point MLP kernels (the FC tails stay exact f32)."""
+    """encoder_forward with the split-precision per-point MLP kernels ('f16x3' or 'bf16x3')."""
     B, N, _ = x.shape
     ns = _nsplit(B, N, TILE_POINTS)
-    kw = dict(nsplit=ns, split=True, tile_points=TILE_POINTS)
-    g = ops.pointmlp_max(x, W['stn.w1'], W['stn.b1'], W['stn.w2.s'], W['stn.b2'], W['stn.w3.s'], W['stn.b3'], True, **kw)
+    el, sfx = ('f16', '.h') if PRECISION == 'f16x3' else ('bf16', '.s')
+    kw = dict(nsplit=ns, split=el, tile_points=TILE_POINTS)
+    g = ops.pointmlp_max(x, W['stn.w1'], W['stn.b1'], W['stn.w2' + sfx], W['stn.b2'], W['stn.w3' + sfx], W['stn.b3'], True, **kw)
     h = _dense(W, 'stn.fc1', g, 512, W['stn.fc1b'], relu=True)
     h = _dense(W, 'stn.fc2', h, 256, W['stn.fc2b'], relu=True)
     t3 = _dense(W, 'stn.fc3', h, 9, W['stn.fc3b'], eye_k=3)
-    g = ops.pointmlp_max(x, W['enc.w1'], W['enc.b1'], W['fstn.w2.s'], W['fstn.b2'], W['fstn.w3.s'], W['fstn.b3'], True,
-                         t3=t3, mid_mode=1, wm=W['fstn.wm.s'], bm=W['fstn.bm'], **kw)
+    g = ops.pointmlp_max(x, W['enc.w1'], W['enc.b1'], W['fstn.w2' + sfx], W['fstn.b2'], W['fstn.w3' + sfx], W['fstn.b3'], True,
+                         t3=t3, mid_mode=1, wm=W['fstn.wm' + sfx], bm=W['fstn.bm'], **kw)
     h = _dense(W, 'fstn.fc1', g, 512, W['fstn.fc1b'], relu=True)
     h = _dense(W, 'fstn.fc2', h, 256, W['fstn.fc2b'], relu=True)
     t64 = _dense(W, 'fstn.fc3', h, 4096, W['fstn.fc3b'], eye_k=64)
-    r = ops.pointmlp_max(x, W['enc.w1'], W['enc.b1'], W['enc.w2.s'], W['enc.b2'], W['enc.w3.s'], W['enc.b3'], False,
+    r = ops.pointmlp_max(x, W['enc.w1'], W['enc.b1'], W['enc.w2' + sfx], W['enc.b2'], W['enc.w3' + sfx], W['enc.b3'], False,
                          t3=t3, mid_mode=2, t64=t64, pointfeat=want_pointfeat, **kw)
     if want_pointfeat:
         return r[0], t3, t64, r[1]

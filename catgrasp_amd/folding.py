@@ -47,8 +47,20 @@ def bf16_split(w):
     return hi, lo
 
 
+def f16_split(w):
+    """float32 array -> (hi, lo) uint16 IEEE-half bit patterns, round-to-nearest-even, lo = half(w - hi)."""
+    w = np.asarray(w, dtype=np.float32)
+    hi = w.astype(np.float16)
+    lo = (w - hi.astype(np.float32)).astype(np.float16)
+    return hi.view(np.uint16), lo.view(np.uint16)
+
+
 def pack_b_bf16x3(w):
-    """W:(N,K) (K % 16 == 0) -> flat uint16 array Wp[nb][kc][2 (hi,lo)][lane][8],
+    return pack_b_split(w, 'bf16')
+
+
+def pack_b_split(w, elem='bf16'):
+    """W:(N,K) (K % 16 == 0) -> flat uint16 array Wp[nb][kc][2 (hi,lo)][lane][8] of 16-bit pieces (elem 'bf16' or 'f16'),
     element e of lane l = W[nb*32 + (l&31)][kc*16 + (l>>5)*8 + e], rows zero padded to 32 (see pointmlp_bf16x3.hip)."""
     w = np.asarray(w, dtype=np.float32)
     n, k = w.shape
@@ -56,7 +68,7 @@ def pack_b_bf16x3(w):
     nb = (n + 31) // 32
     wp = np.zeros((nb * 32, k), dtype=np.float32)
     wp[:n] = w
-    hi, lo = bf16_split(wp)
+    hi, lo = bf16_split(wp) if elem == 'bf16' else f16_split(wp)
     out = np.stack([hi, lo], 0)                                   # (2, nb*32, k)
     # [2, nb, 32(l31), kc, 2(lhi), 8(e)] -> [nb, kc, 2, lhi, l31, e]
     out = out.reshape(2, nb, 32, k // 16, 2, 8).transpose(1, 3, 0, 4, 2, 5)
@@ -87,8 +99,14 @@ class DeviceWeights:
         self.t[name] = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32)).to(self.device)
 
     def put_split(self, name, w):
-        """bf16x3 image of a (N,K) weight matrix (int16 storage of the bf16 bit patterns)."""
-        self.t[name] = torch.from_numpy(pack_b_bf16x3(w).view(np.int16)).to(self.device)
+        """Split images of a (N,K) weight matrix (int16 storage of the 16-bit patterns): `name` ('....s') holds the bf16 pieces,
+        the same name ending in '.h' the IEEE-half pieces."""
+        assert name.endswith('.s'), name
+        self.t[name] = torch.from_numpy(pack_b_split(w, 'bf16').view(np.int16)).to(self.device)
+        self.put_half(name[:-2] + '.h', w)
+
+    def put_half(self, name, w):
+        self.t[name] = torch.from_numpy(pack_b_split(w, 'f16').view(np.int16)).to(self.device)
 
     def __contains__(self, k):
         return k in self.t
@@ -114,9 +132,9 @@ def prepare_encoder(sd, prefix, device, out=None):
         w, b = fold_bn(*_conv(sd, q + 'conv3'), _bn(sd, q + 'bn3'))
         W.put(tag + '.w3', pack_b(w)); W.put(tag + '.b3', b); W.put_split(tag + '.w3.s', w)
         w, b = fold_bn(_get(sd, q + 'fc1.weight'), _get(sd, q + 'fc1.bias'), _bn(sd, q + 'bn4'))
-        W.put(tag + '.fc1', pack_b(w)); W.put(tag + '.fc1b', b)
+        W.put(tag + '.fc1', pack_b(w)); W.put(tag + '.fc1b', b); W.put_half(tag + '.fc1.h', w)
         w, b = fold_bn(_get(sd, q + 'fc2.weight'), _get(sd, q + 'fc2.bias'), _bn(sd, q + 'bn5'))
-        W.put(tag + '.fc2', pack_b(w)); W.put(tag + '.fc2b', b)
+        W.put(tag + '.fc2', pack_b(w)); W.put(tag + '.fc2b', b); W.put_half(tag + '.fc2.h', w)
         w, b = _get(sd, q + 'fc3.weight'), _get(sd, q + 'fc3.bias')
         if k == 64:
             # emit the 64x64 feature transform transposed (column j*64+i holds T[i][j]) so the point kernels read a
@@ -124,6 +142,8 @@ def prepare_encoder(sd, prefix, device, out=None):
             perm = np.arange(4096).reshape(64, 64).T.reshape(-1)
             w, b = w[perm], b[perm]
         W.put(tag + '.fc3', pack_b(w)); W.put(tag + '.fc3b', b)
+        if k == 64:
+            W.put_half(tag + '.fc3.h', w)       # 256 -> 4096; the 9-wide stn.fc3 stays exact f32
 
     stn(p + 'stn.', 'stn', 3)
     stn(p + 'fstn.', 'fstn', 64)
@@ -141,9 +161,9 @@ def prepare_cls(sd, device):
     sd = {k.replace('module.', ''): v for k, v in sd.items()}
     W = prepare_encoder(sd, 'feat.', device)
     w, b = fold_bn(_get(sd, 'fc1.weight'), _get(sd, 'fc1.bias'), _bn(sd, 'bn1'))
-    W.put('head.fc1', pack_b(w)); W.put('head.fc1b', b)
+    W.put('head.fc1', pack_b(w)); W.put('head.fc1b', b); W.put_half('head.fc1.h', w)
     w, b = fold_bn(_get(sd, 'fc2.weight'), _get(sd, 'fc2.bias'), _bn(sd, 'bn2'))
-    W.put('head.fc2', pack_b(w)); W.put('head.fc2b', b)
+    W.put('head.fc2', pack_b(w)); W.put('head.fc2b', b); W.put_half('head.fc2.h', w)
     w, b = _get(sd, 'fc3.weight'), _get(sd, 'fc3.bias')
     W.put('head.fc3', pack_b(w)); W.put('head.fc3b', b)
     W.n_out = w.shape[0]

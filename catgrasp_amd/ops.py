@@ -18,7 +18,7 @@ KERNEL_TIMER = None
 def pointmlp_max(x, w1, b1, w2p, b2, w3p, b3, relu3, t3=None, mid_mode=0, wm=None, bm=None, t64=None,
                  nsplit=1, pointfeat=False, split=False, tile_points=256):
     """x:(B,N,6) -> (B,1024) [, pointfeat (B,N,64)].  See cg_pointmlp_max / cg_pointmlp_max_bf16x3 in
-    include/catgrasp_amd.h.  split=True: w2p/w3p/wm are the bf16x3 images (folding.pack_b_bf16x3)."""
+    include/catgrasp_amd.h.  split='f16' / 'bf16': w2p/w3p/wm are the split images of that element type (folding.pack_b_split)."""
     require_cuda(x)
     f32c(x)
     B, N, D = x.shape
@@ -30,13 +30,14 @@ def pointmlp_max(x, w1, b1, w2p, b2, w3p, b3, relu3, t3=None, mid_mode=0, wm=Non
         if timer is not None:
             ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
             ev0.record()
-        st = L.lib().cg_pointmlp_max_bf16x3(_p(x), _c_int(B), _c_int(N), _p(t3), _p(w1), _p(b1), _c_int(mid_mode), _p(wm), _p(bm),
-                                            _p(t64), _p(w2p), _p(b2), _p(w3p), _p(b3), _c_int(int(relu3)), _c_int(nsplit),
-                                            _c_int(tile_points), _p(out), _p(pf), _stream())
+        fn = L.lib().cg_pointmlp_max_f16x3 if split == 'f16' else L.lib().cg_pointmlp_max_bf16x3
+        st = fn(_p(x), _c_int(B), _c_int(N), _p(t3), _p(w1), _p(b1), _c_int(mid_mode), _p(wm), _p(bm),
+                _p(t64), _p(w2p), _p(b2), _p(w3p), _p(b3), _c_int(int(relu3)), _c_int(nsplit),
+                _c_int(tile_points), _p(out), _p(pf), _stream())
         if timer is not None:
             ev1.record()
             timer['events'].append((ev0, ev1, (B, N)))
-        check(st, 'cg_pointmlp_max_bf16x3')
+        check(st, 'cg_pointmlp_max_f16x3' if split == 'f16' else 'cg_pointmlp_max_bf16x3')
         return (out, pf) if pointfeat else out
     timer = KERNEL_TIMER if (KERNEL_TIMER is not None and KERNEL_TIMER['mid_mode'] == mid_mode) else None
     if timer is not None:
@@ -54,17 +55,18 @@ def pointmlp_max(x, w1, b1, w2p, b2, w3p, b3, relu3, t3=None, mid_mode=0, wm=Non
 
 def gemm_bias_act(x, wp, n_out, bias=None, relu=False, eye_k=0, row_bias=None, rows_per_group=1, split=False):
     """act(x @ W^T + bias [+ row_bias[row // rows_per_group]]) with packed W.  x:(M,K).
-    split=True: wp is the bf16x3 split-packed image and the product runs on the split-bf16 MFMA kernel."""
+    split='f16' / 'bf16': wp is the split-packed image of that element type and the product runs on the split MFMA kernel."""
     require_cuda(x)
     f32c(x)
     M, K = x.shape
     y = torch.empty((M, n_out), dtype=torch.float32, device=x.device)
     ld_rb = row_bias.shape[1] if row_bias is not None else 0
-    fn = L.lib().cg_gemm_bias_act_bf16x3 if split else L.lib().cg_gemm_bias_act
+    name = {'f16': 'cg_gemm_bias_act_f16x3', 'bf16': 'cg_gemm_bias_act_bf16x3'}.get(split, 'cg_gemm_bias_act')
+    fn = getattr(L.lib(), name)
     st = fn(_p(x), _c_int(M), _c_int(K), _c_int(K), _p(wp), _c_int(n_out), _p(bias),
             _p(row_bias), _c_int(rows_per_group), _c_int(ld_rb), _c_int(int(relu)),
             _c_int(eye_k), _p(y), _c_int(n_out), _stream())
-    check(st, 'cg_gemm_bias_act_bf16x3' if split else 'cg_gemm_bias_act')
+    check(st, name)
     return y
 
 

@@ -55,6 +55,14 @@ int cg_pointmlp_max_bf16x3(const float* x, int B, int N, const float* t3, const 
                            const unsigned short* w2_split, const float* b2, const unsigned short* w3_split,
                            const float* b3, int relu3, int nsplit, int tile_points, float* out, float* pointfeat,
                            void* stream);
+/* Same with IEEE-half pieces ("f16x3", 11 + 11 significant bits instead of 8 + 8): logits within ~2e-6 of the float64 evaluation,
+ * i.e. float32's own distance, at the same three MFMAs per product block.  Weights packed by folding.pack_b_split(w, 'f16').  The
+ * default arithmetic of the engine.  Activations must stay below 65504 in magnitude (half range). */
+int cg_pointmlp_max_f16x3(const float* x, int B, int N, const float* t3, const float* w1, const float* b1,
+                          int mid_mode, const unsigned short* wm_split, const float* bm, const float* t64,
+                           const unsigned short* w2_split, const float* b2, const unsigned short* w3_split,
+                           const float* b3, int relu3, int nsplit, int tile_points, float* out, float* pointfeat,
+                           void* stream);
 
 /* Y[M,N] = act(X[M,K] . W^T + bias + row_bias[row / rows_per_group]) (+ flattened identity k x k):
  * replaces Linear->BN->ReLU tails (pointnet2.py:178-185, :216-223, :295-298) and the Conv1d(k=1)
@@ -67,6 +75,10 @@ int cg_gemm_bias_act(const float* x, int M, int K, int ldx, const float* w_packe
  * is three bf16 MFMAs with f32 accumulation, X is split on the fly, W is split-packed on the host
  * (folding.pack_b_bf16x3, same layout as cg_pointmlp_max_bf16x3).  K % 16 == 0; other arguments as cg_gemm_bias_act. */
 int cg_gemm_bias_act_bf16x3(const float* x, int M, int K, int ldx, const unsigned short* w_split, int N,
+                            const float* bias, const float* row_bias, int rows_per_group, int ld_rb,
+                            int relu, int eye_k, float* y, int ldy, void* stream);
+/* IEEE-half variant of the above (see cg_pointmlp_max_f16x3). */
+int cg_gemm_bias_act_f16x3(const float* x, int M, int K, int ldx, const unsigned short* w_split, int N,
                             const float* bias, const float* row_bias, int rows_per_group, int ld_rb,
                             int relu, int eye_k, float* y, int ldy, void* stream);
 

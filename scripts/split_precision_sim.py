@@ -1,0 +1,73 @@
+"""Numerical experiment (CPU): logits error of alternative split-precision schemes for the K>=64 per-point layers, against the
+float64 evaluation of the oracle network.  Schemes (MFMA units per product block on gfx950: bf16/f16 = 1, fp8 = 0.5):
+  bf16x3        : hi*hi + lo*hi + hi*lo, all bf16                                   3.0 units  (what ships)
+  f16x3         : same split with f16 pieces                                         3.0 units
+  f16 + 2xfp8   : f16 main term, both correction terms with fp8 (e4m3) operands,      2.0 units
+                  power-of-two block scales per row (MX style)
+  f16 + 1xf16   : f16 main term + x_lo*w_hi only (weights rounded to f16)             2.0 units
+"""
+import sys
+sys.path.insert(0, '.')
+import numpy as np
+import torch
+from catgrasp_amd import synth
+from oracle import pointnet_ref as oref
+
+
+def rnd(x, dt):
+    return x.to(dt).to(torch.float32)
+
+
+def fp8_e4m3(x, dim):
+    """round to e4m3 after a power-of-two scale per slice along `dim` (amax -> [256, 448])"""
+    amax = x.abs().amax(dim=dim, keepdim=True).clamp(min=1e-30)
+    scale = torch.exp2(torch.floor(torch.log2(448.0 / amax)))
+    y = (x * scale).to(torch.float8_e4m3fn).to(torch.float32) / scale
+    return y
+
+
+def mm(w, x, scheme):
+    if scheme == 'bf16x3' or scheme == 'f16x3':
+        dt = torch.bfloat16 if scheme == 'bf16x3' else torch.float16
+        wh = rnd(w, dt); wl = rnd(w - wh, dt); xh = rnd(x, dt); xl = rnd(x - xh, dt)
+        return torch.matmul(wh, xl) + torch.matmul(wl, xh) + torch.matmul(wh, xh)
+    if scheme == 'f16+2xfp8':
+        wh = rnd(w, torch.float16); xh = rnd(x, torch.float16)
+        wl = fp8_e4m3(w - wh, 1); xl = fp8_e4m3(x - xh, 1)                  # residuals, scaled per output row / per point
+        wh8 = fp8_e4m3(wh, 1); xh8 = fp8_e4m3(xh, 1)
+        return torch.matmul(wh8, xl) + torch.matmul(wl, xh8) + torch.matmul(wh, xh)
+    if scheme == 'f16+1xf16':
+        wh = rnd(w, torch.float16); xh = rnd(x, torch.float16); xl = rnd(x - xh, torch.float16)
+        return torch.matmul(wh, xl) + torch.matmul(wh, xh)
+    raise ValueError(scheme)
+
+
+orig = oref._conv_bn
+
+
+def patched(scheme, layers=('conv2', 'conv3')):
+    def conv_bn(x, sd, conv, bn, relu):
+        if any(conv.endswith(l) for l in layers):
+            w = sd[conv + '.weight'][:, :, 0]
+            s = sd[bn + '.weight'] / torch.sqrt(sd[bn + '.running_var'] + 1e-5)
+            y = mm(w * s[:, None], x, scheme) + ((sd[conv + '.bias'] - sd[bn + '.running_mean']) * s + sd[bn + '.bias']).view(1, -1, 1)
+            return torch.relu(y) if relu else y
+        return orig(x, sd, conv, bn, relu)
+    return conv_bn
+
+
+rng = np.random.default_rng(5)
+for gain in (1.0, 1.6, 1.7):
+    for seed in (11, 12):
+        sd = synth.make_state_dict('cls', 6, 10, seed=seed, gain=gain)
+        x = torch.from_numpy(rng.normal(0, 0.5, (8, 2048, 6)).astype(np.float32))
+        oref._conv_bn = orig
+        y64, _ = oref.pointnet_cls_forward(sd, x, torch.float64)
+        y32, _ = oref.pointnet_cls_forward(sd, x)
+        line = f'gain {gain} seed {seed} |logit|max {float(y64.abs().max()):6.1f}  f32 {float(((y32 - y64).abs() / y64.abs().clamp(min=1)).max()):.1e}'
+        for scheme in ('bf16x3', 'f16x3', 'f16+2xfp8', 'f16+1xf16'):
+            oref._conv_bn = patched(scheme)
+            y, _ = oref.pointnet_cls_forward(sd, x)
+            line += f'  {scheme} {float(((y - y64).abs() / y64.abs().clamp(min=1)).max()):.1e}'
+        print(line)
+oref._conv_bn = orig
