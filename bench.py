@@ -28,11 +28,11 @@ sys.path.insert(0, ROOT)
 MAC_PER_POINT_ENC = 9 + 384 + 4096 + 8192 + 131072      # encoder pass (mid_mode 2): T3, conv1, .T64, conv2, conv3
 PEAK_F32_MFMA_TFLOPS = 157.3                            # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0                          # MI355X_MICROARCH.md: BF16/F16 MFMA dense peak (~2.5 PF)
-# HBM bytes per candidate of the encoder-pass kernel from the PMC passes in profiles/r1_pmc_pointmlp.csv
+# HBM bytes per candidate of the encoder-pass kernel (mid_mode 2) of each arithmetic from the PMC passes in profiles/r1_pmc_pointmlp.csv
 # (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate runs, B=4096): 2*FETCH_SIZE (gfx950 correction for wide
 # coalesced reads, MI355X_MICROARCH.md §HBM) + WRITE_SIZE, divided by 4096.  Algorithmic: 49152 B x + 16384 B transform
 # + 4096 B out = 69632 B/candidate; both kernels move the algorithmic bytes and nothing else (no scratch).
-PMC_HBM_BYTES_PER_CANDIDATE = {'bf16x3': (2 * 133760.3 + 16384.0) * 1024 / 4096, 'f16x3': (2 * 133760.3 + 16384.0) * 1024 / 4096,
+PMC_HBM_BYTES_PER_CANDIDATE = {'bf16x3': (2 * 133760.3 + 16384.0) * 1024 / 4096, 'f16x3': (2 * 133762.0 + 16384.0) * 1024 / 4096,
                                'f32': (2 * 133763.3 + 16384.0) * 1024 / 4096}
 
 

@@ -11,7 +11,7 @@ HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-Wall', '-Wno-unused-function']
 # Per-file extras.  The fused MLP kernels reduce MFMA accumulators with fmaxf; under IEEE NaN rules the backend quiets every
 # operand first (v_max x, x), tripling the VALU work of the max epilogue.  Their inputs are finite, so NaNs need no honouring.
-EXTRA_FLAGS = {'pointmlp.hip': ['-fno-honor-nans'], 'pointmlp_bf16x3.hip': ['-fno-honor-nans']}
+EXTRA_FLAGS = {'pointmlp.hip': ['-fno-honor-nans'], 'pointmlp_split.hip': ['-fno-honor-nans']}
 
 
 def sources():
@@ -28,7 +28,7 @@ def _stale(target, deps):
 def build(force=False, verbose=True):
     srcs = sources()
     gen, inc = os.path.join(CSRC, 'gen_l3_asm.py'), os.path.join(CSRC, 'l3_asm.inc')
-    if _stale(inc, [gen]):      # the hand-scheduled instruction stream of pointmlp_bf16x3.hip is generated text
+    if _stale(inc, [gen]):      # the hand-scheduled instruction stream of pointmlp_split.hip is generated text
         subprocess.check_call([sys.executable, gen])
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(('.hpp', '.inc'))]
     hdrs.append(os.path.join(PKG_DIR, '..', 'include', 'catgrasp_amd.h'))

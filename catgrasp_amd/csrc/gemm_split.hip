@@ -1,10 +1,11 @@
 // Split-precision variant of gemm.hip:  Y = act(X . W^T + bias [+ row_bias[row / rows_per_group]]) [+ I_k]
-// with every product block evaluated as three bf16 MFMAs with f32 accumulation (see pointmlp_bf16x3.hip):
-//     x.w ~= x_lo.w_hi + x_hi.w_lo + x_hi.w_hi      on v_mfma_f32_32x32x16_bf16.
-// Used for the per-point segmentation head of PointNetSeg (pointnet2.py:324-328) when the engine runs in 'bf16x3' mode; the
-// per-candidate FC tails stay on the exact-f32 kernel (their share of the step is 2 %, their share of the error budget is not).
-// X (f32) is split while it is staged: 128 rows x 64 columns per workgroup as two bf16 images (144-byte rows: conflict-free
-// ds_read_b128 fragment reads).  W is split and packed on the host (folding.pack_b_bf16x3):
+// with every product block evaluated as three 16-bit MFMAs with f32 accumulation (see pointmlp_split.hip):
+//     x.w ~= x_lo.w_hi + x_hi.w_lo + x_hi.w_hi      on v_mfma_f32_32x32x16_{f16,bf16}.
+// 'f16x3' (IEEE-half pieces, the engine's default): every wide dense layer -- the FC tails (pointnet2.py:178-185, :216-223,
+// :295-298) and the per-point segmentation head (:324-328); the 9- and 10-wide output layers stay on the exact-f32 kernel.
+// 'bf16x3': the segmentation head only (with bf16 pieces the FC tails would cost 4e-5 of the 1e-4 error budget for 3 % of the step).
+// X (f32) is split while it is staged: 128 rows x 64 columns per workgroup as two 16-bit images (144-byte rows: conflict-free
+// ds_read_b128 fragment reads).  W is split and packed on the host (folding.pack_b_split):
 // Wp[nb][kc][2 (hi,lo)][lane][8], element e of lane l = W[nb*32 + (l&31)][kc*16 + (l>>5)*8 + e].
 #include "cg_common.hpp"
 #include "../../include/catgrasp_amd.h"
@@ -17,11 +18,11 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef u32x4 frag;      // a 128-bit operand fragment; F16 selects IEEE half (true) or bf16 (false) pieces, see pointmlp_bf16x3.hip
+typedef u32x4 frag;      // a 128-bit operand fragment; F16 selects IEEE half (true) or bf16 (false) pieces, see pointmlp_split.hip
 
 constexpr int BM = 128;      // rows per workgroup (4 row tiles per wave: each weight fragment feeds 12 MFMAs)
 constexpr int BK = 64;       // K chunk staged in LDS
-constexpr int SR = BK + 8;   // bf16 elements per LDS row
+constexpr int SR = BK + 8;   // 16-bit elements per LDS row
 
 struct GemmArgsB {
   const float* x; int M; int K; int ldx;

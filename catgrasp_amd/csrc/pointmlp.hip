@@ -247,7 +247,7 @@ extern "C" int cg_pointmlp_max(const float* x, int B, int N, const float* t3, co
   if (nsplit < 1) nsplit = 1;
   if (nsplit > ntiles) nsplit = ntiles;
   hipStream_t s = (hipStream_t)stream;
-  // Tail balancing (as in pointmlp_bf16x3.hip): with one workgroup per sample and B >= the number of resident workgroups
+  // Tail balancing (as in pointmlp_split.hip): with one workgroup per sample and B >= the number of resident workgroups
   // (2 per CU), the samples of the last, partially filled scheduling round are split 8 ways so that round is short.
   int n_main = B, tail_split = 1;
   if (nsplit == 1 && ntiles >= 8) {

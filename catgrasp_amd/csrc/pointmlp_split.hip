@@ -1,11 +1,13 @@
 // Split-precision variant of the fused per-point MLP chain + max-pool (see pointmlp.hip for the op sequence it
 // replaces: pointnet2.py:172-176, :210-214, :243-266).
 //
-// Every contraction is evaluated as three bf16 MFMAs with f32 accumulation ("bf16x3"):
-//     x = x_hi + x_lo,  w = w_hi + w_lo  (bf16 each, round-to-nearest-even; lo = bf16(x - x_hi))
-//     x.w ~= x_lo.w_hi + x_hi.w_lo + x_hi.w_hi          (dropped term x_lo.w_lo <= 2^-16 |x.w|)
-// on v_mfma_f32_32x32x16_bf16 (16x the f32-MFMA rate, so 16/3 = 5.3x per contraction).  Measured end-to-end
-// error on the grasp-Q logits is ~1e-5 (tests/test_pointnet_gpu.py), inside the 1e-4 parity bar.
+// Every contraction is evaluated as three 16-bit MFMAs with f32 accumulation:
+//     x = x_hi + x_lo,  w = w_hi + w_lo  (16-bit pieces, round-to-nearest-even; lo = round(x - x_hi))
+//     x.w ~= x_lo.w_hi + x_hi.w_lo + x_hi.w_hi          (the dropped term x_lo.w_lo is below the pieces' resolution)
+// on v_mfma_f32_32x32x16_{f16,bf16} (16x the f32-MFMA rate, so 16/3 = 5.3x per contraction).  The kernel is instantiated for
+// both element types: "f16x3" (IEEE-half pieces, 11 + 11 significant bits; logits within ~2e-6 of the float64 evaluation, which
+// is float32's own distance; activations must stay below 65504) -- the engine's default -- and "bf16x3" (8 + 8 bits, ~2e-5, no
+// range limit).  Both are inside the 1e-4 parity bar (tests/test_pointnet_gpu.py runs every case under both).
 //
 // Layout: one workgroup = 8 waves owns one sample (or a slice of its point tiles); a tile is 256 points; 160 KB LDS,
 // one workgroup per CU.
@@ -16,7 +18,7 @@
 //    is assembled from the lane's own registers plus one v_permlane32_swap with its partner lane (lane^32) per dword:
 //    no LDS round trip and no barrier between layers.  The first layer's K (6 inputs + a constant-1 bias row, padded to
 //    16) rides the same MFMA.
-//  * The 128-wide activation is written to LDS already split into bf16 hi / lo images ([256][136] each; row stride
+//  * The 128-wide activation is written to LDS already split into 16-bit hi / lo images ([256][136] each; row stride
 //    272 B makes the ds_read_b128 fragment reads of the next layer conflict-free), 8 bytes per store.
 //  * In the 128->1024 layer (points = A operand again) wave w owns channel blocks [4w,4w+4) and ALL 8 row tiles, so
 //    each packed weight fragment is fetched from L2 exactly once per workgroup tile (10.7 B/clk/CU at full MFMA rate),
@@ -36,7 +38,7 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int SH = 136;        // bf16 elements per row of the h2 hi / lo images
+constexpr int SH = 136;        // 16-bit elements per row of the h2 hi / lo images
 template <int RT> struct Geo {
   static constexpr int TP = 32 * RT;        // points per tile, one wave per 32-point row tile
   static constexpr int NT = 64 * RT;

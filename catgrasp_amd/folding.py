@@ -61,7 +61,7 @@ def pack_b_bf16x3(w):
 
 def pack_b_split(w, elem='bf16'):
     """W:(N,K) (K % 16 == 0) -> flat uint16 array Wp[nb][kc][2 (hi,lo)][lane][8] of 16-bit pieces (elem 'bf16' or 'f16'),
-    element e of lane l = W[nb*32 + (l&31)][kc*16 + (l>>5)*8 + e], rows zero padded to 32 (see pointmlp_bf16x3.hip)."""
+    element e of lane l = W[nb*32 + (l&31)][kc*16 + (l>>5)*8 + e], rows zero padded to 32 (see pointmlp_split.hip)."""
     w = np.asarray(w, dtype=np.float32)
     n, k = w.shape
     assert k % 16 == 0, k
