@@ -18,6 +18,8 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ int g_half_overflow_gemm = 0;     // see pointmlp_split.hip / cg_half_range_violation
+constexpr float HALF_MAX = 65504.f;
 typedef u32x4 frag;      // a 128-bit operand fragment; F16 selects IEEE half (true) or bf16 (false) pieces, see pointmlp_split.hip
 
 constexpr int BM = 128;      // rows per workgroup (4 row tiles per wave: each weight fragment feeds 12 MFMAs)
@@ -34,8 +36,9 @@ struct GemmArgsB {
 };
 
 template <bool F16>
-__device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
+__device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo, float& amax) {
   if constexpr (F16) {
+    amax = fmaxf(fmaxf(amax, fabsf(a)), fabsf(b));
     const f16x2 h = {(_Float16)a, (_Float16)b};
     hi = __builtin_bit_cast(unsigned, h);
     const f16x2 l = {(_Float16)(a - (float)h[0]), (_Float16)(b - (float)h[1])};
@@ -68,6 +71,7 @@ __global__ __launch_bounds__(256) void gemm_bias_act_split_kernel(GemmArgsB a) {
   const bool active = nb < a.nblocks;
   const int nkc_total = a.K / 16;               // K is a multiple of 16 (checked by the launcher)
   f32x16 c[4];
+  float amax = 0.f;
 #pragma unroll
   for (int rt = 0; rt < 4; ++rt) c[rt] = f32x16{0};
   for (int k0 = 0; k0 < a.K; k0 += BK) {
@@ -79,7 +83,7 @@ __global__ __launch_bounds__(256) void gemm_bias_act_split_kernel(GemmArgsB a) {
         int row = row0 + r; if (row >= a.M) row = a.M - 1;
         const f32x4 v = *(const f32x4*)(a.x + (size_t)row * a.ldx + k0 + cq * 4);
         unsigned h0, l0, h1, l1;
-        split2<F16>(v[0], v[1], h0, l0); split2<F16>(v[2], v[3], h1, l1);
+        split2<F16>(v[0], v[1], h0, l0, amax); split2<F16>(v[2], v[3], h1, l1, amax);
         *(u32x2*)(xh + r * SR + cq * 4) = u32x2{h0, h1};
         *(u32x2*)(xl + r * SR + cq * 4) = u32x2{l0, l1};
       }
@@ -108,6 +112,7 @@ __global__ __launch_bounds__(256) void gemm_bias_act_split_kernel(GemmArgsB a) {
       }
     }
   }
+  if (F16 && !(amax < HALF_MAX)) atomicOr(&g_half_overflow_gemm, 1);
   if (!active) return;
   const int col = nb * 32 + l31;
   if (col >= a.N) return;
@@ -129,6 +134,15 @@ __global__ __launch_bounds__(256) void gemm_bias_act_split_kernel(GemmArgsB a) {
 }
 
 }  // namespace
+
+extern "C" int cg_internal_gemm_half_flag(int reset, int* flag) {
+  int a = 0;
+  hipError_t e = hipMemcpyFromSymbol(&a, HIP_SYMBOL(g_half_overflow_gemm), sizeof(int));
+  if (e != hipSuccess) return (int)e;
+  if (reset && a) { const int z = 0; e = hipMemcpyToSymbol(HIP_SYMBOL(g_half_overflow_gemm), &z, sizeof(int)); if (e != hipSuccess) return (int)e; }
+  *flag = a;
+  return CG_OK;
+}
 
 template <bool F16>
 static int gemm_bias_act_split(const float* x, int M, int K, int ldx, const unsigned short* w_split, int N,

@@ -67,6 +67,11 @@ struct ArgsB {
 // within ~2e-6 of the float64 evaluation -- float32's own distance), bf16 pieces 8 + 8 (~2e-5); both cost 3 MFMAs.
 typedef u32x4 frag;
 
+// Set (never cleared by kernels) when a value handed to the IEEE-half split reaches the half range limit: its hi piece would be
+// inf and the result garbage that the NaN-ignoring max-pool can make look finite.  Queried by cg_half_range_violation().
+__device__ int g_half_overflow = 0;
+constexpr float HALF_MAX = 65504.f;
+
 template <bool F16>
 __device__ __forceinline__ f32x16 mfma_x(frag a, frag b, f32x16 c) {
   if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
@@ -82,8 +87,9 @@ __device__ __forceinline__ f32x16 mfma3(frag ah, frag al, frag bh, frag bl, f32x
 
 // two floats -> packed pair of the high parts and packed pair of the residuals (v_cvt_pk_{bf16,f16}_f32 x2)
 template <bool F16>
-__device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
+__device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo, float& amax) {
   if constexpr (F16) {
+    amax = fmaxf(fmaxf(amax, fabsf(a)), fabsf(b));       // one v_max3_f32 with |.| source modifiers
     const f16x2 h = {(_Float16)a, (_Float16)b};
     hi = __builtin_bit_cast(unsigned, h);
     const f16x2 l = {(_Float16)(a - (float)h[0]), (_Float16)(b - (float)h[1])};
@@ -98,10 +104,10 @@ __device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned&
 }
 
 template <bool F16>
-__device__ __forceinline__ void split8(const f32x4& v0, const f32x4& v1, frag& hi, frag& lo) {
+__device__ __forceinline__ void split8(const f32x4& v0, const f32x4& v1, frag& hi, frag& lo, float& amax) {
   unsigned h[4], l[4];
-  split2<F16>(v0[0], v0[1], h[0], l[0]); split2<F16>(v0[2], v0[3], h[1], l[1]);
-  split2<F16>(v1[0], v1[1], h[2], l[2]); split2<F16>(v1[2], v1[3], h[3], l[3]);
+  split2<F16>(v0[0], v0[1], h[0], l[0], amax); split2<F16>(v0[2], v0[3], h[1], l[1], amax);
+  split2<F16>(v1[0], v1[1], h[2], l[2], amax); split2<F16>(v1[2], v1[3], h[3], l[3], amax);
   hi = frag{h[0], h[1], h[2], h[3]}; lo = frag{l[0], l[1], l[2], l[3]};
 }
 
@@ -110,12 +116,12 @@ __device__ __forceinline__ void split8(const f32x4& v0, const f32x4& v1, frag& h
 // Quads (0,1) feed kc = 0 and (2,3) feed kc = 1; v_permlane32_swap exchanges the upper half of the even quad with the
 // lower half of the odd quad, which lands exactly the partner lane's four channels next to the lane's own four.
 template <bool F16>
-__device__ __forceinline__ void acts_to_frags(const f32x16& c, frag& h0, frag& l0, frag& h1, frag& l1) {
+__device__ __forceinline__ void acts_to_frags(const f32x16& c, frag& h0, frag& l0, frag& h1, frag& l1, float& amax) {
   unsigned H[4][2], L[4][2];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    split2<F16>(c[4 * q], c[4 * q + 1], H[q][0], L[q][0]);
-    split2<F16>(c[4 * q + 2], c[4 * q + 3], H[q][1], L[q][1]);
+    split2<F16>(c[4 * q], c[4 * q + 1], H[q][0], L[q][0], amax);
+    split2<F16>(c[4 * q + 2], c[4 * q + 3], H[q][1], L[q][1], amax);
   }
 #pragma unroll
   for (int q = 0; q < 4; q += 2) {
@@ -185,6 +191,7 @@ __global__ __launch_bounds__(64 * RT, 2) void pointmlp_max_split_kernel(ArgsB a)
   const int t_begin = (int)(((long)ntiles * split) / nsp);
   const int t_end = (int)(((long)ntiles * (split + 1)) / nsp);
 
+  float amax = 0.f;        // largest magnitude this lane handed to the split (half range check, F16 only)
   // ---- once per workgroup: running max, first-layer fragments (W1 | b1 as the k = 6 column), mid-layer fragments
   for (int i = tid; i < 1024; i += NT) rmax[i] = -INFINITY;
   for (int i = tid; i < 128; i += NT) {
@@ -196,7 +203,7 @@ __global__ __launch_bounds__(64 * RT, 2) void pointmlp_max_split_kernel(ArgsB a)
       v1 = f32x4{wr[4], wr[5], a.b1[row], 0.f};
     }
     frag hi, lo;
-    split8<F16>(v0, v1, hi, lo);
+    split8<F16>(v0, v1, hi, lo, amax);
     w1f[(nb * 2) * 64 + ln] = hi;
     w1f[(nb * 2 + 1) * 64 + ln] = lo;
   }
@@ -208,7 +215,7 @@ __global__ __launch_bounds__(64 * RT, 2) void pointmlp_max_split_kernel(ArgsB a)
       const int ln = i & 63, kc = (i >> 6) & 3, nb = i >> 8;
       const float* tp = a.t64 + (size_t)b * 4096 + (nb * 32 + (ln & 31)) * 64 + kc * 16 + (ln >> 5) * 8;
       frag hi, lo;
-      split8<F16>(*(const f32x4*)tp, *(const f32x4*)(tp + 4), hi, lo);
+      split8<F16>(*(const f32x4*)tp, *(const f32x4*)(tp + 4), hi, lo, amax);
       wmf[((nb * 4 + kc) * 2) * 64 + ln] = hi;
       wmf[((nb * 4 + kc) * 2 + 1) * 64 + ln] = lo;
     }
@@ -250,13 +257,13 @@ __global__ __launch_bounds__(64 * RT, 2) void pointmlp_max_split_kernel(ArgsB a)
       f32x4 q0 = {px, py, pz, v1[1]}, q1 = {v2[0], v2[1], 1.f, 0.f};     // k = 6 carries the bias
       if (lhi) { q0 = f32x4{0.f, 0.f, 0.f, 0.f}; q1 = q0; }              // k = 8..15: padding
       frag xh, xl;
-      split8<F16>(q0, q1, xh, xl);
+      split8<F16>(q0, q1, xh, xl, amax);
       // L0: 6(+1) -> 64
       const f32x16 z = {0};
       f32x16 c0 = mfma3<F16>(w1f[lane], w1f[64 + lane], xh, xl, z);
       f32x16 c1 = mfma3<F16>(w1f[128 + lane], w1f[192 + lane], xh, xl, z);
-      acts_to_frags<F16>(relu16(c0), fh[0], fl[0], fh[1], fl[1]);
-      acts_to_frags<F16>(relu16(c1), fh[2], fl[2], fh[3], fl[3]);
+      acts_to_frags<F16>(relu16(c0), fh[0], fl[0], fh[1], fl[1], amax);
+      acts_to_frags<F16>(relu16(c1), fh[2], fl[2], fh[3], fl[3], amax);
     }
     if (MID != 0) {  // mid: 64 -> 64 (shared conv+BN+ReLU, or the per-sample 64x64 feature transform)
       f32x16 c0, c1;
@@ -280,8 +287,8 @@ __global__ __launch_bounds__(64 * RT, 2) void pointmlp_max_split_kernel(ArgsB a)
           *(f32x4*)(pf + 32 + 8 * q) = f32x4{c1[4 * q], c1[4 * q + 1], c1[4 * q + 2], c1[4 * q + 3]};
         }
       }
-      acts_to_frags<F16>(c0, fh[0], fl[0], fh[1], fl[1]);
-      acts_to_frags<F16>(c1, fh[2], fl[2], fh[3], fl[3]);
+      acts_to_frags<F16>(c0, fh[0], fl[0], fh[1], fl[1], amax);
+      acts_to_frags<F16>(c1, fh[2], fl[2], fh[3], fl[3], amax);
     }
     __syncthreads();   // the previous tile's L3 reads of the h2 images are complete
     {  // L2: 64 -> 128, two channel blocks at a time, written split into the hi / lo images
@@ -304,8 +311,8 @@ __global__ __launch_bounds__(64 * RT, 2) void pointmlp_max_split_kernel(ArgsB a)
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             unsigned h0, l0, h1, l1;
-            split2<F16>(c[4 * q], c[4 * q + 1], h0, l0);
-            split2<F16>(c[4 * q + 2], c[4 * q + 3], h1, l1);
+            split2<F16>(c[4 * q], c[4 * q + 1], h0, l0, amax);
+            split2<F16>(c[4 * q + 2], c[4 * q + 3], h1, l1, amax);
             const int off = row * SH + (np * 2 + h) * 32 + 8 * q + 4 * lhi;
             *(u32x2*)(h2hi + off) = u32x2{h0, h1};
             *(u32x2*)(h2lo + off) = u32x2{l0, l1};
@@ -348,6 +355,7 @@ __global__ __launch_bounds__(64 * RT, 2) void pointmlp_max_split_kernel(ArgsB a)
       }
     }
   }
+  if (F16 && !(amax < HALF_MAX)) atomicOr(&g_half_overflow, 1);
   __syncthreads();
   if (t_end > t_begin) {
     for (int ch = tid; ch < 1024; ch += NT) {
@@ -420,6 +428,20 @@ static int pointmlp_max_split(const float* x, int B, int N, const float* t3, con
   if (mid_mode == 0) return launch<0, 8, F16>(a, s);
   if (mid_mode == 1) return launch<1, 8, F16>(a, s);
   return launch<2, 8, F16>(a, s);
+}
+
+extern "C" int cg_internal_gemm_half_flag(int reset, int* flag);      // gemm_split.hip
+
+extern "C" int cg_half_range_violation(int reset, int* flag) {
+  if (!flag) return CG_ERR_ARG;
+  int a = 0, b = 0;
+  hipError_t e = hipMemcpyFromSymbol(&a, HIP_SYMBOL(g_half_overflow), sizeof(int));
+  if (e != hipSuccess) return (int)e;
+  if (reset && a) { const int z = 0; e = hipMemcpyToSymbol(HIP_SYMBOL(g_half_overflow), &z, sizeof(int)); if (e != hipSuccess) return (int)e; }
+  const int rc = cg_internal_gemm_half_flag(reset, &b);
+  if (rc != CG_OK) return rc;
+  *flag = (a | b) ? 1 : 0;
+  return CG_OK;
 }
 
 extern "C" int cg_pointmlp_max_bf16x3(const float* x, int B, int N, const float* t3, const float* w1, const float* b1,

@@ -29,6 +29,15 @@ def set_precision(p):
     PRECISION = p
 
 
+def half_range_violation(reset=True):
+    """True iff an f16x3 kernel met a value outside the IEEE-half range since the last reset (synchronises the device)."""
+    import ctypes
+    from . import _lib as L
+    flag = ctypes.c_int(0)
+    L.check(L.lib().cg_half_range_violation(ctypes.c_int(int(reset)), ctypes.byref(flag)), 'cg_half_range_violation')
+    return bool(flag.value)
+
+
 def _nsplit(B, N, tp=64):
     """Workgroups per sample: keep >= ~1024 workgroups in flight for small batches."""
     ntiles = (N + tp - 1) // tp

@@ -63,6 +63,14 @@ def _device(device):
     return torch.device('cuda', torch.cuda.current_device())
 
 
+def _require_finite(a, what):
+    """The split-half arithmetic ('f16x3') needs activations below 65504.  Its kernels record a violation (the result is then
+    meaningless, and the NaN-ignoring max-pool can even make it look finite); the reference-API entry points turn it into an error."""
+    if (engine.PRECISION == 'f16x3' and engine.half_range_violation()) or not np.isfinite(a).all():
+        raise FloatingPointError(f'{what} are not finite under CATGRASP_AMD_PRECISION={engine.PRECISION}: activations left the range of '
+                                 "the 16-bit pieces -- use engine.set_precision('bf16x3') (no range limit) or 'f32'")
+
+
 class _TransformOnly:
     """Stand-in for the `.dataset` attribute of the reference predicters (predicter.py:60,127): keeps cfg /
     phase; the transform itself runs on the device inside predict*()."""
@@ -125,6 +133,7 @@ class GraspPredicter:
             pinv = torch.from_numpy(transforms.pose_inverse_rows(grasp_poses, cloud.center)).to(self.device)
             probs, label, conf, _ = self.score_on_device(cloud.xyz, cloud.normal, ids_d, pinv)
             probs = probs.cpu().numpy(); label = label.cpu().numpy(); conf = conf.cpu().numpy()
+        _require_finite(probs, 'grasp-Q probabilities')
         return [[label[b], conf[b], probs[b]] for b in range(G)]
 
 
@@ -178,7 +187,9 @@ class NunocsPredicter:
             coords, conf, _ = self.nocs_on_device(cloud.xyz, cloud.normal, torch.from_numpy(ids).to(self.device))
             self.data_transformed = {'cloud_xyz_original': cloud.xyz64[ids[0]].copy(), 'keep_ids': cloud.keep_ids[ids[0]],
                                      'cloud_normal': cloud.normal64[ids[0]].copy()}
-            return coords[0].cpu().numpy(), conf[0].cpu().numpy(), self.data_transformed
+            conf_h = conf[0].cpu().numpy()
+            _require_finite(conf_h, 'NUNOCS confidences')
+            return coords[0].cpu().numpy(), conf_h, self.data_transformed
 
     def predict(self, data, ids=None):
         """predicter.py:135-203: (nocs_cloud, 4x4 nocs_pose) or (None, None).  The 9-D RANSAC alignment

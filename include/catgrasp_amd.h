@@ -325,6 +325,11 @@ int cg_pg_voxelize_fp(const float* feats, const int* rules, int n_rows, int max_
 int cg_iiwa_ik_within_limits(const float* ee_in_base, long E, const double* h_upper7, const double* h_lower7,
                              unsigned char* ok, void* stream);
 
+/* Half-range check of the f16x3 kernels: *flag = 1 iff some value handed to the IEEE-half split since the last reset reached
+ * 65504 in magnitude (its result is then meaningless; re-run with the bf16x3 or f32 entry points).  Synchronous (copies a device
+ * word); reset != 0 clears the condition. */
+int cg_half_range_violation(int reset, int* flag);
+
 #ifdef __cplusplus
 }
 #endif

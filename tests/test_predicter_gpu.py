@@ -153,3 +153,23 @@ def test_dropin_predicters_against_the_real_reference_outputs(cuda_device, mlp_p
     assert clear.mean() > 0.98 and np.array_equal(nocs[clear], p['nocs_cloud'][clear])
     zc = clear[:, 2]
     assert np.abs(conf[zc] - p['nocs_conf_z'][zc]).max() <= 1e-4
+
+
+def test_half_range_violation_is_reported_not_returned(cuda_device, mlp_precision):
+    """The split-half arithmetic needs activations below 65504.  A network whose first layer is scaled by 1e6 leaves that range:
+    predict_batch must raise under 'f16x3' (never hand back inf/NaN scores) and keep working under 'bf16x3' / 'f32'."""
+    from catgrasp_amd.predicter import DEFAULT_GRASP_CFG, GraspPredicter
+    sd = synth.make_state_dict('cls', 6, 10, seed=5)
+    sd = {k: v.clone() for k, v in sd.items()}
+    sd['feat.conv1.weight'] *= 1e6
+    ob = synth.make_scene(1, 1500, seed=4)[0]
+    P = synth.make_candidates(ob, 8, np.random.default_rng(1))
+    gp = GraspPredicter('nut', cfg=DEFAULT_GRASP_CFG, state_dict=sd, device=cuda_device)
+    data = {'cloud_xyz': ob['xyz'], 'cloud_normal': ob['normal']}
+    np.random.seed(0)
+    if mlp_precision == 'f16x3':
+        with pytest.raises(FloatingPointError):
+            gp.predict_batch(data, list(P))
+    else:
+        ret = gp.predict_batch(data, list(P))
+        assert len(ret) == 8 and all(np.isfinite(r[2]).all() for r in ret)
