@@ -191,7 +191,8 @@ __global__ __launch_bounds__(64 * RT, 2) void pointmlp_max_split_kernel(ArgsB a)
   const int t_begin = (int)(((long)ntiles * split) / nsp);
   const int t_end = (int)(((long)ntiles * (split + 1)) / nsp);
 
-  float amax = 0.f;        // largest magnitude this lane handed to the split (half range check, F16 only)
+  float amax = 0.f;        // largest magnitude this lane handed to the split (half range check, F16 only); folded into the
+  int overflow = 0;        // wave-uniform flag before every 128->1024 stream so that no extra VGPR lives across it
   // ---- once per workgroup: running max, first-layer fragments (W1 | b1 as the k = 6 column), mid-layer fragments
   for (int i = tid; i < 1024; i += NT) rmax[i] = -INFINITY;
   for (int i = tid; i < 128; i += NT) {
@@ -320,6 +321,10 @@ __global__ __launch_bounds__(64 * RT, 2) void pointmlp_max_split_kernel(ArgsB a)
         }
       }
     }
+    if constexpr (F16) {
+      if (__builtin_amdgcn_ballot_w64(!(amax < HALF_MAX)) != 0) overflow = 1;
+      amax = 0.f;
+    }
     __syncthreads();
     // ================= L3: 128 -> 1024 + running max.  wave w owns channel blocks [4w, 4w+4) =================
     // The 192-MFMA stream of one channel block is hand-scheduled assembly (gen_l3_asm.py -> l3_asm.inc): exact wait
@@ -355,7 +360,7 @@ __global__ __launch_bounds__(64 * RT, 2) void pointmlp_max_split_kernel(ArgsB a)
       }
     }
   }
-  if (F16 && !(amax < HALF_MAX)) atomicOr(&g_half_overflow, 1);
+  if (F16 && overflow && lane == 0) atomicOr(&g_half_overflow, 1);
   __syncthreads();
   if (t_end > t_begin) {
     for (int ch = tid; ch < 1024; ch += NT) {
