@@ -241,3 +241,26 @@ def test_committed_bench_line_honours_the_contract():
     for k in ('value', 'unit', 'cores', 'kind', 'sample'):
         assert k in c, k
     assert c['kind'] in ('reference', 'port') and c['cores'] >= 1
+
+
+def test_split_packing_half_and_bf16():
+    """folding.pack_b_split: both element types share one fragment layout; hi + lo reproduces the weight to the pieces' resolution."""
+    rng = np.random.default_rng(3)
+    w = rng.normal(0, 1, (70, 48)).astype(np.float32) * np.exp(rng.normal(0, 2, (70, 48))).astype(np.float32)
+    for elem, bits, view in (('bf16', 16, None), ('f16', 21, np.float16)):
+        p = folding.pack_b_split(w, elem)
+        nb, nkc = 3, 3
+        assert p.dtype == np.uint16 and p.shape == (nb * nkc * 2 * 64 * 8,)
+        q = p.reshape(nb, nkc, 2, 64, 8)
+        if elem == 'bf16':
+            f = (q.astype(np.uint32) << 16).view(np.float32)
+        else:
+            f = q.view(np.float16).astype(np.float32)
+        rec = f[:, :, 0] + f[:, :, 1]                                   # hi + lo: (nb, kc, lane, e)
+        # element e of lane l = W[nb*32 + (l&31)][kc*16 + (l>>5)*8 + e], rows zero padded to 32
+        full = np.zeros((nb * 32, 48), np.float32); full[:70] = w
+        lane = np.arange(64)
+        exp = np.stack([[full[n * 32 + (lane & 31)][:, k * 16:(k + 1) * 16].reshape(64, 2, 8)[lane, lane >> 5] for k in range(nkc)] for n in range(nb)])
+        small = np.abs(full).max() * 2.0 ** -24 if elem == 'f16' else 0.0           # half residuals below 2^-24 flush toward zero
+        assert np.all(np.abs(rec - exp) <= np.abs(exp) * 2.0 ** -bits + small + 1e-30)
+    assert np.array_equal(folding.pack_b_bf16x3(w), folding.pack_b_split(w, 'bf16'))
