@@ -56,18 +56,29 @@ def patched(scheme, layers=('conv2', 'conv3')):
     return conv_bn
 
 
-rng = np.random.default_rng(5)
-for gain in (1.0, 1.6, 1.7):
-    for seed in (11, 12):
-        sd = synth.make_state_dict('cls', 6, 10, seed=seed, gain=gain)
-        x = torch.from_numpy(rng.normal(0, 0.5, (8, 2048, 6)).astype(np.float32))
+def logits_error(scheme, sd, x, y64):
+    """max |logits - float64 logits| / max(1, |logits|) of the oracle network with the K>=64 per-point layers in `scheme`."""
+    oref._conv_bn = patched(scheme)
+    try:
+        y, _ = oref.pointnet_cls_forward(sd, x)
+    finally:
         oref._conv_bn = orig
-        y64, _ = oref.pointnet_cls_forward(sd, x, torch.float64)
-        y32, _ = oref.pointnet_cls_forward(sd, x)
-        line = f'gain {gain} seed {seed} |logit|max {float(y64.abs().max()):6.1f}  f32 {float(((y32 - y64).abs() / y64.abs().clamp(min=1)).max()):.1e}'
-        for scheme in ('bf16x3', 'f16x3', 'f16+2xfp8', 'f16+1xf16'):
-            oref._conv_bn = patched(scheme)
-            y, _ = oref.pointnet_cls_forward(sd, x)
-            line += f'  {scheme} {float(((y - y64).abs() / y64.abs().clamp(min=1)).max()):.1e}'
-        print(line)
-oref._conv_bn = orig
+    return float(((y - y64).abs() / y64.abs().clamp(min=1)).max())
+
+
+def main():
+    rng = np.random.default_rng(5)
+    for gain in (1.0, 1.6, 1.7):
+        for seed in (11, 12):
+            sd = synth.make_state_dict('cls', 6, 10, seed=seed, gain=gain)
+            x = torch.from_numpy(rng.normal(0, 0.5, (8, 2048, 6)).astype(np.float32))
+            y64, _ = oref.pointnet_cls_forward(sd, x, torch.float64)
+            y32, _ = oref.pointnet_cls_forward(sd, x)
+            line = f'gain {gain} seed {seed} |logit|max {float(y64.abs().max()):6.1f}  f32 {float(((y32 - y64).abs() / y64.abs().clamp(min=1)).max()):.1e}'
+            for scheme in ('bf16x3', 'f16x3', 'f16+2xfp8', 'f16+1xf16'):
+                line += f'  {scheme} {logits_error(scheme, sd, x, y64):.1e}'
+            print(line)
+
+
+if __name__ == '__main__':
+    main()
