@@ -80,6 +80,17 @@ for tag, center in (('plain', False), ('centred', True)):
                              open_gripper_collision_pts=pts, center_ob_between_gripper=center, filter_ik=False, adjust_collision_pose=False)
     out[f'poses_{tag}'] = np.stack([g.grasp_pose for g in grasps])
     out[f'r_ball_{tag}'] = s.params['r_ball']
+# NocsTransferGraspSampler.__init__ (grasp_sampler.py:302-327): score threshold, best-n, y-centring -- with the REAL grasp class
+rg = np.random.default_rng(8)
+can = []
+for i in range(12):
+    Tg = np.eye(4); Tg[:3, :3] = synth.random_rotation(rg); Tg[:3, 3] = rg.normal(0, 0.01, 3)
+    can.append(ref_sampler.ParallelJawPtGrasp3D(grasp_pose=Tg, perturbation_score=float(rg.uniform())))
+out['transfer_in_poses'] = np.stack([g.grasp_pose for g in can]); out['transfer_in_scores'] = np.array([g.perturbation_score for g in can])
+ts = ref_sampler.NocsTransferGraspSampler(gripper, config, {'canonical_grasps': can}, 'nut', score_larger_than=0.3, max_n_grasp=5,
+                                          center_ob_between_gripper=True)
+out['transfer_kept_poses'] = np.stack([g.get_grasp_pose_matrix() for g in ts.canonical['canonical_grasps']])
+out['transfer_kept_scores'] = np.array([g.perturbation_score for g in ts.canonical['canonical_grasps']])
 np.random.seed(99)
 out['resolution_seed99'] = ref_sampler.compute_cloud_resolution(pts)
 out['hinter_1000'] = ref_sampler.hinter_sampling(min_n_pts=1000, radius=1)[0]

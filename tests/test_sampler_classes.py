@@ -35,6 +35,17 @@ def test_transfer_sampler_selection_and_centring():
     assert len(grasps) == 10 and abs(np.linalg.inv(grasps[9].grasp_pose)[1, 3]) > 0        # the caller's list is not modified
 
 
+def test_transfer_sampler_constructor_matches_the_reference():
+    """The REAL NocsTransferGraspSampler.__init__ on 12 scored canonical grasps (score_larger_than=0.3, max_n_grasp=5, centring on):
+    same survivors, same order, same centred poses."""
+    grasps = [gs.ParallelJawPtGrasp3D(T, perturbation_score=float(s)) for T, s in zip(GOLD['transfer_in_poses'], GOLD['transfer_in_scores'])]
+    s = gs.NocsTransferGraspSampler(_gripper(), None, {'canonical_grasps': grasps}, 'nut', score_larger_than=0.3, max_n_grasp=5,
+                                    center_ob_between_gripper=True)
+    kept = s.canonical['canonical_grasps']
+    assert np.allclose([g.perturbation_score for g in kept], GOLD['transfer_kept_scores'], rtol=0, atol=0)
+    assert np.abs(np.stack([g.get_grasp_pose_matrix() for g in kept]) - GOLD['transfer_kept_poses']).max() < 1e-15
+
+
 def _surface_point(group):
     return group[0, :3, 3] - 0.005 * group[0, :3, 0]          # first pose: depth 0 -> surface + init_bite * approach
 
