@@ -91,6 +91,8 @@ ts = ref_sampler.NocsTransferGraspSampler(gripper, config, {'canonical_grasps': 
                                           center_ob_between_gripper=True)
 out['transfer_kept_poses'] = np.stack([g.get_grasp_pose_matrix() for g in ts.canonical['canonical_grasps']])
 out['transfer_kept_scores'] = np.array([g.perturbation_score for g in ts.canonical['canonical_grasps']])
+for cls in ('nut', 'hnm', 'screw'):
+    out[f'symmetry_{cls}'] = np.stack(ref_sampler.get_symmetry_tfs(cls))          # Utils.get_symmetry_tfs (Utils.py:79-94) via `from Utils import *`
 np.random.seed(99)
 out['resolution_seed99'] = ref_sampler.compute_cloud_resolution(pts)
 out['hinter_1000'] = ref_sampler.hinter_sampling(min_n_pts=1000, radius=1)[0]

@@ -35,6 +35,12 @@ def test_transfer_sampler_selection_and_centring():
     assert len(grasps) == 10 and abs(np.linalg.inv(grasps[9].grasp_pose)[1, 3]) > 0        # the caller's list is not modified
 
 
+def test_symmetry_sets_match_the_reference():
+    from catgrasp_amd import transforms
+    for cls in ('nut', 'hnm', 'screw'):
+        assert np.abs(np.stack(transforms.get_symmetry_tfs(cls)) - GOLD[f'symmetry_{cls}']).max() < 1e-15
+
+
 def test_transfer_sampler_constructor_matches_the_reference():
     """The REAL NocsTransferGraspSampler.__init__ on 12 scored canonical grasps (score_larger_than=0.3, max_n_grasp=5, centring on):
     same survivors, same order, same centred poses."""
