@@ -1,0 +1,46 @@
+// Shared pieces of the split-precision kernels (pointmlp_split.hip, gemm_split.hip).
+//
+// A float is handled as hi + lo 16-bit pieces (round-to-nearest-even, lo = round(x - hi)) and a product block as three MFMAs
+// with f32 accumulation, x.w ~= x_lo.w_hi + x_hi.w_lo + x_hi.w_hi.  Fragments travel as raw 128-bit values; the element type
+// (F16 = true: IEEE half, 11 + 11 significant bits, logits within ~2e-6 of the float64 evaluation = float32's own distance;
+// F16 = false: bf16, 8 + 8 bits, ~2e-5) only matters where a float is split and where the MFMA is issued.
+#pragma once
+#include "cg_common.hpp"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef u32x4 frag;
+
+// IEEE-half range limit: a value at or beyond it has an infinite hi piece and a meaningless result (which a NaN-ignoring
+// max-pool can even make look finite), so the half kernels track the largest magnitude they split and report it
+// (cg_half_range_violation).
+constexpr float HALF_MAX = 65504.f;
+
+template <bool F16>
+__device__ __forceinline__ f32x16 mfma_x(frag a, frag b, f32x16 c) {
+  if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// two floats -> packed pair of the high parts and packed pair of the residuals (v_cvt_pk_{bf16,f16}_f32 x2);
+// amax accumulates the largest magnitude seen (half only: one v_max3_f32 with |.| source modifiers)
+template <bool F16>
+__device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo, float& amax) {
+  if constexpr (F16) {
+    amax = fmaxf(fmaxf(amax, fabsf(a)), fabsf(b));
+    const f16x2 h = {(_Float16)a, (_Float16)b};
+    hi = __builtin_bit_cast(unsigned, h);
+    const f16x2 l = {(_Float16)(a - (float)h[0]), (_Float16)(b - (float)h[1])};
+    lo = __builtin_bit_cast(unsigned, l);
+  } else {
+    const bf16x2 h = {(__bf16)a, (__bf16)b};
+    hi = __builtin_bit_cast(unsigned, h);
+    const float ha = __uint_as_float(hi << 16), hb = __uint_as_float(hi & 0xffff0000u);
+    const bf16x2 l = {(__bf16)(a - ha), (__bf16)(b - hb)};
+    lo = __builtin_bit_cast(unsigned, l);
+  }
+}

@@ -7,20 +7,12 @@
 // X (f32) is split while it is staged: 128 rows x 64 columns per workgroup as two 16-bit images (144-byte rows: conflict-free
 // ds_read_b128 fragment reads).  W is split and packed on the host (folding.pack_b_split):
 // Wp[nb][kc][2 (hi,lo)][lane][8], element e of lane l = W[nb*32 + (l&31)][kc*16 + (l>>5)*8 + e].
-#include "cg_common.hpp"
+#include "cg_split.hpp"
 #include "../../include/catgrasp_amd.h"
 
 namespace {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-__device__ int g_half_overflow_gemm = 0;     // see pointmlp_split.hip / cg_half_range_violation
-constexpr float HALF_MAX = 65504.f;
-typedef u32x4 frag;      // a 128-bit operand fragment; F16 selects IEEE half (true) or bf16 (false) pieces, see pointmlp_split.hip
+__device__ int g_half_overflow_gemm = 0;     // see cg_split.hpp / cg_half_range_violation
 
 constexpr int BM = 128;      // rows per workgroup (4 row tiles per wave: each weight fragment feeds 12 MFMAs)
 constexpr int BK = 64;       // K chunk staged in LDS
@@ -34,29 +26,6 @@ struct GemmArgsB {
   int relu; int eye_k;
   float* y; int ldy;
 };
-
-template <bool F16>
-__device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo, float& amax) {
-  if constexpr (F16) {
-    amax = fmaxf(fmaxf(amax, fabsf(a)), fabsf(b));
-    const f16x2 h = {(_Float16)a, (_Float16)b};
-    hi = __builtin_bit_cast(unsigned, h);
-    const f16x2 l = {(_Float16)(a - (float)h[0]), (_Float16)(b - (float)h[1])};
-    lo = __builtin_bit_cast(unsigned, l);
-  } else {
-    const bf16x2 h = {(__bf16)a, (__bf16)b};
-    hi = __builtin_bit_cast(unsigned, h);
-    const float ha = __uint_as_float(hi << 16), hb = __uint_as_float(hi & 0xffff0000u);
-    const bf16x2 l = {(__bf16)(a - ha), (__bf16)(b - hb)};
-    lo = __builtin_bit_cast(unsigned, l);
-  }
-}
-
-template <bool F16>
-__device__ __forceinline__ f32x16 mfma_x(frag a, frag b, f32x16 c) {
-  if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
 
 template <bool F16>
 __global__ __launch_bounds__(256) void gemm_bias_act_split_kernel(GemmArgsB a) {

@@ -25,18 +25,11 @@
 //    and the max over points is a per-lane reduction over accumulator registers + one lane^32 swap.
 //  * The operand fragments of the first layer and of the 64->64 layer (shared weights, or the per-sample feature
 //    transform split on the fly) are staged once per workgroup in the remaining 20 KB of LDS.
-#include "cg_common.hpp"
+#include "cg_split.hpp"
 #include "../../include/catgrasp_amd.h"
 #include "l3_asm.inc"
 
 namespace {
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int SH = 136;        // 16-bit elements per row of the h2 hi / lo images
 template <int RT> struct Geo {
@@ -62,45 +55,16 @@ struct ArgsB {
   float* out; float* pointfeat;
 };
 
-// Fragments travel as raw 128-bit values; the 16-bit element type (F16 = false: bf16, true: IEEE half) only matters where a
-// float is split into its hi / lo pieces and where the MFMA is issued.  Half pieces carry 11 + 11 significant bits (logits
-// within ~2e-6 of the float64 evaluation -- float32's own distance), bf16 pieces 8 + 8 (~2e-5); both cost 3 MFMAs.
-typedef u32x4 frag;
-
-// Set (never cleared by kernels) when a value handed to the IEEE-half split reaches the half range limit: its hi piece would be
-// inf and the result garbage that the NaN-ignoring max-pool can make look finite.  Queried by cg_half_range_violation().
+// Set (never cleared by kernels) when a value handed to the IEEE-half split reaches the half range limit (cg_split.hpp).
+// Queried by cg_half_range_violation().
 __device__ int g_half_overflow = 0;
-constexpr float HALF_MAX = 65504.f;
 
-template <bool F16>
-__device__ __forceinline__ f32x16 mfma_x(frag a, frag b, f32x16 c) {
-  if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
 // split product block: c += A.B with A = ah + al, B = bh + bl (small terms first)
 template <bool F16>
 __device__ __forceinline__ f32x16 mfma3(frag ah, frag al, frag bh, frag bl, f32x16 c) {
   c = mfma_x<F16>(ah, bl, c);
   c = mfma_x<F16>(al, bh, c);
   return mfma_x<F16>(ah, bh, c);
-}
-
-// two floats -> packed pair of the high parts and packed pair of the residuals (v_cvt_pk_{bf16,f16}_f32 x2)
-template <bool F16>
-__device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo, float& amax) {
-  if constexpr (F16) {
-    amax = fmaxf(fmaxf(amax, fabsf(a)), fabsf(b));       // one v_max3_f32 with |.| source modifiers
-    const f16x2 h = {(_Float16)a, (_Float16)b};
-    hi = __builtin_bit_cast(unsigned, h);
-    const f16x2 l = {(_Float16)(a - (float)h[0]), (_Float16)(b - (float)h[1])};
-    lo = __builtin_bit_cast(unsigned, l);
-  } else {
-    const bf16x2 h = {(__bf16)a, (__bf16)b};
-    hi = __builtin_bit_cast(unsigned, h);
-    const float ha = __uint_as_float(hi << 16), hb = __uint_as_float(hi & 0xffff0000u);
-    const bf16x2 l = {(__bf16)(a - ha), (__bf16)(b - hb)};
-    lo = __builtin_bit_cast(unsigned, l);
-  }
 }
 
 template <bool F16>
