@@ -32,8 +32,22 @@ __device__ __forceinline__ float max16(const f32x16& c) {
 
 // float atomic max valid for any sign (buffer pre-filled with -inf)
 __device__ __forceinline__ void atomic_max_f32(float* addr, float v) {
-  if (v >= 0.f) atomicMax((int*)addr, __float_as_int(v));
+  // by sign BIT: -0.0f must take the unsigned-min branch (its int pattern is INT_MIN and would lose every signed max)
+  if (!(__float_as_uint(v) >> 31)) atomicMax((int*)addr, __float_as_int(v));
   else atomicMin((unsigned int*)addr, __float_as_uint(v));
 }
 
 static inline int cg_hip_status(hipError_t e) { return e == hipSuccess ? CG_OK : (int)e; }
+
+// per-device launch state (function attributes, CU counts) is indexed by the HIP device ordinal
+constexpr int CG_MAX_DEVICES = 64;
+static inline int cg_device_cu_count(int dev) {
+  static int n_cu[CG_MAX_DEVICES] = {};
+  if (dev < 0 || dev >= CG_MAX_DEVICES) return -1;
+  if (n_cu[dev] == 0) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
+    n_cu[dev] = prop.multiProcessorCount;
+  }
+  return n_cu[dev];
+}

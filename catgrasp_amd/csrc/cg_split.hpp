@@ -15,10 +15,15 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef u32x4 frag;
 
-// IEEE-half range limit: a value at or beyond it has an infinite hi piece and a meaningless result (which a NaN-ignoring
-// max-pool can even make look finite), so the half kernels track the largest magnitude they split and report it
-// (cg_half_range_violation).
+// IEEE-half range.  A value at or beyond HALF_MAX has an infinite hi piece and a meaningless result (which a NaN-ignoring
+// max-pool can even make look finite); a tensor whose values all lie below HALF_LOW has its lo pieces in the half
+// subnormals, where they carry an absolute error (2^-25) instead of a relative one.  The half kernels track the largest
+// magnitude they split per layer and OR these bits into the caller's status word (a device int passed per call -- no
+// process-global state); the engine then re-runs the batch with bf16 pieces, which have float32's exponent range.
 constexpr float HALF_MAX = 65504.f;
+constexpr float HALF_LOW = 0.015625f;      // 2^-6: worst relative error of a split value >= 2^-6 is 2^-19 of the tensor's scale
+constexpr int CG_HALF_OVERFLOW = 1;
+constexpr int CG_HALF_UNDERFLOW = 2;
 
 template <bool F16>
 __device__ __forceinline__ f32x16 mfma_x(frag a, frag b, f32x16 c) {

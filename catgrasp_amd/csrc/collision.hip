@@ -223,6 +223,7 @@ struct FilterArgs {
   float res;
   signed char* codes; float* poses_out; signed char* nudge;
   float* ee_out;                              // optional (E,16): ee_in_base for the host IK pass; stops after the dir test
+  int keep_rejected_pose;                     // poses_out of a rejected evaluation: 0 -> zeros, 1 -> its (un-nudged) grasp_in_cam
 };
 
 __global__ __launch_bounds__(64 * WAVES) void filter_grasp_pose_kernel(FilterArgs a) {
@@ -293,7 +294,7 @@ __global__ __launch_bounds__(64 * WAVES) void filter_grasp_pose_kernel(FilterArg
       float v = 0.f;
 #pragma unroll
       for (int k = 0; k < 16; ++k) if (lane == k) v = gic[k];
-      a.poses_out[e * 16 + lane] = (code == 0) ? v : 0.f;
+      a.poses_out[e * 16 + lane] = (code == 0 || a.keep_rejected_pose) ? v : 0.f;
     }
     if (lane == 0) { a.codes[e] = (signed char)code; a.nudge[e] = (signed char)nud; }
   }
@@ -365,7 +366,8 @@ extern "C" int cg_filter_grasp_pose_accel(const float* grasp_poses, int n_pose, 
                                     const float* enclosed_vertices, const int* enclosed_faces, int n_enclosed_faces,
                                     const short* open_keys, int n_open_keys, const short* bg_keys, int n_bg_keys,
                                     float resolution, signed char* codes, float* poses_out, signed char* nudge,
-                                    float* ee_in_base_out, const cg_mesh_grid* h_open_grid, const cg_mesh_grid* h_enc_grid, void* stream) {
+                                    float* ee_in_base_out, const cg_mesh_grid* h_open_grid, const cg_mesh_grid* h_enc_grid,
+                                    int keep_rejected_pose, void* stream) {
   if (n_pose < 0 || n_sym < 0) return CG_ERR_ARG;
   if ((long)n_pose * n_sym == 0) return CG_OK;
   if (!grasp_poses || !symmetry_tfs || !h_nocs_pose || !h_canonical_to_nocs || !h_cam_in_world || !h_ee_in_grasp ||
@@ -389,6 +391,7 @@ extern "C" int cg_filter_grasp_pose_accel(const float* grasp_poses, int n_pose, 
   a.enc_mesh = make_mesh(enclosed_vertices, enclosed_faces, n_enclosed_faces, h_enc_grid);
   a.vox_open = Voxels{open_keys, n_open_keys}; a.vox_bg = Voxels{bg_keys, n_bg_keys};
   a.res = resolution; a.codes = codes; a.poses_out = poses_out; a.nudge = nudge; a.ee_out = ee_in_base_out;
+  a.keep_rejected_pose = keep_rejected_pose;
   long blocks = (E + WAVES - 1) / WAVES;
   if (blocks > 256 * 16) blocks = 256 * 16;      // grid-stride: 16 blocks per CU
   hipLaunchKernelGGL(filter_grasp_pose_kernel, dim3((unsigned)blocks), dim3(64 * WAVES), 0, (hipStream_t)stream, a);
@@ -439,5 +442,5 @@ extern "C" int cg_filter_grasp_pose(const float* grasp_poses, int n_pose, const 
   return cg_filter_grasp_pose_accel(grasp_poses, n_pose, symmetry_tfs, n_sym, h_nocs_pose, h_canonical_to_nocs, h_cam_in_world, h_ee_in_grasp,
                                     h_gripper_in_grasp, filter_approach_dir_face_camera, adjust_collision_pose, ik_ok, gripper_vertices,
                                     gripper_faces, n_gripper_faces, enclosed_vertices, enclosed_faces, n_enclosed_faces, open_keys, n_open_keys,
-                                    bg_keys, n_bg_keys, resolution, codes, poses_out, nudge, ee_in_base_out, nullptr, nullptr, stream);
+                                    bg_keys, n_bg_keys, resolution, codes, poses_out, nudge, ee_in_base_out, nullptr, nullptr, 0, stream);
 }

@@ -12,8 +12,6 @@
 
 namespace {
 
-__device__ int g_half_overflow_gemm = 0;     // see cg_split.hpp / cg_half_range_violation
-
 constexpr int BM = 128;      // rows per workgroup (4 row tiles per wave: each weight fragment feeds 12 MFMAs)
 constexpr int BK = 64;       // K chunk staged in LDS
 constexpr int SR = BK + 8;   // 16-bit elements per LDS row
@@ -25,6 +23,7 @@ struct GemmArgsB {
   const float* row_bias; int rows_per_group; int ld_rb;
   int relu; int eye_k;
   float* y; int ldy;
+  int* status;     // optional device int (F16 only): |= CG_HALF_OVERFLOW / CG_HALF_UNDERFLOW (cg_split.hpp)
 };
 
 template <bool F16>
@@ -81,7 +80,12 @@ __global__ __launch_bounds__(256) void gemm_bias_act_split_kernel(GemmArgsB a) {
       }
     }
   }
-  if (F16 && !(amax < HALF_MAX)) atomicOr(&g_half_overflow_gemm, 1);
+  if constexpr (F16) {      // amax covers this thread's share of the workgroup's X tile over the whole K
+    int flags = 0;
+    if (__builtin_amdgcn_ballot_w64(!(amax < HALF_MAX)) != 0) flags |= CG_HALF_OVERFLOW;
+    if (__builtin_amdgcn_ballot_w64(amax >= HALF_LOW) == 0) flags |= CG_HALF_UNDERFLOW;
+    if (flags && lane == 0 && a.status) atomicOr(a.status, flags);
+  }
   if (!active) return;
   const int col = nb * 32 + l31;
   if (col >= a.N) return;
@@ -104,25 +108,16 @@ __global__ __launch_bounds__(256) void gemm_bias_act_split_kernel(GemmArgsB a) {
 
 }  // namespace
 
-extern "C" int cg_internal_gemm_half_flag(int reset, int* flag) {
-  int a = 0;
-  hipError_t e = hipMemcpyFromSymbol(&a, HIP_SYMBOL(g_half_overflow_gemm), sizeof(int));
-  if (e != hipSuccess) return (int)e;
-  if (reset && a) { const int z = 0; e = hipMemcpyToSymbol(HIP_SYMBOL(g_half_overflow_gemm), &z, sizeof(int)); if (e != hipSuccess) return (int)e; }
-  *flag = a;
-  return CG_OK;
-}
-
 template <bool F16>
 static int gemm_bias_act_split(const float* x, int M, int K, int ldx, const unsigned short* w_split, int N,
                                 const float* bias, const float* row_bias, int rows_per_group, int ld_rb,
-                                int relu, int eye_k, float* y, int ldy, void* stream) {
+                                int relu, int eye_k, float* y, int ldy, int* status, void* stream) {
   if (!x || !w_split || !y) return CG_ERR_ARG;
   if (M < 0 || N <= 0 || K <= 0 || (K % 16) != 0 || (ldx % 4) != 0 || ldx < K || ldy < N) return CG_ERR_ARG;
   if (((uintptr_t)x & 15) != 0) return CG_ERR_ARG;
   if (row_bias && (rows_per_group <= 0 || ld_rb < N)) return CG_ERR_ARG;
   if (M == 0) return CG_OK;
-  GemmArgsB a{x, M, K, ldx, w_split, N, (N + 31) / 32, bias, row_bias, rows_per_group, ld_rb, relu, eye_k, y, ldy};
+  GemmArgsB a{x, M, K, ldx, w_split, N, (N + 31) / 32, bias, row_bias, rows_per_group, ld_rb, relu, eye_k, y, ldy, F16 ? status : nullptr};
   dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((a.nblocks + 3) / 4)), block(256);
   hipLaunchKernelGGL(gemm_bias_act_split_kernel<F16>, grid, block, 0, (hipStream_t)stream, a);
   return cg_hip_status(hipGetLastError());
@@ -131,11 +126,11 @@ static int gemm_bias_act_split(const float* x, int M, int K, int ldx, const unsi
 extern "C" int cg_gemm_bias_act_bf16x3(const float* x, int M, int K, int ldx, const unsigned short* w_split, int N,
                                        const float* bias, const float* row_bias, int rows_per_group, int ld_rb,
                                        int relu, int eye_k, float* y, int ldy, void* stream) {
-  return gemm_bias_act_split<false>(x, M, K, ldx, w_split, N, bias, row_bias, rows_per_group, ld_rb, relu, eye_k, y, ldy, stream);
+  return gemm_bias_act_split<false>(x, M, K, ldx, w_split, N, bias, row_bias, rows_per_group, ld_rb, relu, eye_k, y, ldy, nullptr, stream);
 }
 
 extern "C" int cg_gemm_bias_act_f16x3(const float* x, int M, int K, int ldx, const unsigned short* w_split, int N,
                                        const float* bias, const float* row_bias, int rows_per_group, int ld_rb,
-                                       int relu, int eye_k, float* y, int ldy, void* stream) {
-  return gemm_bias_act_split<true>(x, M, K, ldx, w_split, N, bias, row_bias, rows_per_group, ld_rb, relu, eye_k, y, ldy, stream);
+                                       int relu, int eye_k, float* y, int ldy, int* status, void* stream) {
+  return gemm_bias_act_split<true>(x, M, K, ldx, w_split, N, bias, row_bias, rows_per_group, ld_rb, relu, eye_k, y, ldy, status, stream);
 }

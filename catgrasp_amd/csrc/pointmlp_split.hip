@@ -53,11 +53,8 @@ struct ArgsB {
   int n_main;            // samples [0, n_main) use `nsplit` workgroups each, samples [n_main, B) `tail_split` (tail balancing)
   int tail_split;
   float* out; float* pointfeat;
+  int* status;           // optional device int (F16 only): |= CG_HALF_OVERFLOW / CG_HALF_UNDERFLOW, see cg_split.hpp
 };
-
-// Set (never cleared by kernels) when a value handed to the IEEE-half split reaches the half range limit (cg_split.hpp).
-// Queried by cg_half_range_violation().
-__device__ int g_half_overflow = 0;
 
 // split product block: c += A.B with A = ah + al, B = bh + bl (small terms first)
 template <bool F16>
@@ -155,8 +152,17 @@ __global__ __launch_bounds__(64 * RT, 2) void pointmlp_max_split_kernel(ArgsB a)
   const int t_begin = (int)(((long)ntiles * split) / nsp);
   const int t_end = (int)(((long)ntiles * (split + 1)) / nsp);
 
-  float amax = 0.f;        // largest magnitude this lane handed to the split (half range check, F16 only); folded into the
-  int overflow = 0;        // wave-uniform flag before every 128->1024 stream so that no extra VGPR lives across it
+  float amax = 0.f;        // largest magnitude this lane handed to the split since the last fold (half range check, F16 only)
+  int flags = 0;           // wave-uniform CG_HALF_* bits; amax is folded into it after every layer, so no VGPR lives across L3
+  auto fold = [&](bool check_low) {
+    if constexpr (F16) {
+      if (__builtin_amdgcn_ballot_w64(!(amax < HALF_MAX)) != 0) flags |= CG_HALF_OVERFLOW;
+      // a layer output whose every value in this wave's 32-point tile is below HALF_LOW sits in / near the half subnormals:
+      // the lo pieces then carry an absolute, not a relative, error (2^-25) -- report it so the caller can re-run in bf16
+      if (check_low && __builtin_amdgcn_ballot_w64(amax >= HALF_LOW) == 0) flags |= CG_HALF_UNDERFLOW;
+      amax = 0.f;
+    }
+  };
   // ---- once per workgroup: running max, first-layer fragments (W1 | b1 as the k = 6 column), mid-layer fragments
   for (int i = tid; i < 1024; i += NT) rmax[i] = -INFINITY;
   for (int i = tid; i < 128; i += NT) {
@@ -185,6 +191,7 @@ __global__ __launch_bounds__(64 * RT, 2) void pointmlp_max_split_kernel(ArgsB a)
       wmf[((nb * 4 + kc) * 2 + 1) * 64 + ln] = lo;
     }
   }
+  fold(false);             // staged first-layer weights / feature transform: range only
   float t3r[9];
   if (a.t3) {
 #pragma unroll
@@ -223,12 +230,14 @@ __global__ __launch_bounds__(64 * RT, 2) void pointmlp_max_split_kernel(ArgsB a)
       if (lhi) { q0 = f32x4{0.f, 0.f, 0.f, 0.f}; q1 = q0; }              // k = 8..15: padding
       frag xh, xl;
       split8<F16>(q0, q1, xh, xl, amax);
+      fold(false);
       // L0: 6(+1) -> 64
       const f32x16 z = {0};
       f32x16 c0 = mfma3<F16>(w1f[lane], w1f[64 + lane], xh, xl, z);
       f32x16 c1 = mfma3<F16>(w1f[128 + lane], w1f[192 + lane], xh, xl, z);
       acts_to_frags<F16>(relu16(c0), fh[0], fl[0], fh[1], fl[1], amax);
       acts_to_frags<F16>(relu16(c1), fh[2], fl[2], fh[3], fl[3], amax);
+      fold(true);
     }
     if (MID != 0) {  // mid: 64 -> 64 (shared conv+BN+ReLU, or the per-sample 64x64 feature transform)
       f32x16 c0, c1;
@@ -254,6 +263,7 @@ __global__ __launch_bounds__(64 * RT, 2) void pointmlp_max_split_kernel(ArgsB a)
       }
       acts_to_frags<F16>(c0, fh[0], fl[0], fh[1], fl[1], amax);
       acts_to_frags<F16>(c1, fh[2], fl[2], fh[3], fl[3], amax);
+      fold(true);
     }
     __syncthreads();   // the previous tile's L3 reads of the h2 images are complete
     {  // L2: 64 -> 128, two channel blocks at a time, written split into the hi / lo images
@@ -285,10 +295,7 @@ __global__ __launch_bounds__(64 * RT, 2) void pointmlp_max_split_kernel(ArgsB a)
         }
       }
     }
-    if constexpr (F16) {
-      if (__builtin_amdgcn_ballot_w64(!(amax < HALF_MAX)) != 0) overflow = 1;
-      amax = 0.f;
-    }
+    fold(true);
     __syncthreads();
     // ================= L3: 128 -> 1024 + running max.  wave w owns channel blocks [4w, 4w+4) =================
     // The 192-MFMA stream of one channel block is hand-scheduled assembly (gen_l3_asm.py -> l3_asm.inc): exact wait
@@ -324,7 +331,7 @@ __global__ __launch_bounds__(64 * RT, 2) void pointmlp_max_split_kernel(ArgsB a)
       }
     }
   }
-  if (F16 && overflow && lane == 0) atomicOr(&g_half_overflow, 1);
+  if (F16 && flags && lane == 0 && a.status) atomicOr(a.status, flags);
   __syncthreads();
   if (t_end > t_begin) {
     for (int ch = tid; ch < 1024; ch += NT) {
@@ -342,15 +349,16 @@ __global__ void fill_kernel_b(float* p, size_t n, float v) {
 }
 
 template <int MID, int RT, bool F16>
-int launch(const ArgsB& a, hipStream_t s) {
+int launch(const ArgsB& a, hipStream_t s, int dev) {
   constexpr int NT = Geo<RT>::NT;
   constexpr size_t LDS_BYTES = Geo<RT>::LDS_BYTES;
   auto kern = pointmlp_max_split_kernel<MID, RT, F16>;
-  static bool attr_set = false;     // per instantiation
-  if (!attr_set) {
+  static bool attr_set[CG_MAX_DEVICES] = {};     // per instantiation and per device (the attribute is per device)
+  if (dev < 0 || dev >= CG_MAX_DEVICES) return CG_ERR_UNSUPPORTED;
+  if (!attr_set[dev]) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
     if (e != hipSuccess) return (int)e;
-    attr_set = true;
+    attr_set[dev] = true;
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)(a.n_main * a.nsplit + (a.B - a.n_main) * a.tail_split)), dim3(NT), LDS_BYTES, s, a);
   return cg_hip_status(hipGetLastError());
@@ -363,7 +371,7 @@ static int pointmlp_max_split(const float* x, int B, int N, const float* t3, con
                               int mid_mode, const unsigned short* wm_split, const float* bm, const float* t64,
                               const unsigned short* w2_split, const float* b2, const unsigned short* w3_split,
                               const float* b3, int relu3, int nsplit, int tile_points, float* out, float* pointfeat,
-                              void* stream) {
+                              int* status, void* stream) {
   if (B < 0 || N <= 0 || mid_mode < 0 || mid_mode > 2) return CG_ERR_ARG;
   if (tile_points != 256) return CG_ERR_UNSUPPORTED;      // one geometry: 256-point tiles, 8 waves, one workgroup per CU
   if (B == 0) return CG_OK;
@@ -379,13 +387,11 @@ static int pointmlp_max_split(const float* x, int B, int N, const float* t3, con
   // for a whole sample's duration while the rest of the chip idles; they are split one workgroup per tile instead (atomic max
   // into a -inf pre-filled row), so the final round lasts one tile, not ntiles.
   int n_main = B, tail_split = 1;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return CG_ERR_UNSUPPORTED;
   if (nsplit == 1 && ntiles > 1) {
-    static int n_cu = 0;
-    if (n_cu == 0) {
-      int dev = 0; hipDeviceProp_t prop;
-      if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return CG_ERR_UNSUPPORTED;
-      n_cu = prop.multiProcessorCount;
-    }
+    const int n_cu = cg_device_cu_count(dev);
+    if (n_cu <= 0) return CG_ERR_UNSUPPORTED;
     if (B >= n_cu && (B % n_cu) != 0) { n_main = B - B % n_cu; tail_split = ntiles; }
   }
   if (nsplit > 1 || tail_split > 1) {
@@ -393,24 +399,10 @@ static int pointmlp_max_split(const float* x, int B, int N, const float* t3, con
     const size_t n = (size_t)(B - first) * 1024;
     hipLaunchKernelGGL(fill_kernel_b, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, out + (size_t)first * 1024, n, -INFINITY);
   }
-  ArgsB a{x, B, N, t3, w1, b1, wm_split, bm, t64, w2_split, b2, w3_split, b3, relu3, nsplit, n_main, tail_split, out, pointfeat};
-  if (mid_mode == 0) return launch<0, 8, F16>(a, s);
-  if (mid_mode == 1) return launch<1, 8, F16>(a, s);
-  return launch<2, 8, F16>(a, s);
-}
-
-extern "C" int cg_internal_gemm_half_flag(int reset, int* flag);      // gemm_split.hip
-
-extern "C" int cg_half_range_violation(int reset, int* flag) {
-  if (!flag) return CG_ERR_ARG;
-  int a = 0, b = 0;
-  hipError_t e = hipMemcpyFromSymbol(&a, HIP_SYMBOL(g_half_overflow), sizeof(int));
-  if (e != hipSuccess) return (int)e;
-  if (reset && a) { const int z = 0; e = hipMemcpyToSymbol(HIP_SYMBOL(g_half_overflow), &z, sizeof(int)); if (e != hipSuccess) return (int)e; }
-  const int rc = cg_internal_gemm_half_flag(reset, &b);
-  if (rc != CG_OK) return rc;
-  *flag = (a | b) ? 1 : 0;
-  return CG_OK;
+  ArgsB a{x, B, N, t3, w1, b1, wm_split, bm, t64, w2_split, b2, w3_split, b3, relu3, nsplit, n_main, tail_split, out, pointfeat, F16 ? status : nullptr};
+  if (mid_mode == 0) return launch<0, 8, F16>(a, s, dev);
+  if (mid_mode == 1) return launch<1, 8, F16>(a, s, dev);
+  return launch<2, 8, F16>(a, s, dev);
 }
 
 extern "C" int cg_pointmlp_max_bf16x3(const float* x, int B, int N, const float* t3, const float* w1, const float* b1,
@@ -418,13 +410,13 @@ extern "C" int cg_pointmlp_max_bf16x3(const float* x, int B, int N, const float*
                                       const unsigned short* w2_split, const float* b2, const unsigned short* w3_split,
                                       const float* b3, int relu3, int nsplit, int tile_points, float* out, float* pointfeat,
                                       void* stream) {
-  return pointmlp_max_split<false>(x, B, N, t3, w1, b1, mid_mode, wm_split, bm, t64, w2_split, b2, w3_split, b3, relu3, nsplit, tile_points, out, pointfeat, stream);
+  return pointmlp_max_split<false>(x, B, N, t3, w1, b1, mid_mode, wm_split, bm, t64, w2_split, b2, w3_split, b3, relu3, nsplit, tile_points, out, pointfeat, nullptr, stream);
 }
 
 extern "C" int cg_pointmlp_max_f16x3(const float* x, int B, int N, const float* t3, const float* w1, const float* b1,
                                       int mid_mode, const unsigned short* wm_split, const float* bm, const float* t64,
                                       const unsigned short* w2_split, const float* b2, const unsigned short* w3_split,
                                       const float* b3, int relu3, int nsplit, int tile_points, float* out, float* pointfeat,
-                                      void* stream) {
-  return pointmlp_max_split<true>(x, B, N, t3, w1, b1, mid_mode, wm_split, bm, t64, w2_split, b2, w3_split, b3, relu3, nsplit, tile_points, out, pointfeat, stream);
+                                      int* status, void* stream) {
+  return pointmlp_max_split<true>(x, B, N, t3, w1, b1, mid_mode, wm_split, bm, t64, w2_split, b2, w3_split, b3, relu3, nsplit, tile_points, out, pointfeat, status, stream);
 }

@@ -29,13 +29,58 @@ def set_precision(p):
     PRECISION = p
 
 
-def half_range_violation(reset=True):
-    """True iff an f16x3 kernel met a value outside the IEEE-half range since the last reset (synchronises the device)."""
-    import ctypes
-    from . import _lib as L
-    flag = ctypes.c_int(0)
-    L.check(L.lib().cg_half_range_violation(ctypes.c_int(int(reset)), ctypes.byref(flag)), 'cg_half_range_violation')
-    return bool(flag.value)
+HALF_OVERFLOW, HALF_UNDERFLOW = 1, 2        # CG_STATUS_HALF_* bits of include/catgrasp_amd.h
+_warned = set()
+
+
+def new_status(device, n=1):
+    """Caller-owned status words for the f16x3 kernels (zeroed int32 device tensor, one word per guarded batch)."""
+    import torch
+    return torch.zeros((n,), dtype=torch.int32, device=device)
+
+
+def _warn_once(key, msg):
+    if key not in _warned:
+        _warned.add(key)
+        import warnings
+        warnings.warn(msg, RuntimeWarning, stacklevel=3)
+
+
+def warn_range(bits):
+    _warn_once(('range', bits), f'catgrasp_amd: f16x3 range guard tripped (bits={bits}: 1 = a value >= 65504, 2 = a layer output '
+                                'below 2^-6); re-evaluating the affected batches with bf16x3 pieces')
+
+
+class precision:
+    """Context manager: run a block under another arithmetic."""
+
+    def __init__(self, p):
+        self.p = p
+
+    def __enter__(self):
+        global PRECISION
+        self.old, PRECISION = PRECISION, self.p
+
+    def __exit__(self, *exc):
+        global PRECISION
+        PRECISION = self.old
+
+
+def run_guarded(forward, W, x):
+    """forward(W, x, status) under the active arithmetic.  Under 'f16x3' the half kernels report values that left the half range
+    (or layer outputs that sank into the half subnormals) in a per-call status word; such a batch is evaluated again with bf16
+    pieces -- float32's exponent range, ~2e-5 instead of ~2e-6 logits error, still inside the 1e-4 bar -- so a valid checkpoint
+    never raises and never returns range-damaged numbers.  Costs one 4-byte read-back per call."""
+    if PRECISION != 'f16x3':
+        return forward(W, x, None)
+    st = new_status(x.device)
+    out = forward(W, x, st)
+    bits = int(st.item())
+    if bits:
+        warn_range(bits)
+        with precision('bf16x3'):
+            out = forward(W, x, None)
+    return out
 
 
 def _nsplit(B, N, tp=64):
@@ -46,22 +91,22 @@ def _nsplit(B, N, tp=64):
     return max(1, min(ntiles, (1024 + B - 1) // B))
 
 
-def _dense(W, name, x, n_out, bias, **kw):
+def _dense(W, name, x, n_out, bias, status=None, **kw):
     """One folded Linear/Conv1d(k=1) layer on the GEMM kernel of the active arithmetic.  'f16x3': every wide layer has a half
     image (FC tails and segmentation head; the 9- and 10-wide output layers stay exact f32).  'bf16x3': only the per-point
     segmentation head -- measured, splitting the per-candidate FC tails with bf16 pieces buys 3 % of the step and raises the
     logits error from ~2e-5 to ~6e-5 of the 1e-4 bar."""
-    if PRECISION == 'f16x3' and (name + '.h') in W:
-        return ops.gemm_bias_act(x, W[name + '.h'], n_out, bias, split='f16', **kw)
+    if PRECISION == 'f16x3' and W.half_ok.get(name + '.h', False):       # a layer whose weights do not fit the half pieces stays f32
+        return ops.gemm_bias_act(x, W[name + '.h'], n_out, bias, split='f16', status=status, **kw)
     if PRECISION == 'bf16x3' and (name + '.s') in W:
         return ops.gemm_bias_act(x, W[name + '.s'], n_out, bias, split='bf16', **kw)
     return ops.gemm_bias_act(x, W[name], n_out, bias, **kw)
 
 
-def encoder_forward(W, x, want_pointfeat=False):
+def encoder_forward(W, x, want_pointfeat=False, status=None):
     """x:(B,N,6) cuda f32 -> global feature (B,1024), trans (B,9), trans_feat TRANSPOSED (B,4096) [, pointfeat]."""
     if PRECISION != 'f32':
-        return _encoder_forward_split(W, x, want_pointfeat)
+        return _encoder_forward_split(W, x, want_pointfeat, status)
     B, N, _ = x.shape
     ns = _nsplit(B, N)
     g = ops.pointmlp_max(x, W['stn.w1'], W['stn.b1'], W['stn.w2'], W['stn.b2'], W['stn.w3'], W['stn.b3'], True,
@@ -81,46 +126,55 @@ def encoder_forward(W, x, want_pointfeat=False):
     return r, t3, t64
 
 
-def _encoder_forward_split(W, x, want_pointfeat=False):
-    """encoder_forward with the split-precision per-point MLP kernels ('f16x3' or 'bf16x3')."""
+def _encoder_forward_split(W, x, want_pointfeat=False, status=None):
+    """encoder_forward with the split-precision per-point MLP kernels ('f16x3' or 'bf16x3').  Under 'f16x3' a pass whose
+    pre-split weight images do not fit the half pieces (folding.put_half: non-finite in half, or all below 2^-6) runs with
+    the bf16 images instead."""
     B, N, _ = x.shape
     ns = _nsplit(B, N, TILE_POINTS)
-    el, sfx = ('f16', '.h') if PRECISION == 'f16x3' else ('bf16', '.s')
-    kw = dict(nsplit=ns, split=el, tile_points=TILE_POINTS)
-    g = ops.pointmlp_max(x, W['stn.w1'], W['stn.b1'], W['stn.w2' + sfx], W['stn.b2'], W['stn.w3' + sfx], W['stn.b3'], True, **kw)
-    h = _dense(W, 'stn.fc1', g, 512, W['stn.fc1b'], relu=True)
-    h = _dense(W, 'stn.fc2', h, 256, W['stn.fc2b'], relu=True)
+
+    def point_pass(w1, tag, relu3, mid=None, **kw):
+        names = [tag + '.w2', tag + '.w3'] + ([mid] if mid else [])
+        half = PRECISION == 'f16x3' and all(W.half_ok.get(n + '.h', False) for n in names)
+        sfx = '.h' if half else '.s'
+        extra = dict(wm=W[mid + sfx], bm=W[mid[:-3] + '.bm']) if mid else {}
+        return ops.pointmlp_max(x, W[w1 + '.w1'], W[w1 + '.b1'], W[tag + '.w2' + sfx], W[tag + '.b2'], W[tag + '.w3' + sfx], W[tag + '.b3'],
+                                relu3, nsplit=ns, split='f16' if half else 'bf16', tile_points=TILE_POINTS,
+                                status=status if half else None, **extra, **kw)
+
+    g = point_pass('stn', 'stn', True)
+    h = _dense(W, 'stn.fc1', g, 512, W['stn.fc1b'], relu=True, status=status)
+    h = _dense(W, 'stn.fc2', h, 256, W['stn.fc2b'], relu=True, status=status)
     t3 = _dense(W, 'stn.fc3', h, 9, W['stn.fc3b'], eye_k=3)
-    g = ops.pointmlp_max(x, W['enc.w1'], W['enc.b1'], W['fstn.w2' + sfx], W['fstn.b2'], W['fstn.w3' + sfx], W['fstn.b3'], True,
-                         t3=t3, mid_mode=1, wm=W['fstn.wm' + sfx], bm=W['fstn.bm'], **kw)
-    h = _dense(W, 'fstn.fc1', g, 512, W['fstn.fc1b'], relu=True)
-    h = _dense(W, 'fstn.fc2', h, 256, W['fstn.fc2b'], relu=True)
-    t64 = _dense(W, 'fstn.fc3', h, 4096, W['fstn.fc3b'], eye_k=64)
-    r = ops.pointmlp_max(x, W['enc.w1'], W['enc.b1'], W['enc.w2' + sfx], W['enc.b2'], W['enc.w3' + sfx], W['enc.b3'], False,
-                         t3=t3, mid_mode=2, t64=t64, pointfeat=want_pointfeat, **kw)
+    g = point_pass('enc', 'fstn', True, mid='fstn.wm', t3=t3, mid_mode=1)
+    h = _dense(W, 'fstn.fc1', g, 512, W['fstn.fc1b'], relu=True, status=status)
+    h = _dense(W, 'fstn.fc2', h, 256, W['fstn.fc2b'], relu=True, status=status)
+    t64 = _dense(W, 'fstn.fc3', h, 4096, W['fstn.fc3b'], eye_k=64, status=status)
+    r = point_pass('enc', 'enc', False, t3=t3, mid_mode=2, t64=t64, pointfeat=want_pointfeat)
     if want_pointfeat:
         return r[0], t3, t64, r[1]
     return r, t3, t64
 
 
-def cls_forward(W, x):
-    """PointNetCls.forward in eval mode.  x:(B,N,6) -> logits (B,n_out), trans_feat (B,64,64)."""
+def cls_forward(W, x, status=None):
+    """PointNetCls.forward in eval mode.  x:(B,N,6) -> logits (B,n_out), trans_feat (B,64,64).
+    status: optional device int32 word collecting the f16x3 range bits of this batch (see run_guarded)."""
     B = x.shape[0]
-    g, t3, t64 = encoder_forward(W, x)
-    h = _dense(W, 'head.fc1', g, 512, W['head.fc1b'], relu=True)
-    h = _dense(W, 'head.fc2', h, 256, W['head.fc2b'], relu=True)
+    g, t3, t64 = encoder_forward(W, x, status=status)
+    h = _dense(W, 'head.fc1', g, 512, W['head.fc1b'], relu=True, status=status)
+    h = _dense(W, 'head.fc2', h, 256, W['head.fc2b'], relu=True, status=status)
     logits = _dense(W, 'head.fc3', h, W.n_out, W['head.fc3b'])
     return logits, t64.view(B, 64, 64).transpose(1, 2)      # the FC kernel emits the transform transposed
 
 
-def seg_forward(W, x):
+def seg_forward(W, x, status=None):
     """PointNetSeg.forward in eval mode.  x:(B,N,6) -> (B,N,n_out), trans_feat (B,64,64)."""
     B, N, _ = x.shape
-    g, t3, t64, pf = encoder_forward(W, x, want_pointfeat=True)
+    g, t3, t64, pf = encoder_forward(W, x, want_pointfeat=True, status=status)
     # conv1 over cat([global(1024) repeated, pointfeat(64)]) = Wg.g (per cloud) + Wp.pointfeat (per point)
-    gb = _dense(W, 'seg.c1g', g, 512, W['seg.c1b'])
-    h = _dense(W, 'seg.c1p', pf.view(B * N, 64), 512, None, relu=True, row_bias=gb, rows_per_group=N)
-    h = _dense(W, 'seg.c2', h, 256, W['seg.c2b'], relu=True)
-    h = _dense(W, 'seg.c3', h, 128, W['seg.c3b'], relu=True)
-    y = _dense(W, 'seg.c4', h, W.n_out, W['seg.c4b'])
+    gb = _dense(W, 'seg.c1g', g, 512, W['seg.c1b'], status=status)
+    h = _dense(W, 'seg.c1p', pf.view(B * N, 64), 512, None, relu=True, row_bias=gb, rows_per_group=N, status=status)
+    h = _dense(W, 'seg.c2', h, 256, W['seg.c2b'], relu=True, status=status)
+    h = _dense(W, 'seg.c3', h, 128, W['seg.c3b'], relu=True, status=status)
+    y = _dense(W, 'seg.c4', h, W.n_out, W['seg.c4b'], status=status)
     return y.view(B, N, W.n_out), t64.view(B, 64, 64).transpose(1, 2)

@@ -8,6 +8,7 @@ import numpy as np
 import torch
 
 BN_EPS = 1e-5
+HALF_MAX, HALF_LOW = 65504.0, 2.0 ** -6        # csrc/cg_split.hpp
 
 
 def fold_bn(w, b, bn=None):
@@ -94,6 +95,7 @@ class DeviceWeights:
     def __init__(self, device):
         self.device = device
         self.t = {}
+        self.half_ok = {}       # name of a half ('.h') image -> usable by the f16x3 kernels (see put_half)
 
     def put(self, name, arr):
         self.t[name] = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32)).to(self.device)
@@ -106,7 +108,17 @@ class DeviceWeights:
         self.put_half(name[:-2] + '.h', w)
 
     def put_half(self, name, w):
-        self.t[name] = torch.from_numpy(pack_b_split(w, 'f16').view(np.int16)).to(self.device)
+        """IEEE-half split image of a folded weight matrix + the pre-screen of its range: the image is used by the f16x3
+        kernels only if every weight is finite in half (|w| < 65504 after BN folding -- a blown-up BN scale can exceed it) and
+        the matrix is not uniformly tiny (max |w| >= 2^-6: below that the lo pieces sit in the half subnormals).  Layers that
+        fail the screen run with bf16 pieces / exact f32 instead (engine._dense, engine._encoder_forward_split)."""
+        w = np.asarray(w, dtype=np.float32)
+        if not np.isfinite(w).all():
+            raise ValueError(f'non-finite folded weights in layer {name[:-2]} (checkpoint or BatchNorm statistics are corrupt)')
+        amax = float(np.abs(w).max()) if w.size else 0.0
+        self.half_ok[name] = bool(amax < HALF_MAX and amax >= HALF_LOW)
+        with np.errstate(over='ignore'):
+            self.t[name] = torch.from_numpy(pack_b_split(w, 'f16').view(np.int16)).to(self.device)
 
     def __contains__(self, k):
         return k in self.t

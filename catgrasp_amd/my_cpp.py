@@ -156,9 +156,10 @@ class _MeshGridC(ctypes.Structure):
 class MeshGrid:
     """Broad phase for filterGraspPose on large gripper meshes: a uniform grid in the mesh frame whose cells list the
     triangles that can touch a voxel centred in the cell (see cg_mesh_grid).  Purely an accelerator: the narrow phase and
-    therefore every result is unchanged."""
+    therefore every result is unchanged.  Built on the device (cg_mesh_grid_count / _fill: one thread per triangle, atomic
+    cell counts, prefix sum, per-cell sort); `builder='host'` keeps the numpy construction the device build is tested against."""
 
-    def __init__(self, V, F, resolution, device, cell=None):
+    def __init__(self, V, F, resolution, device, cell=None, builder='device', V_dev=None, F_dev=None):
         V = np.asarray(V, dtype=np.float64); F = np.asarray(F, dtype=np.int64)
         res = float(np.float32(resolution))
         inflate = 2.0 * (res * np.sqrt(3.0) / 2.0) + 3e-5          # sigma_min >= 0.5, plus float32 slack
@@ -167,6 +168,36 @@ class MeshGrid:
         lo = V.min(axis=0) - inflate - 1e-6
         hi = V.max(axis=0) + inflate + 1e-6
         dims = np.maximum(np.ceil((hi - lo) / cell).astype(np.int64), 1)
+        ncell = int(dims[0] * dims[1] * dims[2])
+        if builder == 'host':
+            start, tids = self._host_lists(V, F, lo, dims, cell, inflate, ncell)
+            self.cell_start = torch.from_numpy(start).to(device)
+            self.tri_ids = torch.from_numpy(tids if len(tids) else np.zeros((1,), np.int32)).to(device)
+            self.n_entries = int(len(tids))
+        else:
+            Vd = V_dev if V_dev is not None else torch.from_numpy(np.ascontiguousarray(V, dtype=np.float32)).to(device)
+            Fd = F_dev if F_dev is not None else torch.from_numpy(np.ascontiguousarray(F, dtype=np.int32)).to(device)
+            org = (ctypes.c_double * 3)(*[float(v) for v in lo])
+            dm = (ctypes.c_int * 3)(*[int(v) for v in dims])
+            counts = torch.zeros((ncell,), dtype=torch.int32, device=device)
+            check(L.lib().cg_mesh_grid_count(_p(Vd), _p(Fd), _c_int(len(F)), org, ctypes.c_double(cell), ctypes.c_double(inflate), dm,
+                                             _p(counts), _stream()), 'cg_mesh_grid_count')
+            start = torch.zeros((ncell + 1,), dtype=torch.int32, device=device)
+            torch.cumsum(counts, 0, out=start[1:])
+            self.n_entries = int(start[-1].item())
+            self.cell_start = start
+            self.tri_ids = torch.empty((max(self.n_entries, 1),), dtype=torch.int32, device=device)
+            counts.zero_()
+            check(L.lib().cg_mesh_grid_fill(_p(Vd), _p(Fd), _c_int(len(F)), org, ctypes.c_double(cell), ctypes.c_double(inflate), dm,
+                                            _p(start), _p(counts), _p(self.tri_ids), _stream()), 'cg_mesh_grid_fill')
+        self.c = _MeshGridC()
+        for i in range(3):
+            self.c.origin[i] = float(lo[i]); self.c.dims[i] = int(dims[i])
+        self.c.cell = float(cell); self.c.resolution = res
+        self.c.cell_start = self.cell_start.data_ptr(); self.c.tri_ids = self.tri_ids.data_ptr()
+
+    @staticmethod
+    def _host_lists(V, F, lo, dims, cell, inflate, ncell):
         tri = V[F]                                                   # (nf,3,3)
         tlo = np.clip(np.floor((tri.min(axis=1) - inflate - lo) / cell).astype(np.int64), 0, dims - 1)
         thi = np.clip(np.floor((tri.max(axis=1) + inflate - lo) / cell).astype(np.int64), 0, dims - 1)
@@ -179,17 +210,49 @@ class MeshGrid:
         cells = np.concatenate(cells) if cells else np.zeros((0,), dtype=np.int64)
         tids = np.concatenate(tids) if tids else np.zeros((0,), dtype=np.int32)
         order = np.argsort(cells, kind='stable')
-        ncell = int(dims[0] * dims[1] * dims[2])
         counts = np.bincount(cells, minlength=ncell)
         start = np.zeros(ncell + 1, dtype=np.int32); start[1:] = np.cumsum(counts)
-        self.cell_start = torch.from_numpy(start).to(device)
-        self.tri_ids = torch.from_numpy(np.ascontiguousarray(tids[order], dtype=np.int32) if len(tids) else np.zeros((1,), np.int32)).to(device)
-        self.c = _MeshGridC()
-        for i in range(3):
-            self.c.origin[i] = float(lo[i]); self.c.dims[i] = int(dims[i])
-        self.c.cell = float(cell); self.c.resolution = res
-        self.c.cell_start = self.cell_start.data_ptr(); self.c.tri_ids = self.tri_ids.data_ptr()
-        self.n_entries = int(len(tids))
+        return start, np.ascontiguousarray(tids[order], dtype=np.int32)
+
+
+def _digest(*arrays):
+    import hashlib
+    h = hashlib.blake2b(digest_size=16)
+    for a in arrays:
+        a = np.ascontiguousarray(a)
+        h.update(str((a.dtype, a.shape)).encode()); h.update(a.view(np.uint8).reshape(-1).data)
+    return h.digest()
+
+
+class _LRU:
+    def __init__(self, cap):
+        from collections import OrderedDict
+        self.cap, self.d = cap, OrderedDict()
+
+    def get(self, key, make):
+        if key in self.d:
+            self.d.move_to_end(key)
+            return self.d[key]
+        v = make()
+        self.d[key] = v
+        while len(self.d) > self.cap:
+            self.d.popitem(last=False)
+        return v
+
+    def clear(self):
+        self.d.clear()
+
+
+# The reference rebuilds its BVHs and octrees inside every filterGraspPose call, once per OpenMP thread (common.cpp:176-182).
+# Here the device-resident pieces are keyed on the CONTENT of the arrays the 20-argument call passes (a 16-byte blake2b of
+# the bytes: ~0.1 ms for a 20k-point cloud), so the per-object calls of grasp_sampler.py:216 and :345, which pass the same
+# gripper meshes every time and the same clouds twice per object, reuse them.  clear_scene_cache() drops everything.
+_mesh_cache = _LRU(8)       # (mesh bytes, resolution, device) -> (V, F device tensors, MeshGrid | None)
+_cloud_cache = _LRU(32)     # (cloud bytes, resolution, device) -> voxel keys
+
+
+def clear_scene_cache():
+    _mesh_cache.clear(); _cloud_cache.clear()
 
 
 class GripperScene:
@@ -197,25 +260,41 @@ class GripperScene:
     gripper meshes and the two voxelised collision clouds.  Build once, filter many pose batches."""
 
     def __init__(self, gripper_vertices, gripper_faces, gripper_enclosed_vertices, gripper_enclosed_faces,
-                 gripper_collision_pts, gripper_enclosed_collision_pts, octo_resolution, device=None, accel=True):
+                 gripper_collision_pts, gripper_enclosed_collision_pts, octo_resolution, device=None, accel=True, cache=True):
         dev = device or _device()
         self.device = dev
-        V, F = _mesh(gripper_vertices, gripper_faces, 'gripper')
-        Ve, Fe = _mesh(gripper_enclosed_vertices, gripper_enclosed_faces, 'gripper_enclosed')
-        self.V = torch.from_numpy(V).to(dev); self.F = torch.from_numpy(F).to(dev)
-        self.Ve = torch.from_numpy(Ve).to(dev); self.Fe = torch.from_numpy(Fe).to(dev)
         self.res = float(np.float32(octo_resolution))
-        self.keys_open = voxelize(gripper_collision_pts, self.res, dev)
-        self.keys_bg = voxelize(gripper_enclosed_collision_pts, self.res, dev)
-        # broad-phase grids (result-neutral accelerator; accel=False forces the exhaustive kernel path)
-        self.grid_open = MeshGrid(V, F, self.res, dev) if accel and len(F) else None
-        self.grid_enc = MeshGrid(Ve, Fe, self.res, dev) if accel and len(Fe) else None
+
+        def mesh(V, F, what):
+            V, F = _mesh(V, F, what)
+
+            def make():
+                Vd = torch.from_numpy(V).to(dev); Fd = torch.from_numpy(F).to(dev)
+                grid = MeshGrid(V, F, self.res, dev, V_dev=Vd, F_dev=Fd) if accel and len(F) else None
+                return Vd, Fd, grid
+            return _mesh_cache.get((_digest(V, F), self.res, str(dev), bool(accel)), make) if cache else make()
+
+        def cloud(pts):
+            if isinstance(pts, torch.Tensor) or not cache:
+                return voxelize(pts, self.res, dev)
+            a = np.asarray(pts)
+            if a.ndim != 2 or a.shape[1] != 3:
+                raise ValueError(f'point cloud shape wrong: {a.shape}')
+            a = np.ascontiguousarray(a, dtype=np.float32)
+            return _cloud_cache.get((_digest(a), self.res, str(dev)), lambda: voxelize(a, self.res, dev))
+
+        self.V, self.F, self.grid_open = mesh(gripper_vertices, gripper_faces, 'gripper')
+        self.Ve, self.Fe, self.grid_enc = mesh(gripper_enclosed_vertices, gripper_enclosed_faces, 'gripper_enclosed')
+        self.keys_open = cloud(gripper_collision_pts)
+        self.keys_bg = cloud(gripper_enclosed_collision_pts)
 
 
 def filter_on_device(scene, grasp_poses, symmetry_tfs, nocs_pose, canonical_to_nocs_transform, cam_in_world, ee_in_grasp,
-                     gripper_in_grasp, filter_approach_dir_face_camera, filter_ik, adjust_collision_pose, upper=None, lower=None):
+                     gripper_in_grasp, filter_approach_dir_face_camera, filter_ik, adjust_collision_pose, upper=None, lower=None,
+                     keep_rejected_pose=False):
     """Device-tensor form: grasp_poses (n,4,4)/(n,16) and symmetry_tfs (m,4,4) float32 cuda tensors (or arrays).
-    Returns codes (E) int8, poses (E,4,4) float32, nudge (E) int8 as cuda tensors, E = n*m in input order."""
+    Returns codes (E) int8, poses (E,4,4) float32, nudge (E) int8 as cuda tensors, E = n*m in input order.
+    keep_rejected_pose: rejected evaluations keep their composed grasp_in_cam in `poses` instead of zeros."""
     dev = scene.device
 
     def dev_poses(x, name):
@@ -249,7 +328,8 @@ def filter_on_device(scene, grasp_poses, symmetry_tfs, nocs_pose, canonical_to_n
             _c_int(int(bool(filter_approach_dir_face_camera))), _c_int(int(bool(adjust_collision_pose))), _p(ik_ok),
             _p(scene.V), _p(scene.F), _c_int(scene.F.shape[0]), _p(scene.Ve), _p(scene.Fe), _c_int(scene.Fe.shape[0]),
             _p(scene.keys_open), _c_int(scene.keys_open.shape[0]), _p(scene.keys_bg), _c_int(scene.keys_bg.shape[0]),
-            ctypes.c_float(scene.res), _p(codes), _p(poses), _p(nudge), _p(ee_out), go, ge, _stream()), 'cg_filter_grasp_pose_accel')
+            ctypes.c_float(scene.res), _p(codes), _p(poses), _p(nudge), _p(ee_out), go, ge, _c_int(int(bool(keep_rejected_pose))), _stream()),
+              'cg_filter_grasp_pose_accel')
 
     ik_ok = None
     if filter_ik and E > 0:
@@ -298,7 +378,7 @@ def filterGraspPose(grasp_poses, symmetry_tfs, nocs_pose, canonical_to_nocs_tran
                                               adjust_collision_pose, upper, lower, gripper_vertices, gripper_faces,
                                               gripper_enclosed_vertices, gripper_enclosed_faces, gripper_collision_pts,
                                               gripper_enclosed_collision_pts, octo_resolution, verbose)
-    return [poses[e].copy() for e in np.nonzero(codes == 0)[0]]
+    return list(poses[codes == 0])        # one fancy-index copy; the rows are views into it (the reference returns fresh arrays too)
 
 
 def _float_loop_count(limit, step):
@@ -338,7 +418,7 @@ def augmentGraspPoses(R0, selected_point, sphere_pts, inplane_rot_step, hand_dep
                                          ctypes.c_float(approach_step), ctypes.c_float(init_bite), _p(out), _stream()),
           'cg_augment_grasp_poses')
     poses = out.cpu().numpy().reshape(total, 4, 4)
-    return [poses[i].copy() for i in range(total)]
+    return list(poses)
 
 
 def makeOccupancyGridFromCloudScan(pts, K, resolution, return_tensor=False):

@@ -16,7 +16,7 @@ KERNEL_TIMER = None
 
 
 def pointmlp_max(x, w1, b1, w2p, b2, w3p, b3, relu3, t3=None, mid_mode=0, wm=None, bm=None, t64=None,
-                 nsplit=1, pointfeat=False, split=False, tile_points=256):
+                 nsplit=1, pointfeat=False, split=False, tile_points=256, status=None):
     """x:(B,N,6) -> (B,1024) [, pointfeat (B,N,64)].  See cg_pointmlp_max / cg_pointmlp_max_bf16x3 in
     include/catgrasp_amd.h.  split='f16' / 'bf16': w2p/w3p/wm are the split images of that element type (folding.pack_b_split)."""
     require_cuda(x)
@@ -30,10 +30,13 @@ def pointmlp_max(x, w1, b1, w2p, b2, w3p, b3, relu3, t3=None, mid_mode=0, wm=Non
         if timer is not None:
             ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
             ev0.record()
-        fn = L.lib().cg_pointmlp_max_f16x3 if split == 'f16' else L.lib().cg_pointmlp_max_bf16x3
-        st = fn(_p(x), _c_int(B), _c_int(N), _p(t3), _p(w1), _p(b1), _c_int(mid_mode), _p(wm), _p(bm),
+        args = (_p(x), _c_int(B), _c_int(N), _p(t3), _p(w1), _p(b1), _c_int(mid_mode), _p(wm), _p(bm),
                 _p(t64), _p(w2p), _p(b2), _p(w3p), _p(b3), _c_int(int(relu3)), _c_int(nsplit),
-                _c_int(tile_points), _p(out), _p(pf), _stream())
+                _c_int(tile_points), _p(out), _p(pf))
+        if split == 'f16':      # status: caller-owned device int that collects the half range bits (None: not tracked)
+            st = L.lib().cg_pointmlp_max_f16x3(*args, _p(status), _stream())
+        else:
+            st = L.lib().cg_pointmlp_max_bf16x3(*args, _stream())
         if timer is not None:
             ev1.record()
             timer['events'].append((ev0, ev1, (B, N)))
@@ -53,7 +56,7 @@ def pointmlp_max(x, w1, b1, w2p, b2, w3p, b3, relu3, t3=None, mid_mode=0, wm=Non
     return (out, pf) if pointfeat else out
 
 
-def gemm_bias_act(x, wp, n_out, bias=None, relu=False, eye_k=0, row_bias=None, rows_per_group=1, split=False):
+def gemm_bias_act(x, wp, n_out, bias=None, relu=False, eye_k=0, row_bias=None, rows_per_group=1, split=False, status=None):
     """act(x @ W^T + bias [+ row_bias[row // rows_per_group]]) with packed W.  x:(M,K).
     split='f16' / 'bf16': wp is the split-packed image of that element type and the product runs on the split MFMA kernel."""
     require_cuda(x)
@@ -63,9 +66,10 @@ def gemm_bias_act(x, wp, n_out, bias=None, relu=False, eye_k=0, row_bias=None, r
     ld_rb = row_bias.shape[1] if row_bias is not None else 0
     name = {'f16': 'cg_gemm_bias_act_f16x3', 'bf16': 'cg_gemm_bias_act_bf16x3'}.get(split, 'cg_gemm_bias_act')
     fn = getattr(L.lib(), name)
-    st = fn(_p(x), _c_int(M), _c_int(K), _c_int(K), _p(wp), _c_int(n_out), _p(bias),
+    args = (_p(x), _c_int(M), _c_int(K), _c_int(K), _p(wp), _c_int(n_out), _p(bias),
             _p(row_bias), _c_int(rows_per_group), _c_int(ld_rb), _c_int(int(relu)),
-            _c_int(eye_k), _p(y), _c_int(n_out), _stream())
+            _c_int(eye_k), _p(y), _c_int(n_out))
+    st = fn(*args, _p(status), _stream()) if split == 'f16' else fn(*args, _stream())
     check(st, name)
     return y
 

@@ -148,7 +148,7 @@ class PointNetCls(_HipCached):
         if _use_hip(self, x):
             if self._n_in != 6:
                 raise NotImplementedError('HIP path is built for the 6-channel (xyz+normal) input of config_grasp.yml')
-            return engine.cls_forward(self._device_weights(x.device), x.float().contiguous())
+            return engine.run_guarded(engine.cls_forward, self._device_weights(x.device), x.float().contiguous())
         g, _, trans_feat = self.feat(x.permute(0, 2, 1))
         h = F.relu(self.bn1(self.fc1(g)))
         h = F.relu(self.bn2(self.fc2(self.dropout(h))))
@@ -175,7 +175,7 @@ class PointNetSeg(_HipCached):
         if _use_hip(self, x):
             if self._n_in != 6:
                 raise NotImplementedError('HIP path is built for the 6-channel (xyz+normal) input of config_nunocs.yml')
-            return engine.seg_forward(self._device_weights(x.device), x.float().contiguous())
+            return engine.run_guarded(engine.seg_forward, self._device_weights(x.device), x.float().contiguous())
         f, _, trans_feat = self.feat(x.permute(0, 2, 1))
         h = F.relu(self.bn1(self.conv1(f)))
         h = F.relu(self.bn2(self.conv2(h)))

@@ -63,14 +63,6 @@ def _device(device):
     return torch.device('cuda', torch.cuda.current_device())
 
 
-def _require_finite(a, what):
-    """The split-half arithmetic ('f16x3') needs activations below 65504.  Its kernels record a violation (the result is then
-    meaningless, and the NaN-ignoring max-pool can even make it look finite); the reference-API entry points turn it into an error."""
-    if (engine.PRECISION == 'f16x3' and engine.half_range_violation()) or not np.isfinite(a).all():
-        raise FloatingPointError(f'{what} are not finite under CATGRASP_AMD_PRECISION={engine.PRECISION}: activations left the range of '
-                                 "the 16-bit pieces -- use engine.set_precision('bf16x3') (no range limit) or 'f32'")
-
-
 class _TransformOnly:
     """Stand-in for the `.dataset` attribute of the reference predicters (predicter.py:60,127): keeps cfg /
     phase; the transform itself runs on the device inside predict*()."""
@@ -100,6 +92,7 @@ class GraspPredicter:
         self._W = folding.prepare_cls(sd, self.device)
         self._mean, self._inv_std = transforms.normalizer_device(self.cfg, self.device)
         self.chunk = int(chunk)
+        self.rng = os.environ.get('CATGRASP_AMD_RNG', 'numpy')
 
     # ---- device-resident API (what bench.py and the multi-GPU path use) ----
     def upload_cloud(self, data):
@@ -111,30 +104,64 @@ class GraspPredicter:
         G = ids.shape[0]
         C = len(self.cfg['classes']) - 1
         logits = torch.empty((G, C), dtype=torch.float32, device=self.device)
-        for s in range(0, G, self.chunk):
+        starts = list(range(0, G, self.chunk))
+        guard = engine.PRECISION == 'f16x3'
+        status = engine.new_status(self.device, len(starts)) if guard else None      # one range word per chunk
+
+        def run(s, st):
             e = min(G, s + self.chunk)
             x = ops.build_grasp_input(cloud_xyz, cloud_normal, ids[s:e], pose_inv[s:e], self._mean, self._inv_std)
-            logits[s:e] = engine.cls_forward(self._W, x)[0]
+            logits[s:e] = engine.cls_forward(self._W, x, st)[0]
+        for k, s in enumerate(starts):
+            run(s, status[k:k + 1] if guard else None)
+        if guard and G:
+            bits = status.cpu().numpy()          # ONE read-back per call; chunks that left the half range are re-run with bf16 pieces
+            if bits.any():
+                engine.warn_range(int(np.bitwise_or.reduce(bits)))
+                with engine.precision('bf16x3'):
+                    for k in np.nonzero(bits)[0]:
+                        run(starts[k], None)
         return ops.softmax_pg(logits)
 
     # ---- reference API ----
-    def predict_batch(self, data, grasp_poses, ids=None):
+    def predict_batch(self, data, grasp_poses, ids=None, rng=None):
         """predicter.py:67-94.  Returns [[pred_label, confidence, probs(10,) float32], ...] per grasp pose.
-        `ids` (G,n_pts): explicit resample indices into the z>=0.1 filtered cloud; by default they are drawn
-        from numpy's global RNG exactly like the reference (one np.random.choice per pose)."""
+        `ids` (G,n_pts): explicit resample indices into the z>=0.1 filtered cloud.  Without them the per-pose resampling
+        draw of GraspDataset.transform (dataset_grasp.py:72-73) comes from
+          rng='numpy'  (default; $CATGRASP_AMD_RNG): numpy's GLOBAL generator, one np.random.choice per pose exactly like the
+                       reference's python loop -- seeding numpy reproduces the reference's draws, but the loop runs on the host
+                       (~75 us per pose: 13k poses/s);
+          rng='device': the same distribution drawn by a counter-based generator on the device (cg_draw_resample_ids; seeded
+                       from one draw of numpy's global generator, so it is still reproducible under np.random.seed) -- no
+                       host loop and no 8 KB/pose upload."""
         with torch.no_grad():
             G = len(grasp_poses)
             if G == 0:
                 return []
             cloud = self.upload_cloud(data)
+            n_pts = self.cfg['n_pts']
             if ids is None:
-                ids = transforms.draw_ids_reference(cloud.n, self.cfg['n_pts'], G)
-            ids_d = torch.from_numpy(np.ascontiguousarray(ids, dtype=np.int32)).to(self.device)
+                rng = rng or self.rng
+                if rng == 'device':
+                    ids_d = transforms.draw_ids_device(cloud.n, n_pts, G, self.device, seed=int(np.random.randint(0, 2 ** 31)))
+                elif rng == 'numpy':
+                    ids_d = torch.from_numpy(transforms.draw_ids_reference(cloud.n, n_pts, G)).to(self.device)
+                else:
+                    raise ValueError(f"rng must be 'numpy' or 'device', not {rng!r}")
+            else:
+                ids = np.ascontiguousarray(ids, dtype=np.int32)
+                if ids.shape != (G, n_pts):
+                    raise ValueError(f'ids shape {ids.shape} != {(G, n_pts)}')
+                if ids.size and (ids.min() < 0 or ids.max() >= cloud.n):      # numpy indexing in the reference raises too
+                    raise IndexError(f'resample index out of range for a cloud of {cloud.n} valid points')
+                ids_d = torch.from_numpy(ids).to(self.device)
             pinv = torch.from_numpy(transforms.pose_inverse_rows(grasp_poses, cloud.center)).to(self.device)
             probs, label, conf, _ = self.score_on_device(cloud.xyz, cloud.normal, ids_d, pinv)
             probs = probs.cpu().numpy(); label = label.cpu().numpy(); conf = conf.cpu().numpy()
-        _require_finite(probs, 'grasp-Q probabilities')
-        return [[label[b], conf[b], probs[b]] for b in range(G)]
+        if not np.isfinite(probs).all():
+            raise FloatingPointError('grasp-Q probabilities are not finite (non-finite weights or activations beyond float32)')
+        # [label, confidence, probs row] per pose like predicter.py:87-91; map/zip builds the 3 x G objects without python indexing
+        return list(map(list, zip(label, conf, probs)))
 
 
 class NunocsPredicter:
@@ -170,7 +197,7 @@ class NunocsPredicter:
     def nocs_on_device(self, cloud_xyz, cloud_normal, ids):
         """cloud (M,3) f32 cuda, ids (B,n_pts) i32 cuda -> coords (B,n_pts,3) in {k/bins-0.5}, conf_z (B,n_pts), logits."""
         x = ops.build_nunocs_input(cloud_xyz, cloud_normal, ids, self._mean, self._inv_std)
-        logits = engine.seg_forward(self._W, x)[0]
+        logits = engine.run_guarded(engine.seg_forward, self._W, x)[0]
         B, N, _ = logits.shape
         nb = self.cfg['ce_loss_bins']
         coords, conf = ops.nunocs_decode(logits.view(B * N, 3 * nb), nb)
@@ -188,7 +215,8 @@ class NunocsPredicter:
             self.data_transformed = {'cloud_xyz_original': cloud.xyz64[ids[0]].copy(), 'keep_ids': cloud.keep_ids[ids[0]],
                                      'cloud_normal': cloud.normal64[ids[0]].copy()}
             conf_h = conf[0].cpu().numpy()
-            _require_finite(conf_h, 'NUNOCS confidences')
+            if not np.isfinite(conf_h).all():
+                raise FloatingPointError('NUNOCS confidences are not finite (non-finite weights or activations beyond float32)')
             return coords[0].cpu().numpy(), conf_h, self.data_transformed
 
     def predict(self, data, ids=None):

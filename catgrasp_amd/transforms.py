@@ -26,13 +26,48 @@ def draw_ids_reference(n_valid, n_pts, count):
     return out
 
 
-def draw_ids_device(n_valid, n_pts, count, device, generator=None):
-    """Statistically equivalent draw on the device (NOT numpy's stream): a random permutation prefix per
-    row when n_valid >= n_pts, iid uniform indices otherwise.  -> (count, n_pts) int32 cuda tensor."""
-    if n_valid < n_pts:
-        return torch.randint(0, n_valid, (count, n_pts), device=device, generator=generator, dtype=torch.int32)
-    keys = torch.rand((count, n_valid), device=device, generator=generator)
-    return keys.argsort(dim=1)[:, :n_pts].to(torch.int32).contiguous()
+_draw_counter = [0]
+
+
+def draw_ids_device(n_valid, n_pts, count, device, generator=None, seed=None, base=0, out=None):
+    """The same draw on the device (cg_draw_resample_ids; NOT numpy's stream): per row a uniform n_pts-subset of
+    [0,n_valid) in uniform order when n_valid >= n_pts (= np.random.choice(replace=False)), iid uniform indices otherwise
+    (= replace=True).  Counter-based: `seed` (or the next draw of `generator`, or a process-wide counter seeded from numpy's
+    global generator) fixes every row.  -> (count, n_pts) int32 cuda tensor, each id offset by `base`."""
+    import ctypes
+    from . import _lib as L
+    if seed is None:
+        if generator is not None:
+            seed = int(torch.randint(0, 2 ** 62, (1,), generator=generator, device=generator.device).item())
+        else:
+            if _draw_counter[0] == 0:
+                _draw_counter[0] = int(np.random.randint(1, 2 ** 31)) << 20
+            _draw_counter[0] += 1
+            seed = _draw_counter[0]
+    if out is None:
+        out = torch.empty((count, n_pts), dtype=torch.int32, device=device)
+    assert out.shape == (count, n_pts) and out.dtype == torch.int32 and out.is_contiguous() and out.is_cuda
+    st = L.lib().cg_draw_resample_ids(ctypes.c_int(n_valid), ctypes.c_int(n_pts), ctypes.c_long(count), ctypes.c_ulonglong(seed & (2 ** 64 - 1)),
+                                      ctypes.c_int(base), L._p(out), L._stream())
+    if st == -2:        # CG_ERR_UNSUPPORTED: without replacement from > 65535 points -- random-key sort instead
+        keys = torch.rand((count, n_valid), device=device, generator=generator)
+        out.copy_(keys.argsort(dim=1)[:, :n_pts].to(torch.int32) + base)
+        return out
+    L.check(st, 'cg_draw_resample_ids')
+    return out
+
+
+def pose_inverse_rows_device(poses, center):
+    """pose_inverse_rows for poses that already live on the device: (E,4,4)/(E,16) float32 cuda tensor -> (E,12) float32
+    (cg_pose_inverse_rows: float64 arithmetic on the device, rounded once)."""
+    import ctypes
+    from . import _lib as L
+    p = poses.reshape(-1, 16)
+    assert p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()
+    out = torch.empty((p.shape[0], 12), dtype=torch.float32, device=p.device)
+    c = (ctypes.c_double * 3)(*[float(v) for v in np.asarray(center, dtype=np.float64).reshape(3)])
+    L.check(L.lib().cg_pose_inverse_rows(L._p(p), ctypes.c_long(p.shape[0]), c, L._p(out), L._stream()), 'cg_pose_inverse_rows')
+    return out
 
 
 class DeviceCloud:
@@ -42,6 +77,12 @@ class DeviceCloud:
     def __init__(self, cloud_xyz, cloud_normal, device):
         xyz = np.asarray(cloud_xyz, dtype=np.float64)
         nrm = np.asarray(cloud_normal, dtype=np.float64)
+        if xyz.ndim != 2 or xyz.shape[1] != 3 or nrm.shape != xyz.shape:
+            raise ValueError(f'cloud_xyz {xyz.shape} / cloud_normal {nrm.shape} must both be (M,3)')
+        # the fused MLP kernels max-pool with NaN-ignoring arithmetic (-fno-honor-nans): a NaN/Inf point would be silently
+        # pooled away instead of poisoning the result as it does in the reference, so it is rejected at the boundary
+        if not (np.isfinite(xyz).all() and np.isfinite(nrm).all()):
+            raise ValueError('cloud_xyz / cloud_normal contain NaN or Inf')
         m = valid_mask(xyz)
         self.keep_ids = np.arange(len(xyz))[m]
         self.xyz64 = xyz[m].reshape(-1, 3)
@@ -59,6 +100,8 @@ def pose_inverse_rows(grasp_poses, center):
     P = np.asarray(grasp_poses, dtype=np.float64).reshape(-1, 4, 4)
     if len(P) == 0:
         return np.zeros((0, 12), dtype=np.float32)
+    if not np.isfinite(P).all():
+        raise ValueError('grasp_poses contain NaN or Inf')
     Pinv = np.linalg.inv(P)
     # normals use inv(R) of the rotation block alone (dataset_grasp.py:70); for a valid pose (last row 0 0 0 1)
     # that is the upper-left block of inv(P).

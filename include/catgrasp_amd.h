@@ -57,12 +57,18 @@ int cg_pointmlp_max_bf16x3(const float* x, int B, int N, const float* t3, const 
                            void* stream);
 /* Same with IEEE-half pieces ("f16x3", 11 + 11 significant bits instead of 8 + 8): logits within ~2e-6 of the float64 evaluation,
  * i.e. float32's own distance, at the same three MFMAs per product block.  Weights packed by folding.pack_b_split(w, 'f16').  The
- * default arithmetic of the engine.  Activations must stay below 65504 in magnitude (half range). */
+ * default arithmetic of the engine.  The half pieces have a limited exponent range; `status` (optional device int, owned and
+ * zeroed by the caller, one per call or per batch -- there is no process-global state) gets CG_STATUS_HALF_OVERFLOW OR-ed in if
+ * a value handed to the split reached 65504 (the result is then meaningless) and CG_STATUS_HALF_UNDERFLOW if a whole layer
+ * output of some 32-point tile stayed below 2^-6 (its low pieces then sit in the half subnormals: absolute instead of relative
+ * error).  On either bit re-run the batch with the bf16x3 (float32 exponent range) or f32 entry point. */
+#define CG_STATUS_HALF_OVERFLOW 1
+#define CG_STATUS_HALF_UNDERFLOW 2
 int cg_pointmlp_max_f16x3(const float* x, int B, int N, const float* t3, const float* w1, const float* b1,
                           int mid_mode, const unsigned short* wm_split, const float* bm, const float* t64,
                            const unsigned short* w2_split, const float* b2, const unsigned short* w3_split,
                            const float* b3, int relu3, int nsplit, int tile_points, float* out, float* pointfeat,
-                           void* stream);
+                           int* status, void* stream);
 
 /* Y[M,N] = act(X[M,K] . W^T + bias + row_bias[row / rows_per_group]) (+ flattened identity k x k):
  * replaces Linear->BN->ReLU tails (pointnet2.py:178-185, :216-223, :295-298) and the Conv1d(k=1)
@@ -77,10 +83,10 @@ int cg_gemm_bias_act(const float* x, int M, int K, int ldx, const float* w_packe
 int cg_gemm_bias_act_bf16x3(const float* x, int M, int K, int ldx, const unsigned short* w_split, int N,
                             const float* bias, const float* row_bias, int rows_per_group, int ld_rb,
                             int relu, int eye_k, float* y, int ldy, void* stream);
-/* IEEE-half variant of the above (see cg_pointmlp_max_f16x3). */
+/* IEEE-half variant of the above; `status` as in cg_pointmlp_max_f16x3 (the split operand here is X). */
 int cg_gemm_bias_act_f16x3(const float* x, int M, int K, int ldx, const unsigned short* w_split, int N,
                             const float* bias, const float* row_bias, int rows_per_group, int ld_rb,
-                            int relu, int eye_k, float* y, int ldy, void* stream);
+                            int relu, int eye_k, float* y, int ldy, int* status, void* stream);
 
 /* softmax / argmax / confidence (predicter.py:86-91) and p_G = sum_k p_k * k / C
  * (run_grasp_simulation.py:313).  logits (B,C) -> probs (B,C), label (B) i32, conf (B), p_g (B). */
@@ -162,7 +168,9 @@ int cg_filter_grasp_pose(const float* grasp_poses, int n_pose, const float* symm
                          const short* open_keys, int n_open_keys, const short* bg_keys, int n_bg_keys,
                          float resolution, signed char* codes, float* poses_out, signed char* nudge,
                          float* ee_in_base_out, void* stream);
-/* Same, with optional broad-phase grids (HOST descriptors, NULL = exhaustive) for the open / enclosed gripper mesh. */
+/* Same, with optional broad-phase grids (HOST descriptors, NULL = exhaustive) for the open / enclosed gripper mesh.
+ * keep_rejected_pose != 0: poses_out of a REJECTED evaluation holds its composed, column-normalised (un-nudged) grasp_in_cam
+ * (common.cpp:191-197) instead of zeros, so a fixed-size batch can be scored without a compaction step. */
 int cg_filter_grasp_pose_accel(const float* grasp_poses, int n_pose, const float* symmetry_tfs, int n_sym,
                                const float* h_nocs_pose, const float* h_canonical_to_nocs, const float* h_cam_in_world,
                                const float* h_ee_in_grasp, const float* h_gripper_in_grasp,
@@ -172,8 +180,34 @@ int cg_filter_grasp_pose_accel(const float* grasp_poses, int n_pose, const float
                                const float* enclosed_vertices, const int* enclosed_faces, int n_enclosed_faces,
                                const short* open_keys, int n_open_keys, const short* bg_keys, int n_bg_keys,
                                float resolution, signed char* codes, float* poses_out, signed char* nudge,
-                               float* ee_in_base_out, const cg_mesh_grid* h_open_grid, const cg_mesh_grid* h_enc_grid, void* stream);
+                               float* ee_in_base_out, const cg_mesh_grid* h_open_grid, const cg_mesh_grid* h_enc_grid,
+                               int keep_rejected_pose, void* stream);
 
+/* Device build of cg_mesh_grid (replaces a per-triangle host loop): triangle t is listed in every cell its bounding box,
+ * inflated by `inflate`, overlaps (float64 cell arithmetic).  h_origin[3], h_dims[3]: HOST.  Two passes around a host-side
+ * exclusive prefix sum: cg_mesh_grid_count adds into counts (prod(dims), pre-zeroed); cg_mesh_grid_fill writes tri_ids
+ * (cell_start[prod(dims)] entries) using cursor (prod(dims), pre-zeroed) and then sorts every cell's list ascending. */
+int cg_mesh_grid_count(const float* vertices, const int* faces, int n_faces, const double* h_origin, double cell, double inflate,
+                       const int* h_dims, int* counts, void* stream);
+int cg_mesh_grid_fill(const float* vertices, const int* faces, int n_faces, const double* h_origin, double cell, double inflate,
+                      const int* h_dims, const int* cell_start, int* cursor, int* tri_ids, void* stream);
+
+
+/* ---------------------------------------------------------------------------------------------
+ * Host-loop replacements around the two networks (the reference-API entry points were host-capped).
+ * ------------------------------------------------------------------------------------------- */
+
+/* The per-candidate resampling draw of GraspDataset.transform (dataset_grasp.py:72-73: np.random.choice(M, n_pts,
+ * replace = M < n_pts), once per pose in the loop of predicter.py:71-74) for `count` candidates at once:
+ * out (count,n_pts) i32 = base + a uniform n_pts-subset of [0,n_valid) in uniform order (n_valid >= n_pts; partial
+ * Fisher-Yates in LDS, n_valid <= 65535 else CG_ERR_UNSUPPORTED) or iid uniform indices (n_valid < n_pts).
+ * Counter-based Philox4x32-10 keyed by `seed`: reproducible, but NOT numpy's stream. */
+int cg_draw_resample_ids(int n_valid, int n_pts, long count, unsigned long long seed, int base, int* out, void* stream);
+
+/* inv(grasp_pose) of dataset_grasp.py:69-70 for poses already on the device: poses (n,16) f32 row-major 4x4 with last
+ * row 0 0 0 1 -> out (n,12) rows [R | t] with x_grasp = R x_centred + t, where x_centred = x_cam - h_center (HOST,
+ * 3 doubles).  float64 arithmetic, rounded once (same contract as the host helper transforms.pose_inverse_rows). */
+int cg_pose_inverse_rows(const float* poses, long n_poses, const double* h_center, float* out, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * PointNet++ grouping primitives (pointnet2.py:14-149).  Index tensors are int64 like the reference's.
@@ -324,11 +358,6 @@ int cg_pg_voxelize_fp(const float* feats, const int* rules, int n_rows, int max_
  * ok[e] = 1 iff some solution lies inside the limits. */
 int cg_iiwa_ik_within_limits(const float* ee_in_base, long E, const double* h_upper7, const double* h_lower7,
                              unsigned char* ok, void* stream);
-
-/* Half-range check of the f16x3 kernels: *flag = 1 iff some value handed to the IEEE-half split since the last reset reached
- * 65504 in magnitude (its result is then meaningless; re-run with the bf16x3 or f32 entry points).  Synchronous (copies a device
- * word); reset != 0 clears the condition. */
-int cg_half_range_violation(int reset, int* flag);
 
 #ifdef __cplusplus
 }

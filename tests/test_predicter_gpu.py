@@ -155,21 +155,81 @@ def test_dropin_predicters_against_the_real_reference_outputs(cuda_device, mlp_p
     assert np.abs(conf[zc] - p['nocs_conf_z'][zc]).max() <= 1e-4
 
 
-def test_half_range_violation_is_reported_not_returned(cuda_device, mlp_precision):
-    """The split-half arithmetic needs activations below 65504.  A network whose first layer is scaled by 1e6 leaves that range:
-    predict_batch must raise under 'f16x3' (never hand back inf/NaN scores) and keep working under 'bf16x3' / 'f32'."""
+def _rel_logit_err(gp, sd, ob, P, ids):
+    """max |logits - f64 oracle| / max |oracle| of the product's nn.Module forward on one candidate batch"""
+    x = np.stack([tref.grasp_transform(ob['xyz'].copy(), ob['normal'].copy(), P[i], ids[i])['input'] for i in range(len(P))])
+    xt = torch.from_numpy(x).float()
+    ref = oref.pointnet_cls_forward(sd, xt, torch.float64)[0]
+    with torch.no_grad():
+        y = gp.model(xt.to(gp.device))[0].cpu().double()
+    assert torch.isfinite(y).all()
+    return float((y - ref).abs().max() / ref.abs().max())
+
+
+@pytest.mark.parametrize('case', ['activations_1e6', 'weights_beyond_half', 'activations_subnormal', 'weights_tiny'])
+def test_half_range_guard_falls_back_instead_of_failing(cuda_device, mlp_precision, case):
+    """the split-half arithmetic ('f16x3', the default) has IEEE-half's exponent range.  A checkpoint whose
+    activations or folded weights leave it -- upwards (>= 65504) or downwards (whole layer outputs / weight matrices below 2^-6,
+    where the low pieces sink into the half subnormals) -- must neither raise nor return damaged scores: the kernels report the
+    condition in a per-call status word and the engine re-evaluates with bf16 pieces (float32's exponent range); layers whose
+    weight images fail the pre-screen never use the half kernels.  All four nets compute (up to rounding) ordinary functions;
+    every arithmetic mode must stay within 1e-4 (relative to the logit scale) of the float64 evaluation."""
+    import warnings
     from catgrasp_amd.predicter import DEFAULT_GRASP_CFG, GraspPredicter
-    sd = synth.make_state_dict('cls', 6, 10, seed=5)
-    sd = {k: v.clone() for k, v in sd.items()}
-    sd['feat.conv1.weight'] *= 1e6
+    sd = {k: v.clone() for k, v in synth.make_state_dict('cls', 6, 10, seed=5).items()}
+    if case == 'activations_1e6':
+        sd['feat.conv1.weight'] *= 1e6
+    elif case == 'weights_beyond_half':
+        sd['feat.bn3.weight'] *= 3e6            # folded 128->1024 weights ~ 3e6 * 0.14: not representable in half
+        sd['fc1.weight'] /= 3e6                 # ... and the global feature it produces (~1e6) overflows the next layer's split
+    elif case == 'activations_subnormal':
+        # ReLU is positively homogeneous: scaling one layer's output by 1e-5 and the consumers' weights by 1e5 leaves the function
+        # unchanged, but every activation of that layer is now < 2^-6 (most of them half subnormals)
+        sd['feat.bn1.weight'] *= 1e-5; sd['feat.bn1.bias'] *= 1e-5
+        sd['feat.fstn.conv1.weight'] *= 1e5; sd['feat.conv2.weight'] *= 1e5
+    else:
+        sd['feat.stn.bn2.weight'] *= 1e-4; sd['feat.stn.bn2.bias'] *= 1e-4       # folded 64->128 weights ~ 1e-5: all below 2^-6
+        sd['feat.stn.conv3.weight'] *= 1e4                                       # same function (ReLU homogeneity)
     ob = synth.make_scene(1, 1500, seed=4)[0]
     P = synth.make_candidates(ob, 8, np.random.default_rng(1))
+    ids = np.stack([np.random.default_rng(i).choice(len(ob['xyz']), 2048, replace=True) for i in range(len(P))])
+    gp = GraspPredicter('nut', cfg=DEFAULT_GRASP_CFG, state_dict=sd, device=cuda_device)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore', RuntimeWarning)
+        assert _rel_logit_err(gp, sd, ob, P, ids) <= 1e-4
+        ret = gp.predict_batch({'cloud_xyz': ob['xyz'], 'cloud_normal': ob['normal']}, list(P), ids=ids)
+    assert len(ret) == 8 and all(np.isfinite(r[2]).all() and abs(float(r[2].sum()) - 1) < 1e-5 for r in ret)
+    if mlp_precision == 'f16x3' and case in ('weights_beyond_half', 'weights_tiny'):
+        assert not all(gp._W.half_ok.values())          # the pre-screen took those layers off the half kernels
+
+
+def test_predict_batch_device_rng_and_id_validation(cuda_device):
+    """rng='device' draws the per-pose resampling on the device (no host loop); it is reproducible under np.random.seed, every row
+    is a duplicate-free subset when the cloud has >= n_pts points, and the scores follow the same oracle.  Explicit ids are range
+    checked like the reference's numpy indexing."""
+    from catgrasp_amd import transforms
+    from catgrasp_amd.predicter import DEFAULT_GRASP_CFG, GraspPredicter
+    sd = synth.make_state_dict('cls', 6, 10, seed=5)
+    ob = synth.make_scene(1, 2500, seed=4)[0]
+    P = synth.make_candidates(ob, 40, np.random.default_rng(1))
     gp = GraspPredicter('nut', cfg=DEFAULT_GRASP_CFG, state_dict=sd, device=cuda_device)
     data = {'cloud_xyz': ob['xyz'], 'cloud_normal': ob['normal']}
-    np.random.seed(0)
-    if mlp_precision == 'f16x3':
-        with pytest.raises(FloatingPointError):
-            gp.predict_batch(data, list(P))
-    else:
-        ret = gp.predict_batch(data, list(P))
-        assert len(ret) == 8 and all(np.isfinite(r[2]).all() for r in ret)
+    np.random.seed(7); a = gp.predict_batch(data, list(P), rng='device')
+    np.random.seed(7); b = gp.predict_batch(data, list(P), rng='device')
+    assert all(np.array_equal(x[2], y[2]) for x, y in zip(a, b))
+    ids = transforms.draw_ids_device(2500, 2048, 300, cuda_device, seed=11).cpu().numpy()
+    assert ids.min() >= 0 and ids.max() < 2500 and all(len(np.unique(r)) == 2048 for r in ids)
+    assert len({r.tobytes() for r in ids}) == 300
+    # every index is (close to) equally likely and every output slot is uniform: chi-square-free sanity bounds
+    cnt = np.bincount(ids.reshape(-1), minlength=2500)
+    assert 200 < cnt.min() and cnt.max() <= 300          # binomial(300, 0.82) per index: mean 245.8, sd 6.7
+    assert abs(ids[:, 0].mean() - 1249.5) < 150 and abs(ids[:, -1].mean() - 1249.5) < 150
+    rep = transforms.draw_ids_device(700, 2048, 50, cuda_device, seed=3).cpu().numpy()       # with replacement
+    assert rep.min() >= 0 and rep.max() < 700 and rep.shape == (50, 2048)
+    ref = tref.predict_batch_post(oref.pointnet_cls_forward(sd, torch.from_numpy(np.stack(
+        [tref.grasp_transform(ob['xyz'].copy(), ob['normal'].copy(), P[i], ids[i])['input'] for i in range(len(P))])).float())[0].numpy())
+    got = gp.predict_batch(data, list(P), ids=ids[:len(P)])
+    assert max(float(np.abs(g[2] - r[2]).max()) for g, r in zip(got, ref)) <= 1e-4
+    bad = ids[:len(P)].copy(); bad[3, 5] = 2500
+    with pytest.raises(IndexError):
+        gp.predict_batch(data, list(P), ids=bad)
