@@ -1,17 +1,26 @@
 #!/usr/bin/env python
 """bench.py -- grasp candidates scored + collision-checked per second (BASELINE.json metric).
 
-One "step" = one pass of the hot path over one batch of synthetic input on every rank:
-  NUNOCS net over the scene's objects  ->  filterGraspPose over the rank's candidates  ->
-  grasp-Q net (input transform + PointNetCls + softmax + p_G) over the same candidates
-  [-> one RCCL all_gather of the packed (p_G, code) records when --gpus > 1].
-Workload (config.workload): BASELINE.json configs[1] scale -- nut clutter pile, 20k-pt scene
-(8 objects x 2500 pts), 10k candidates per GPU, fp32 -- with the configs[2] stages (NUNOCS + collision)
-included because the metric is "scored + collision-checked".  All inputs are resident in HBM before
-the timed region; weights are seeded random (the reference ships no checkpoints), data synthetic.
+One "step" = one pass of the hot path over one batch of synthetic candidates (catgrasp_amd/workload.py: SceneBatch.score_slice):
+  NUNOCS net over the scene's objects
+  -> filterGraspPose with the reference's two live call shapes: canonical grasps x category symmetries with
+     adjust_collision_pose=True (dexnet/grasping/grasp_sampler.py:345) and cone poses with symmetry=[I] (:216)
+  -> on the device: inverse of every resulting grasp_in_cam, the per-candidate resampling draw of GraspDataset.transform,
+     the input transform, PointNetCls, softmax, p_G -- every candidate is scored AND collision-checked (fixed work per step)
+  -> one all_gather of the packed (p_G, code) records when --gpus > 1 (catgrasp_amd/distributed.py).
+
+Workloads (config.workload):
+  C3 (default; BASELINE.json configs[2]): nut clutter pile, 20k-pt scene (8 objects x 2500 pts), 12 nut symmetries,
+      50,000 candidates PER GPU; --gpus N is weak scaling (every rank scores its own 50k candidates of the same scene).
+  C4 (--scaling strong; configs[3]): screw category, 40k-pt scene (16 x 2500), 72 symmetries, --candidates-total (200,000)
+      candidates in TOTAL cut into contiguous slices over the ranks.
+All inputs are resident in HBM before the timed region; weights are seeded random (the reference ships no checkpoints).
+`value` is measured under --precision (default f32: exact-f32 MFMA, the reference's arithmetic); the split-precision modes of
+the product (f16x3 -- its default --, bf16x3) are measured in the same run and reported under `secondary`.
 
 Launch: python bench.py --gpus 1 --steps K --warmup W
-        python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+        python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+        ... bench.py --gpus 8 --scaling strong --candidates-total 200000        (C4)
 """
 import argparse
 import json
@@ -27,128 +36,161 @@ sys.path.insert(0, ROOT)
 
 MAC_PER_POINT_ENC = 9 + 384 + 4096 + 8192 + 131072      # encoder pass (mid_mode 2): T3, conv1, .T64, conv2, conv3
 PEAK_F32_MFMA_TFLOPS = 157.3                            # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
-PEAK_BF16_MFMA_TFLOPS = 2500.0                          # MI355X_MICROARCH.md: BF16/F16 MFMA dense peak (~2.5 PF)
-# HBM bytes per candidate of the encoder-pass kernel (mid_mode 2) of each arithmetic from the PMC passes in profiles/r1_pmc_pointmlp.csv
-# (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate runs, B=4096): 2*FETCH_SIZE (gfx950 correction for wide
-# coalesced reads, MI355X_MICROARCH.md §HBM) + WRITE_SIZE, divided by 4096.  Algorithmic: 49152 B x + 16384 B transform
-# + 4096 B out = 69632 B/candidate; both kernels move the algorithmic bytes and nothing else (no scratch).
+PEAK_16BIT_MFMA_TFLOPS = 2500.0                         # MI355X_MICROARCH.md: BF16/F16 MFMA dense peak (~2.5 PF)
+PEAK_HBM_GBS = 8000.0                                   # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+# Algorithmic HBM bytes per candidate of the encoder-pass kernel: 49152 B x + 16384 B feature transform + 4096 B out.
+ALG_HBM_BYTES_PER_CANDIDATE = 49152 + 16384 + 4096
+# Measured HBM bytes per candidate of the same kernel: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, B = 4096),
+# 2*FETCH_SIZE (gfx950 correction, MI355X_MICROARCH.md §HBM) + WRITE_SIZE, / 4096 -- profiles/r1_pmc_pointmlp.csv.  A CONSTANT
+# from that profile, not a counter read in this run (PMC collection needs its own rocprofv3 pass).
 PMC_HBM_BYTES_PER_CANDIDATE = {'bf16x3': (2 * 133760.3 + 16384.0) * 1024 / 4096, 'f16x3': (2 * 133762.0 + 16384.0) * 1024 / 4096,
                                'f32': (2 * 133763.3 + 16384.0) * 1024 / 4096}
+DTYPE = {'f32': 'f32 (exact-f32 MFMA: every product and accumulation in float32, as the reference)',
+         'f16x3': 'f32 in/out/accumulate; wide-layer products as 3x f16 MFMA on hi+lo half pieces (f16x3 split, 22 significant bits)',
+         'bf16x3': 'f32 in/out/accumulate; wide-layer products as 3x bf16 MFMA on hi+lo bf16 pieces (bf16x3 split, 16 significant bits)'}
 
 
-def build_workload(device, G, seed, n_objects=8, pts_per_object=2500, kind='nut'):
-    from catgrasp_amd import my_cpp, synth, transforms
-    objs = synth.make_scene(n_objects, pts_per_object, seed=0, kind=kind)           # same scene on every rank
-    gripper = synth.make_gripper()
-    rng = np.random.default_rng(1000 + seed)
-    per = [G // n_objects + (1 if k < G % n_objects else 0) for k in range(n_objects)]
-    clouds, offsets, pose_rows, poses_dev, scenes, ids = [], [], [], [], [], []
-    off = 0
-    gen = torch.Generator(device=device); gen.manual_seed(1234 + seed)
-    for k, ob in enumerate(objs):
-        dc = transforms.DeviceCloud(ob['xyz'], ob['normal'], device)
-        clouds.append(dc); offsets.append(off)
-        P = synth.make_candidates(ob, per[k], rng, gripper['hand_depth'], gripper['init_bite'])
-        pose_rows.append(transforms.pose_inverse_rows(P, dc.center))
-        poses_dev.append(torch.from_numpy(P.astype(np.float32).reshape(-1, 16)).to(device))
-        bg = synth.background_points(objs, k, gripper['diameter'])
-        scenes.append(my_cpp.GripperScene(gripper['vertices'], gripper['faces'], gripper['enclosed_vertices'],
-                                          gripper['enclosed_faces'], ob['xyz'], bg, 0.0005, device))
-        ids.append(transforms.draw_ids_device(dc.n, 2048, per[k], device, gen) + off)
-        off += dc.n
-    wl = {
-        'objs': objs, 'gripper': gripper, 'per': per, 'scenes': scenes, 'poses_dev': poses_dev,
-        'cloud_xyz': torch.cat([c.xyz for c in clouds]).contiguous(),
-        'cloud_normal': torch.cat([c.normal for c in clouds]).contiguous(),
-        'ids': torch.cat(ids).contiguous(),
-        'pose_inv': torch.from_numpy(np.concatenate(pose_rows)).to(device),
-        'nunocs_ids': torch.stack([transforms.draw_ids_device(c.n, 8192, 1, device, gen)[0] + o
-                                   for c, o in zip(clouds, offsets)]).contiguous(),
-        'G': G,
-    }
-    return wl
+def subdivide(V, F, times):
+    """Loop-free 1:4 midpoint subdivision (the api block wants a >= 5k-triangle gripper: 36 x 4^4 = 9216)."""
+    V = np.asarray(V, dtype=np.float32); F = np.asarray(F, dtype=np.int32)
+    for _ in range(times):
+        a, b, c = V[F[:, 0]], V[F[:, 1]], V[F[:, 2]]
+        n0 = len(V)
+        mids = np.stack([(a + b) / 2, (b + c) / 2, (c + a) / 2], axis=1).reshape(-1, 3).astype(np.float32)
+        i = n0 + 3 * np.arange(len(F))
+        F = np.concatenate([np.stack([F[:, 0], i, i + 2], 1), np.stack([i, F[:, 1], i + 1], 1), np.stack([i + 2, i + 1, F[:, 2]], 1),
+                            np.stack([i, i + 1, i + 2], 1)]).astype(np.int32)
+        V = np.concatenate([V, mids])
+    return V, F
 
 
-def run_step(wl, gp, npred, gather_buf=None, world=1):
-    from catgrasp_amd import my_cpp
-    I4 = np.eye(4, dtype=np.float32)
-    # (1) NUNOCS canonicaliser over every object cloud of the scene
-    coords, conf, _ = npred.nocs_on_device(wl['cloud_xyz'], wl['cloud_normal'], wl['nunocs_ids'])
-    # (2) collision filter (cone-sampler call shape: symmetry=[I], nocs_pose=I, approach-dir filter on).
-    #     One call per object as in the reference; the per-object kernels are small (1250 wavefronts each), so they are
-    #     issued on separate HIP streams and run concurrently, then joined back into the main stream.
-    codes = []
-    sym = wl.setdefault('_sym', torch.eye(4, device=wl['cloud_xyz'].device).reshape(1, 16).contiguous())
-    side = wl.setdefault('_streams', [torch.cuda.Stream(device=wl['cloud_xyz'].device) for _ in range(len(wl['scenes']))])
-    main = torch.cuda.current_stream()
-    fork = torch.cuda.Event(); fork.record(main)
-    for k, sc in enumerate(wl['scenes']):
-        with torch.cuda.stream(side[k]):
-            side[k].wait_event(fork)
-            c, _, _ = my_cpp.filter_on_device(sc, wl['poses_dev'][k], sym, I4, I4, I4, I4, wl['gripper']['gripper_in_grasp'],
-                                              True, False, False)
-        codes.append(c)
-    for st in side:
-        main.wait_stream(st)
-    codes = torch.cat(codes)
-    # (3) grasp-Q scoring of every candidate
-    probs, label, conf_q, p_g = gp.score_on_device(wl['cloud_xyz'], wl['cloud_normal'], wl['ids'], wl['pose_inv'])
-    # (4) packed per-candidate record: p_G (f32) + code (as f32 lane) -> one all_gather over xGMI
-    rec = torch.stack([p_g, codes.float()], dim=1).contiguous()
-    if world > 1:
-        if torch.distributed.get_backend() == 'nccl':
-            torch.distributed.all_gather_into_tensor(gather_buf, rec)
-        else:           # dev only (CATGRASP_BENCH_BACKEND=gloo): exercise the multi-rank control flow on a 1-GPU box
-            parts = [torch.empty(rec.shape, dtype=rec.dtype) for _ in range(world)]
-            torch.distributed.all_gather(parts, rec.cpu())
-            gather_buf.copy_(torch.cat(parts))
-        return gather_buf
-    return rec
+def api_block(batch, gp, device, n=50000):
+    """Wall-clock of the REFERENCE entry points exactly as run_grasp_simulation.py:176,310 call them (python lists / numpy arrays in,
+    python lists out; includes every host-side conversion, upload, download and list build), next to the device-resident number."""
+    from catgrasp_amd import engine, my_cpp, synth
+    out = {}
+    ob = batch.objs[0]
+    data = {'cloud_xyz': ob['xyz'], 'cloud_normal': ob['normal']}
+    rng = np.random.default_rng(5)
+    base = synth.make_candidates(ob, 2000, rng, batch.gripper['hand_depth'], batch.gripper['init_bite'])
+    poses = list(base[rng.integers(0, len(base), n)])                 # list of (4,4) float64, like grasps[i].get_grasp_pose_matrix()
+
+    def wall(fn, reps):
+        ts = []
+        for _ in range(reps):
+            torch.cuda.synchronize(); t0 = time.perf_counter(); r = fn(); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+        return float(np.median(ts)), r
+    pb = []
+    for prec in dict.fromkeys([engine.PRECISION, 'f16x3']):
+        with engine.precision(prec):
+            gp.predict_batch(data, poses[:2000], rng='device')        # warm-up
+            t, ret = wall(lambda: gp.predict_batch(data, poses, rng='device'), 3)
+        assert len(ret) == n and len(ret[0]) == 3 and ret[0][2].shape == (10,)
+        pb.append({'poses': n, 'rng': 'device', 'precision': prec, 'wall_s': round(t, 4), 'candidates_per_s': round(n / t, 1)})
+    m = 5000
+    np.random.seed(0)
+    t, _ = wall(lambda: gp.predict_batch(data, poses[:m], rng='numpy'), 1)
+    pb.append({'poses': m, 'rng': 'numpy (the reference\'s global-generator draw, one np.random.choice per pose on the host)',
+               'precision': engine.PRECISION, 'wall_s': round(t, 4), 'candidates_per_s': round(m / t, 1)})
+    out['predict_batch'] = pb
+    # filterGraspPose, 20 positional arguments, >= 5k-triangle gripper meshes, nut symmetries, pose nudging on
+    g = batch.gripper
+    V, F = subdivide(g['vertices'], g['faces'], 4)
+    Ve, Fe = subdivide(g['enclosed_vertices'], g['enclosed_faces'], 4)
+    from catgrasp_amd import transforms
+    sym = transforms.get_symmetry_tfs('nut')
+    n_can = (n + len(sym) - 1) // len(sym)
+    can = list(np.linalg.inv(batch.nocs_pose[0]) @ base[rng.integers(0, len(base), n_can)])
+    bg = synth.background_points(batch.objs, 0, g['diameter'])
+    I4 = np.eye(4)
+    args = (can, sym, batch.nocs_pose[0], I4, I4, I4, g['gripper_in_grasp'], True, False, True, [0] * 7, [0] * 7, V, F, Ve, Fe, ob['xyz'], bg,
+            0.0005, False)
+    my_cpp.clear_scene_cache()
+    t_cold, surv = wall(lambda: my_cpp.filterGraspPose(*args), 1)
+    t_warm, surv = wall(lambda: my_cpp.filterGraspPose(*args), 3)
+    E = n_can * len(sym)
+    out['filterGraspPose'] = {'evaluations': E, 'canonical_grasps': n_can, 'symmetries': len(sym), 'gripper_triangles': [int(len(F)), int(len(Fe))],
+                              'adjust_collision_pose': True, 'survivors': len(surv),
+                              'cold_wall_s': round(t_cold, 4), 'cold_evaluations_per_s': round(E / t_cold, 1),
+                              'warm_wall_s': round(t_warm, 4), 'warm_evaluations_per_s': round(E / t_warm, 1),
+                              'note': 'cold = first call on these meshes/clouds (device mesh-grid build + voxelisation); warm = the '
+                                      'content-keyed scene cache is hit, as on the second per-object call of grasp_sampler.py'}
+    return out
 
 
-def cpu_baseline(wl, sd_cls, sd_seg, n_score=400, n_coll=4096):
-    """The CPU oracle (a port of the reference path, oracle/) timed on this box's host cores on a bounded
-    sample: python GraspDataset.transform loop + PointNetCls fp32 forward in chunks of 200
-    (predicter.py:67-91), the C/OpenMP filterGraspPose restatement, and the NUNOCS forward amortised."""
+def cpu_baseline(batch, sd_cls, sd_seg, n_score=100, n_coll=4096):
+    """BASELINE.md §3 on this box's host cores, bounded to ~30 s: the reference's op sequence (F.conv1d / F.batch_norm / F.linear
+    port, oracle/pointnet_ref.py -- the reference package cannot travel to the GPU box) in chunks of 200 (predicter.py:69) fed by
+    the restated per-candidate GraspDataset.transform python loop; the C/OpenMP filterGraspPose restatement over all cores with
+    its per-call structure build; one NUNOCS forward per object amortised.  3 warm-ups, median of 5, thread scan logged."""
     from oracle import collision_oracle as co
     from oracle import pointnet_ref as oref
     from oracle import transforms_ref as tref
-    from catgrasp_amd import synth
-    nthreads = min(os.cpu_count(), 16)      # best of an 8..256-thread scan on the 256-core bench host (oversubscription hurts)
+    ob = batch.objs[0]; g = batch.gripper
+    seg_nocs = next(s for s in batch.segs if s.kind == 'nocs' and s.obj == 0)
+    seg_cone = next(s for s in batch.segs if s.kind == 'cone' and s.obj == 0)
+    P = batch.host_poses(seg_cone)
+    psd = oref.prepared_state_dict(sd_cls)
+    host = os.cpu_count()
+    scan = {}
+    xs = np.stack([tref.grasp_transform(ob['xyz'].copy(), ob['normal'].copy(), P[i], tref.draw_ids(len(ob['xyz']), 2048))['input'] for i in range(24)])
+    xw = torch.from_numpy(xs).float()
+    with torch.no_grad():
+        for nt in sorted({min(host, t) for t in (8, 16, 32, 64, 128, host)}):
+            torch.set_num_threads(nt)
+            oref.pointnet_cls_forward_nnops(psd, xw[:8])
+            t0 = time.perf_counter(); oref.pointnet_cls_forward_nnops(psd, xw); scan[nt] = round((time.perf_counter() - t0) / len(xw) * 1e3, 2)
+    nthreads = min(scan, key=scan.get)
     torch.set_num_threads(nthreads)
-    ob = wl['objs'][0]; g = wl['gripper']
-    rng = np.random.default_rng(7)
-    P = synth.make_candidates(ob, max(n_score, n_coll), rng, g['hand_depth'], g['init_bite'])
-    with torch.no_grad():
-        oref.pointnet_cls_forward(sd_cls, torch.zeros(8, 2048, 6))     # warm-up (thread pool, allocator)
-    t0 = time.time()
-    xs = []
-    for i in range(n_score):
-        ids = tref.draw_ids(len(ob['xyz']), 2048)
-        xs.append(tref.grasp_transform(ob['xyz'].copy(), ob['normal'].copy(), P[i], ids)['input'])
-    x = torch.from_numpy(np.stack(xs)).float()
-    with torch.no_grad():
-        logits = torch.cat([oref.pointnet_cls_forward(sd_cls, x[s:s + 200])[0] for s in range(0, n_score, 200)])   # predicter.py:69 batch 200
-    tref.predict_batch_post(logits.numpy())
-    t_score = (time.time() - t0) / n_score
-    bg = synth.background_points(wl['objs'], 0, g['diameter'])
+
+    def transform_loop(n):
+        return np.stack([tref.grasp_transform(ob['xyz'].copy(), ob['normal'].copy(), P[i], tref.draw_ids(len(ob['xyz']), 2048))['input']
+                         for i in range(n)])
+
+    def net(x):
+        with torch.no_grad():
+            return torch.cat([oref.pointnet_cls_forward_nnops(psd, x[s:s + 200])[0] for s in range(0, len(x), 200)])
+    for _ in range(3):
+        net(xw)
+    t_tr, t_net = [], []
+    for _ in range(5):
+        t0 = time.perf_counter(); x = torch.from_numpy(transform_loop(n_score)).float(); t1 = time.perf_counter()
+        tref.predict_batch_post(net(x).numpy()); t2 = time.perf_counter()
+        t_tr.append((t1 - t0) / n_score); t_net.append((t2 - t1) / n_score)
+    t_transform, t_netonly = float(np.median(t_tr)), float(np.median(t_net))
+    # collision: both call shapes, half the sample each, per-call structure build included (as common.cpp:176-182)
+    bg = __import__('catgrasp_amd.synth', fromlist=['x']).background_points(batch.objs, 0, g['diameter'])
     I4 = np.eye(4)
-    t0 = time.time()
-    co.filter_grasp_pose(P[:n_coll], [I4], I4, I4, I4, I4, g['gripper_in_grasp'], 1, 0, 0, g['vertices'], g['faces'],
+    from catgrasp_amd import transforms
+    sym = transforms.get_symmetry_tfs('nut' if batch.kind == 'nut' else 'screw')
+    n_can = max(1, (n_coll // 2) // len(sym))
+    can = batch.host_poses(seg_nocs)[:n_can]
+    t0 = time.perf_counter()
+    co.filter_grasp_pose(can, sym, batch.nocs_pose[0], I4, I4, I4, g['gripper_in_grasp'], 1, 0, 1, g['vertices'], g['faces'],
                          g['enclosed_vertices'], g['enclosed_faces'], ob['xyz'], bg, 0.0005)
-    t_coll = (time.time() - t0) / n_coll
-    t0 = time.time()
+    co.filter_grasp_pose(P[:n_coll // 2], [I4], I4, I4, I4, I4, g['gripper_in_grasp'], 1, 0, 0, g['vertices'], g['faces'],
+                         g['enclosed_vertices'], g['enclosed_faces'], ob['xyz'], bg, 0.0005)
+    t_coll = (time.perf_counter() - t0) / (n_can * len(sym) + n_coll // 2)
+    pss = oref.prepared_state_dict(sd_seg)
+    t0 = time.perf_counter()
     ids = tref.draw_ids(len(ob['xyz']), 8192)
     xin = tref.nunocs_transform(ob['xyz'].copy(), ob['normal'].copy(), ids)['input']
     with torch.no_grad():
-        lg, _ = oref.pointnet_seg_forward(sd_seg, torch.from_numpy(xin[None]).float())
+        lg, _ = oref.pointnet_seg_forward_nnops(pss, torch.from_numpy(xin[None]).float())
     tref.nunocs_decode(lg[0].numpy(), 100)
-    t_nunocs = (time.time() - t0) * len(wl['objs']) / wl['G']
-    per_cand = t_score + t_coll + t_nunocs
-    return {'value': round(1.0 / per_cand, 2), 'unit': 'candidates/s', 'cores': nthreads, 'host_cores': os.cpu_count(), 'kind': 'port',
-            'sample': f'{n_score} candidates scored (python transform loop + fp32 torch oracle, {nthreads} threads) '
-                      f'+ {n_coll} candidates collision-filtered (C/OpenMP oracle) + 1 NUNOCS forward amortised over {wl["G"]}',
-            'score_ms_per_candidate': round(t_score * 1e3, 3), 'collision_ms_per_candidate': round(t_coll * 1e3, 4)}
+    t_nunocs_obj = time.perf_counter() - t0
+    per_rank = batch.n_total
+    per_cand = t_transform + t_netonly + t_coll + t_nunocs_obj * len(batch.objs) / per_rank
+    return {'value': round(1.0 / per_cand, 2), 'unit': 'candidates/s', 'cores': nthreads, 'host_cores': host, 'kind': 'port',
+            'collision_threads': co.num_threads(),
+            'sample': f'{n_score} candidates x (3 warm-ups, median of 5): python transform loop + PointNetCls fp32 in chunks of 200 through '
+                      f'F.conv1d/F.batch_norm/F.linear on {nthreads} torch threads (best of the scan); {n_can * len(sym) + n_coll // 2} '
+                      f'evaluations collision-filtered by the C/OpenMP oracle on {co.num_threads()} threads (both call shapes, structure build '
+                      f'included); 1 NUNOCS forward amortised over {per_rank} candidates',
+            'net_only_ms_per_candidate': round(t_netonly * 1e3, 3), 'transform_ms_per_candidate': round(t_transform * 1e3, 3),
+            'net_plus_transform_candidates_per_s': round(1.0 / (t_transform + t_netonly), 2),
+            'collision_ms_per_evaluation': round(t_coll * 1e3, 5), 'nunocs_ms_per_object': round(t_nunocs_obj * 1e3, 1),
+            'thread_scan_ms_per_candidate': scan}
 
 
 def main():
@@ -156,12 +198,15 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--candidates', type=int, default=10000, help='grasp candidates per GPU per step')
+    ap.add_argument('--scaling', choices=['weak', 'strong'], default='weak')
+    ap.add_argument('--candidates', type=int, default=50000, help='weak scaling: grasp candidates per GPU per step (C3: 50,000)')
+    ap.add_argument('--candidates-total', type=int, default=200000, help='strong scaling: candidates per step over ALL GPUs (C4: 200,000)')
+    ap.add_argument('--precision', choices=['f32', 'f16x3', 'bf16x3'], default='f32',
+                    help='arithmetic of the timed path (`value`): f32 = exact-f32 MFMA (the reference\'s arithmetic); f16x3 / bf16x3 = split MFMA '
+                         'products (3 MFMAs on hi+lo 16-bit pieces, f32 accumulation; logits within ~2e-6 / ~2e-5 of the float64 evaluation)')
+    ap.add_argument('--secondary', default='f16x3,bf16x3', help='comma list of further precisions measured in the same run ("" = none)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--precision', choices=['f16x3', 'bf16x3', 'f32'], default='f16x3',
-                    help='arithmetic of the timed path: f16x3 / bf16x3 = split MFMA products (x = hi + lo half / bf16 pieces, 3 MFMAs per '
-                         'product block, f32 accumulation; logits within ~2e-6 / ~2e-5 of the float64 evaluation; bar 1e-4), f32 = exact-f32 MFMA')
-    ap.add_argument('--no-secondary', action='store_true', help='skip the second measurement with the other precision')
+    ap.add_argument('--no-api', action='store_true', help='skip the reference-API wall-clock block')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -182,101 +227,144 @@ def main():
             torch.distributed.init_process_group(backend, rank=rank, world_size=world)
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
 
-    from catgrasp_amd import ops, synth
+    from catgrasp_amd import distributed as cgd
+    from catgrasp_amd import engine, ops, synth
     from catgrasp_amd.predicter import DEFAULT_GRASP_CFG, DEFAULT_NUNOCS_CFG, GraspPredicter, NunocsPredicter
+    from catgrasp_amd.workload import SceneBatch
+    strong = args.scaling == 'strong'
+    cat = 'screw' if strong else 'nut'
     sd_cls = synth.make_state_dict('cls', 6, 10, seed=0)
     sd_seg = synth.make_state_dict('seg', 6, 300, seed=1)
-    gp = GraspPredicter('nut', cfg=DEFAULT_GRASP_CFG, state_dict=sd_cls, device=device)
-    npred = NunocsPredicter('nut', cfg=DEFAULT_NUNOCS_CFG, state_dict=sd_seg, device=device)
-    G = args.candidates
-    wl = build_workload(device, G, seed=rank)
-    gather_buf = torch.empty((world * G, 2), dtype=torch.float32, device=device) if world > 1 else None
+    gp = GraspPredicter(cat, cfg=DEFAULT_GRASP_CFG, state_dict=sd_cls, device=device)
+    npred = NunocsPredicter(cat, cfg=DEFAULT_NUNOCS_CFG, state_dict=sd_seg, device=device)
+    if strong:      # C4: one fixed batch cut into `world` contiguous slices
+        n_total = args.candidates_total
+        per, bounds = cgd.shard_bounds(n_total, world)
+        batch = SceneBatch(device, gp, npred, kind='screw', n_objects=16, pts_per_object=2500, per_replica=n_total, replicas=1,
+                           materialize=bounds[rank])
+    else:           # C3: every rank scores its own replica of the candidate set (global order is replica-major: slice r == replica r)
+        n_total = args.candidates * world
+        batch = SceneBatch(device, gp, npred, kind='nut', n_objects=8, pts_per_object=2500, per_replica=args.candidates, replicas=world,
+                           materialize=(rank * args.candidates, (rank + 1) * args.candidates))
+    assert batch.n_total == n_total
 
     def barrier():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    from catgrasp_amd import engine
-
     def measure(precision):
         engine.set_precision(precision)
+        marks = []
         with torch.no_grad():
             for _ in range(args.warmup):
-                run_step(wl, gp, npred, gather_buf, world)
+                cgd.score_sharded(batch.score_slice, n_total)
             barrier()
-            ops.KERNEL_TIMER = {'mid_mode': 2, 'events': []}
+            ops.KERNEL_TIMER = {'mid_mode': 2, 'events': [], 'bgi_events': []}
             t0 = time.perf_counter()
             for _ in range(args.steps):
-                out = run_step(wl, gp, npred, gather_buf, world)
+                out = cgd.score_sharded(batch.score_slice, n_total, marks=marks)
             barrier()
-            dt = time.perf_counter() - t0
+            dt_local = time.perf_counter() - t0
             timer, ops.KERNEL_TIMER = ops.KERNEL_TIMER, None
-        t = torch.tensor([dt], dtype=torch.float64, device=device if backend == 'nccl' else 'cpu')
+        t = torch.tensor([dt_local], dtype=torch.float64, device=device if backend == 'nccl' else 'cpu')
         if world > 1:
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
+        score_ms = float(np.mean([a.elapsed_time(b) for a, b, _ in marks]))
+        gather_ms = float(np.mean([b.elapsed_time(c) for _, b, c in marks]))
+        per_rank = [score_ms, gather_ms, dt_local / args.steps * 1e3]
+        if world > 1:
+            lst = [None] * world
+            torch.distributed.all_gather_object(lst, per_rank)
+            per_rank = lst
+        else:
+            per_rank = [per_rank]
         ev = timer['events']
         k_ms = [a.elapsed_time(b) for a, b, _ in ev]
-        k_flops = [2.0 * MAC_PER_POINT_ENC * B * N for _, _, (B, N) in ev]
-        avg_ms = float(np.mean(k_ms)) if k_ms else float('nan')
-        achieved = float(np.mean(k_flops)) / (avg_ms * 1e-3) / 1e12 if k_ms else float('nan')
-        avg_B = float(np.mean([B * N / 2048.0 for _, _, (B, N) in ev])) if ev else None
-        return dt, avg_ms, achieved, len(k_ms), out, avg_B
+        cand = [B * N / 2048.0 for _, _, (B, N) in ev]
+        res = {'dt': dt, 'out': out, 'launches': len(k_ms), 'per_rank': per_rank,
+               'avg_ms': float(np.mean(k_ms)) if k_ms else float('nan'), 'avg_cand': float(np.mean(cand)) if cand else 0.0}
+        res['tflops'] = 2.0 * MAC_PER_POINT_ENC * 2048 * res['avg_cand'] / (res['avg_ms'] * 1e-3) / 1e12 if k_ms else float('nan')
+        bgi = timer['bgi_events']
+        if bgi:
+            b_ms = float(np.mean([a.elapsed_time(b) for a, b, _ in bgi]))
+            b_bytes = float(np.mean([g * (2048 * (4 + 24) + 48) for _, _, g in bgi])) + batch.cloud_xyz.numel() * 8
+            res['bgi'] = {'bound': 'hbm', 'kernel': 'build_grasp_input_staged_kernel (gather resampled points + pose transform; 24 B written + 4 B id read per point)',
+                          'achieved': round(b_bytes / (b_ms * 1e-3) / 1e9, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                          'frac': round(b_bytes / (b_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), 'avg_launch_ms': round(b_ms, 4), 'launches': len(bgi),
+                          'algorithmic_bytes_per_launch': int(b_bytes)}
+        return res
 
-    def roofline(precision, achieved, avg_ms, n, avg_B=None):
-        def traffic(prec):
-            per = PMC_HBM_BYTES_PER_CANDIDATE.get(prec)
-            return None if (per is None or avg_B is None) else int(per * avg_B)
+    def roofline(precision, r):
+        per = PMC_HBM_BYTES_PER_CANDIDATE[precision]
+        hbm_gbs = ALG_HBM_BYTES_PER_CANDIDATE * r['avg_cand'] / (r['avg_ms'] * 1e-3) / 1e9
+        common = {'achieved': round(r['tflops'], 2), 'unit': 'TFLOP/s', 'avg_launch_ms': round(r['avg_ms'], 4), 'launches': r['launches'],
+                  'candidates_per_launch': round(r['avg_cand'], 1), 'flop_per_candidate_launch': 2 * MAC_PER_POINT_ENC * 2048,
+                  'traffic': int(per * r['avg_cand']),
+                  'traffic_source': 'constant from profiles/r1_pmc_pointmlp.csv (2*FETCH_SIZE + WRITE_SIZE per candidate at B=4096) x candidates per '
+                                    'launch -- not a counter read in this run; algorithmic bytes are 69,632 B/candidate',
+                  'hbm_achieved_gbs': round(hbm_gbs, 1), 'hbm_frac': round(hbm_gbs / PEAK_HBM_GBS, 5)}
         if precision == 'f32':
-            return {'bound': 'mfma', 'kernel': 'pointmlp_max_kernel<2> (encoder pass: conv1, x.T64, conv2, conv3, max; exact-f32 MFMA)',
-                    'achieved': round(achieved, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                    'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': traffic('f32'), 'traffic_unit': 'HBM bytes per launch (PMC)',
-                    'avg_launch_ms': round(avg_ms, 4),
-                    'launches': n, 'flop_per_candidate_launch': 2 * MAC_PER_POINT_ENC * 2048}
+            return dict({'bound': 'mfma', 'kernel': 'pointmlp_max_kernel<2> (encoder pass: conv1, x.T64, conv2, conv3, max; exact-f32 MFMA)',
+                         'peak': PEAK_F32_MFMA_TFLOPS, 'frac': round(r['tflops'] / PEAK_F32_MFMA_TFLOPS, 4)}, **common)
         el = 'f16' if precision == 'f16x3' else 'bf16'
-        return {'bound': 'mfma', 'kernel': f'pointmlp_max_split_kernel<2, 8, {"true" if el == "f16" else "false"}> (encoder pass; 3 {el} MFMAs per algorithmic product block)',
-                'achieved': round(achieved, 2), 'peak': PEAK_BF16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': round(achieved / PEAK_BF16_MFMA_TFLOPS, 4), 'traffic': traffic(precision), 'traffic_unit': 'HBM bytes per launch (PMC)',
-                'avg_launch_ms': round(avg_ms, 4),
-                'launches': n, 'flop_per_candidate_launch': 2 * MAC_PER_POINT_ENC * 2048,
-                'issued_mfma_tflops': round(3 * achieved, 1), 'issued_frac': round(3 * achieved / PEAK_BF16_MFMA_TFLOPS, 4),
-                'note': 'achieved counts ALGORITHMIC flops; the split issues 3 16-bit MFMA flops per algorithmic flop, '
-                        'so the ceiling for algorithmic flops is peak/3 = 833 TFLOP/s (f16 and bf16 MFMA share the 2.5 PFLOP/s dense peak)'}
+        return dict({'bound': 'mfma',
+                     'kernel': f'pointmlp_max_split_kernel<2, 8, {"true" if el == "f16" else "false"}> (encoder pass; 3 {el} MFMAs per algorithmic product block)',
+                     'peak': PEAK_16BIT_MFMA_TFLOPS, 'frac': round(r['tflops'] / PEAK_16BIT_MFMA_TFLOPS, 4),
+                     'issued_mfma_tflops': round(3 * r['tflops'], 1), 'issued_frac': round(3 * r['tflops'] / PEAK_16BIT_MFMA_TFLOPS, 4),
+                     'note': 'achieved counts ALGORITHMIC flops; the split issues 3 16-bit MFMA flops per algorithmic flop, so the ceiling for '
+                             'algorithmic flops is peak/3 = 833 TFLOP/s'}, **common)
 
-    dt, avg_ms, achieved, n_launch, out, avg_B = measure(args.precision)
-    secondary = None
-    if not args.no_secondary:
-        other = 'f32' if args.precision != 'f32' else 'f16x3'
-        ref_out = out.clone()
-        dt2, avg2, ach2, n2, out2, avg_B2 = measure(other)
-        pg_diff = float((out2[:, 0] - ref_out[:, 0]).abs().max().item())
-        secondary = {'precision': other, 'value': round(world * G * args.steps / dt2, 1), 'ms_per_step': round(dt2 / args.steps * 1e3, 3),
-                     'roofline': roofline(other, ach2, avg2, n2, avg_B2), 'max_abs_p_G_difference_between_precisions': pg_diff,
-                     'codes_identical': bool(torch.equal(out2[:, 1], ref_out[:, 1]))}
-        engine.set_precision(args.precision)
+    prim = measure(args.precision)
+    ref_out = prim['out'].clone()
+    secondary = []
+    for other in [p for p in args.secondary.split(',') if p and p != args.precision]:
+        r = measure(other)
+        secondary.append({'precision': other, 'dtype': DTYPE[other], 'value': round(n_total * args.steps / r['dt'], 1),
+                          'ms_per_step': round(r['dt'] / args.steps * 1e3, 3), 'roofline': roofline(other, r),
+                          'max_abs_p_G_difference_vs_primary': float((r['out'][:, 0] - ref_out[:, 0]).abs().max().item()),
+                          'codes_identical_to_primary': bool(torch.equal(r['out'][:, 1], ref_out[:, 1]))})
+    engine.set_precision(args.precision)
 
     if rank == 0:
-        ms_step = dt / args.steps * 1e3
-        value = world * G * args.steps / dt
+        dt = prim['dt']
+        codes = ref_out[:, 1].long()
         line = {
-            'metric': 'grasp candidates scored+collision-checked /sec, 20k-pt clutter scene',
-            'value': round(value, 1), 'unit': 'candidates/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': round(ms_step, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32' if args.precision == 'f32' else
-                     f'f32 in/out/accumulate; wide-layer products as 3x {"f16" if args.precision == "f16x3" else "bf16"} MFMA ({args.precision} split)',
+            'metric': 'grasp candidates scored+collision-checked /sec, 20k-pt clutter scene' if not strong else
+                      'grasp candidates scored+collision-checked /sec, 40k-pt scene, candidates sharded over the GPUs',
+            'value': round(n_total * args.steps / dt, 1), 'unit': 'candidates/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None,
+            'dtype': DTYPE[args.precision],
             'data': 'synthetic (seeded clouds/candidates/gripper, random-init weights)',
-            'config': {'workload': 'nut clutter pile, 20k-pt scene (8 objects x 2500 pts), '
-                                   f'{G} candidates/GPU: NUNOCS(8x8192) + filterGraspPose + grasp-Q PointNetCls(2048x6)',
-                       'candidates_per_gpu': G, 'scene_points': int(wl['cloud_xyz'].shape[0]), 'parallelism': f'candidate-shard x{world}'},
-            'roofline': roofline(args.precision, achieved, avg_ms, n_launch, avg_B),
+            'config': {'workload': ('C4 (BASELINE.json configs[3]): screw category, 40k-pt scene (16 objects x 2500 pts), '
+                                    f'{n_total} candidates in total over {world} GPU(s)' if strong else
+                                    'C3 (BASELINE.json configs[2]): nut clutter pile, 20k-pt scene (8 objects x 2500 pts), '
+                                    f'{args.candidates} candidates/GPU') +
+                                   f': NUNOCS PointNetSeg(8192x6) per object + filterGraspPose [canonical grasps x {batch.n_sym} symmetries with '
+                                   'adjust_collision_pose=True (grasp_sampler.py:345) and cone poses with symmetry=[I] (grasp_sampler.py:216)] + '
+                                   'device pose inverse + per-candidate resampling draw + grasp-Q PointNetCls(2048x6) + softmax/p_G for EVERY candidate',
+                       'candidates_per_gpu': n_total // world, 'candidates_total': n_total, 'scene_points': int(batch.cloud_xyz.shape[0]),
+                       'symmetries': batch.n_sym,
+                       'evaluations_nocs_shape_adjust_true': int(sum(s.count for s in batch.segs if s.kind == 'nocs')),
+                       'evaluations_cone_shape_adjust_false': int(sum(s.count for s in batch.segs if s.kind == 'cone')),
+                       'reject_code_histogram_0keep_1dir_2ik_3open_4enclosed': torch.bincount(codes, minlength=5).tolist(),
+                       'parallelism': f'candidate-shard x{world} ({args.scaling})'},
+            'roofline': roofline(args.precision, prim),
+            'per_rank_ms': {'columns': ['local scoring (HIP events)', 'all_gather of the (p_G, code) records (HIP events)', 'step wall-clock'],
+                            'ranks': [[round(v, 3) for v in pr] for pr in prim['per_rank']]},
         }
-        if secondary is not None:
+        if 'bgi' in prim:
+            line['roofline_hbm'] = prim['bgi']
+        if secondary:
             line['secondary'] = secondary
+        if world == 1 and not args.no_api:
+            line['api'] = api_block(batch, gp, device)
         if world == 1 and not args.no_cpu_baseline:
-            line['cpu_baseline'] = cpu_baseline(wl, sd_cls, sd_seg)
+            line['cpu_baseline'] = cpu_baseline(batch, sd_cls, sd_seg)
         print(json.dumps(line), flush=True)
     if world > 1:
+        torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 
 

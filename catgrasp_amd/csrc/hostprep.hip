@@ -60,13 +60,14 @@ struct Stream {
 // spread over the banks; n_pts steps of Fisher-Yates give a uniform n_pts-subset in uniform order, which is what
 // np.random.choice(replace=False) returns.  Outputs leave in 16-byte groups per lane.
 __global__ __launch_bounds__(64) void draw_ids_perm_kernel(int n_valid, int n_pts, long count, unsigned k0, unsigned k1,
-                                                           int base, int R, int* __restrict__ out) {
+                                                           int base, int R, long row_offset, int* __restrict__ out) {
   extern __shared__ unsigned short perm[];
   const int r = threadIdx.x;
   const long row = (long)blockIdx.x * R + r;
   if (r >= R || row >= count) return;
   for (int k = 0; k < n_valid; ++k) perm[(size_t)k * R + r] = (unsigned short)k;
-  Stream s{k0, k1, (unsigned)row, (unsigned)(row >> 32) << 24, U4{0, 0, 0, 0}, 0};
+  const long grow = row + row_offset;          // the stream is a function of the GLOBAL row: a shard draws what the whole would
+  Stream s{k0, k1, (unsigned)grow, (unsigned)(grow >> 32) << 24, U4{0, 0, 0, 0}, 0};
   int* o = out + row * n_pts;
   const bool vec = ((n_pts & 3) == 0) && (((uintptr_t)out & 15) == 0);
   int q[4];
@@ -86,11 +87,12 @@ __global__ __launch_bounds__(64) void draw_ids_perm_kernel(int n_valid, int n_pt
 
 // n_valid < n_pts (or a cloud too large for the LDS permutation): iid uniform indices = np.random.choice(replace=True)
 __global__ __launch_bounds__(256) void draw_ids_iid_kernel(int n_valid, int n_pts, long count, unsigned k0, unsigned k1,
-                                                           int base, int* __restrict__ out) {
+                                                           int base, long row_offset, int* __restrict__ out) {
   const long total = count * n_pts;
   const long g = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (g >= total) return;
-  Stream s{k0, k1 ^ 0x5bd1e995u, (unsigned)(g >> 2), (unsigned)(g >> 34) << 24, U4{0, 0, 0, 0}, 0};
+  const long gg = g + row_offset * n_pts;      // n_pts % 4 == 0 (checked by the launcher): quads never straddle rows
+  Stream s{k0, k1 ^ 0x5bd1e995u, (unsigned)(gg >> 2), (unsigned)(gg >> 34) << 24, U4{0, 0, 0, 0}, 0};
   for (int k = 0; k < 4 && g + k < total; ++k) out[g + k] = (int)s.below((unsigned)n_valid) + base;
 }
 
@@ -183,8 +185,9 @@ inline bool geom_ok(const double* o, double cell, double inflate, const int* dim
 
 }  // namespace
 
-extern "C" int cg_draw_resample_ids(int n_valid, int n_pts, long count, unsigned long long seed, int base, int* out, void* stream) {
-  if (n_valid <= 0 || n_pts <= 0 || count < 0) return CG_ERR_ARG;
+extern "C" int cg_draw_resample_ids(int n_valid, int n_pts, long count, unsigned long long seed, int base, long row_offset, int* out,
+                                    void* stream) {
+  if (n_valid <= 0 || n_pts <= 0 || count < 0 || row_offset < 0) return CG_ERR_ARG;
   if (count == 0) return CG_OK;
   if (!out) return CG_ERR_ARG;
   const unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
@@ -200,13 +203,14 @@ extern "C" int cg_draw_resample_ids(int n_valid, int n_pts, long count, unsigned
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
         if (e != hipSuccess) return (int)e;
       }
-      hipLaunchKernelGGL(kern, dim3((unsigned)((count + R - 1) / R)), dim3(64), bytes, s, n_valid, n_pts, count, k0, k1, base, R, out);
+      hipLaunchKernelGGL(kern, dim3((unsigned)((count + R - 1) / R)), dim3(64), bytes, s, n_valid, n_pts, count, k0, k1, base, R, row_offset, out);
       return cg_hip_status(hipGetLastError());
     }
   }
   if (n_valid >= n_pts) return CG_ERR_UNSUPPORTED;       // without replacement from > 65535 points: not on this path
+  if ((n_pts & 3) != 0) return CG_ERR_UNSUPPORTED;
   const long total = count * n_pts;
-  hipLaunchKernelGGL(draw_ids_iid_kernel, dim3((unsigned)((total + 1023) / 1024)), dim3(256), 0, s, n_valid, n_pts, count, k0, k1, base, out);
+  hipLaunchKernelGGL(draw_ids_iid_kernel, dim3((unsigned)((total + 1023) / 1024)), dim3(256), 0, s, n_valid, n_pts, count, k0, k1, base, row_offset, out);
   return cg_hip_status(hipGetLastError());
 }
 

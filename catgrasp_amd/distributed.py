@@ -19,32 +19,45 @@ def shard_bounds(n_total, world):
 
 def gather_records(local_rec, per, n_total, group=None):
     """local_rec: (n_local, C) tensor of this rank's slice (n_local <= per).  Pads to `per` rows (all_gather
-    needs equal counts), gathers over all ranks in one collective and trims to (n_total, C), in candidate order."""
+    needs equal counts), gathers over all ranks in one collective and trims to (n_total, C), in candidate order.
+    Device tensors go through ONE all_gather_into_tensor (RCCL over xGMI); under a gloo group (CPU tests, 1-GPU dev runs)
+    the same buffers are exchanged through host memory."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1:
         return local_rec[:n_total]
     C = local_rec.shape[1]
     buf = torch.zeros((per, C), dtype=local_rec.dtype, device=local_rec.device)
     buf[:local_rec.shape[0]] = local_rec
-    out = torch.empty((world * per, C), dtype=local_rec.dtype, device=local_rec.device)
-    if local_rec.is_cuda:
+    if dist.get_backend(group) == 'nccl':
+        out = torch.empty((world * per, C), dtype=local_rec.dtype, device=local_rec.device)
         dist.all_gather_into_tensor(out, buf, group=group)
-    else:   # gloo (CPU tests)
-        parts = [torch.empty_like(buf) for _ in range(world)]
-        dist.all_gather(parts, buf, group=group)
-        out = torch.cat(parts, 0)
+    else:
+        hbuf = buf.cpu()
+        parts = [torch.empty_like(hbuf) for _ in range(world)]
+        dist.all_gather(parts, hbuf, group=group)
+        out = torch.cat(parts, 0).to(local_rec.device)
     return out[:n_total]
 
 
-def score_sharded(score_fn, n_total, group=None):
+def score_sharded(score_fn, n_total, group=None, marks=None):
     """Run score_fn(lo, hi) -> (hi-lo, C) on this rank's slice and return the full (n_total, C) record array
-    on every rank.  score_fn sees global candidate indices."""
+    on every rank.  score_fn sees global candidate indices.  `marks` (optional list): receives three device events per call
+    -- start, after the local scoring, after the gather -- for per-phase timing."""
     if dist.is_initialized():
         rank, world = dist.get_rank(group), dist.get_world_size(group)
     else:
         rank, world = 0, 1
     per, bounds = shard_bounds(n_total, world)
     lo, hi = bounds[rank]
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if marks is not None else None
+    if ev:
+        ev[0].record()
     rec = score_fn(lo, hi)
     assert rec.shape[0] == hi - lo
-    return gather_records(rec, per, n_total, group)
+    if ev:
+        ev[1].record()
+    out = gather_records(rec, per, n_total, group)
+    if ev:
+        ev[2].record()
+        marks.append(ev)
+    return out

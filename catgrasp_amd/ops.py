@@ -11,7 +11,7 @@ _c_long = ctypes.c_long
 
 # bench.py hook: when set to {'mid_mode': m, 'events': []}, every cg_pointmlp_max launch with that mid_mode is
 # bracketed by HIP events on the launch stream (torch's current stream) so the kernel's average duration can be
-# measured live over the timed region.
+# measured live over the timed region; with a 'bgi_events' list, every cg_build_grasp_input launch too.
 KERNEL_TIMER = None
 
 
@@ -109,9 +109,16 @@ def build_grasp_input(cloud_xyz, cloud_normal, ids, pose_inv, mean=None, inv_std
     assert pose_inv.shape == (G, 12)
     if out is None:
         out = torch.empty((G, n_pts, 6), dtype=torch.float32, device=ids.device)
-    check(L.lib().cg_build_grasp_input(_p(cloud_xyz), _p(cloud_normal), _c_int(cloud_xyz.shape[0]), _p(ids), _p(pose_inv),
-                                       _p(mean), _p(inv_std), _c_int(G), _c_int(n_pts), _p(out), _stream()),
-          'cg_build_grasp_input')
+    timer = KERNEL_TIMER if (KERNEL_TIMER is not None and 'bgi_events' in KERNEL_TIMER) else None
+    if timer is not None:
+        ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    st = L.lib().cg_build_grasp_input(_p(cloud_xyz), _p(cloud_normal), _c_int(cloud_xyz.shape[0]), _p(ids), _p(pose_inv),
+                                      _p(mean), _p(inv_std), _c_int(G), _c_int(n_pts), _p(out), _stream())
+    if timer is not None:
+        ev1.record()
+        timer['bgi_events'].append((ev0, ev1, G))
+    check(st, 'cg_build_grasp_input')
     return out
 
 

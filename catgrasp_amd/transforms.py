@@ -29,11 +29,12 @@ def draw_ids_reference(n_valid, n_pts, count):
 _draw_counter = [0]
 
 
-def draw_ids_device(n_valid, n_pts, count, device, generator=None, seed=None, base=0, out=None):
+def draw_ids_device(n_valid, n_pts, count, device, generator=None, seed=None, base=0, out=None, row_offset=0):
     """The same draw on the device (cg_draw_resample_ids; NOT numpy's stream): per row a uniform n_pts-subset of
     [0,n_valid) in uniform order when n_valid >= n_pts (= np.random.choice(replace=False)), iid uniform indices otherwise
     (= replace=True).  Counter-based: `seed` (or the next draw of `generator`, or a process-wide counter seeded from numpy's
-    global generator) fixes every row.  -> (count, n_pts) int32 cuda tensor, each id offset by `base`."""
+    global generator) and the global row index `row_offset + r` fix every row, so a shard of a batch draws what the whole batch
+    would.  -> (count, n_pts) int32 cuda tensor, each id offset by `base`."""
     import ctypes
     from . import _lib as L
     if seed is None:
@@ -48,10 +49,13 @@ def draw_ids_device(n_valid, n_pts, count, device, generator=None, seed=None, ba
         out = torch.empty((count, n_pts), dtype=torch.int32, device=device)
     assert out.shape == (count, n_pts) and out.dtype == torch.int32 and out.is_contiguous() and out.is_cuda
     st = L.lib().cg_draw_resample_ids(ctypes.c_int(n_valid), ctypes.c_int(n_pts), ctypes.c_long(count), ctypes.c_ulonglong(seed & (2 ** 64 - 1)),
-                                      ctypes.c_int(base), L._p(out), L._stream())
-    if st == -2:        # CG_ERR_UNSUPPORTED: without replacement from > 65535 points -- random-key sort instead
-        keys = torch.rand((count, n_valid), device=device, generator=generator)
-        out.copy_(keys.argsort(dim=1)[:, :n_pts].to(torch.int32) + base)
+                                      ctypes.c_int(base), ctypes.c_long(row_offset), L._p(out), L._stream())
+    if st == -2:        # CG_ERR_UNSUPPORTED: a shape outside the kernel's (without replacement from > 65535 points; n_pts % 4 != 0)
+        gen = torch.Generator(device=device); gen.manual_seed((seed + 0x9E3779B97F4A7C15 * (row_offset + 1)) % (2 ** 63))
+        if n_valid < n_pts:
+            out.copy_(torch.randint(0, n_valid, (count, n_pts), device=device, generator=gen, dtype=torch.int32) + base)
+        else:
+            out.copy_(torch.rand((count, n_valid), device=device, generator=gen).argsort(dim=1)[:, :n_pts].to(torch.int32) + base)
         return out
     L.check(st, 'cg_draw_resample_ids')
     return out

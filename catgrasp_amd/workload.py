@@ -1,0 +1,230 @@
+"""The hot path over one scene as ONE shardable batch of candidate evaluations -- what bench.py times and what the multi-GPU
+path partitions (catgrasp_amd/distributed.py).
+
+Per object the reference's CombinedGraspSampler (dexnet/grasping/grasp_sampler.py:360-370) produces candidates through two
+filterGraspPose call shapes, and every survivor is scored by GraspPredicter.predict_batch (run_grasp_simulation.py:296-319):
+  * 'nocs' segment  grasp_sampler.py:345 -- canonical grasps x the category's symmetry transforms (nut 12, hnm 2, screw 72;
+                    Utils.py:79-94), nocs_pose = the object's NUNOCS 9-D pose, adjust_collision_pose=True;
+  * 'cone' segment  grasp_sampler.py:216 -- camera-frame cone-sampler poses, symmetry_tfs=[I], nocs_pose=I.
+A candidate = one (pose, symmetry) evaluation.  The batch is the concatenation of all segments in a fixed global order; any
+contiguous slice [lo, hi) of it can be evaluated independently of the rest (read-only scene data is replicated), and the result
+of a slice does not depend on how the batch was cut: shard union == whole, bit for bit (tests/test_workload_gpu.py).
+
+The planning / slicing arithmetic is plain python (covered on CPU, also under a 2-rank gloo group with the device stages replaced
+at the tensor level: tests/test_distributed_gloo.py); `SceneBatch` holds the device state and issues the kernels.
+"""
+from dataclasses import dataclass
+
+import numpy as np
+
+SYMMETRY_COUNT = {'nut': 12, 'hnm': 2, 'screw': 72}        # Utils.py:79-94
+
+
+@dataclass(frozen=True)
+class Segment:
+    replica: int        # weak scaling: which rank's copy of the candidate set (same scene, different candidate seeds)
+    obj: int
+    kind: str           # 'nocs' | 'cone'
+    n_pose: int
+    n_sym: int
+    start: int          # global index of the segment's first evaluation
+    adjust: bool
+
+    @property
+    def count(self):
+        return self.n_pose * self.n_sym
+
+
+def plan_segments(n_objects, per_replica, n_sym, replicas=1, nocs_fraction=0.5):
+    """Global evaluation order: replica-major, then object, then [nocs segment, cone segment].  `per_replica` evaluations are
+    split evenly over the objects (remainder to the first ones); within an object ~nocs_fraction of them come from canonical
+    grasps x n_sym symmetries (adjust=True) and the rest from cone poses (adjust=False).  -> (segments, n_total)."""
+    segs, start = [], 0
+    for r in range(replicas):
+        for k in range(n_objects):
+            per = per_replica // n_objects + (1 if k < per_replica % n_objects else 0)
+            n_can = int(round(per * nocs_fraction / n_sym))
+            n_cone = per - n_can * n_sym
+            if n_cone < 0:
+                n_can, n_cone = per // n_sym, per - (per // n_sym) * n_sym
+            for kind, n_pose, ns, adj in (('nocs', n_can, n_sym, True), ('cone', n_cone, 1, False)):
+                if n_pose > 0:
+                    segs.append(Segment(r, k, kind, n_pose, ns, start, adj))
+                    start += n_pose * ns
+    return segs, start
+
+
+def intersect(segs, lo, hi):
+    """Segments touched by the global slice [lo, hi) with the local evaluation range of each: [(segment, a, b)]."""
+    out = []
+    for s in segs:
+        a, b = max(lo, s.start) - s.start, min(hi, s.start + s.count) - s.start
+        if a < b:
+            out.append((s, a, b))
+    return out
+
+
+def split_eval_range(n_sym, a, b):
+    """Evaluations [a, b) of an (n_pose x n_sym) block (e = i*n_sym + j) as at most three full rectangles
+    (i0, i1, j0, j1) in evaluation order -- what one filterGraspPose call (poses [i0,i1) x symmetries [j0,j1)) can express:
+    a partial head group, the whole groups in the middle, a partial tail group."""
+    out = []
+    if a >= b:
+        return out
+    i0, j0 = divmod(a, n_sym)
+    i1, j1 = divmod(b, n_sym)
+    if i0 == i1:
+        return [(i0, i0 + 1, j0, j1)]
+    if j0:
+        out.append((i0, i0 + 1, j0, n_sym)); i0 += 1
+    if i1 > i0:
+        out.append((i0, i1, 0, n_sym))
+    if j1:
+        out.append((i1, i1 + 1, 0, j1))
+    return out
+
+
+def pack_records(p_g, codes):
+    """The per-candidate record that crosses xGMI: (p_G, reject code) as two float32 lanes, 8 B/candidate."""
+    import torch
+    return torch.stack([p_g.float(), codes.float()], dim=1).contiguous()
+
+
+class SceneBatch:
+    """Device state of one synthetic scene + its candidate batch (SURVEY.md §8(d) inputs).  `score_slice(lo, hi)` runs the hot
+    path over global evaluations [lo, hi): NUNOCS net over the slice's objects -> filterGraspPose (both call shapes) -> device
+    pose inversion + resampling draw + grasp-Q net -> packed (p_G, code) records."""
+
+    def __init__(self, device, grasp_predicter, nunocs_predicter, kind='nut', n_objects=8, pts_per_object=2500, per_replica=50000,
+                 replicas=1, scene_seed=0, nocs_scale=0.02, materialize=None):
+        # materialize: (lo, hi) global evaluation range whose candidate poses are generated up front (default: all)
+        import torch
+        from . import my_cpp, synth, transforms
+        self.device, self.gp, self.npred, self.kind = device, grasp_predicter, nunocs_predicter, kind
+        self.objs = synth.make_scene(n_objects, pts_per_object, seed=scene_seed, kind=kind)       # same scene on every rank
+        self.gripper = synth.make_gripper()
+        cat = 'nut' if kind == 'nut' else 'screw'
+        self.n_sym = SYMMETRY_COUNT[cat]
+        self.segs, self.n_total = plan_segments(n_objects, per_replica, self.n_sym, replicas)
+        self.sym = torch.from_numpy(np.stack(transforms.get_symmetry_tfs(cat)).astype(np.float32).reshape(-1, 16)).to(device)
+        self.eye = torch.eye(4, device=device).reshape(1, 16).contiguous()
+        self.clouds, self.offsets, self.scenes, self.nocs_pose = [], [], [], []
+        off = 0
+        for k, ob in enumerate(self.objs):
+            dc = transforms.DeviceCloud(ob['xyz'], ob['normal'], device)
+            self.clouds.append(dc); self.offsets.append(off); off += dc.n
+            bg = synth.background_points(self.objs, k, self.gripper['diameter'])
+            g = self.gripper
+            self.scenes.append(my_cpp.GripperScene(g['vertices'], g['faces'], g['enclosed_vertices'], g['enclosed_faces'], ob['xyz'], bg,
+                                                   0.0005, device))
+            self.nocs_pose.append(ob['pose'] @ np.diag([nocs_scale, nocs_scale, nocs_scale, 1.0]))
+        self.cloud_xyz = torch.cat([c.xyz for c in self.clouds]).contiguous()
+        self.cloud_normal = torch.cat([c.normal for c in self.clouds]).contiguous()
+        gen = torch.Generator(device=device); gen.manual_seed(1234)
+        n_n = nunocs_predicter.cfg['n_pts'] if nunocs_predicter is not None else 8192
+        self.nunocs_ids = torch.stack([transforms.draw_ids_device(c.n, n_n, 1, device, gen, base=o)[0]
+                                       for c, o in zip(self.clouds, self.offsets)]).contiguous()
+        self._poses = {}
+        self._streams = [torch.cuda.Stream(device=device) for _ in range(n_objects)]
+        self.draw_seed = 0x5eed
+        lo, hi = (0, self.n_total) if materialize is None else materialize        # a rank only builds the segments it will evaluate
+        for s, _, _ in intersect(self.segs, lo, hi):
+            self.segment_poses(s)
+
+    # ---- candidate poses of a segment: a deterministic function of (replica, object, kind), so any rank can build any segment
+    def segment_poses(self, seg):
+        import torch
+        from . import synth
+        key = (seg.replica, seg.obj, seg.kind)
+        if key not in self._poses:
+            rng = np.random.default_rng([1000 + seg.replica, seg.obj, 0 if seg.kind == 'nocs' else 1])
+            P = synth.make_candidates(self.objs[seg.obj], seg.n_pose, rng, self.gripper['hand_depth'], self.gripper['init_bite'])
+            if seg.kind == 'nocs':          # canonical grasps live in the object's NUNOCS frame (grasp_sampler.py:337-339)
+                P = np.linalg.inv(self.nocs_pose[seg.obj]) @ P
+            self._poses[key] = torch.from_numpy(P.astype(np.float32).reshape(-1, 16)).to(self.device)
+        return self._poses[key]
+
+    def host_poses(self, seg):
+        return self.segment_poses(seg).cpu().numpy().astype(np.float64).reshape(-1, 4, 4)
+
+    # ---- device stages (replaced at the tensor level by the CPU control-flow test)
+    def run_nunocs(self, obj_ids):
+        import torch
+        ids = self.nunocs_ids[torch.as_tensor(obj_ids, device=self.device)]
+        return self.npred.nocs_on_device(self.cloud_xyz, self.cloud_normal, ids)
+
+    def run_filter(self, seg, i0, i1, j0, j1):
+        """-> codes (E) int8, grasp_in_cam (E,16) f32 (rejected evaluations keep their composed pose) for poses [i0,i1) x syms [j0,j1)."""
+        from . import my_cpp
+        I4 = np.eye(4, dtype=np.float32)
+        g = self.gripper
+        if seg.kind == 'nocs':
+            sym, nocs = self.sym[j0:j1], self.nocs_pose[seg.obj]
+        else:
+            sym, nocs = self.eye, I4
+        codes, poses, _ = my_cpp.filter_on_device(self.scenes[seg.obj], self.segment_poses(seg)[i0:i1], sym, nocs, I4, I4, I4,
+                                                  g['gripper_in_grasp'], True, False, seg.adjust, keep_rejected_pose=True)
+        return codes, poses.view(-1, 16)
+
+    def run_prep(self, obj, poses, row_offset, pinv_out, ids_out):
+        """grasp_in_cam (E,16) of one object -> rows of the scoring inputs: device pose inversion (re-expressed for the object's
+        centred cloud) and the per-candidate resampling draw of GraspDataset.transform, keyed by the GLOBAL evaluation index."""
+        from . import transforms
+        dc = self.clouds[obj]
+        pinv_out.copy_(transforms.pose_inverse_rows_device(poses, dc.center))
+        transforms.draw_ids_device(dc.n, self.gp.cfg['n_pts'], poses.shape[0], self.device, seed=self.draw_seed,
+                                   base=self.offsets[obj], row_offset=row_offset, out=ids_out)
+
+    def run_net(self, ids, pinv):
+        """-> p_G (E): input transform + PointNetCls + softmax + p_G for every candidate of the slice in one batch."""
+        return self.gp.score_on_device(self.cloud_xyz, self.cloud_normal, ids, pinv)[3]
+
+    def alloc(self, n):
+        import torch
+        return (torch.empty((n, 12), dtype=torch.float32, device=self.device),
+                torch.empty((n, self.gp.cfg['n_pts']), dtype=torch.int32, device=self.device))
+
+    # ---- the step
+    def score_slice(self, lo, hi):
+        import torch
+        parts = intersect(self.segs, lo, hi)
+        if not parts:
+            return torch.empty((0, 2), dtype=torch.float32, device=self.device)
+        self.run_nunocs(sorted({s.obj for s, _, _ in parts}))
+        # filter: the per-segment kernels are small (a few thousand wavefronts), so objects run concurrently on side streams
+        on_gpu = self.device.type == 'cuda'
+        if on_gpu:
+            main = torch.cuda.current_stream()
+            fork = torch.cuda.Event(); fork.record(main)
+        codes, poses = [], []
+        for s, a, b in parts:
+            if on_gpu:
+                st = self._streams[s.obj]
+                ctx = torch.cuda.stream(st)
+                ctx.__enter__()
+                st.wait_event(fork)
+            try:
+                for i0, i1, j0, j1 in split_eval_range(s.n_sym, a, b):
+                    c, p = self.run_filter(s, i0, i1, j0, j1)
+                    codes.append(c); poses.append(p)
+            finally:
+                if on_gpu:
+                    ctx.__exit__(None, None, None)
+        if on_gpu:
+            for st in {self._streams[s.obj] for s, _, _ in parts}:
+                main.wait_stream(st)
+        codes = torch.cat(codes)
+        poses = torch.cat(poses)
+        # scoring inputs: one prep per run of consecutive evaluations of the same object (the pose inverse is per object cloud)
+        runs = []
+        for s, a, b in parts:
+            if runs and runs[-1][0] == s.obj and runs[-1][1] + runs[-1][2] == s.start + a:
+                runs[-1][2] += b - a
+            else:
+                runs.append([s.obj, s.start + a, b - a])
+        pinv, ids = self.alloc(hi - lo)
+        pos = 0
+        for obj, g0, n in runs:
+            self.run_prep(obj, poses[pos:pos + n], g0, pinv[pos:pos + n], ids[pos:pos + n])
+            pos += n
+        return pack_records(self.run_net(ids, pinv), codes)

@@ -201,8 +201,10 @@ int cg_mesh_grid_fill(const float* vertices, const int* faces, int n_faces, cons
  * replace = M < n_pts), once per pose in the loop of predicter.py:71-74) for `count` candidates at once:
  * out (count,n_pts) i32 = base + a uniform n_pts-subset of [0,n_valid) in uniform order (n_valid >= n_pts; partial
  * Fisher-Yates in LDS, n_valid <= 65535 else CG_ERR_UNSUPPORTED) or iid uniform indices (n_valid < n_pts).
- * Counter-based Philox4x32-10 keyed by `seed`: reproducible, but NOT numpy's stream. */
-int cg_draw_resample_ids(int n_valid, int n_pts, long count, unsigned long long seed, int base, int* out, void* stream);
+ * Counter-based Philox4x32-10 keyed by `seed` and the global row index row_offset + r: reproducible, independent of how a
+ * batch is split into calls (a GPU shard draws exactly what the unsharded batch would), but NOT numpy's stream. */
+int cg_draw_resample_ids(int n_valid, int n_pts, long count, unsigned long long seed, int base, long row_offset, int* out,
+                         void* stream);
 
 /* inv(grasp_pose) of dataset_grasp.py:69-70 for poses already on the device: poses (n,16) f32 row-major 4x4 with last
  * row 0 0 0 1 -> out (n,12) rows [R | t] with x_grasp = R x_centred + t, where x_centred = x_cam - h_center (HOST,

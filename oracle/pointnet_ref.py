@@ -197,3 +197,75 @@ def pointnet_seg_forward(state_dict, x, dtype=torch.float32):
     y = _conv_bn(y, sd, 'conv3', 'bn3', True)
     y = _conv_bn(y, sd, 'conv4', None, False)
     return y.permute(0, 2, 1), trans_feat
+
+
+# --------------------------------------------------------------------------------------
+# The same two forwards issued through the torch ops the reference's nn.Modules call (Conv1d -> F.conv1d,
+# BatchNorm1d(eval) -> F.batch_norm(training=False), Linear -> F.linear): the CPU baseline bench.py times, because it
+# costs what the reference's own CPU forward costs (the reference package itself cannot travel to the GPU box).
+# Checked against the explicit restatement above in tests/test_oracle_golden.py.
+# --------------------------------------------------------------------------------------
+def _nn_conv_bn(x, sd, conv, bn, relu):
+    import torch.nn.functional as F
+    y = F.conv1d(x, sd[conv + '.weight'], sd[conv + '.bias'])
+    if bn is not None:
+        y = F.batch_norm(y, sd[bn + '.running_mean'], sd[bn + '.running_var'], sd[bn + '.weight'], sd[bn + '.bias'], False, 0.1, BN_EPS)
+    return F.relu(y) if relu else y
+
+
+def _nn_fc_bn(x, sd, fc, bn, relu):
+    import torch.nn.functional as F
+    y = F.linear(x, sd[fc + '.weight'], sd[fc + '.bias'])
+    if bn is not None:
+        y = F.batch_norm(y, sd[bn + '.running_mean'], sd[bn + '.running_var'], sd[bn + '.weight'], sd[bn + '.bias'], False, 0.1, BN_EPS)
+    return F.relu(y) if relu else y
+
+
+def _nn_stn(sd, p, x, k):
+    x = _nn_conv_bn(x, sd, p + 'conv1', p + 'bn1', True)
+    x = _nn_conv_bn(x, sd, p + 'conv2', p + 'bn2', True)
+    x = _nn_conv_bn(x, sd, p + 'conv3', p + 'bn3', True)
+    x = torch.max(x, 2, keepdim=True)[0].view(-1, 1024)
+    x = _nn_fc_bn(x, sd, p + 'fc1', p + 'bn4', True)
+    x = _nn_fc_bn(x, sd, p + 'fc2', p + 'bn5', True)
+    x = _nn_fc_bn(x, sd, p + 'fc3', None, False)
+    return (x + torch.eye(k, dtype=x.dtype).reshape(1, k * k)).view(-1, k, k)
+
+
+def _nn_encoder(sd, p, x, global_feat):
+    B, D, N = x.shape
+    trans = _nn_stn(sd, p + 'stn.', x, 3)
+    xt = x.transpose(2, 1)
+    xt = torch.cat([torch.bmm(xt[:, :, :3], trans), xt[:, :, 3:]], dim=2)
+    x = _nn_conv_bn(xt.transpose(2, 1), sd, p + 'conv1', p + 'bn1', True)
+    trans_feat = _nn_stn(sd, p + 'fstn.', x, 64)
+    x = torch.bmm(x.transpose(2, 1), trans_feat).transpose(2, 1)
+    pointfeat = x
+    x = _nn_conv_bn(x, sd, p + 'conv2', p + 'bn2', True)
+    x = _nn_conv_bn(x, sd, p + 'conv3', p + 'bn3', False)
+    g = torch.max(x, 2, keepdim=True)[0].view(-1, 1024)
+    if global_feat:
+        return g, trans, trans_feat
+    return torch.cat([g.view(-1, 1024, 1).repeat(1, 1, N), pointfeat], 1), trans, trans_feat
+
+
+def prepared_state_dict(state_dict, dtype=torch.float32):
+    """Tensors of a reference-layout state_dict converted once (the nn-ops forwards accept the result as `state_dict`)."""
+    return _sd(state_dict, dtype)
+
+
+def pointnet_cls_forward_nnops(sd, x):
+    """PointNetCls.forward (pointnet2.py:289-299) through F.conv1d / F.batch_norm / F.linear; sd from prepared_state_dict."""
+    g, _, trans_feat = _nn_encoder(sd, 'feat.', torch.as_tensor(x).to(sd['fc1.weight'].dtype).permute(0, 2, 1), True)
+    y = _nn_fc_bn(g, sd, 'fc1', 'bn1', True)
+    y = _nn_fc_bn(y, sd, 'fc2', 'bn2', True)
+    return _nn_fc_bn(y, sd, 'fc3', None, False), trans_feat
+
+
+def pointnet_seg_forward_nnops(sd, x):
+    """PointNetSeg.forward (pointnet2.py:316-329) through the same torch ops."""
+    f, _, trans_feat = _nn_encoder(sd, 'feat.', torch.as_tensor(x).to(sd['conv1.weight'].dtype).permute(0, 2, 1), False)
+    y = _nn_conv_bn(f, sd, 'conv1', 'bn1', True)
+    y = _nn_conv_bn(y, sd, 'conv2', 'bn2', True)
+    y = _nn_conv_bn(y, sd, 'conv3', 'bn3', True)
+    return _nn_conv_bn(y, sd, 'conv4', None, False).permute(0, 2, 1), trans_feat

@@ -1,5 +1,8 @@
-"""CPU test (no GPU) of the multi-GPU path: world_size-2 `gloo` processes shard the candidates, score their
-slice with a deterministic stand-in scorer, and the single all_gather reassembles the unsharded result."""
+"""CPU tests (no GPU) of the multi-GPU path: world_size-2 `gloo` processes run the REAL step control flow of bench.py
+(catgrasp_amd/workload.py: segment plan, slice intersection, rectangle splitting, per-object prep runs, record packing;
+catgrasp_amd/distributed.py: shard bounds, padding, the single all_gather, trimming) with the four device stages replaced at the
+tensor level by deterministic functions of the GLOBAL evaluation index -- so the gathered result must equal the unsharded one
+exactly, for weak-scaling layouts (slice == replica) and strong-scaling cuts that run through symmetry groups and objects."""
 import os
 import socket
 
@@ -8,6 +11,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from catgrasp_amd import distributed as cgd
+from catgrasp_amd import workload
 
 
 def _free_port():
@@ -15,44 +19,90 @@ def _free_port():
     return p
 
 
-def _fake_scores(lo, hi):
-    i = torch.arange(lo, hi, dtype=torch.float32)
-    return torch.stack([torch.sin(i) * 0.5 + 0.5, (i % 5)], dim=1)       # (p_G, code)
+class HostBatch(workload.SceneBatch):
+    """SceneBatch with its device stages mocked on CPU tensors; everything else is the product's code."""
+
+    def __init__(self, n_objects, per_replica, n_sym, replicas):
+        self.device = torch.device('cpu')
+        self.n_sym = n_sym
+        self.segs, self.n_total = workload.plan_segments(n_objects, per_replica, n_sym, replicas)
+        self.nunocs_calls = []
+
+    def run_nunocs(self, obj_ids):
+        self.nunocs_calls.append(list(obj_ids))
+
+    def run_filter(self, seg, i0, i1, j0, j1):
+        i = torch.arange(i0, i1).view(-1, 1); j = torch.arange(j0, j1).view(1, -1)
+        e = (seg.start + i * seg.n_sym + j).reshape(-1)                     # evaluation order of a (poses x symmetries) launch
+        codes = ((e * 7 + seg.obj) % 5).to(torch.int8)
+        poses = (e.view(-1, 1) * 16 + torch.arange(16).view(1, -1)).float() * (1.0 if seg.adjust else -1.0)
+        return codes, poses
+
+    def alloc(self, n):
+        return torch.empty((n, 12)), torch.empty((n, 4), dtype=torch.int32)
+
+    def run_prep(self, obj, poses, row_offset, pinv_out, ids_out):
+        pinv_out.copy_(poses[:, :12] + 1000.0 * obj)
+        ids_out.copy_((row_offset + torch.arange(poses.shape[0])).view(-1, 1).to(torch.int32) * 4 + torch.arange(4, dtype=torch.int32))
+
+    def run_net(self, ids, pinv):
+        return torch.sin(ids[:, 1].float() * 0.37) * 0.25 + pinv[:, 3] * 1e-6
 
 
-def _worker(rank, world, port, n_total, q):
+def _worker(rank, world, port, cfg, q):
     os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
-        out = cgd.score_sharded(_fake_scores, n_total)
-        q.put((rank, out.clone()))
+        b = HostBatch(*cfg)
+        out = cgd.score_sharded(b.score_slice, b.n_total)
+        q.put((rank, out.clone(), b.nunocs_calls))
         dist.barrier()
     finally:
         dist.destroy_process_group()
 
 
-def _run(n_total, world=2):
+def _run(cfg, world=2):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, cfg, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = dict(q.get(timeout=120) for _ in range(world))
+    got = [q.get(timeout=120) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    return res
+    return {r: (o, c) for r, o, c in got}
 
 
-def test_sharded_equals_unsharded_world2():
-    for n_total in (1001, 8, 1):            # uneven tail, tiny, fewer candidates than ranks
-        res = _run(n_total)
-        ref = _fake_scores(0, n_total)
+def test_sharded_step_equals_unsharded_world2():
+    for cfg in ((3, 101, 12, 2),        # weak layout: 2 replicas x 101 candidates, slice r == replica r
+                (4, 1001, 12, 1),       # strong: odd total, the cut falls inside a symmetry group
+                (16, 2000, 72, 1),      # C4 shape in small: 16 objects, 72 symmetries
+                (2, 3, 12, 1), (1, 1, 12, 1)):     # fewer candidates than ranks
+        whole = HostBatch(*cfg)
+        ref = whole.score_slice(0, whole.n_total)
+        assert ref.shape == (whole.n_total, 2)
+        res = _run(cfg)
         for r in (0, 1):
-            assert res[r].shape == ref.shape and torch.equal(res[r], ref)
+            assert res[r][0].shape == ref.shape and torch.equal(res[r][0], ref), cfg
+        if cfg[3] == 2:                 # weak scaling: every rank ran the NUNOCS stage over all objects of its replica
+            assert res[0][1] == [list(range(cfg[0]))] and res[1][1] == [list(range(cfg[0]))]
+
+
+def test_slicing_arithmetic():
+    segs, n = workload.plan_segments(8, 50000, 12, 1)
+    assert n == 50000 and segs[0].count == 260 * 12 and segs[1].count == 3130 and all(s.count > 0 for s in segs)
+    assert sum(s.count for s in segs) == n and all(a.start + a.count == b.start for a, b in zip(segs[:-1], segs[1:]))
+    for n_sym, a, b in ((12, 5, 7), (12, 5, 40), (12, 12, 36), (1, 3, 9), (12, 0, 5), (72, 71, 73), (12, 0, 0)):
+        rects = workload.split_eval_range(n_sym, a, b)
+        ev = [i * n_sym + j for i0, i1, j0, j1 in rects for i in range(i0, i1) for j in range(j0, j1)]
+        assert ev == list(range(a, b)) and len(rects) <= 3
+    per, bounds = cgd.shard_bounds(200000, 8)
+    assert per == 25000 and bounds[7] == (175000, 200000)
+    assert cgd.shard_bounds(10, 4)[1] == [(0, 3), (3, 6), (6, 9), (9, 10)] and cgd.shard_bounds(2, 4)[1][3] == (2, 2)
 
 
 def test_single_process_path():
-    out = cgd.score_sharded(_fake_scores, 17)
-    assert torch.equal(out, _fake_scores(0, 17))
+    b = HostBatch(3, 50, 12, 1)
+    assert torch.equal(cgd.score_sharded(b.score_slice, b.n_total), b.score_slice(0, b.n_total))

@@ -41,6 +41,13 @@ def test_models_match_reference_golden(gold, tag):
     y64 = (oref.pointnet_cls_forward if kind == 'cls' else oref.pointnet_seg_forward)(sd, x, torch.float64)[0].numpy()
     y64 = y64 if kind == 'cls' else y64[:, ::3, ::4]
     assert np.abs(y64 - ref).max() <= 5e-5 * max(1.0, np.abs(ref).max())
+    # the torch-nn-ops formulation (what bench.py's cpu_baseline times) is pinned to the same golden outputs
+    psd = oref.prepared_state_dict(sd)
+    with torch.no_grad():
+        yn, tfn = (oref.pointnet_cls_forward_nnops if kind == 'cls' else oref.pointnet_seg_forward_nnops)(psd, x)
+    yn = yn.numpy() if kind == 'cls' else yn.numpy()[:, ::3, ::4]
+    assert np.abs(yn - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+    assert np.abs(tfn.numpy()[:, ::7, ::5] - gold[tag + '_tf']).max() <= 2e-5
 
 
 def test_primitives_match_reference_golden(gold):
