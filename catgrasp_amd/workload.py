@@ -228,3 +228,36 @@ class SceneBatch:
             self.run_prep(obj, poses[pos:pos + n], g0, pinv[pos:pos + n], ids[pos:pos + n])
             pos += n
         return pack_records(self.run_net(ids, pinv), codes)
+
+
+def build_flat_workload(device, G, seed, n_objects=8, pts_per_object=2500, kind='nut'):
+    """A pre-expanded candidate batch (camera-frame poses, host-inverted pose rows and resample ids already on the device): the
+    inputs of score_on_device / filter_on_device without the step logic.  Used by the full-size property tests."""
+    import torch
+    from . import my_cpp, synth, transforms
+    objs = synth.make_scene(n_objects, pts_per_object, seed=0, kind=kind)
+    gripper = synth.make_gripper()
+    rng = np.random.default_rng(1000 + seed)
+    per = [G // n_objects + (1 if k < G % n_objects else 0) for k in range(n_objects)]
+    clouds, offsets, pose_rows, poses_dev, scenes, ids = [], [], [], [], [], []
+    off = 0
+    gen = torch.Generator(device=device); gen.manual_seed(1234 + seed)
+    for k, ob in enumerate(objs):
+        dc = transforms.DeviceCloud(ob['xyz'], ob['normal'], device)
+        clouds.append(dc); offsets.append(off)
+        P = synth.make_candidates(ob, per[k], rng, gripper['hand_depth'], gripper['init_bite'])
+        pose_rows.append(transforms.pose_inverse_rows(P, dc.center))
+        poses_dev.append(torch.from_numpy(P.astype(np.float32).reshape(-1, 16)).to(device))
+        bg = synth.background_points(objs, k, gripper['diameter'])
+        scenes.append(my_cpp.GripperScene(gripper['vertices'], gripper['faces'], gripper['enclosed_vertices'],
+                                          gripper['enclosed_faces'], ob['xyz'], bg, 0.0005, device))
+        ids.append(transforms.draw_ids_device(dc.n, 2048, per[k], device, gen, base=off))
+        off += dc.n
+    return {'objs': objs, 'gripper': gripper, 'per': per, 'scenes': scenes, 'poses_dev': poses_dev,
+            'cloud_xyz': torch.cat([c.xyz for c in clouds]).contiguous(),
+            'cloud_normal': torch.cat([c.normal for c in clouds]).contiguous(),
+            'ids': torch.cat(ids).contiguous(),
+            'pose_inv': torch.from_numpy(np.concatenate(pose_rows)).to(device),
+            'nunocs_ids': torch.stack([transforms.draw_ids_device(c.n, 8192, 1, device, gen, base=o)[0]
+                                       for c, o in zip(clouds, offsets)]).contiguous(),
+            'G': G}

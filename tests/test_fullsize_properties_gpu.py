@@ -10,8 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-import bench
-from catgrasp_amd import distributed, my_cpp, synth
+from catgrasp_amd import distributed, my_cpp, synth, workload
 from catgrasp_amd.predicter import DEFAULT_GRASP_CFG, DEFAULT_NUNOCS_CFG, GraspPredicter, NunocsPredicter
 from oracle import collision_oracle as co
 from oracle import pointnet_ref as oref
@@ -21,14 +20,14 @@ pytestmark = pytest.mark.gpu
 
 
 def _candidate_owner(wl):
-    """global candidate index -> (object k, local index j), following bench.build_workload's per-object blocks"""
+    """global candidate index -> (object k, local index j), following workload.build_flat_workload's per-object blocks"""
     start = np.concatenate([[0], np.cumsum(wl['per'])])
     return start
 
 
 @pytest.mark.parametrize('n_obj,G,kind', [(8, 10000, 'nut'), (16, 200000, 'screw')])
 def test_scoring_properties_at_baseline_sizes(cuda_device, n_obj, G, kind):
-    wl = bench.build_workload(cuda_device, G, seed=0, n_objects=n_obj, pts_per_object=2500, kind=kind)
+    wl = workload.build_flat_workload(cuda_device, G, seed=0, n_objects=n_obj, pts_per_object=2500, kind=kind)
     assert wl['cloud_xyz'].shape[0] == n_obj * 2500 and wl['ids'].shape == (G, 2048)
     sd = synth.make_state_dict('cls', 6, 10, seed=0)
     gp = GraspPredicter(kind, cfg=DEFAULT_GRASP_CFG, state_dict=sd, device=cuda_device)
@@ -75,7 +74,7 @@ def test_mixed_category_bin_at_c5_size(cuda_device, mlp_precision):
     if mlp_precision != 'bf16x3':
         pytest.skip('configs[4] names the bf16 MFMA path')
     G = 500000
-    wl = bench.build_workload(cuda_device, G, seed=2, n_objects=24, pts_per_object=2500, kind='mixed')
+    wl = workload.build_flat_workload(cuda_device, G, seed=2, n_objects=24, pts_per_object=2500, kind='mixed')
     kinds = [ob['kind'] for ob in wl['objs']]
     assert set(kinds) == {'nut', 'screw'} and wl['cloud_xyz'].shape[0] == 60000
     start = _candidate_owner(wl)
@@ -108,7 +107,7 @@ def test_mixed_category_bin_at_c5_size(cuda_device, mlp_precision):
 
 def test_collision_and_nunocs_properties_at_c3_size(cuda_device):
     G = 50000
-    wl = bench.build_workload(cuda_device, G, seed=1, n_objects=8, pts_per_object=2500)
+    wl = workload.build_flat_workload(cuda_device, G, seed=1, n_objects=8, pts_per_object=2500)
     g = wl['gripper']
     I4 = np.eye(4)
     sym_h = np.stack([nut_symmetry(i) for i in range(12)])      # nut: 12 symmetry transforms (Utils.py:79-94)
