@@ -156,6 +156,35 @@ def _encoder_forward_split(W, x, want_pointfeat=False, status=None):
     return r, t3, t64
 
 
+def stn3d_forward(W, x, status=None):
+    """A standalone STN3d (pointnet2.py:170-185).  x:(B,N,6) -> (B,9) row-major 3x3."""
+    B, N, _ = x.shape
+    if PRECISION == 'f32':
+        g = ops.pointmlp_max(x, W['stn.w1'], W['stn.b1'], W['stn.w2'], W['stn.b2'], W['stn.w3'], W['stn.b3'], True, nsplit=_nsplit(B, N))
+    else:
+        half = PRECISION == 'f16x3' and all(W.half_ok.get(n + '.h', False) for n in ('stn.w2', 'stn.w3'))
+        sfx = '.h' if half else '.s'
+        g = ops.pointmlp_max(x, W['stn.w1'], W['stn.b1'], W['stn.w2' + sfx], W['stn.b2'], W['stn.w3' + sfx], W['stn.b3'], True,
+                             nsplit=_nsplit(B, N, TILE_POINTS), split='f16' if half else 'bf16', tile_points=TILE_POINTS,
+                             status=status if half else None)
+    h = _dense(W, 'stn.fc1', g, 512, W['stn.fc1b'], relu=True, status=status)
+    h = _dense(W, 'stn.fc2', h, 256, W['stn.fc2b'], relu=True, status=status)
+    return _dense(W, 'stn.fc3', h, 9, W['stn.fc3b'], eye_k=3)
+
+
+def encoder_module_forward(W, x, global_feat, status=None):
+    """A standalone PointNetEncoder(feature_transform=True).forward (pointnet2.py:240-271) with the module's return layout.
+    x:(B,N,6) -> (global (B,1024) | cat([global repeated, pointfeat]) (B,1088,N), trans (B,3,3), trans_feat (B,64,64))."""
+    import torch
+    B, N, _ = x.shape
+    r = encoder_forward(W, x, want_pointfeat=not global_feat, status=status)
+    g, t3, t64 = r[0], r[1], r[2]
+    trans, trans_feat = t3.view(B, 3, 3), t64.view(B, 64, 64).transpose(1, 2)
+    if global_feat:
+        return g, trans, trans_feat
+    return torch.cat([g.view(B, 1024, 1).expand(-1, -1, N), r[3].transpose(1, 2)], 1), trans, trans_feat
+
+
 def cls_forward(W, x, status=None):
     """PointNetCls.forward in eval mode.  x:(B,N,6) -> logits (B,n_out), trans_feat (B,64,64).
     status: optional device int32 word collecting the f16x3 range bits of this batch (see run_guarded)."""

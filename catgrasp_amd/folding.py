@@ -127,38 +127,48 @@ class DeviceWeights:
         return self.t[k]
 
 
+def _prepare_tnet(W, sd, q, tag, k):
+    """Fold/pack one STN3d (k=3) / STNkd (k=64) (pointnet2.py:153-223): parameters under prefix q, stored under tag."""
+    w, b = fold_bn(*_conv(sd, q + 'conv1'), _bn(sd, q + 'bn1'))
+    if k == 3:
+        W.put(tag + '.w1', w); W.put(tag + '.b1', b)          # 6 -> 64 on VALU, unpacked
+    else:
+        W.put(tag + '.wm', pack_b(w)); W.put(tag + '.bm', b)   # 64 -> 64, packed
+        W.put_split(tag + '.wm.s', w)
+    w, b = fold_bn(*_conv(sd, q + 'conv2'), _bn(sd, q + 'bn2'))
+    W.put(tag + '.w2', pack_b(w)); W.put(tag + '.b2', b); W.put_split(tag + '.w2.s', w)
+    w, b = fold_bn(*_conv(sd, q + 'conv3'), _bn(sd, q + 'bn3'))
+    W.put(tag + '.w3', pack_b(w)); W.put(tag + '.b3', b); W.put_split(tag + '.w3.s', w)
+    w, b = fold_bn(_get(sd, q + 'fc1.weight'), _get(sd, q + 'fc1.bias'), _bn(sd, q + 'bn4'))
+    W.put(tag + '.fc1', pack_b(w)); W.put(tag + '.fc1b', b); W.put_half(tag + '.fc1.h', w)
+    w, b = fold_bn(_get(sd, q + 'fc2.weight'), _get(sd, q + 'fc2.bias'), _bn(sd, q + 'bn5'))
+    W.put(tag + '.fc2', pack_b(w)); W.put(tag + '.fc2b', b); W.put_half(tag + '.fc2.h', w)
+    w, b = _get(sd, q + 'fc3.weight'), _get(sd, q + 'fc3.bias')
+    if k == 64:
+        # emit the 64x64 feature transform transposed (column j*64+i holds T[i][j]) so the point kernels read a
+        # lane's consecutive-k operand elements with 16-byte loads; the identity stays on the diagonal.
+        perm = np.arange(4096).reshape(64, 64).T.reshape(-1)
+        w, b = w[perm], b[perm]
+    W.put(tag + '.fc3', pack_b(w)); W.put(tag + '.fc3b', b)
+    if k == 64:
+        W.put_half(tag + '.fc3.h', w)       # 256 -> 4096; the 9-wide stn.fc3 stays exact f32
+
+
+def prepare_stn3d(sd, device):
+    """A standalone STN3d(channel=6) (pointnet2.py:153-185)."""
+    sd = {k.replace('module.', ''): v for k, v in sd.items()}
+    W = DeviceWeights(device)
+    _prepare_tnet(W, sd, '', 'stn', 3)
+    return W
+
+
 def prepare_encoder(sd, prefix, device, out=None):
     """Fold/pack PointNetEncoder(feature_transform=True) weights (pointnet2.py:226-238)."""
+    sd = {k.replace('module.', ''): v for k, v in sd.items()}
     W = out or DeviceWeights(device)
     p = prefix
-
-    def stn(q, tag, k):
-        w, b = fold_bn(*_conv(sd, q + 'conv1'), _bn(sd, q + 'bn1'))
-        if k == 3:
-            W.put(tag + '.w1', w); W.put(tag + '.b1', b)          # 6 -> 64 on VALU, unpacked
-        else:
-            W.put(tag + '.wm', pack_b(w)); W.put(tag + '.bm', b)   # 64 -> 64, packed
-            W.put_split(tag + '.wm.s', w)
-        w, b = fold_bn(*_conv(sd, q + 'conv2'), _bn(sd, q + 'bn2'))
-        W.put(tag + '.w2', pack_b(w)); W.put(tag + '.b2', b); W.put_split(tag + '.w2.s', w)
-        w, b = fold_bn(*_conv(sd, q + 'conv3'), _bn(sd, q + 'bn3'))
-        W.put(tag + '.w3', pack_b(w)); W.put(tag + '.b3', b); W.put_split(tag + '.w3.s', w)
-        w, b = fold_bn(_get(sd, q + 'fc1.weight'), _get(sd, q + 'fc1.bias'), _bn(sd, q + 'bn4'))
-        W.put(tag + '.fc1', pack_b(w)); W.put(tag + '.fc1b', b); W.put_half(tag + '.fc1.h', w)
-        w, b = fold_bn(_get(sd, q + 'fc2.weight'), _get(sd, q + 'fc2.bias'), _bn(sd, q + 'bn5'))
-        W.put(tag + '.fc2', pack_b(w)); W.put(tag + '.fc2b', b); W.put_half(tag + '.fc2.h', w)
-        w, b = _get(sd, q + 'fc3.weight'), _get(sd, q + 'fc3.bias')
-        if k == 64:
-            # emit the 64x64 feature transform transposed (column j*64+i holds T[i][j]) so the point kernels read a
-            # lane's consecutive-k operand elements with 16-byte loads; the identity stays on the diagonal.
-            perm = np.arange(4096).reshape(64, 64).T.reshape(-1)
-            w, b = w[perm], b[perm]
-        W.put(tag + '.fc3', pack_b(w)); W.put(tag + '.fc3b', b)
-        if k == 64:
-            W.put_half(tag + '.fc3.h', w)       # 256 -> 4096; the 9-wide stn.fc3 stays exact f32
-
-    stn(p + 'stn.', 'stn', 3)
-    stn(p + 'fstn.', 'fstn', 64)
+    _prepare_tnet(W, sd, p + 'stn.', 'stn', 3)
+    _prepare_tnet(W, sd, p + 'fstn.', 'fstn', 64)
     w, b = fold_bn(*_conv(sd, p + 'conv1'), _bn(sd, p + 'bn1'))
     W.put('enc.w1', w); W.put('enc.b1', b)
     w, b = fold_bn(*_conv(sd, p + 'conv2'), _bn(sd, p + 'bn2'))

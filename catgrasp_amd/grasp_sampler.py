@@ -174,6 +174,12 @@ class PointConeGraspSampler(GraspSampler):
         sample_ids = np.arange(len(points_for_sample))
         np.random.shuffle(sample_ids)
         sample_ids = sample_ids[:max_num_samples]
+        # the reference re-seeds numpy's GLOBAL generator with its own first state word at every surface point
+        # (`seed = np.random.get_state()[1][0]` :183, `np.random.seed(seed)` in sample_one_surface_point): nothing random is drawn
+        # there, but the generator state a later predict_batch / RANSAC sees is the re-seeded one -- reproduce it
+        seed = np.random.get_state()[1][0]
+        if len(sample_ids):
+            np.random.seed(seed)
         self.info = {}
         poses = cone_grasp_poses(points_for_sample, normals_for_sample, sample_ids, sphere_pts, self.params['r_ball'], self.gripper.hand_depth,
                                  self.gripper.init_bite, approach_step, center_ob_between_gripper=center_ob_between_gripper, info=self.info)

@@ -11,6 +11,8 @@ Execution:
   * training mode (or grad enabled)    -> ordinary differentiable torch ops, so the reference trainers
     keep working (training is out of scope of the HIP path).
   * eval mode on a CPU tensor           -> RuntimeError: there is no CPU inference fallback.
+The same rule holds for the building blocks used on their own: STN3d and PointNetEncoder dispatch to the fused HIP passes, and a
+free-standing STNkd (which only exists fused into the encoder passes) raises instead of silently running stock torch ops.
 """
 import torch
 import torch.nn as nn
@@ -40,6 +42,16 @@ def _use_hip(module, x):
     return True
 
 
+def _cached_weights(module, device, prepare):
+    """Folded/packed device weights of `module`, rebuilt when a parameter/buffer changed (tensor version counters) or moved."""
+    key = (str(device),) + tuple(int(t._version) for t in module.state_dict().values())
+    cache = module.__dict__.get('_cg_cache')
+    if cache is None or cache[0] != key:
+        cache = (key, prepare(module.state_dict(), device))
+        module.__dict__['_cg_cache'] = cache
+    return cache[1]
+
+
 class _TNet(nn.Module):
     """Shared body of STN3d / STNkd: per-point MLP cin->64->128->1024, max-pool, 1024->512->256->k*k, + I."""
 
@@ -57,6 +69,11 @@ class _TNet(nn.Module):
         self._k = k
 
     def forward(self, x):
+        if _use_hip(self, x):
+            return self._hip_forward(x)
+        return self._torch_forward(x)
+
+    def _torch_forward(self, x):
         for i in (1, 2, 3):
             x = F.relu(getattr(self, f'bn{i}')(getattr(self, f'conv{i}')(x)))
         x = x.max(dim=2)[0]
@@ -69,12 +86,27 @@ class _TNet(nn.Module):
 class STN3d(_TNet):
     def __init__(self, channel):
         super().__init__(channel, 3)
+        self._channel = channel
+
+    def _hip_forward(self, x):
+        """Eval-mode inference of a standalone STN3d: the fused STN pass + FC tail (engine.stn3d_forward)."""
+        if self._channel != 6:
+            raise NotImplementedError('HIP path is built for the 6-channel (xyz+normal) input')
+        W = _cached_weights(self, x.device, folding.prepare_stn3d)
+        return engine.run_guarded(engine.stn3d_forward, W, x.float().transpose(1, 2).contiguous()).view(-1, 3, 3)
 
 
 class STNkd(_TNet):
     def __init__(self, k=64):
         super().__init__(k, k)
         self.k = k
+
+    def _hip_forward(self, x):
+        # The HIP pass that contains STNkd (<1>) starts from the 6-channel points and applies the encoder's conv1 first; a
+        # free-standing STNkd on an arbitrary 64-channel tensor has no kernel.  No silent torch fallback on an inference path:
+        raise NotImplementedError('catgrasp_amd.pointnet2.STNkd has no standalone HIP inference path (it is fused into '
+                                  'PointNetEncoder / PointNetCls / PointNetSeg); call the enclosing module, or run it with grad '
+                                  'enabled / in train() mode for the differentiable torch ops')
 
 
 class PointNetEncoder(nn.Module):
@@ -93,16 +125,27 @@ class PointNetEncoder(nn.Module):
             self.fstn = STNkd(k=64)
 
     def forward(self, x):
-        """Differentiable torch path (training).  x:(B,D,N)."""
+        """x:(B,D,N).  Eval-mode inference on a HIP tensor runs the fused passes (the same kernels PointNetCls / PointNetSeg use);
+        training / grad-enabled calls use the differentiable torch ops below."""
+        if _use_hip(self, x):
+            if x.shape[1] != 6 or not self.feature_transform:
+                raise NotImplementedError('HIP path is built for PointNetEncoder(feature_transform=True, channel=6)')
+            W = _cached_weights(self, x.device, lambda sd, dev: folding.prepare_encoder(sd, '', dev))
+            xt = x.float().transpose(1, 2).contiguous()
+            gf = self.global_feat
+            return engine.run_guarded(lambda w, xx, st: engine.encoder_module_forward(w, xx, gf, st), W, xt)
+        return self._torch_forward(x)
+
+    def _torch_forward(self, x):
         B, D, N = x.shape
-        trans = self.stn(x)
+        trans = self.stn._torch_forward(x)
         pts = x.transpose(2, 1)
         xyz = torch.bmm(pts[:, :, :3], trans)
         pts = torch.cat([xyz, pts[:, :, 3:]], dim=2) if D > 3 else xyz
         h = F.relu(self.bn1(self.conv1(pts.transpose(2, 1))))
         trans_feat = None
         if self.feature_transform:
-            trans_feat = self.fstn(h)
+            trans_feat = self.fstn._torch_forward(h)
             h = torch.bmm(h.transpose(2, 1), trans_feat).transpose(2, 1)
         pointfeat = h
         h = F.relu(self.bn2(self.conv2(h)))
@@ -119,13 +162,7 @@ class _HipCached(nn.Module):
     _kind = None
 
     def _device_weights(self, device):
-        key = (str(device),) + tuple(int(t._version) for t in self.state_dict().values())
-        cache = self.__dict__.get('_cg_cache')
-        if cache is None or cache[0] != key:
-            prep = folding.prepare_cls if self._kind == 'cls' else folding.prepare_seg
-            cache = (key, prep(self.state_dict(), device))
-            self.__dict__['_cg_cache'] = cache
-        return cache[1]
+        return _cached_weights(self, device, folding.prepare_cls if self._kind == 'cls' else folding.prepare_seg)
 
 
 class PointNetCls(_HipCached):
@@ -149,7 +186,7 @@ class PointNetCls(_HipCached):
             if self._n_in != 6:
                 raise NotImplementedError('HIP path is built for the 6-channel (xyz+normal) input of config_grasp.yml')
             return engine.run_guarded(engine.cls_forward, self._device_weights(x.device), x.float().contiguous())
-        g, _, trans_feat = self.feat(x.permute(0, 2, 1))
+        g, _, trans_feat = self.feat._torch_forward(x.permute(0, 2, 1))
         h = F.relu(self.bn1(self.fc1(g)))
         h = F.relu(self.bn2(self.fc2(self.dropout(h))))
         return self.fc3(h), trans_feat
@@ -176,7 +213,7 @@ class PointNetSeg(_HipCached):
             if self._n_in != 6:
                 raise NotImplementedError('HIP path is built for the 6-channel (xyz+normal) input of config_nunocs.yml')
             return engine.run_guarded(engine.seg_forward, self._device_weights(x.device), x.float().contiguous())
-        f, _, trans_feat = self.feat(x.permute(0, 2, 1))
+        f, _, trans_feat = self.feat._torch_forward(x.permute(0, 2, 1))
         h = F.relu(self.bn1(self.conv1(f)))
         h = F.relu(self.bn2(self.conv2(h)))
         h = F.relu(self.bn3(self.conv3(h)))

@@ -78,6 +78,7 @@ for tag, center in (('plain', False), ('centred', True)):
     grasps = s.sample_grasps(background_pts=np.zeros((1, 3)), points_for_sample=pts.copy(), normals_for_sample=nrm.copy(), max_num_samples=8,
                              n_sphere_dir=5, approach_step=0.01, ee_in_grasp=np.eye(4), cam_in_world=np.eye(4), upper=[0] * 7, lower=[0] * 7,
                              open_gripper_collision_pts=pts, center_ob_between_gripper=center, filter_ik=False, adjust_collision_pose=False)
+    out[f'post_call_draws_{tag}'] = np.random.randint(0, 2 ** 31, 4)     # numpy's GLOBAL generator as the reference leaves it (:183, :226)
     out[f'poses_{tag}'] = np.stack([g.grasp_pose for g in grasps])
     out[f'r_ball_{tag}'] = s.params['r_ball']
 # NocsTransferGraspSampler.__init__ (grasp_sampler.py:302-327): score threshold, best-n, y-centring -- with the REAL grasp class

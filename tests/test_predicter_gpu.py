@@ -127,6 +127,52 @@ def test_pointnet2_modules_dropin(cuda_device):
     assert ((ys.cpu() - rs).abs() / rs.abs().clamp(min=1)).max().item() <= 1e-4
 
 
+def test_standalone_building_blocks_run_on_the_hip_passes(cuda_device, mlp_precision):
+    """`from pointnet2 import *` users who call STN3d / PointNetEncoder directly in eval mode get the fused HIP passes
+    (not a silent stock-torch second backend); a free-standing STNkd, which has no kernel of its own, raises."""
+    from catgrasp_amd import ops
+    from catgrasp_amd import pointnet2 as p2
+    sd = synth.make_state_dict('seg', 6, 300, seed=12)
+    x = torch.from_numpy(np.random.default_rng(2).normal(0, 0.5, (3, 6, 700)).astype(np.float32))       # (B,D,N) like the reference
+    calls = []
+    real = ops.pointmlp_max
+    ops.pointmlp_max = lambda *a, **k: (calls.append(k.get('mid_mode', 0)), real(*a, **k))[1]
+    try:
+        for gf in (True, False):
+            enc = p2.PointNetEncoder(global_feat=gf, feature_transform=True, channel=6)
+            enc.load_state_dict({k[5:]: v for k, v in sd.items() if k.startswith('feat.')})
+            enc.cuda().eval()
+            calls.clear()
+            with torch.no_grad():
+                out, trans, tf = enc(x.cuda())
+            assert calls == [0, 1, 2]                                   # the three fused passes ran, not torch conv1d
+            psd = oref.prepared_state_dict({k[5:]: v for k, v in sd.items() if k.startswith('feat.')})
+            ref, rtrans, rtf = oref._nn_encoder(psd, '', x, gf)
+            assert out.shape == ref.shape
+            for a, b in ((out, ref), (trans, rtrans), (tf, rtf)):
+                assert ((a.cpu() - b).abs() / b.abs().clamp(min=1)).max().item() <= 1e-4
+        stn = p2.STN3d(6)
+        stn.load_state_dict({k[9:]: v for k, v in sd.items() if k.startswith('feat.stn.')})
+        stn.cuda().eval()
+        calls.clear()
+        with torch.no_grad():
+            t = stn(x.cuda())
+        assert calls == [0] and t.shape == (3, 3, 3)
+        rt = oref._nn_stn(oref.prepared_state_dict({k[9:]: v for k, v in sd.items() if k.startswith('feat.stn.')}), '', x, 3)
+        assert (t.cpu() - rt).abs().max().item() <= 1e-4
+        with torch.enable_grad():                                       # grad-enabled call: differentiable torch ops, same function
+            t2 = stn(x.cuda())
+        assert calls == [0] and (t2.detach().cpu() - rt).abs().max().item() <= 1e-4
+    finally:
+        ops.pointmlp_max = real
+    kd = p2.STNkd(64).cuda().eval()
+    with pytest.raises(NotImplementedError):
+        with torch.no_grad():
+            kd(torch.zeros(2, 64, 100, device=cuda_device))
+    with torch.enable_grad():
+        assert kd(torch.zeros(2, 64, 100, device=cuda_device)).shape == (2, 64, 64)
+
+
 def test_dropin_predicters_against_the_real_reference_outputs(cuda_device, mlp_precision):
     """The headline parity test: catgrasp_amd.predicter run with the same numpy seed, weights and normaliser as the REAL
     reference predicter (outputs committed in tests/golden/predicter_golden.npz by make_golden_predicter.py) must return the

@@ -95,6 +95,9 @@ def test_point_cone_sampler_reproduces_the_reference_candidate_list(cuda_device)
     s = gs.PointConeGraspSampler(_gripper(), None)
     np.random.seed(4242)
     mine = s.candidate_poses(pts.copy(), nrm.copy(), max_num_samples=8, n_sphere_dir=5, approach_step=0.01)
+    # the reference re-seeds numpy's global generator at every surface point: whatever runs next (predict_batch's resampling,
+    # the RANSAC draws) must see the same stream as in the reference pipeline
+    assert np.array_equal(np.random.randint(0, 2 ** 31, 4), GOLD['post_call_draws_plain'])
     gold = GOLD['poses_plain']
     assert abs(float(GOLD['r_ball_plain']) - s.params['r_ball']) < 1e-12     # incl. the doublings made while sampling (:243-247)
     radii = s.info['radii']
