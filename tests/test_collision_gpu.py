@@ -312,3 +312,36 @@ def test_broad_phase_grid_is_result_neutral(cuda_device):
     a = my_cpp.filterGraspPoseDetailed(*_args(P_can, [I4, S], nocs_pose, g, objs[0]['xyz'], bg, False, True), accel=True)
     ora = _oracle(P_can, [I4, S], nocs_pose, g, objs[0]['xyz'], bg, 0, 1)
     _check(a, ora)
+
+
+def test_device_narrow_phase_equals_the_exact_clipping_oracle(cuda_device):
+    """The HIP narrow phase pinned to the INDEPENDENT decision procedure (oracle/tribox_exact.py: rational polygon clipping, no
+    separating axes), not only to its C twin: one-triangle meshes on a 1/32 lattice, translated by lattice vectors (exact in
+    float32), against a single occupied leaf of edge 1/16 -- every contact configuration included."""
+    import ctypes
+    from catgrasp_amd import _lib as L
+    from oracle import tribox_exact as tx
+    rng = np.random.default_rng(4)
+    res = 1.0 / 16
+    key = np.array([[3, -2, 1, 0]], dtype=np.int16)
+    centre = (key[0, :3].astype(np.float64) + 0.5) * res
+    keys = torch.from_numpy(key).to(cuda_device)
+    F = torch.tensor([[0, 1, 2]], dtype=torch.int32, device=cuda_device)
+    n_hit = n_total = n_touch = 0
+    for _ in range(40):
+        tri = rng.integers(-6, 7, (3, 3)) / 32.0
+        shifts = rng.integers(-8, 9, (200, 3)) / 32.0 + np.round(centre * 32) / 32.0
+        poses = np.tile(np.eye(4, dtype=np.float32), (200, 1, 1)); poses[:, :3, 3] = shifts
+        V = torch.from_numpy(tri.astype(np.float32)).to(cuda_device)
+        out = torch.zeros((200,), dtype=torch.uint8, device=cuda_device)
+        L.check(L.lib().cg_mesh_voxels_collide(L._p(V), L._p(F), ctypes.c_int(1), L._p(torch.from_numpy(poses.reshape(200, 16)).to(cuda_device)),
+                                               ctypes.c_long(200), L._p(keys), ctypes.c_int(1), ctypes.c_float(res), L._p(out), L._stream()),
+                'cg_mesh_voxels_collide')
+        got = out.cpu().numpy().astype(bool)
+        for i in range(200):
+            a, b, d = tri + shifts[i]
+            want = tx.tri_box_intersect(centre, res / 2, a, b, d, exact=True)
+            assert got[i] == want, (tri, shifts[i], got[i], want)
+            n_hit += want; n_total += 1
+            n_touch += want and not tx.tri_box_intersect(centre, res / 2 * (1 - 2.0 ** -10), a, b, d, exact=True)
+    assert 500 < n_hit < n_total - 500 and n_touch > 50

@@ -1,7 +1,9 @@
 """CPU tests (no GPU) of the collision oracle (oracle/collision_ref.c).  PARITY UNPINNED: FCL/octomap are
 absent, so instead of golden vectors the restatement is checked against independent formulations:
-octomap's published key formula in numpy float64, an exact rational-free float64 triangle/box test by
-dense sampling, and control-flow invariants of filterGraspPose (my_cpp/common.cpp:156-321)."""
+octomap's published key formula in numpy float64; an INDEPENDENT triangle/box decision procedure (polygon clipping in exact
+rationals / float64, oracle/tribox_exact.py -- no separating axes) that the float32 SAT must match in BOTH directions; properties
+FCL's mesh-vs-octree semantics imply (monotone in the voxel set, invariant under re-triangulation, surface-only); and
+control-flow invariants of filterGraspPose (my_cpp/common.cpp:156-321)."""
 import numpy as np
 
 from catgrasp_amd import synth
@@ -24,34 +26,70 @@ def test_voxel_keys_follow_octomap_formula():
     assert co.voxelize(np.ones((1, 3)) * 99999, 0.0005).shape == (0, 3)
 
 
-def _tri_box_truth(c, h, a, b, d, n=60):
-    """float64 ground truth by exact clipping-free reasoning: the triangle intersects the box iff some point of
-    the triangle lies inside; sample barycentric grid densely (used only on clearly separated / overlapping cases)."""
-    u, v = np.meshgrid(np.linspace(0, 1, n), np.linspace(0, 1, n))
-    m = u + v <= 1
-    p = a + u[m][:, None] * (b - a) + v[m][:, None] * (d - a)
-    return bool((np.abs(p - c) <= h).all(axis=1).any())
-
-
-def test_tri_box_sat_agrees_with_sampling_on_clear_cases():
-    rng = np.random.default_rng(1)
-    h = 0.5
-    n_checked = 0
-    for _ in range(3000):
-        c = rng.normal(0, 0.3, 3)
-        a, b, d = (rng.normal(0, 1.0, 3) for _ in range(3))
+def test_tri_box_sat_equals_exact_clipping_on_dyadic_inputs_both_directions():
+    """Coordinates on a 1/16 lattice: every product and sum of the float32 SAT is exact, so it must agree EXACTLY with the
+    rational clipping oracle -- including all touching configurations (the lattice makes them common: ~15 % of the cases have a
+    vertex on a face plane, edges through cube edges, triangles coplanar with a face).  A predicate that over-reports (or
+    under-reports) contact fails here."""
+    from oracle import tribox_exact as tx
+    rng = np.random.default_rng(11)
+    n_hit = n_miss = n_touch = n_mutant_caught = 0
+    for _ in range(8000):
+        h = rng.integers(1, 9) / 16.0
+        c = rng.integers(-16, 17, 3) / 16.0
+        scale = rng.choice([4, 16, 40])
+        a, b, d = (c + rng.integers(-scale, scale + 1, 3) / 16.0 for _ in range(3))
+        if _ % 4 == 0:          # contact family: 1..3 vertices exactly on a face plane of the cube
+            ax, side = rng.integers(0, 3), rng.choice([-1.0, 1.0])
+            for v in (a, b, d)[:rng.integers(1, 4)]:
+                v[ax] = c[ax] + side * h
+        want = tx.tri_box_intersect(c, h, a, b, d, exact=True)
         got = co.tri_box_overlap(c, h, a, b, d)
-        inflated = _tri_box_truth(c, h * 1.05, a, b, d)
-        shrunk = _tri_box_truth(c, h * 0.95, a, b, d)
-        if shrunk:
-            assert got, 'triangle has a point well inside the box but SAT says disjoint'
-            n_checked += 1
-        if not got:
-            assert not shrunk
-        if not inflated:
-            # no sample even in an inflated box; SAT may still say overlap only for thin slivers the grid missed
-            pass
-    assert n_checked > 200
+        assert got == want, (c, h, a, b, d, got, want)
+        n_hit += want; n_miss += not want
+        n_mutant_caught += co.tri_box_overlap(c, h + 1 / 64, a, b, d) != want      # an over-reporting predicate (cube inflated by 1/64)
+        if want and not tx.tri_box_intersect(c, h * (1 - 2.0 ** -10), a, b, d, exact=True):
+            n_touch += 1                                    # intersects the closed cube but not a slightly smaller one: contact only
+    assert n_hit > 1000 and n_miss > 1000 and n_touch > 100, (n_hit, n_miss, n_touch)
+    assert n_mutant_caught > 20          # ... would have failed the equality above on this many cases: the test is two-sided
+    # hand-made contact cases: vertex on a face, edge along a cube edge, coplanar with a face, point contact at a corner
+    z = np.zeros(3)
+    for a, b, d, want in (((1, 0, 0), (2, 1, 0), (2, -1, 0), True), ((1, 1, -3), (1, 1, 3), (5, 5, 0), True),
+                          ((-3, -3, 1), (3, -3, 1), (0, 3, 1), True), ((1, 1, 1), (2, 1, 1), (1, 2, 2), True),
+                          ((1.0625, 0, 0), (2, 1, 0), (2, -1, 0), False), ((-3, -3, 1.0625), (3, -3, 1.0625), (0, 3, 1.0625), False)):
+        a, b, d = np.array(a, float), np.array(b, float), np.array(d, float)
+        assert tx.tri_box_intersect(z, 1.0, a, b, d) == want == co.tri_box_overlap(z, 1.0, a, b, d)
+
+
+def test_tri_box_sat_agrees_with_clipping_on_random_float32_inputs_outside_an_epsilon_band():
+    """10^5 random + near-grazing float32 cases against float64 clipping, two-sided: if the triangle intersects the cube shrunk by
+    eps the SAT must report overlap; if it misses the cube grown by eps the SAT must report disjoint.  eps = 4e-6 of the scene
+    scale (float32 rounding of the 13 axis tests; coordinates are O(1))."""
+    from oracle import tribox_exact as tx
+    rng = np.random.default_rng(1)
+    eps = 4e-6
+    n_in = n_out = n_band = 0
+    for i in range(100000):
+        h = np.float32(rng.uniform(0.05, 0.6))
+        c = rng.normal(0, 0.3, 3).astype(np.float32)
+        if i % 3 == 0:       # grazing family: a triangle in a plane at distance ~h from the centre along a random axis
+            ax = rng.integers(0, 3)
+            a, b, d = (rng.normal(0, 1.0, 3) for _ in range(3))
+            off = c[ax] + (h + rng.normal(0, 3e-6)) * rng.choice([-1, 1])
+            a[ax] = off + rng.normal(0, 1e-6); b[ax] = off + rng.normal(0, 1e-6); d[ax] = off + rng.normal(0, 1e-6)
+        else:
+            a, b, d = (rng.normal(0, 1.0, 3) for _ in range(3))
+        a, b, d = a.astype(np.float32), b.astype(np.float32), d.astype(np.float32)
+        got = co.tri_box_overlap(c, h, a, b, d)
+        if tx.tri_box_intersect(c, float(h) - eps, a, b, d, exact=False):
+            assert got, ('under-reports', c, h, a, b, d)
+            n_in += 1
+        elif not tx.tri_box_intersect(c, float(h) + eps, a, b, d, exact=False):
+            assert not got, ('over-reports', c, h, a, b, d)
+            n_out += 1
+        else:
+            n_band += 1
+    assert n_in > 20000 and n_out > 20000 and 0 < n_band < 20000, (n_in, n_out, n_band)
 
 
 def test_tri_box_symmetry_and_containment():
@@ -135,3 +173,51 @@ def test_sdf_oracle_trilinear_reproduces_linear_fields_and_lattice_values():
     assert np.array_equal(sdf_ref.signed_distance(data, np.array([[0.5], [1.5], [2.5]]), fast=True), data[0, 2, 2:3])  # half-even
     g, origin, res = sdf_ref.box_sdf_grid([0, 0, 0], [0.01, 0.02, 0.005], 0.001, 5)
     assert g.shape == (30, 30, 30) and g.min() < 0 < g.max()
+
+
+def _subdivide(V, F):
+    a, b, c = V[F[:, 0]], V[F[:, 1]], V[F[:, 2]]
+    n0 = len(V)
+    mids = np.stack([(a + b) / 2, (b + c) / 2, (c + a) / 2], axis=1).reshape(-1, 3)
+    i = n0 + 3 * np.arange(len(F))
+    F2 = np.concatenate([np.stack([F[:, 0], i, i + 2], 1), np.stack([i, F[:, 1], i + 1], 1), np.stack([i + 2, i + 1, F[:, 2]], 1),
+                         np.stack([i, i + 1, i + 2], 1)]).astype(np.int32)
+    return np.concatenate([V, mids]).astype(np.float32), F2
+
+
+def test_mesh_vs_voxels_properties_implied_by_fcl_semantics():
+    """What ANY correct mesh-vs-octree collision must satisfy, whatever its narrow phase: (i) monotone in the voxel set,
+    (ii) invariant under re-triangulating the same surface (flip a quad's diagonal / split every triangle in four), (iii)
+    surface-only: leaves strictly inside a closed mesh, away from its surface, do not collide, (iv) rigid motion of both."""
+    rng = np.random.default_rng(5)
+    res = 0.0005
+    V, F = synth.box_mesh([-0.008, -0.004, -0.002], [0.008, 0.004, 0.002])       # dyadic-free metric box, closed surface
+    V = V.astype(np.float32)
+    F_flip = F.copy()
+    for q in range(0, 12, 2):        # the two triangles of each face share a diagonal: use the other diagonal
+        t0, t1 = F[q], F[q + 1]
+        quad = [t0[0], t0[1], t0[2]] + [v for v in t1 if v not in t0]
+        shared = [v for v in t0 if v in t1]
+        others = [v for v in quad if v not in shared]
+        F_flip[q] = [others[0], shared[0], others[1]]; F_flip[q + 1] = [others[0], others[1], shared[1]]
+    V4, F4 = _subdivide(V, F)
+    n_hit = 0
+    for trial in range(300):
+        T = np.eye(4, dtype=np.float32); T[:3, :3] = synth.random_rotation(rng); T[:3, 3] = rng.uniform(-0.004, 0.004, 3)
+        pts = (rng.uniform(-0.012, 0.012, (rng.integers(1, 40), 3))).astype(np.float32)
+        keys = co.voxelize(pts, res)
+        r = co.mesh_voxels_collide(V, F, T, keys, res)
+        n_hit += r
+        assert r == co.mesh_voxels_collide(V, F_flip, T, keys, res)                       # (ii) other diagonal
+        assert r == co.mesh_voxels_collide(V4, F4, T, keys, res)                          # (ii) 1:4 subdivision
+        sub = keys[rng.random(len(keys)) < 0.5]
+        if co.mesh_voxels_collide(V, F, T, sub, res):                                     # (i) subset hit => superset hit
+            assert r
+        extra = np.concatenate([keys, co.voxelize(rng.uniform(-0.012, 0.012, (5, 3)).astype(np.float32), res)])
+        if r:
+            assert co.mesh_voxels_collide(V, F, T, np.unique(extra, axis=0), res)
+        # (iii) points strictly inside the posed box, > one voxel diagonal from every face, never collide on their own
+        inner = rng.uniform([-0.0065, -0.0025, -0.0008], [0.0065, 0.0025, 0.0008], (20, 3))
+        inner = (inner @ T[:3, :3].T.astype(np.float64) + T[:3, 3]).astype(np.float32)
+        assert not co.mesh_voxels_collide(V, F, T, co.voxelize(inner, res), res)
+    assert 60 < n_hit < 280
