@@ -102,6 +102,74 @@ __global__ __launch_bounds__(256) void voxelize_fp_kernel(const float* __restric
   out[(size_t)row * C + c] = acc;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// voxelization_idx (src/voxelize/voxelize.cpp:11-151; predicter.py:285) and bfs_cluster (src/bfs_cluster/bfs_cluster.cpp:34-121;
+// pointgroup.py:240,245).  The reference runs both on the HOST (std::map insertion order; a sequential queue BFS) and copies
+// the tensors over.  Device formulation:
+//  * voxelization_idx = sort the packed (batch,x,y,z) keys (stable: ties keep point order), number the runs by their first
+//    point index (= the reference's first-appearance order), and fill the two maps -- kernels below + a device sort/scan.
+//  * bfs_cluster = connected components of the same-label neighbour graph by min-label propagation with pointer jumping;
+//    clusters are numbered by their smallest point index, which is the order the reference's seed loop discovers them in.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void voxel_pack_kernel(const long long* __restrict__ coords, int n, int ncol, long long* __restrict__ keys,
+                                                         int* __restrict__ err_flag) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const long long* c = coords + (size_t)i * ncol;
+  long long key = 0; bool ok = true;
+  if (ncol == 4) { ok = c[0] >= 0 && c[0] < 32768; key = c[0]; }
+  for (int j = ncol - 3; j < ncol; ++j) { ok = ok && c[j] >= 0 && c[j] < 65536; key = (key << 16) | (c[j] & 0xffff); }
+  if (!ok && err_flag) *err_flag = 1;
+  keys[i] = key;
+}
+
+__global__ __launch_bounds__(256) void segment_heads_kernel(const long long* __restrict__ sorted_keys, int n, int* __restrict__ head) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  head[j] = (j == 0 || sorted_keys[j] != sorted_keys[j - 1]) ? 1 : 0;
+}
+
+// sorted position j -> point perm[j], run seg[j] (starting at seg_start), voxel id vid[seg[j]];  mode 3/4: every member listed,
+// mode 1: the first member (outputRows.front(), voxelize.cpp:124-129), mode 2: the last (back(), :130-135), mode 0: the only one.
+__global__ __launch_bounds__(256) void voxel_fill_maps_kernel(const long long* __restrict__ perm, const int* __restrict__ seg,
+                                                              const int* __restrict__ seg_start, const int* __restrict__ vid, int n,
+                                                              int width, int mode, int* __restrict__ input_map, int* __restrict__ output_map) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const int sg = seg[j], v = vid[sg], p = (int)perm[j];
+  const int pos = j - seg_start[sg];
+  const bool last = (j == n - 1) || (seg[j + 1] != sg);
+  input_map[p] = v;
+  int* row = output_map + (size_t)v * width;
+  if (mode == 3 || mode == 4) {
+    row[1 + pos] = p;
+    if (last) row[0] = pos + 1;
+  } else {
+    if (pos == 0) row[0] = 1;
+    if ((mode == 2) ? last : (pos == 0)) row[1] = p;
+  }
+}
+
+__global__ __launch_bounds__(256) void cc_propagate_kernel(const int* __restrict__ label, const int* __restrict__ nbr,
+                                                           const int* __restrict__ start_len, int n, int* __restrict__ comp,
+                                                           int* __restrict__ changed) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int li = label[i];
+  const int s = start_len[2 * i], e = s + start_len[2 * i + 1];
+  int c = comp[i];
+  for (int q = s; q < e; ++q) { const int j = nbr[q]; if (label[j] == li) c = min(c, comp[j]); }
+  c = min(c, comp[c]);                                   // pointer jumping
+  bool ch = false;
+  if (c < comp[i]) { atomicMin(comp + i, c); ch = true; }
+  for (int q = s; q < e; ++q) {                          // push to the neighbours too: the relation is used symmetrically
+    const int j = nbr[q];
+    if (label[j] == li && comp[j] > c) { atomicMin(comp + j, c); ch = true; }
+  }
+  if (ch) *changed = 1;
+}
+
 }  // namespace
 
 extern "C" int cg_pg_ballquery_batch_p(const float* xyz, const int* batch_idxs, const int* batch_offsets, int n, float radius, int pass,
@@ -143,5 +211,41 @@ extern "C" int cg_pg_voxelize_fp(const float* feats, const int* rules, int n_row
   const long waves = (long)n_rows * ((C + 63) / 64);
   hipLaunchKernelGGL(voxelize_fp_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, feats, rules, n_rows, max_active,
                      C, average, out);
+  return cg_hip_status(hipGetLastError());
+}
+
+extern "C" int cg_pg_voxel_pack_keys(const long long* coords, int n, int ncol, long long* keys, int* err_flag, void* stream) {
+  if (n < 0 || (ncol != 3 && ncol != 4)) return CG_ERR_ARG;
+  if (n == 0) return CG_OK;
+  if (!coords || !keys) return CG_ERR_ARG;
+  hipLaunchKernelGGL(voxel_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, coords, n, ncol, keys, err_flag);
+  return cg_hip_status(hipGetLastError());
+}
+
+extern "C" int cg_pg_segment_heads(const long long* sorted_keys, int n, int* head, void* stream) {
+  if (n < 0) return CG_ERR_ARG;
+  if (n == 0) return CG_OK;
+  if (!sorted_keys || !head) return CG_ERR_ARG;
+  hipLaunchKernelGGL(segment_heads_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, sorted_keys, n, head);
+  return cg_hip_status(hipGetLastError());
+}
+
+extern "C" int cg_pg_voxel_fill_maps(const long long* perm, const int* seg, const int* seg_start, const int* vid, int n, int width, int mode,
+                                     int* input_map, int* output_map, void* stream) {
+  if (n < 0 || width < 2 || mode < 0 || mode > 4) return CG_ERR_ARG;
+  if (n == 0) return CG_OK;
+  if (!perm || !seg || !seg_start || !vid || !input_map || !output_map) return CG_ERR_ARG;
+  hipLaunchKernelGGL(voxel_fill_maps_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, perm, seg, seg_start, vid,
+                     n, width, mode, input_map, output_map);
+  return cg_hip_status(hipGetLastError());
+}
+
+extern "C" int cg_pg_cc_propagate(const int* semantic_label, const int* ball_query_idxs, const int* start_len, int n, int* comp,
+                                  int* changed, void* stream) {
+  if (n < 0) return CG_ERR_ARG;
+  if (n == 0) return CG_OK;
+  if (!semantic_label || !start_len || !comp || !changed) return CG_ERR_ARG;
+  hipLaunchKernelGGL(cc_propagate_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, semantic_label,
+                     ball_query_idxs, start_len, n, comp, changed);
   return cg_hip_status(hipGetLastError());
 }

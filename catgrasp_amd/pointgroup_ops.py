@@ -82,3 +82,78 @@ def voxelization(feats, map_rule, mode=4):
     check(L.lib().cg_pg_voxelize_fp(_p(feats), _p(rules), _c_int(M), _c_int(width - 1), _c_int(C), _c_int(int(mode == 4)), _p(out), _stream()),
           'cg_pg_voxelize_fp')
     return out
+
+
+def voxelization_idx(coords, batchsize, mode=4):
+    """pointgroup_ops.voxelization_idx (Voxelization_Idx.forward; voxelize.cpp:11-151; called at predicter.py:285):
+    coords (N,4) [batch,x,y,z] or (N,3) int64 -> (output_coords (M,ncol) int64, input_map (N) int32, output_map (M, 1+maxActive)
+    int32).  Voxels are numbered in order of first appearance; output_map row = [count, member point ids ascending, 0 ...]
+    (mode 3/4), [1, first] (mode 1), [1, last] (mode 2).  The reference builds the maps on the host from CPU tensors; here the
+    coordinates stay on the device (the returned tensors live on coords.device)."""
+    require_cuda(coords)
+    coords = coords.contiguous().long()
+    n, ncol = coords.shape
+    dev = coords.device
+    if n == 0:
+        return coords.new_zeros((0, ncol)), torch.zeros((0,), dtype=torch.int32, device=dev), torch.zeros((0, 2), dtype=torch.int32, device=dev)
+    lib = L.lib()
+    keys = torch.empty((n,), dtype=torch.int64, device=dev)
+    err = torch.zeros((1,), dtype=torch.int32, device=dev)
+    check(lib.cg_pg_voxel_pack_keys(_p(coords), _c_int(n), _c_int(ncol), _p(keys), _p(err), _stream()), 'cg_pg_voxel_pack_keys')
+    skeys, perm = torch.sort(keys, stable=True)                         # ties keep point order
+    head = torch.empty((n,), dtype=torch.int32, device=dev)
+    check(lib.cg_pg_segment_heads(_p(skeys), _c_int(n), _p(head), _stream()), 'cg_pg_segment_heads')
+    seg = (torch.cumsum(head, 0) - 1).int()
+    seg_start = torch.nonzero(head, as_tuple=False).reshape(-1).int()  # also: its length M and the sync point
+    if int(err.item()):
+        raise ValueError('voxelization_idx: coordinates must lie in [0, 65536) and batch indices in [0, 32768)')
+    M = seg_start.shape[0]
+    first_pt = perm[seg_start.long()]                                   # smallest point index of every run (stable sort)
+    order = torch.argsort(first_pt)                                     # runs in first-appearance order
+    vid = torch.empty((M,), dtype=torch.int32, device=dev)
+    vid[order] = torch.arange(M, dtype=torch.int32, device=dev)
+    if mode in (3, 4):
+        counts = torch.diff(torch.cat([seg_start, torch.tensor([n], dtype=torch.int32, device=dev)]))
+        max_active = max(int(counts.max().item()), 1)
+    else:
+        max_active = 1
+        if mode == 0 and M != n:
+            raise ValueError('voxelization_idx mode 0 needs unique coordinates')
+    input_map = torch.empty((n,), dtype=torch.int32, device=dev)
+    output_map = torch.zeros((M, max_active + 1), dtype=torch.int32, device=dev)
+    check(lib.cg_pg_voxel_fill_maps(_p(perm), _p(seg), _p(seg_start), _p(vid), _c_int(n), _c_int(max_active + 1), _c_int(int(mode)),
+                                    _p(input_map), _p(output_map), _stream()), 'cg_pg_voxel_fill_maps')
+    output_coords = coords[output_map[:, 1].long()]                     # voxelize_outputmap: coords of rule[1]
+    return output_coords, input_map, output_map
+
+
+def bfs_cluster(semantic_label, ball_query_idxs, start_len, threshold):
+    """pointgroup_ops.bfs_cluster (BFSCluster.forward; bfs_cluster.cpp:34-121; called at pointgroup.py:240,245):
+    -> (cluster_idxs (sumNPoint,2) int32 [cluster id, point id], cluster_offsets (nCluster+1) int32).  Clusters = connected
+    components of the neighbour graph restricted to equal semantic labels with >= threshold points, numbered by their smallest
+    point index (the order the reference's seed loop finds them).  Members are listed in ascending point index; the reference
+    lists them in queue-visit order (same sets).  The neighbour relation is used symmetrically (it is symmetric unless the ball
+    query's 1000-neighbour / n*meanActive caps truncated a list)."""
+    require_cuda(semantic_label, ball_query_idxs, start_len)
+    label = semantic_label.contiguous().int(); nbr = ball_query_idxs.contiguous().int(); sl = start_len.contiguous().int()
+    n = sl.shape[0]
+    dev = label.device
+    comp = torch.arange(n, dtype=torch.int32, device=dev)
+    changed = torch.zeros((1,), dtype=torch.int32, device=dev)
+    lib = L.lib()
+    for _ in range(max(n, 1) + 1):
+        changed.zero_()
+        for _ in range(4):                                              # a few sweeps per host round trip
+            check(lib.cg_pg_cc_propagate(_p(label), _p(nbr), _p(sl), _c_int(n), _p(comp), _p(changed), _stream()), 'cg_pg_cc_propagate')
+        if int(changed.item()) == 0:
+            break
+    sizes = torch.bincount(comp.long(), minlength=n)
+    keep = sizes[comp.long()] >= threshold
+    root, pts = comp[keep], torch.arange(n, dtype=torch.int32, device=dev)[keep]
+    order = torch.sort(root.long() * n + pts.long()).indices          # by (root, point id)
+    root, pts = root[order], pts[order]
+    uniq, inverse, counts = torch.unique_consecutive(root, return_inverse=True, return_counts=True)
+    cluster_idxs = torch.stack([inverse.int(), pts], dim=1).contiguous()
+    offsets = torch.zeros((uniq.shape[0] + 1,), dtype=torch.int32, device=dev)
+    offsets[1:] = torch.cumsum(counts, 0).int()
+    return cluster_idxs, offsets

@@ -22,7 +22,7 @@ from . import engine, folding
 from . import primitives as _prim
 
 __all__ = ['square_distance', 'index_points', 'farthest_point_sample', 'query_ball_point', 'sample_and_group',
-           'sample_and_group_all', 'STN3d', 'STNkd', 'PointNetEncoder', 'PointNetCls', 'PointNetSeg']
+           'sample_and_group_all', 'STN3d', 'STNkd', 'PointNetEncoder', 'PointNetCls', 'PointNetSeg', 'PointNetSetAbstraction']
 
 # PointNet++ primitives (pointnet2.py:14-149): HIP implementations with the reference's tensor signatures
 square_distance = _prim.square_distance
@@ -218,3 +218,40 @@ class PointNetSeg(_HipCached):
         h = F.relu(self.bn2(self.conv2(h)))
         h = F.relu(self.bn3(self.conv3(h)))
         return self.conv4(h).permute(0, 2, 1), trans_feat
+
+
+class PointNetSetAbstraction(nn.Module):
+    """The set-abstraction layer the reference's primitives were written for (pointnet2.py:14-149 define sample_and_group and
+    friends, but the reference never assembles them into a layer -- SURVEY.md §0 F1; BASELINE.json's north_star names it):
+        new_xyz, new_points = sample_and_group(npoint, radius, nsample, xyz, points)
+        new_points -> (B, 3+D, K, S) -> [Conv2d(1x1) -> BatchNorm2d -> ReLU] per mlp width -> max over the K neighbours
+    forward(xyz (B,N,3), points (B,N,D) | None) -> (new_xyz (B,S,3), new_points (B,S,C_last)).
+    Eval-mode inference on a HIP tensor: FPS + ball query + ONE fused group->MLP->max kernel (primitives.group_mlp_max), the
+    grouped tensor never exists; training / grad-enabled calls use the torch ops on the grouped tensor."""
+
+    def __init__(self, npoint, radius, nsample, in_channel, mlp):
+        super().__init__()
+        self.npoint, self.radius, self.nsample, self.in_channel = npoint, radius, nsample, in_channel
+        self.mlp_convs = nn.ModuleList(); self.mlp_bns = nn.ModuleList()
+        last = in_channel
+        for c in mlp:
+            self.mlp_convs.append(nn.Conv2d(last, c, 1)); self.mlp_bns.append(nn.BatchNorm2d(c))
+            last = c
+
+    def forward(self, xyz, points, start=None):
+        if _use_hip(self, xyz):
+            def prep(sd, dev):
+                layers = [(sd[f'mlp_convs.{i}.weight'].detach().cpu().double().numpy(), sd[f'mlp_convs.{i}.bias'].detach().cpu().double().numpy(),
+                           tuple(sd[f'mlp_bns.{i}.{k}'].detach().cpu().double().numpy() for k in ('weight', 'bias', 'running_mean', 'running_var')))
+                          for i in range(len(self.mlp_convs))]
+                return _prim.SetAbstractionWeights(layers, self.in_channel, dev)
+            W = _cached_weights(self, xyz.device, prep)
+            fps_idx = farthest_point_sample(xyz, self.npoint, start)
+            new_xyz = index_points(xyz, fps_idx)
+            idx = query_ball_point(self.radius, self.nsample, xyz, new_xyz)
+            return new_xyz, _prim.group_mlp_max(xyz, points, new_xyz, idx, W).permute(0, 2, 1)
+        new_xyz, new_points = sample_and_group(self.npoint, self.radius, self.nsample, xyz, points, start=start)
+        h = new_points.permute(0, 3, 2, 1)                      # (B, 3+D, K, S)
+        for conv, bn in zip(self.mlp_convs, self.mlp_bns):
+            h = F.relu(bn(conv(h)))
+        return new_xyz, torch.max(h, 2)[0].permute(0, 2, 1)

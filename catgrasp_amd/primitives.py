@@ -118,3 +118,57 @@ def sample_and_group_all(xyz, points):
     if points is not None:
         return new_xyz, torch.cat([grouped_xyz, points.view(B, 1, N, -1)], dim=-1)
     return new_xyz, grouped_xyz
+
+
+class SetAbstractionWeights:
+    """Folded (eval BatchNorm) + MFMA-packed weights of a shared per-neighbour MLP [Conv2d(1x1) -> BatchNorm2d -> ReLU] x L."""
+
+    def __init__(self, layers, in_channel, device):
+        """layers: [(conv weight (Cout,Cin[,1,1]), conv bias (Cout), (bn weight, bn bias, running_mean, running_var) or None), ...]"""
+        import numpy as np
+        from . import folding
+        if not 1 <= len(layers) <= 4:
+            raise ValueError('1..4 layers')
+        if in_channel > 16:
+            raise NotImplementedError('fused set abstraction: 3 + D <= 16 input channels')
+        self.cin, self.cout, self.w, self.b = [], [], [], []
+        prev = in_channel
+        for li, (w, b, bn) in enumerate(layers):
+            w = np.asarray(w, dtype=np.float64).reshape(np.shape(w)[0], -1)
+            if w.shape[1] != prev:
+                raise ValueError(f'layer {li}: expected {prev} input channels, got {w.shape[1]}')
+            if w.shape[0] % 32 or w.shape[0] > 256:
+                raise NotImplementedError('fused set abstraction: layer widths must be multiples of 32, <= 256')
+            wf, bf = folding.fold_bn(w, b, bn)
+            if li == 0:
+                wf = np.concatenate([wf, np.zeros((wf.shape[0], 16 - prev))], axis=1)
+            self.cin.append(wf.shape[1]); self.cout.append(wf.shape[0])
+            self.w.append(torch.from_numpy(folding.pack_b(wf)).to(device))
+            self.b.append(torch.from_numpy(bf.astype(np.float32)).to(device))
+            prev = w.shape[0]
+        self.in_channel = in_channel
+
+
+def group_mlp_max(xyz, points, new_xyz, idx, W):
+    """The consumer of sample_and_group fused into one kernel (cg_sa_group_mlp_max): neighbourhoods idx (B,S,K) of xyz/points
+    around new_xyz -> centred coordinates ++ features -> shared MLP W (SetAbstractionWeights) -> max over the K neighbours.
+    -> (B, C_out, S) float32, the layout torch.max(new_points, 2)[0] has in a PointNet++ set-abstraction layer."""
+    require_cuda(xyz, new_xyz, idx)
+    xyz = _f32(xyz); new_xyz = _f32(new_xyz)
+    idx = idx.contiguous().long()
+    B, N, _ = xyz.shape
+    S, K = idx.shape[1], idx.shape[2]
+    D = 0
+    if points is not None:
+        points = _f32(points); D = points.shape[2]
+    if 3 + D != W.in_channel:
+        raise ValueError(f'weights expect {W.in_channel} input channels, got 3 + {D}')
+    out = torch.empty((B, W.cout[-1], S), dtype=torch.float32, device=xyz.device)
+    err = torch.zeros((1,), dtype=torch.int32, device=xyz.device)
+    L_ = len(W.w)
+    cin = (ctypes.c_int * L_)(*W.cin); cout = (ctypes.c_int * L_)(*W.cout)
+    wp = (ctypes.c_void_p * L_)(*[t.data_ptr() for t in W.w]); bp = (ctypes.c_void_p * L_)(*[t.data_ptr() for t in W.b])
+    check(L.lib().cg_sa_group_mlp_max(_p(xyz), _p(points), _p(new_xyz), _p(idx), _c_int(B), _c_int(N), _c_int(S), _c_int(K), _c_int(D),
+                                      _c_int(L_), cin, cout, wp, bp, _p(out), _p(err), _stream()), 'cg_sa_group_mlp_max')
+    _raise_if(err, 'group_mlp_max (a query ball was empty or an index is out of range)')
+    return out

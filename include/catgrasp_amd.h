@@ -354,6 +354,38 @@ int cg_pg_get_iou(const int* proposals_idx, const int* proposals_offset, const l
 int cg_pg_voxelize_fp(const float* feats, const int* rules, int n_rows, int max_active, int C, int average, float* out,
                       void* stream);
 
+/* voxelization_idx (PointGroup/lib/pointgroup_ops/src/voxelize/voxelize.cpp:11-151; called at predicter.py:285), device pieces
+ * around a stable device sort of the packed keys (the host side, catgrasp_amd/pointgroup_ops.py, owns sort/scan/allocation):
+ *  cg_pg_voxel_pack_keys : coords (n, ncol) int64, ncol 4 = [batch,x,y,z] or 3 -> keys (n) = batch<<48 | x<<32 | y<<16 | z;
+ *                          *err_flag = 1 if a coordinate is outside [0,65536) or a batch index outside [0,32768).
+ *  cg_pg_segment_heads   : head[j] = 1 iff sorted_keys[j] starts a run of equal keys.
+ *  cg_pg_voxel_fill_maps : for sorted position j (point perm[j], run seg[j] starting at seg_start[seg[j]], voxel vid[seg[j]]):
+ *                          input_map[point] = voxel; output_map (M, width) row = [count, member point ids ...] (mode 3 / 4:
+ *                          all members ascending; 1: first; 2: last; 0: the only one), pre-zeroed by the caller. */
+int cg_pg_voxel_pack_keys(const long long* coords, int n, int ncol, long long* keys, int* err_flag, void* stream);
+int cg_pg_segment_heads(const long long* sorted_keys, int n, int* head, void* stream);
+int cg_pg_voxel_fill_maps(const long long* perm, const int* seg, const int* seg_start, const int* vid, int n, int width, int mode,
+                          int* input_map, int* output_map, void* stream);
+
+/* bfs_cluster (src/bfs_cluster/bfs_cluster.cpp:34-121; called at PointGroup/model/pointgroup/pointgroup.py:240,245): one sweep
+ * of min-label propagation with pointer jumping over the CSR neighbour lists (ball_query_idxs, start_len (n,2)) restricted to
+ * equal semantic labels; comp (n) starts as 0..n-1; *changed is set when any entry dropped.  Iterate to the fixed point:
+ * comp[i] = smallest point index of i's connected component. */
+int cg_pg_cc_propagate(const int* semantic_label, const int* ball_query_idxs, const int* start_len, int n, int* comp, int* changed,
+                       void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused PointNet++ set abstraction (north_star: "grouped per-neighbourhood MLP reductions"): the consumer of
+ * sample_and_group (pointnet2.py:101-129) -- new_points = cat(xyz[idx] - new_xyz, points[idx]) -> [Conv2d(1x1)+BN+ReLU] x L ->
+ * max over the K neighbours -- without materialising the grouped tensor.  xyz (B,N,3), points (B,N,D) or NULL (D = 0),
+ * new_xyz (B,S,3), idx (B,S,K) int64 (query_ball_point output) -> out (B, cout[L-1], S).  Layers (HOST arrays of length
+ * n_layers <= 4): BatchNorm folded, weights packed like cg_gemm_bias_act's (folding.pack_b), layer 0 with its 3 + D input columns
+ * zero-padded to cin[0] = 16; cout multiples of 32, <= 256.  *err_flag (device, pre-zeroed) = 1 on an out-of-range index (the
+ * reference's index_points raises).  Exact-f32 MFMA. */
+int cg_sa_group_mlp_max(const float* xyz, const float* points, const float* new_xyz, const long long* idx, int B, int N, int S, int K,
+                        int D, int n_layers, const int* h_cin, const int* h_cout, const float* const* h_w_packed,
+                        const float* const* h_bias, float* out, int* err_flag, void* stream);
+
 /* get_ik_within_limits(...).size() > 0 (my_cpp/common.cpp:9-72, called at :230-236 of filterGraspPose): closed-form IK of the
  * KUKA LBR iiwa14 with the redundancy joint (index 2) at 0 -- what the reference's generated IKFast file solves -- one thread
  * per pose, float64.  ee_in_base (E,16) float32 row-major 4x4 on the device, h_upper7 / h_lower7 HOST joint limits,

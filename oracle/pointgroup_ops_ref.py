@@ -68,3 +68,53 @@ def voxelize_fp(feats, rules, average):
         for i in range(1, n + 1):
             out[r] = (out[r] + mult * feats[rules[r, i]]).astype(np.float32)
     return out
+
+
+def voxelization_idx(coords, mode=4):
+    """voxelize.cpp:58-151 (voxelize_inputmap + voxelize_outputmap): an insertion-ordered map from coordinate to voxel id."""
+    coords = np.asarray(coords, dtype=np.int64)
+    table, rows = {}, []
+    input_map = np.zeros((len(coords),), dtype=np.int32)
+    for i, c in enumerate(coords):
+        k = tuple(c.tolist())
+        if k not in table:
+            table[k] = len(rows); rows.append([])
+        rows[table[k]].append(i)
+        input_map[i] = table[k]
+    if mode in (3, 4):
+        max_active = max([len(r) for r in rows] + [1])
+        out_map = np.zeros((len(rows), max_active + 1), dtype=np.int32)
+        for v, r in enumerate(rows):
+            out_map[v, 0] = len(r); out_map[v, 1:1 + len(r)] = r
+    else:
+        out_map = np.zeros((len(rows), 2), dtype=np.int32)
+        for v, r in enumerate(rows):
+            out_map[v] = [1, r[0] if mode in (0, 1) else r[-1]]
+    out_coords = coords[out_map[:, 1]] if len(rows) else np.zeros((0, coords.shape[1]), dtype=np.int64)
+    return out_coords, input_map, out_map
+
+
+def bfs_cluster(semantic_label, ball_query_idxs, start_len, threshold):
+    """bfs_cluster.cpp:34-121: seed loop over unvisited points in index order, queue BFS over same-label neighbours;
+    -> (cluster_idxs (sumNPoint,2) in visit order, cluster_offsets)."""
+    from collections import deque
+    n = len(start_len)
+    visited = np.zeros(n, dtype=bool)
+    clusters = []
+    for i in range(n):
+        if visited[i]:
+            continue
+        cc = [i]; visited[i] = True
+        q = deque([i])
+        while q:
+            cur = q.popleft()
+            s, l = start_len[cur]
+            for j in ball_query_idxs[s:s + l]:
+                if semantic_label[j] != semantic_label[cur] or visited[j]:
+                    continue
+                cc.append(int(j)); visited[j] = True; q.append(int(j))
+        if len(cc) >= threshold:
+            clusters.append(cc)
+    idxs = np.array([[c, p] for c, cc in enumerate(clusters) for p in cc], dtype=np.int32).reshape(-1, 2)
+    offsets = np.concatenate([[0], np.cumsum([len(cc) for cc in clusters])]).astype(np.int32)
+    return idxs, offsets

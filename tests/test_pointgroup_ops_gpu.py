@@ -61,3 +61,53 @@ def test_get_iou_and_voxelize(cuda_device):
     for mode, avg in ((4, True), (3, False)):
         v = pg.voxelization(torch.from_numpy(feats).to(cuda_device), torch.from_numpy(rules).to(cuda_device), mode).cpu().numpy()
         assert np.array_equal(v, ref.voxelize_fp(feats, rules, avg))
+
+
+def test_voxelization_idx_matches_the_host_rulebook(cuda_device):
+    """voxelize.cpp builds the maps with an insertion-ordered std::map on the host; the device sort/scan formulation must return
+    the identical three tensors (first-appearance voxel order, ascending members), for every mode and both coordinate layouts."""
+    from catgrasp_amd import pointgroup_ops as pg
+    rng = np.random.default_rng(3)
+    n = 5000
+    coords4 = np.concatenate([rng.integers(0, 3, (n, 1)), rng.integers(0, 12, (n, 3))], axis=1).astype(np.int64)   # many duplicates
+    coords4 = coords4[np.argsort(coords4[:, 0], kind='stable')]          # batches contiguous like the real loader, order inside random
+    for coords, modes in ((coords4, (4, 3, 1, 2)), (coords4[:, 1:], (4,))):
+        for mode in modes:
+            oc, im, om = pg.voxelization_idx(torch.from_numpy(coords).to(cuda_device), 3, mode)
+            roc, rim, rom = ref.voxelization_idx(coords, mode)
+            assert np.array_equal(oc.cpu().numpy(), roc) and np.array_equal(im.cpu().numpy(), rim) and np.array_equal(om.cpu().numpy(), rom)
+    uniq = np.unique(coords4, axis=0)
+    rng.shuffle(uniq)
+    oc, im, om = pg.voxelization_idx(torch.from_numpy(uniq).to(cuda_device), 3, 0)
+    assert np.array_equal(im.cpu().numpy(), np.arange(len(uniq))) and np.array_equal(oc.cpu().numpy(), uniq)
+    # the rule book drives the pooling kernel exactly like the reference's (predicter.py:285-286)
+    feats = rng.normal(size=(n, 7)).astype(np.float32)
+    _, _, om = pg.voxelization_idx(torch.from_numpy(coords4).to(cuda_device), 3, 4)
+    pooled = pg.voxelization(torch.from_numpy(feats).to(cuda_device), om, 4).cpu().numpy()
+    assert np.array_equal(pooled, ref.voxelize_fp(feats, ref.voxelization_idx(coords4, 4)[2], True))
+    with pytest.raises(ValueError):
+        pg.voxelization_idx(torch.tensor([[0, 1, 2, 70000]], device=cuda_device), 1, 4)
+
+
+def test_bfs_cluster_matches_the_host_bfs(cuda_device):
+    """bfs_cluster.cpp's sequential queue BFS vs min-label propagation on the device: same clusters (as point sets), same
+    numbering (by smallest point index), same offsets; chains (worst case for propagation), isolated points, label boundaries."""
+    from catgrasp_amd import pointgroup_ops as pg
+    rng = np.random.default_rng(5)
+    blobs = [rng.normal(c, 0.02, (m, 3)) for c, m in (((0, 0, 0), 400), ((0.3, 0, 0), 300), ((0, 0.3, 0), 90), ((1, 1, 1), 30))]
+    chain = np.stack([np.linspace(2, 3.5, 300), np.zeros(300), np.zeros(300)], 1)          # a 300-point path: diameter 299
+    xyz = np.concatenate(blobs + [chain, rng.uniform(5, 9, (40, 3))]).astype(np.float32)
+    perm = rng.permutation(len(xyz)); xyz = xyz[perm]
+    label = rng.integers(0, 2, len(xyz)).astype(np.int32)                                  # two classes interleaved in space
+    n = len(xyz)
+    bi = np.zeros(n, dtype=np.int32); bo = np.array([0, n], dtype=np.int32)
+    t = lambda a: torch.from_numpy(a).to(cuda_device)
+    idx, start_len = pg.ballquery_batch_p(t(xyz), t(bi), t(bo), 0.03, 300)
+    for thr in (1, 50):
+        ci, co_ = pg.bfs_cluster(t(label), idx, start_len, thr)
+        rci, rco = ref.bfs_cluster(label, idx.cpu().numpy(), start_len.cpu().numpy(), thr)
+        ci, co_ = ci.cpu().numpy(), co_.cpu().numpy()
+        assert np.array_equal(co_, rco) and np.array_equal(ci[:, 0], rci[:, 0])
+        for c in range(len(rco) - 1):
+            assert np.array_equal(ci[rco[c]:rco[c + 1], 1], np.sort(rci[rco[c]:rco[c + 1], 1]))
+    assert len(rco) - 1 >= 3

@@ -99,3 +99,44 @@ def test_sample_and_group(cuda_device):
     nx, npnts = p2.sample_and_group_all(xyz.to(cuda_device), feats.to(cuda_device))
     rx, rp = oref.sample_and_group_all(xyz, feats)
     assert torch.equal(nx.cpu(), rx) and torch.equal(npnts.cpu(), rp)
+
+
+@pytest.mark.parametrize('D,K,mlp', [(6, 32, [64, 64, 128]), (0, 16, [32, 64]), (13, 64, [128, 128, 256]), (3, 40, [64])])
+def test_fused_set_abstraction_matches_sample_and_group_plus_torch_ops(cuda_device, D, K, mlp):
+    """Row X1: group -> shared MLP -> max in one kernel vs the reference pipeline it replaces: sample_and_group
+    (pointnet2.py:101-129, restated in oracle/pointnet_ref.py and pinned to the real one) followed by the torch
+    Conv2d / BatchNorm2d(eval) / ReLU / max ops, float32, on the same FPS start and the same (exact) ball-query indices."""
+    import torch.nn.functional as F
+    from catgrasp_amd import pointnet2 as p2
+    from oracle import pointnet_ref as oref
+    torch.manual_seed(7)
+    B, N, S = 3, 1500, 96
+    xyz = torch.rand(B, N, 3) * 0.4
+    pts = torch.randn(B, N, D) * 0.5 if D else None
+    sa = p2.PointNetSetAbstraction(S, 0.08, K, 3 + D, mlp)
+    with torch.no_grad():
+        for bn in sa.mlp_bns:
+            bn.running_mean.normal_(0, 0.1); bn.running_var.uniform_(0.5, 1.5); bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(0, 0.1)
+    start = torch.tensor([5, 700, 1499])
+    new_xyz_r, new_points_r, _, fps_r = oref.sample_and_group(S, 0.08, K, xyz, pts, start=start)
+    # ball-query membership can legitimately flip inside the float rounding band of d^2 around r^2 (tested in
+    # test_query_ball_point); group the oracle on the device's neighbour lists so this test isolates the fused layer
+    idx = p2.query_ball_point(0.08, K, xyz.cuda(), new_xyz_r.cuda()).cpu()
+    assert (idx != oref.query_ball_point(0.08, K, xyz, new_xyz_r)).float().mean().item() < 1e-3
+    grouped = oref.index_points(xyz, idx) - new_xyz_r.view(B, S, 1, 3)
+    new_points_r = torch.cat([grouped, oref.index_points(pts, idx)], dim=-1) if D else grouped
+    h = new_points_r.permute(0, 3, 2, 1)
+    sa.eval()
+    with torch.no_grad():
+        for conv, bn in zip(sa.mlp_convs, sa.mlp_bns):
+            h = F.relu(bn(conv(h)))
+        ref = torch.max(h, 2)[0].permute(0, 2, 1)
+        sa.cuda()
+        new_xyz, new_points = sa(xyz.cuda(), pts.cuda() if D else None, start=start)
+    assert torch.equal(new_xyz.cpu(), new_xyz_r)
+    assert new_points.shape == ref.shape == (B, S, mlp[-1])
+    assert (new_points.cpu() - ref).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item())
+    # grad-enabled call: the differentiable torch path over the grouped tensor computes the same function
+    with torch.enable_grad():
+        _, np2 = sa(xyz.cuda(), pts.cuda() if D else None, start=start)
+    assert (np2.detach().cpu() - ref).abs().max().item() <= 1e-4 * max(1.0, ref.abs().max().item())
