@@ -330,7 +330,7 @@ def test_device_narrow_phase_equals_the_exact_clipping_oracle(cuda_device):
     n_hit = n_total = n_touch = 0
     for _ in range(40):
         tri = rng.integers(-6, 7, (3, 3)) / 32.0
-        shifts = rng.integers(-8, 9, (200, 3)) / 32.0 + np.round(centre * 32) / 32.0
+        shifts = rng.integers(-4, 5, (200, 3)) / 32.0 + np.round(centre * 32) / 32.0
         poses = np.tile(np.eye(4, dtype=np.float32), (200, 1, 1)); poses[:, :3, 3] = shifts
         V = torch.from_numpy(tri.astype(np.float32)).to(cuda_device)
         out = torch.zeros((200,), dtype=torch.uint8, device=cuda_device)
@@ -344,4 +344,4 @@ def test_device_narrow_phase_equals_the_exact_clipping_oracle(cuda_device):
             assert got[i] == want, (tri, shifts[i], got[i], want)
             n_hit += want; n_total += 1
             n_touch += want and not tx.tri_box_intersect(centre, res / 2 * (1 - 2.0 ** -10), a, b, d, exact=True)
-    assert 500 < n_hit < n_total - 500 and n_touch > 50
+    assert 500 < n_hit < n_total - 500 and n_touch > 100, (n_hit, n_total, n_touch)
