@@ -1,9 +1,12 @@
 """TEST INFRASTRUCTURE ONLY (oracle) -- numpy restatement of my_cpp directionVecToRotation / augmentGraspPoses
 (my_cpp/common.cpp:75-153), float32 loop counters, SVD orthonormalisation (R = U V^T) like Eigen::JacobiSVD.
 
-PARITY UNPINNED for augmentGraspPoses itself (my_cpp cannot be built here and nothing in the reference calls or tests it);
-its building block has a python twin, Utils.directionVecToRotation, whose REAL outputs pin `direction_vec_to_rotation` in
-tests/golden/host_golden.npz (tests/test_oracle_host_golden.py)."""
+PINNED to the reference's own C++: my_cpp as a whole cannot be built here, but these two functions need Eigen alone (vendored in
+the reference tree), so oracle/build_ref.py:build_augment compiles them from the lines where they lie into
+oracle/_ref/libaugment_ref.so; tests/golden/make_golden_augment.py runs that binary and commits tests/golden/augment_golden.npz
+(207 directions incl. the degenerate ones, 4 augmentGraspPoses calls = 1104 poses), against which this restatement
+(tests/test_oracle_host_golden.py, <= 1e-6) and the HIP kernel (tests/test_collision_gpu.py, <= 1e-5) are checked.  The python twin
+Utils.directionVecToRotation additionally pins `direction_vec_to_rotation` in tests/golden/host_golden.npz."""
 import numpy as np
 
 

@@ -224,6 +224,13 @@ def test_augment_grasp_poses(cuda_device):
     with pytest.raises(ValueError):
         my_cpp.augmentGraspPoses(np.eye(4), p, sph, 30.0, 0.04, 0.002, 0.005)
     assert my_cpp.augmentGraspPoses(R0, p, np.zeros((0, 3)), 30.0, 0.04, 0.002, 0.005)[0].shape == (4, 4)
+    # ... and against the REFERENCE's own C++ (common.cpp:118-153 compiled by oracle/build_ref.py; tests/golden/augment_golden.npz)
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'augment_golden.npz'))
+    for k in range(4):
+        rot, depth, step, bite = (float(v) for v in g[f'aug{k}_params'])
+        got = np.array(my_cpp.augmentGraspPoses(g[f'aug{k}_R0'], g[f'aug{k}_p'], g[f'aug{k}_sphere'], rot, depth, step, bite))
+        assert got.shape == g[f'aug{k}_poses'].shape and np.abs(got - g[f'aug{k}_poses']).max() <= 1e-5
 
 
 def test_make_occupancy_grid_from_cloud_scan(cuda_device):

@@ -148,3 +148,28 @@ def test_predicter_glue_against_real_predict_batch():
     clear = p['nocs_top2_gap'] > 1e-4
     assert clear.mean() > 0.99 and np.array_equal(coords[clear], p['nocs_cloud'][clear])
     assert np.abs(conf[clear[:, 2]] - p['nocs_conf_z'][clear[:, 2]]).max() < 1e-5
+
+
+def test_augment_oracle_matches_the_reference_cpp():
+    """oracle/augment_ref.py vs the reference's OWN C++ directionVecToRotation / augmentGraspPoses (my_cpp/common.cpp:75-153,
+    compiled by oracle/build_ref.py:build_augment; outputs in tests/golden/augment_golden.npz)."""
+    import os
+    from oracle import augment_ref
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'augment_golden.npz'))
+    R = np.array([augment_ref.direction_vec_to_rotation(d, [1, 0, 0]) for d in g['dvr_dirs']])
+    assert np.abs(R - g['dvr_R']).max() <= 1e-6
+    for k in range(4):
+        rot, depth, step, bite = (float(v) for v in g[f'aug{k}_params'])
+        mine = augment_ref.augment_grasp_poses(g[f'aug{k}_R0'], g[f'aug{k}_p'], g[f'aug{k}_sphere'], rot, depth, step, bite)
+        gold = g[f'aug{k}_poses']
+        assert mine.shape == gold.shape and np.abs(mine - gold).max() <= 1e-6
+        # the reference itself emits 3x as many sphere rotations (its loop bound is sphere_pts.size(), reading past the matrix)
+        S = len(g[f'aug{k}_sphere'])
+        assert int(g[f'aug{k}_n_reference']) >= len(gold) and (S == 0) == (int(g[f'aug{k}_n_reference']) == len(gold))
+    if os.path.exists(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'oracle', '_ref', 'libaugment_ref.so')):
+        import ctypes
+        lib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'oracle', '_ref', 'libaugment_ref.so'))
+        out = np.zeros(9, dtype=np.float32)
+        d = np.array([0.3, -0.5, 0.8], dtype=np.float32); r = np.array([1, 0, 0], dtype=np.float32)
+        lib.ref_direction_vec_to_rotation(d.ctypes.data_as(ctypes.c_void_p), r.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p))
+        assert np.abs(out.reshape(3, 3) - augment_ref.direction_vec_to_rotation(d, r)).max() <= 1e-6
