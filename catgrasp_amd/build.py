@@ -27,9 +27,10 @@ def _stale(target, deps):
 
 def build(force=False, verbose=True):
     srcs = sources()
-    gen, inc = os.path.join(CSRC, 'gen_l3_asm.py'), os.path.join(CSRC, 'l3_asm.inc')
-    if _stale(inc, [gen]):      # the hand-scheduled instruction stream of pointmlp_split.hip is generated text
-        subprocess.check_call([sys.executable, gen])
+    for g, i in (('gen_l3_asm.py', 'l3_asm.inc'), ('gen_l3_f32_asm.py', 'l3_f32_asm.inc')):
+        gen, inc = os.path.join(CSRC, g), os.path.join(CSRC, i)
+        if _stale(inc, [gen]):      # the hand-scheduled instruction streams of pointmlp_split.hip / pointmlp.hip are generated text
+            subprocess.check_call([sys.executable, gen])
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(('.hpp', '.inc'))]
     hdrs.append(os.path.join(PKG_DIR, '..', 'include', 'catgrasp_amd.h'))
     objs = []

@@ -15,6 +15,7 @@
 // max over points is a per-lane reduction over the 16 accumulator registers + one lane^32 swap.
 #include "cg_common.hpp"
 #include "../../include/catgrasp_amd.h"
+#include "l3_f32_asm.inc"
 
 namespace {
 
@@ -180,35 +181,27 @@ __global__ __launch_bounds__(256) void pointmlp_max_kernel(Args a) {
       }
     }
     __syncthreads();
-    // ---- L3: 128 -> 1024 + running max over points.  wave w owns channel blocks [8w, 8w+8) ----
+    // ---- L3: 128 -> 1024 + running max over points.  wave w owns channel blocks [8w, 8w+8), two at a time x both row tiles.
+    // The 1024-MFMA stream of the tile is hand-scheduled assembly (gen_l3_f32_asm.py -> l3_f32_asm.inc): operands prefetched one
+    // whole k-step ahead into a double buffer in accumulation registers; it returns the per-lane maxima of the 8 blocks.
     {
-      const float* ar0 = h2 + l31 * S128 + lhi * 4;
-      const float* ar1 = ar0 + 32 * S128;
+      const unsigned ar = (unsigned)(uintptr_t)(h2 + l31 * S128 + lhi * 4);      // generic -> LDS byte address = low 32 bits
+      const unsigned voff = (unsigned)((w * 8 * 16) * 64 + lane) * 16u;          // this wave's first weight fragment
+      float m00, m01, m10, m11, m20, m21, m30, m31, t0, t1;
+      unsigned vo0, vo1;
+      asm volatile(CG_L3_F32_ASM
+                   : [m00] "=&v"(m00), [m01] "=&v"(m01), [m10] "=&v"(m10), [m11] "=&v"(m11), [m20] "=&v"(m20), [m21] "=&v"(m21),
+                     [m30] "=&v"(m30), [m31] "=&v"(m31), [t0] "=&v"(t0), [t1] "=&v"(t1), [vo0] "=&v"(vo0), [vo1] "=&v"(vo1)
+                   : [voff] "v"(voff), [ar] "v"(ar), [wb] "s"(a.w3)
+                   : "memory", CG_L3_F32_CLOBBERS);
+      const float mm[4][2] = {{m00, m01}, {m10, m11}, {m20, m21}, {m30, m31}};
+#pragma unroll
       for (int p = 0; p < 4; ++p) {
-        const int nb0 = w * 8 + p * 2;
-        const f32x4* bp0 = (const f32x4*)a.w3 + (size_t)(nb0 * 16) * 64 + lane;
-        const f32x4* bp1 = bp0 + 16 * 64;
-        f32x16 c00 = {0}, c01 = {0}, c10 = {0}, c11 = {0};
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) {
-          f32x4 b0 = bp0[ks * 64];
-          f32x4 b1 = bp1[ks * 64];
-          f32x4 a0 = *(const f32x4*)(ar0 + ks * 8);
-          f32x4 a1 = *(const f32x4*)(ar1 + ks * 8);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            c00 = mfma32(a0[j], b0[j], c00);
-            c01 = mfma32(a0[j], b1[j], c01);
-            c10 = mfma32(a1[j], b0[j], c10);
-            c11 = mfma32(a1[j], b1[j], c11);
-          }
-        }
-        float m0 = fmaxf(max16(c00), max16(c10));
-        float m1 = fmaxf(max16(c01), max16(c11));
+        float m0 = mm[p][0], m1 = mm[p][1];
         m0 = fmaxf(m0, __shfl_xor(m0, 32));
         m1 = fmaxf(m1, __shfl_xor(m1, 32));
         if (lane < 32) {
-          const int ch0 = nb0 * 32 + lane;
+          const int ch0 = (w * 8 + p * 2) * 32 + lane;
           rmax[ch0] = fmaxf(rmax[ch0], m0);
           rmax[ch0 + 32] = fmaxf(rmax[ch0 + 32], m1);
         }

@@ -1,0 +1,37 @@
+"""Summarise a rocprofv3 --pmc run (--output-format csv) into a small per-kernel CSV of counter means for profiles/.
+usage: python scripts/pmc_summary.py <dir with *_counter_collection.csv [+ *_kernel_trace.csv]> <out.csv> [kernel-name filter]"""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+d, out = sys.argv[1], sys.argv[2]
+flt = sys.argv[3] if len(sys.argv) > 3 else ''
+vals = defaultdict(list)
+for path in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
+    per_dispatch = defaultdict(float)
+    names = {}
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            k = r.get('Kernel_Name') or r.get('kernel_name')
+            if flt and flt not in k:
+                continue
+            key = (r.get('Dispatch_Id') or r.get('dispatch_id'), r.get('Counter_Name') or r.get('counter_name'))
+            per_dispatch[key] += float(r.get('Counter_Value') or r.get('counter_value'))
+            names[key[0]] = k
+    for (disp, cname), v in per_dispatch.items():
+        vals[(names[disp].split('(')[0], cname)].append(v)
+for path in glob.glob(os.path.join(d, '**', '*kernel_trace.csv'), recursive=True):
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            k = r.get('Kernel_Name')
+            if flt and flt not in k:
+                continue
+            vals[(k.split('(')[0], 'duration_ns')].append(float(r['End_Timestamp']) - float(r['Start_Timestamp']))
+with open(out, 'w') as f:
+    f.write('kernel,counter,mean,launches\n')
+    for (k, c), v in sorted(vals.items()):
+        v = v[len(v) // 3:] if len(v) >= 6 else v          # drop warm-up launches
+        f.write(f'"{k[:120]}",{c},{sum(v) / len(v):.0f},{len(v)}\n')
+print(open(out).read()[:6000])
