@@ -6,6 +6,17 @@ import os
 import sys
 from collections import defaultdict
 
+def short(k):
+    """'void (anonymous namespace)::kern<2, 8, true>((anonymous namespace)::Args)' -> 'kern<2, 8, true>'"""
+    k = k.replace('(anonymous namespace)::', '').replace('void ', '')
+    depth = 0
+    for i, ch in enumerate(k):
+        depth += ch == '<'; depth -= ch == '>'
+        if ch == '(' and depth == 0:
+            return k[:i]
+    return k
+
+
 d, out = sys.argv[1], sys.argv[2]
 flt = sys.argv[3] if len(sys.argv) > 3 else ''
 vals = defaultdict(list)
@@ -21,14 +32,14 @@ for path in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursiv
             per_dispatch[key] += float(r.get('Counter_Value') or r.get('counter_value'))
             names[key[0]] = k
     for (disp, cname), v in per_dispatch.items():
-        vals[(names[disp].split('(')[0], cname)].append(v)
+        vals[(short(names[disp]), cname)].append(v)
 for path in glob.glob(os.path.join(d, '**', '*kernel_trace.csv'), recursive=True):
     with open(path) as f:
         for r in csv.DictReader(f):
             k = r.get('Kernel_Name')
             if flt and flt not in k:
                 continue
-            vals[(k.split('(')[0], 'duration_ns')].append(float(r['End_Timestamp']) - float(r['Start_Timestamp']))
+            vals[(short(k), 'duration_ns')].append(float(r['End_Timestamp']) - float(r['Start_Timestamp']))
 with open(out, 'w') as f:
     f.write('kernel,counter,mean,launches\n')
     for (k, c), v in sorted(vals.items()):
