@@ -244,12 +244,10 @@ extern "C" int cg_pointmlp_max(const float* x, int B, int N, const float* t3, co
   // (2 per CU), the samples of the last, partially filled scheduling round are split 8 ways so that round is short.
   int n_main = B, tail_split = 1;
   if (nsplit == 1 && ntiles >= 8) {
-    static int slots = 0;
-    if (slots == 0) {
-      int dev = 0; hipDeviceProp_t prop;
-      if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return CG_ERR_UNSUPPORTED;
-      slots = 2 * prop.multiProcessorCount;
-    }
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return CG_ERR_UNSUPPORTED;
+    const int slots = 2 * cg_device_cu_count(dev);          // resident workgroups (57 KB of LDS each): two per CU
+    if (slots <= 0) return CG_ERR_UNSUPPORTED;
     if (B >= slots && (B % slots) != 0) { n_main = B - B % slots; tail_split = 8; }
   }
   if (nsplit > 1 || tail_split > 1) {
