@@ -12,7 +12,8 @@
 // staged in a wave-private LDS strip, every layer is  act(W' x + b')  with BatchNorm folded on the host, evaluated as
 // v_mfma_f32_32x32x2_f32 (exact f32) with the neighbours as the M dimension and the channels as N, activations ping-pong between
 // two wave-private LDS strips, and the last layer's max over neighbours is a per-lane reduction over the 16 accumulator
-// registers + one lane^32 exchange -- no workgroup barrier anywhere in the kernel.
+// registers + one lane^32 exchange -- no workgroup barrier anywhere in the kernel.  The strips are as wide as the widest STORED
+// activation, so e.g. the 64-64-128 layer runs 8 waves per workgroup (2 per SIMD) in 139 KB of LDS.
 #include "cg_common.hpp"
 #include "../../include/catgrasp_amd.h"
 
@@ -34,9 +35,11 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 
-template <int CMAX, int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void sa_group_mlp_max_kernel(SAArgs a) {
-  constexpr int CS = CMAX + 4;                      // row stride (floats): conflict-free 16-byte fragment reads
+// CS: row stride (floats) of the wave-private activation strips = widest STORED activation (layer inputs; the last layer's output
+// goes straight from the accumulators into the max) + 4 -> conflict-free 16-byte fragment reads.  A run-time value, so narrow
+// networks get small strips and therefore more resident waves (the chain inside a wave is latency bound: more waves = more overlap).
+template <int CMAX>
+__global__ __launch_bounds__(512) void sa_group_mlp_max_kernel(SAArgs a, int CS, int WAVES) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int l31 = lane & 31, lhi = lane >> 5;
@@ -113,20 +116,23 @@ __global__ __launch_bounds__(64 * WAVES) void sa_group_mlp_max_kernel(SAArgs a) 
   }
 }
 
-template <int CMAX, int WAVES>
-int launch_sa(const SAArgs& a, hipStream_t s, int dev) {
-  constexpr size_t LDS = (size_t)WAVES * 2 * 32 * (CMAX + 4) * 4;
-  static_assert(LDS <= 160 * 1024, "LDS budget");
-  auto kern = sa_group_mlp_max_kernel<CMAX, WAVES>;
+template <int CMAX>
+int launch_sa(const SAArgs& a, int cs, hipStream_t s, int dev) {
+  const size_t per_wave = (size_t)2 * 32 * cs * 4;
+  int waves = (int)((size_t)(156 * 1024) / per_wave);
+  if (waves > 8) waves = 8;
+  if (waves < 1) return CG_ERR_UNSUPPORTED;
+  const size_t lds = per_wave * waves;
+  auto kern = sa_group_mlp_max_kernel<CMAX>;
   static bool attr_set[CG_MAX_DEVICES] = {};
   if (dev < 0 || dev >= CG_MAX_DEVICES) return CG_ERR_UNSUPPORTED;
   if (!attr_set[dev]) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
     attr_set[dev] = true;
   }
   const long groups = (long)a.B * a.S;
-  hipLaunchKernelGGL(kern, dim3((unsigned)((groups + WAVES - 1) / WAVES)), dim3(64 * WAVES), LDS, s, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)((groups + waves - 1) / waves)), dim3(64 * waves), lds, s, a, cs, waves);
   return cg_hip_status(hipGetLastError());
 }
 
@@ -143,17 +149,18 @@ extern "C" int cg_sa_group_mlp_max(const float* xyz, const float* points, const 
   SAArgs a{};
   a.xyz = xyz; a.points = D > 0 ? points : nullptr; a.new_xyz = new_xyz; a.idx = idx;
   a.B = B; a.N = N; a.S = S; a.K = K; a.D = D; a.nlayers = n_layers; a.out = out; a.err_flag = err_flag;
-  int cmax = 0;
+  int cmax = 0, cstore = C0;
   for (int l = 0; l < n_layers; ++l) {
     if (!h_w_packed[l] || !h_bias[l]) return CG_ERR_ARG;
     if (h_cin[l] != (l == 0 ? C0 : h_cout[l - 1])) return CG_ERR_ARG;          // layer 0: K padded to 16 by the host
     if (h_cout[l] <= 0 || (h_cout[l] % 32) != 0) return CG_ERR_UNSUPPORTED;
     a.cin[l] = h_cin[l]; a.cout[l] = h_cout[l]; a.w[l] = h_w_packed[l]; a.b[l] = h_bias[l];
     if (h_cout[l] > cmax) cmax = h_cout[l];
+    if (l + 1 < n_layers && h_cout[l] > cstore) cstore = h_cout[l];
   }
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return CG_ERR_UNSUPPORTED;
-  if (cmax <= 128) return launch_sa<128, 4>(a, (hipStream_t)stream, dev);
-  if (cmax <= 256) return launch_sa<256, 2>(a, (hipStream_t)stream, dev);
+  if (cmax <= 128) return launch_sa<128>(a, cstore + 4, (hipStream_t)stream, dev);
+  if (cmax <= 256) return launch_sa<256>(a, cstore + 4, (hipStream_t)stream, dev);
   return CG_ERR_UNSUPPORTED;
 }

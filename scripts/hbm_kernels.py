@@ -3,7 +3,7 @@ meaningful only for the scan/gather kernels").  For each kernel: ALGORITHMIC byt
 time measured with HIP events on the launch stream, against the 8 TB/s HBM3E peak (MI355X_MICROARCH.md).  Latency-bound
 kernels (FPS: sequential dependency over npoint; the collision filter: L2/LDS gathers) are reported with their own unit.
 
-    python scripts/hbm_kernels.py > profiles/r1_hbm_kernels.json          (on the GPU box)
+    python scripts/hbm_kernels.py > profiles/r2_hbm_kernels.json          (on the GPU box)
 """
 import json
 import sys
@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, '.')
-from catgrasp_amd import my_cpp, ops, primitives, synth   # noqa: E402
+from catgrasp_amd import my_cpp, ops, pointgroup_ops, primitives, synth, transforms   # noqa: E402
 
 PEAK = 8000.0   # GB/s
 dev = torch.device('cuda:0')
@@ -96,4 +96,45 @@ row('filter_grasp_pose_kernel (broad-phase grid)', t_f, Pn * (64 + 66), '64 B po
     bound='L2/LDS gather latency', extra={'evaluations_per_s': round(Pn / t_f), 'voxels_open': int(sc.keys_open.shape[0]), 'voxels_background': int(sc.keys_bg.shape[0]),
                                          'cache_level_bytes': 'every evaluation scans the 8-byte keys of both voxel sets (L2-resident): evaluations x (voxels_open + voxels_background) x 8 B',
                                          'cache_level_GBps': round(Pn / t_f * (int(sc.keys_open.shape[0]) + int(sc.keys_bg.shape[0])) * 8 / 1e9, 1)})
+# --- round 2: the host-loop replacements and the fused set-abstraction layer
+G50 = 50000
+ids_out = torch.empty((G50, 2048), dtype=torch.int32, device=dev)
+t_d = timed(lambda: transforms.draw_ids_device(2500, 2048, G50, dev, seed=7, out=ids_out), iters=10)
+row('draw_ids_perm_kernel (resampling draw, 50k candidates)', t_d, G50 * 2048 * 4, '2048 x 4 B ids written per candidate', bound='LDS latency (sequential Fisher-Yates per row)',
+    extra={'rows_per_s': round(G50 / t_d), 'note': 'one lane per candidate, permutation array in LDS; the reference draws these on the host: ~75 us per candidate'})
+poses50 = torch.from_numpy(synth.make_candidates(objs[0], 2000, np.random.default_rng(1)).astype(np.float32).reshape(-1, 16)).to(dev).repeat(25, 1).contiguous()
+t_pi = timed(lambda: transforms.pose_inverse_rows_device(poses50, np.zeros(3)))
+row('pose_inverse_rows_kernel', t_pi, G50 * (64 + 48), '64 B pose in + 48 B rows out per candidate (launch-latency bound at this size)')
+import bench as _bench          # noqa: E402  (subdivide)
+Vb, Fb = _bench.subdivide(gr['vertices'], gr['faces'], 4)
+Vd, Fd = torch.from_numpy(Vb).to(dev), torch.from_numpy(Fb).to(dev)
+t_mg = timed(lambda: my_cpp.MeshGrid(Vb, Fb, 0.0005, dev, V_dev=Vd, F_dev=Fd), iters=5, warm=1)
+row('mesh_grid_count/fill/sort (9216-triangle gripper)', t_mg, len(Fb) * 36, 'wall time of the whole device build incl. its one read-back', bound='launch latency',
+    extra={'note': 'the numpy builder it replaces: 0.22 s per mesh'})
+sa = primitives.SetAbstractionWeights([(np.random.default_rng(0).normal(0, 0.2, (64, 9)), np.zeros(64), None), (np.random.default_rng(1).normal(0, 0.1, (64, 64)), np.zeros(64), None),
+                                       (np.random.default_rng(2).normal(0, 0.1, (128, 64)), np.zeros(128), None)], 9, dev)
+idx_sa = primitives.query_ball_point(0.02, K, pts, new)
+idx_sa = torch.where(idx_sa >= N, torch.zeros_like(idx_sa), idx_sa)
+t_sa = timed(lambda: primitives.group_mlp_max(pts, feat, new, idx_sa, sa))
+mac = S * K * (16 * 64 + 64 * 64 + 64 * 128)
+row('sa_group_mlp_max_kernel (N=20000, S=1024, K=32, mlp 9->64->64->128)', t_sa, S * K * (8 + 36) + S * (12 + 512),
+    '8 B index + 36 B gathered row per neighbour + 12 B centroid in + 512 B out per neighbourhood (the unfused pipeline writes and re-reads S x K x (9 + 64 + 64 + 128) x 4 B = 35 MB)',
+    bound='mfma (exact f32)', extra={'TFLOPs': round(2 * mac / t_sa / 1e12, 2), 'frac_of_157.3_TFLOPs': round(2 * mac / t_sa / 1e12 / 157.3, 4),
+                                     'note': 'one wave per neighbourhood; 1024 neighbourhoods = 256 workgroups: launch/latency bound at this size'})
+Bb = 16
+ptsB = (torch.rand(Bb, N, 3, device=dev, generator=g) * 0.1).contiguous(); featB = torch.randn(Bb, N, 6, device=dev, generator=g)
+newB = ptsB[:, :S].contiguous()
+idxB = primitives.query_ball_point(0.02, K, ptsB, newB); idxB = torch.where(idxB >= N, torch.zeros_like(idxB), idxB)
+t_sb = timed(lambda: primitives.group_mlp_max(ptsB, featB, newB, idxB, sa))
+row('sa_group_mlp_max_kernel (16 clouds)', t_sb, Bb * (S * K * (8 + 36) + S * (12 + 512)), 'as above x 16 clouds', bound='mfma (exact f32)',
+    extra={'TFLOPs': round(2 * mac * Bb / t_sb / 1e12, 2), 'frac_of_157.3_TFLOPs': round(2 * mac * Bb / t_sb / 1e12 / 157.3, 4)})
+coords = torch.cat([torch.zeros(100000, 1, dtype=torch.long, device=dev), torch.randint(0, 64, (100000, 3), device=dev, generator=g)], 1)
+t_vx = timed(lambda: pointgroup_ops.voxelization_idx(coords, 1, 4), iters=5, warm=1)
+row('voxelization_idx (100k points; pack + device sort + scans + fill)', t_vx, 100000 * (32 + 4 + 8), 'wall time of the whole op incl. two read-backs', bound='launch latency / sort')
+xyz_c = torch.rand(20000, 3, device=dev, generator=g) * 0.3
+bi = torch.zeros(20000, dtype=torch.int32, device=dev); bo = torch.tensor([0, 20000], dtype=torch.int32, device=dev)
+nb_idx, nb_sl = pointgroup_ops.ballquery_batch_p(xyz_c, bi, bo, 0.01, 50)
+lab = torch.randint(0, 2, (20000,), device=dev, generator=g).int()
+t_cc = timed(lambda: pointgroup_ops.bfs_cluster(lab, nb_idx, nb_sl, 10), iters=5, warm=1)
+row('bfs_cluster (20k points, label propagation to the fixed point)', t_cc, nb_idx.numel() * 4 + 20000 * 16, 'wall time of the whole op incl. its convergence read-backs', bound='latency (iterative)')
 print(json.dumps({'device': torch.cuda.get_device_name(0), 'hbm_peak_GBps': PEAK, 'kernels': rows}, indent=1))
