@@ -58,17 +58,13 @@ struct Stream {
 // One lane per output row.  n_valid >= n_pts: the row's permutation array lives in LDS as u16, rows interleaved
 // (element k of row r at [k*R + r]) so the lanes' sequential initialisation is conflict-free and their random accesses
 // spread over the banks; n_pts steps of Fisher-Yates give a uniform n_pts-subset in uniform order, which is what
-// np.random.choice(replace=False) returns.  Outputs leave in 16-byte groups per lane.  The R rows that fit the LDS are spread over
-// the workgroup's 4 waves (one per SIMD): the chain of a row is latency bound, four instruction streams overlap it.
-constexpr int DRAW_WAVES = 4;
-__global__ __launch_bounds__(64 * DRAW_WAVES) void draw_ids_perm_kernel(int n_valid, int n_pts, long count, unsigned k0, unsigned k1,
-                                                                        int base, int R, long row_offset, int* __restrict__ out) {
+// np.random.choice(replace=False) returns.  Outputs leave in 16-byte groups per lane.
+__global__ __launch_bounds__(64) void draw_ids_perm_kernel(int n_valid, int n_pts, long count, unsigned k0, unsigned k1,
+                                                           int base, int R, long row_offset, int* __restrict__ out) {
   extern __shared__ unsigned short perm[];
-  const int rpw = (R + DRAW_WAVES - 1) / DRAW_WAVES;            // rows per wave
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int r = wv * rpw + lane;
+  const int r = threadIdx.x;
   const long row = (long)blockIdx.x * R + r;
-  if (lane >= rpw || r >= R || row >= count) return;
+  if (r >= R || row >= count) return;
   for (int k = 0; k < n_valid; ++k) perm[(size_t)k * R + r] = (unsigned short)k;
   const long grow = row + row_offset;          // the stream is a function of the GLOBAL row: a shard draws what the whole would
   Stream s{k0, k1, (unsigned)grow, (unsigned)(grow >> 32) << 24, U4{0, 0, 0, 0}, 0};
@@ -199,7 +195,7 @@ extern "C" int cg_draw_resample_ids(int n_valid, int n_pts, long count, unsigned
   if (n_valid >= n_pts && n_valid <= 65535) {
     constexpr size_t LDS = 128 * 1024;
     int R = (int)(LDS / ((size_t)n_valid * 2));
-    if (R > 64 * DRAW_WAVES) R = 64 * DRAW_WAVES;
+    if (R > 64) R = 64;
     if (R >= 1) {
       const size_t bytes = (size_t)R * n_valid * 2;
       auto kern = draw_ids_perm_kernel;
@@ -207,7 +203,7 @@ extern "C" int cg_draw_resample_ids(int n_valid, int n_pts, long count, unsigned
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
         if (e != hipSuccess) return (int)e;
       }
-      hipLaunchKernelGGL(kern, dim3((unsigned)((count + R - 1) / R)), dim3(64 * DRAW_WAVES), bytes, s, n_valid, n_pts, count, k0, k1, base, R, row_offset, out);
+      hipLaunchKernelGGL(kern, dim3((unsigned)((count + R - 1) / R)), dim3(64), bytes, s, n_valid, n_pts, count, k0, k1, base, R, row_offset, out);
       return cg_hip_status(hipGetLastError());
     }
   }
