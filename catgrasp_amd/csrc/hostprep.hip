@@ -65,22 +65,37 @@ __global__ __launch_bounds__(64) void draw_ids_perm_kernel(int n_valid, int n_pt
   const int r = threadIdx.x;
   const long row = (long)blockIdx.x * R + r;
   if (r >= R || row >= count) return;
-  for (int k = 0; k < n_valid; ++k) perm[(size_t)k * R + r] = (unsigned short)k;
+  for (int k = 0; k < n_valid; ++k) perm[k * R + r] = (unsigned short)k;
   const long grow = row + row_offset;          // the stream is a function of the GLOBAL row: a shard draws what the whole would
-  Stream s{k0, k1, (unsigned)grow, (unsigned)(grow >> 32) << 24, U4{0, 0, 0, 0}, 0};
+  const unsigned c0 = (unsigned)grow, c2 = (unsigned)(grow >> 32);
   int* o = out + row * n_pts;
   const bool vec = ((n_pts & 3) == 0) && (((uintptr_t)out & 15) == 0);
-  int q[4];
-  for (int i = 0; i < n_pts; ++i) {
-    const int j = i + (int)s.below((unsigned)(n_valid - i));
-    const unsigned short a = perm[(size_t)i * R + r], b = perm[(size_t)j * R + r];
-    perm[(size_t)j * R + r] = a;              // a[i] itself is never read again
-    const int v = (int)b + base;
-    if (vec) {
-      q[i & 3] = v;
-      if ((i & 3) == 3) *(int4*)(o + i - 3) = make_int4(q[0], q[1], q[2], q[3]);
-    } else {
-      o[i] = v;
+  // 16 steps per batch: their random words do not depend on the permutation, so the four Philox blocks of a batch are
+  // independent chains (instruction-level parallelism) instead of sitting inside the swap chain, and the swap chain itself is
+  // only the LDS read -> write of one step (LDS operations of a wave execute in order).  j = i + floor(u * (n - i) / 2^32): the
+  // multiply-shift map without rejection (bias <= n / 2^32 < 1e-6 relative).
+  for (int i0 = 0; i0 < n_pts; i0 += 16) {
+    U4 rb[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) rb[q] = philox4x32_10(U4{c0, (unsigned)(i0 >> 2) + q, c2, 0u}, k0, k1);
+    int q4[4];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int i = i0 + t;
+      if (i < n_pts) {
+        const U4& w = rb[t >> 2];
+        const unsigned u = ((t & 3) == 0) ? w.x : ((t & 3) == 1) ? w.y : ((t & 3) == 2) ? w.z : w.w;
+        const int j = i + (int)__umulhi(u, (unsigned)(n_valid - i));
+        const unsigned short pa = perm[i * R + r], pb = perm[j * R + r];
+        perm[j * R + r] = pa;               // a[i] itself is never read again
+        const int v = (int)pb + base;
+        if (vec) {
+          q4[t & 3] = v;
+          if ((t & 3) == 3) *(int4*)(o + i - 3) = make_int4(q4[0], q4[1], q4[2], q4[3]);
+        } else {
+          o[i] = v;
+        }
+      }
     }
   }
 }
