@@ -219,13 +219,21 @@ def test_symmetry_sets_form_groups():
         transforms.get_symmetry_tfs('bolt')
 
 
-def test_committed_bench_line_honours_the_contract():
-    """profiles/r1_bench_line.json is the JSON line bench.py printed on the MI355X for this round: every field of the driver's
-    contract (and the roofline / cpu_baseline objects) must be present and self-consistent."""
+@pytest.mark.parametrize('name', ['r1_bench_line.json', 'r2_bench_line.json'])
+def test_committed_bench_line_honours_the_contract(name):
+    """profiles/r<N>_bench_line.json is the JSON line bench.py printed on the MI355X in that round: every field of the driver's
+    contract (and the roofline / cpu_baseline objects) must be present and self-consistent; from round 2 on the line is measured
+    on BASELINE.json's C3 configuration in the reference's arithmetic."""
     import json
     import os
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles', 'r1_bench_line.json')
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles', name)
     d = json.loads(open(path).read())
+    if name.startswith('r2'):
+        assert d['config']['candidates_per_gpu'] == 50000 and d['config']['workload'].startswith('C3') and d['dtype'].startswith('f32 ')
+        assert d['config']['evaluations_nocs_shape_adjust_true'] + d['config']['evaluations_cone_shape_adjust_false'] == 50000
+        assert {x['precision'] for x in d['secondary']} == {'f16x3', 'bf16x3'} and all(x['codes_identical_to_primary'] for x in d['secondary'])
+        assert d['api']['predict_batch'][0]['poses'] == 50000 and d['api']['filterGraspPose']['gripper_triangles'][0] >= 5000
+        assert d['roofline']['frac'] > 0.85 and d['value'] > 50000
     for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype',
               'data', 'config', 'roofline', 'cpu_baseline'):
         assert k in d, k
