@@ -40,7 +40,8 @@ struct Args {
 };
 
 // LDS layout (floats): [h2 / hA region: TP*S128] [hB: TP*S64] [xs: TP*XS] [rmax: 1024]
-constexpr int LDS_FLOATS = TP * S128 + TP * S64 + TP * XS + 1024;
+constexpr int WM_FLOATS = 2 * 8 * 64 * 4;          // the 64 -> 64 layer's B fragments [nb 2][ks 8][lane 64][4]: 16 KB
+constexpr int LDS_FLOATS = TP * S128 + TP * S64 + TP * XS + 1024 + WM_FLOATS;
 
 template <int MID>
 __global__ __launch_bounds__(256) void pointmlp_max_kernel(Args a) {
@@ -50,6 +51,7 @@ __global__ __launch_bounds__(256) void pointmlp_max_kernel(Args a) {
   float* hB = smem + TP * S128;
   float* xs = hB + TP * S64;
   float* rmax = xs + TP * XS;
+  f32x4* wms = (f32x4*)(rmax + 1024);      // MID != 0: tile-invariant mid-layer weight fragments, staged once per workgroup
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -83,15 +85,38 @@ __global__ __launch_bounds__(256) void pointmlp_max_kernel(Args a) {
   const float* xb = a.x + (size_t)b * a.N * 6;
   const int l31 = lane & 31;
   const int lhi = lane >> 5;
+  // Tile-invariant operands of the front layers, fetched ONCE per workgroup instead of once per tile with their L2 latency exposed
+  // between two barriers: the 64 -> 128 weight fragments of this wave's channel block live in registers, the 64 -> 64 fragments
+  // (shared weights, or this sample's feature transform) in LDS.
+  f32x4 w2r[8];
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) w2r[ks] = ((const f32x4*)a.w2)[(w * 8 + ks) * 64 + lane];
+  if (MID == 1) {
+    for (int i = tid; i < 2 * 8 * 64; i += 256) wms[i] = ((const f32x4*)a.wm)[i];
+  }
+  if (MID == 2) {      // t64 is stored TRANSPOSED (Tt[n][k] = T[k][n]): a lane's 4 consecutive k are one 16-byte load
+    for (int i = tid; i < 2 * 8 * 64; i += 256) {
+      const int ln = i & 63, ks = (i >> 6) & 7, nb = i >> 9;
+      wms[i] = *(const f32x4*)(a.t64 + (size_t)b * 4096 + (nb * 32 + (ln & 31)) * 64 + ks * 8 + (ln >> 5) * 4);
+    }
+  }
+  // the next tile's points travel from HBM during the current tile's 128 -> 1024 stream
+  f32x2 xn0 = {0.f, 0.f}, xn1 = xn0, xn2 = xn0;
+  auto fetch_points = [&](int tile) {
+    if (tid < TP && tile < t_end) {
+      int p = tile * TP + tid;
+      if (p >= a.N) p = a.N - 1;        // replicate the last point: max-pool is idempotent
+      const f32x2* src = (const f32x2*)(xb + (size_t)p * 6);
+      xn0 = src[0]; xn1 = src[1]; xn2 = src[2];
+    }
+  };
+  fetch_points(t_begin);
 
   for (int tile = t_begin; tile < t_end; ++tile) {
     __syncthreads();   // previous tile's L3 reads of h2 / our rmax init are complete
     // ---- stage input points (apply the 3x3 input transform to xyz, leave normals) ----
     if (tid < TP) {
-      int p = tile * TP + tid;
-      if (p >= a.N) p = a.N - 1;        // replicate the last point: max-pool is idempotent
-      const f32x2* src = (const f32x2*)(xb + (size_t)p * 6);
-      f32x2 v0 = src[0], v1 = src[1], v2 = src[2];
+      const f32x2 v0 = xn0, v1 = xn1, v2 = xn2;
       float px = v0[0], py = v0[1], pz = v1[0];
       if (a.t3) {
         float qx = px * t3r[0] + py * t3r[3] + pz * t3r[6];
@@ -104,6 +129,7 @@ __global__ __launch_bounds__(256) void pointmlp_max_kernel(Args a) {
       *(f32x4*)(xs + tid * XS) = o0;
       *(f32x4*)(xs + tid * XS + 4) = o1;
     }
+    fetch_points(tile + 1);
     __syncthreads();
     // ---- L0: 6 -> 64 on VALU.  thread = (channel, 16-point group) ----
     {
@@ -129,13 +155,7 @@ __global__ __launch_bounds__(256) void pointmlp_max_kernel(Args a) {
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
         f32x4 av = *(const f32x4*)(arow + ks * 8);
-        f32x4 bv;
-        if (MID == 1) {
-          bv = ((const f32x4*)a.wm)[(nb * 8 + ks) * 64 + lane];
-        } else {
-          // t64 is stored TRANSPOSED (Tt[n][k] = T[k][n]): the lane's 4 consecutive k are one 16-byte load
-          bv = *(const f32x4*)(a.t64 + (size_t)b * 4096 + (nb * 32 + l31) * 64 + ks * 8 + lhi * 4);
-        }
+        const f32x4 bv = wms[(nb * 8 + ks) * 64 + lane];
 #pragma unroll
         for (int j = 0; j < 4; ++j) c = mfma32(av[j], bv[j], c);
       }
@@ -159,10 +179,9 @@ __global__ __launch_bounds__(256) void pointmlp_max_kernel(Args a) {
       f32x16 c0 = {0}, c1 = {0};
       const float* ar0 = hB + l31 * S64 + lhi * 4;
       const float* ar1 = ar0 + 32 * S64;
-      const f32x4* bp = (const f32x4*)a.w2 + (w * 8) * 64 + lane;
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
-        f32x4 bv = bp[ks * 64];
+        const f32x4 bv = w2r[ks];
         f32x4 a0 = *(const f32x4*)(ar0 + ks * 8);
         f32x4 a1 = *(const f32x4*)(ar1 + ks * 8);
 #pragma unroll
@@ -256,7 +275,16 @@ extern "C" int cg_pointmlp_max(const float* x, int B, int N, const float* t3, co
     hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, out + (size_t)first * 1024, n, -INFINITY);
   }
   Args a{x, B, N, t3, w1, b1, wm_packed, bm, t64, w2_packed, b2, w3_packed, b3, relu3, nsplit, n_main, tail_split, out, pointfeat};
-  const size_t lds = LDS_FLOATS * sizeof(float);
+  const size_t lds = LDS_FLOATS * sizeof(float);          // 73,728 B: above the 64 KB default limit -> per-device function attribute
+  int dev_l = 0;
+  if (hipGetDevice(&dev_l) != hipSuccess || dev_l < 0 || dev_l >= CG_MAX_DEVICES) return CG_ERR_UNSUPPORTED;
+  static bool attr_set[3][CG_MAX_DEVICES] = {};
+  const void* kerns[3] = {(const void*)pointmlp_max_kernel<0>, (const void*)pointmlp_max_kernel<1>, (const void*)pointmlp_max_kernel<2>};
+  if (!attr_set[mid_mode][dev_l]) {
+    hipError_t e = hipFuncSetAttribute(kerns[mid_mode], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    attr_set[mid_mode][dev_l] = true;
+  }
   dim3 grid((unsigned)(n_main * nsplit + (B - n_main) * tail_split)), block(256);
   if (mid_mode == 0) hipLaunchKernelGGL(pointmlp_max_kernel<0>, grid, block, lds, s, a);
   else if (mid_mode == 1) hipLaunchKernelGGL(pointmlp_max_kernel<1>, grid, block, lds, s, a);
