@@ -192,24 +192,20 @@ class SceneBatch:
             return torch.empty((0, 2), dtype=torch.float32, device=self.device)
         self.run_nunocs(sorted({s.obj for s, _, _ in parts}))
         # filter: the per-segment kernels are small (a few thousand wavefronts), so objects run concurrently on side streams
+        import contextlib
         on_gpu = self.device.type == 'cuda'
         if on_gpu:
             main = torch.cuda.current_stream()
             fork = torch.cuda.Event(); fork.record(main)
         codes, poses = [], []
         for s, a, b in parts:
-            if on_gpu:
-                st = self._streams[s.obj]
-                ctx = torch.cuda.stream(st)
-                ctx.__enter__()
-                st.wait_event(fork)
-            try:
+            st = self._streams[s.obj] if on_gpu else None
+            with (torch.cuda.stream(st) if on_gpu else contextlib.nullcontext()):
+                if on_gpu:
+                    st.wait_event(fork)
                 for i0, i1, j0, j1 in split_eval_range(s.n_sym, a, b):
                     c, p = self.run_filter(s, i0, i1, j0, j1)
                     codes.append(c); poses.append(p)
-            finally:
-                if on_gpu:
-                    ctx.__exit__(None, None, None)
         if on_gpu:
             for st in {self._streams[s.obj] for s, _, _ in parts}:
                 main.wait_stream(st)
