@@ -45,7 +45,7 @@ ALG_HBM_BYTES_PER_CANDIDATE = 49152 + 16384 + 4096
 # of this round) and profiles/r1_pmc_pointmlp.csv (split kernels, unchanged since).  CONSTANTS from those profiles, not counters read
 # in this run (PMC collection needs its own rocprofv3 pass).
 PMC_HBM_BYTES_PER_CANDIDATE = {'bf16x3': (2 * 133760.3 + 16384.0) * 1024 / 4096, 'f16x3': (2 * 133762.0 + 16384.0) * 1024 / 4096,
-                               'f32': (2 * 133859.0 + 16384.0) * 1024 / 4096}
+                               'f32': (2 * 133937.0 + 16384.0) * 1024 / 4096}
 DTYPE = {'f32': 'f32 (exact-f32 MFMA: every product and accumulation in float32, as the reference)',
          'f16x3': 'f32 in/out/accumulate; wide-layer products as 3x f16 MFMA on hi+lo half pieces (f16x3 split, 22 significant bits)',
          'bf16x3': 'f32 in/out/accumulate; wide-layer products as 3x bf16 MFMA on hi+lo bf16 pieces (bf16x3 split, 16 significant bits)'}

@@ -14,7 +14,7 @@ from . import ops
 
 # Arithmetic of the wide dense layers (inputs, outputs, accumulators and everything outside them are float32 in every mode):
 # 'f32'   : exact-f32 MFMA kernels (bitwise an fmaf chain per dot product) -- the reference's arithmetic and the DEFAULT.  On an
-#           MI355X it scores 81k candidates/s end to end (0.92 of the f32 matrix peak), above the 50k target of BASELINE.json.
+#           MI355X it scores 82k candidates/s end to end (0.93 of the f32 matrix peak), above the 50k target of BASELINE.json.
 # 'f16x3' : opt-in fast mode.  Split-half MFMA kernels (x = hi + lo IEEE-half pieces, 3 f16 MFMAs per product block, f32 accumulate)
 #           for every wide layer: logits within ~2e-6 of the float64 evaluation -- float32's own distance -- at 3.2x the f32 rate.  Half
 #           has a narrow exponent range: the kernels report range excursions per call and the engine re-runs such batches with bf16
