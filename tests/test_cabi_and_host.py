@@ -32,6 +32,27 @@ def test_argument_errors_are_reported_not_crashed():
     assert lib.cg_filter_grasp_pose(null, -1, null, 1, null, null, null, null, null, 0, 0, null, null, null, 0, null, null, 0,
                                     null, 0, null, 0, ctypes.c_float(0.0005), null, null, null, null, null) == -1
     assert lib.cg_voxel_keys(one, ctypes.c_long(5), ctypes.c_float(-1.0), one, null) == -1
+    # round-2 entry points
+    L, D3, I3 = ctypes.c_long, (ctypes.c_double * 3)(0, 0, 0), (ctypes.c_int * 3)(4, 4, 4)
+    assert lib.cg_draw_resample_ids(0, 2048, L(4), ctypes.c_ulonglong(1), 0, L(0), one, null) == -1               # empty cloud
+    assert lib.cg_draw_resample_ids(2500, 2048, L(4), ctypes.c_ulonglong(1), 0, L(-1), one, null) == -1           # negative row offset
+    assert lib.cg_draw_resample_ids(70000, 2048, L(4), ctypes.c_ulonglong(1), 0, L(0), one, null) == -2           # > 65535 without replacement
+    assert lib.cg_draw_resample_ids(2500, 2048, L(0), ctypes.c_ulonglong(1), 0, L(0), null, null) == 0
+    assert lib.cg_pose_inverse_rows(one, L(3), None, one, null) == -1                                             # no centre
+    assert lib.cg_pose_inverse_rows(null, L(0), D3, null, null) == 0
+    assert lib.cg_mesh_grid_count(one, one, 5, D3, ctypes.c_double(0.0), ctypes.c_double(0.001), I3, one, null) == -1      # cell size 0
+    assert lib.cg_mesh_grid_fill(one, one, 5, D3, ctypes.c_double(0.002), ctypes.c_double(0.001), I3, null, one, one, null) == -1
+    cin, cout = (ctypes.c_int * 2)(16, 64), (ctypes.c_int * 2)(64, 48)
+    ptrs = (ctypes.c_void_p * 2)(16, 16)
+    assert lib.cg_sa_group_mlp_max(one, null, one, one, 1, 100, 4, 32, 0, 2, cin, cout, ptrs, ptrs, one, null, null) == -2      # width not a multiple of 32
+    cout[1] = 64
+    assert lib.cg_sa_group_mlp_max(one, null, one, one, 1, 100, 4, 32, 5, 2, cin, cout, ptrs, ptrs, one, null, null) == -1      # D > 0 without features
+    assert lib.cg_sa_group_mlp_max(one, one, one, one, 1, 100, 4, 32, 14, 2, cin, cout, ptrs, ptrs, one, null, null) == -2      # 3 + D > 16
+    assert lib.cg_sa_group_mlp_max(one, null, one, one, 0, 100, 4, 32, 0, 2, cin, cout, ptrs, ptrs, one, null, null) == 0
+    assert lib.cg_pg_voxel_pack_keys(one, 5, 2, one, null, null) == -1                                            # ncol must be 3 or 4
+    assert lib.cg_pg_voxel_fill_maps(one, one, one, one, 5, 1, 4, one, one, null) == -1                           # width < 2
+    assert lib.cg_pg_cc_propagate(one, one, one, 5, null, one, null) == -1
+    assert lib.cg_pointmlp_max_f16x3(null, 1, 64, null, null, null, 0, null, null, null, null, null, null, null, 0, 1, 256, null, null, null, null) == -1
     # zero-sized work is a successful no-op
     assert lib.cg_softmax_pg(one, 0, 10, one, one, one, one, null) == 0
     assert lib.cg_voxel_keys(null, ctypes.c_long(0), ctypes.c_float(0.001), null, null) == 0
