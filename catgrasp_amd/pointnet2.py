@@ -39,6 +39,10 @@ def _use_hip(module, x):
     if not x.is_cuda:
         raise RuntimeError('catgrasp_amd.pointnet2: eval-mode inference needs a CUDA/HIP tensor '
                            '(the HIP kernels are the only inference path; there is no CPU fallback)')
+    # The fused kernels max-pool with NaN-ignoring arithmetic (-fno-honor-nans): where the reference would hand back NaN outputs, a
+    # NaN / Inf input point would be pooled away silently -- reject it instead (one reduction over the input + a 1-byte read-back).
+    if not bool(torch.isfinite(x).all()):
+        raise ValueError('catgrasp_amd.pointnet2: the input contains NaN or Inf')
     return True
 
 

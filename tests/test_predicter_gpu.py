@@ -117,6 +117,15 @@ def test_pointnet2_modules_dropin(cuda_device):
     with pytest.raises(RuntimeError):
         with torch.no_grad():
             m.cpu()(x)
+    m.cuda()
+    bad = x.clone(); bad[1, 7, 2] = float('nan')                # the reference would return NaN logits; here it is an error,
+    with pytest.raises(ValueError):                             # never a silently max-pooled-away point
+        with torch.no_grad():
+            m(bad.cuda())
+    with pytest.raises(ValueError):
+        GraspPredicterData = {'cloud_xyz': np.full((100, 3), np.inf), 'cloud_normal': np.zeros((100, 3))}
+        from catgrasp_amd import transforms
+        transforms.DeviceCloud(GraspPredicterData['cloud_xyz'], GraspPredicterData['cloud_normal'], cuda_device)
     ss = synth.make_state_dict('seg', 6, 300, seed=10)
     s = p2.PointNetSeg(6, 300)
     s.load_state_dict(ss)
