@@ -65,51 +65,89 @@ __global__ __launch_bounds__(256) void index_points_kernel(const float* __restri
 
 // ---------------------------------------------------------------- farthest point sampling
 // One workgroup (1024 threads) per cloud.  Thread t owns points t, t+1024, ... (PPT of them) in registers.
-// Each of the npoint rounds: update the running min distance to the chosen set, find the arg-max
-// (first index on ties) with wave shuffles + one LDS exchange between the 16 waves.
-template <int PPT>
-__global__ __launch_bounds__(1024) void fps_kernel(const float* __restrict__ xyz, const long long* __restrict__ start, int N, int npoint,
-                                                   long long* __restrict__ out) {
-  __shared__ float red_v[2][16];
-  __shared__ int red_i[2][16];
+// Each of the npoint rounds: update the running min distance to the chosen set, then one arg-max over the cloud (first index on
+// ties).  The round is a dependent chain, so its latency is what counts:
+//  * (distance, index) travel as ONE 64-bit key  bits(dist) << 32 | (INT_MAX - index)  (distances are >= 0, so their bit patterns
+//    order like the values; the low word makes the smaller index win ties) reduced with DPP row operations -- quad_perm, row
+//    mirrors, row broadcasts: ~8 cycles each instead of a ds_bpermute per value and step;
+//  * the winner's COORDINATES travel with it through LDS (the owning lane publishes them), so the next round does not start with
+//    a dependent global load of xyz[farthest];
+//  * one workgroup barrier per round (double-buffered exchange).
+// Round-1 form (ds_bpermute shuffles + centroid re-read from global memory): 4.1 us per round at N = 20,000.
+__device__ __forceinline__ unsigned long long dpp_max_u64(unsigned long long k, unsigned long long o) { return o > k ? o : k; }
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned long long dpp_step(unsigned long long k) {
+  const unsigned lo = (unsigned)k, hi = (unsigned)(k >> 32);
+  const unsigned olo = (unsigned)__builtin_amdgcn_update_dpp((int)lo, (int)lo, CTRL, ROW_MASK, 0xf, false);
+  const unsigned ohi = (unsigned)__builtin_amdgcn_update_dpp((int)hi, (int)hi, CTRL, ROW_MASK, 0xf, false);
+  return dpp_max_u64(k, ((unsigned long long)ohi << 32) | olo);
+}
+
+// max over the 16 lanes of every DPP row (all lanes of the row get it)
+__device__ __forceinline__ unsigned long long row_max_u64(unsigned long long k) {
+  k = dpp_step<0xB1, 0xf>(k);      // quad_perm [1,0,3,2]
+  k = dpp_step<0x4E, 0xf>(k);      // quad_perm [2,3,0,1]
+  k = dpp_step<0x141, 0xf>(k);     // row_half_mirror
+  k = dpp_step<0x140, 0xf>(k);     // row_mirror
+  return k;
+}
+
+// max over the wavefront, returned in every lane
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long k) {
+  k = row_max_u64(k);
+  k = dpp_step<0x142, 0xa>(k);     // row_bcast15 into rows 1 and 3
+  k = dpp_step<0x143, 0xc>(k);     // row_bcast31 into rows 2 and 3: lane 63 holds the wave maximum
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)k, 63);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(k >> 32), 63);
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+// NT threads, thread t owns points t, t+NT, ...: 1024 threads (<= 128 registers each) for clouds up to 8,192 points, 512 threads
+// (<= 256 registers: 40-48 points per thread without spilling) for clouds up to 24,576.
+template <int NT, int PPT>
+__global__ __launch_bounds__(NT) void fps_kernel(const float* __restrict__ xyz, const long long* __restrict__ start, int N, int npoint,
+                                                 long long* __restrict__ out) {
+  __shared__ unsigned long long red_k[2][16];
+  __shared__ float red_c[2][16][4];
   const int b = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (tid < 32) red_k[tid >> 4][tid & 15] = 0ull;          // slots of absent waves: key 0 loses against every real candidate
+  __syncthreads();
   const float* xb = xyz + (size_t)b * N * 3;
   float px[PPT], py[PPT], pz[PPT], dist[PPT];
 #pragma unroll
   for (int k = 0; k < PPT; ++k) {
-    const int p = tid + k * 1024;
+    const int p = tid + k * NT;
     if (p < N) { px[k] = xb[p * 3 + 0]; py[k] = xb[p * 3 + 1]; pz[k] = xb[p * 3 + 2]; dist[k] = 1e10f; }
-    else { px[k] = 0.f; py[k] = 0.f; pz[k] = 0.f; dist[k] = -1.0f; }   // never selected (all real distances >= 0)
+    else { px[k] = 0.f; py[k] = 0.f; pz[k] = 0.f; dist[k] = 0.0f; }    // padding: distance 0 and the largest indices -> loses every tie
   }
   int farthest = (int)start[b];
+  float cx = xb[farthest * 3 + 0], cy = xb[farthest * 3 + 1], cz = xb[farthest * 3 + 2];
   for (int it = 0; it < npoint; ++it) {
     if (tid == 0) out[(size_t)b * npoint + it] = farthest;
-    const float cx = xb[farthest * 3 + 0], cy = xb[farthest * 3 + 1], cz = xb[farthest * 3 + 2];
-    float bv = -2.0f; int bi = 0x7fffffff;
+    float bv = -1.0f, bx = 0.f, by = 0.f, bz = 0.f; int bi = 0x7fffffff;
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
       const float dx = px[k] - cx, dy = py[k] - cy, dz = pz[k] - cz;
       const float d = (dx * dx + dy * dy) + dz * dz;        // torch.sum((xyz - centroid) ** 2, -1)
-      if (d < dist[k]) dist[k] = d;                          // mask = dist < distance (padding keeps -1)
-      const int p = tid + k * 1024;
-      if (dist[k] > bv) { bv = dist[k]; bi = p; }            // ascending p within a thread: first maximum kept
+      const int p = tid + k * NT;
+      if (p < N && d < dist[k]) dist[k] = d;                 // mask = dist < distance
+      if (dist[k] > bv) { bv = dist[k]; bi = p; bx = px[k]; by = py[k]; bz = pz[k]; }      // ascending p within a thread: first maximum kept
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const float ov = __shfl_xor(bv, o); const int oi = __shfl_xor(bi, o);
-      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-    }
+    const unsigned long long key = ((unsigned long long)__float_as_uint(bv) << 32) | (unsigned)(0x7fffffff - bi);
+    const unsigned long long wmax = wave_max_u64(key);
     const int buf = it & 1;
-    if (lane == 0) { red_v[buf][wv] = bv; red_i[buf][wv] = bi; }
-    __syncthreads();
-    bv = red_v[buf][0]; bi = red_i[buf][0];
-#pragma unroll
-    for (int k = 1; k < 16; ++k) {
-      const float ov = red_v[buf][k]; const int oi = red_i[buf][k];
-      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    if (key == wmax) {           // exactly one lane per wave (indices are unique)
+      red_k[buf][wv] = key;
+      red_c[buf][wv][0] = bx; red_c[buf][wv][1] = by; red_c[buf][wv][2] = bz;
     }
-    farthest = bi;
+    __syncthreads();
+    unsigned long long k16 = red_k[buf][lane & 15];
+    const unsigned long long best = row_max_u64(k16);
+    const int win = __builtin_ctzll(__ballot(k16 == best));      // the wave that holds the winner (lanes 0..15 answer first)
+    farthest = 0x7fffffff - (int)(unsigned)best;
+    cx = red_c[buf][win][0]; cy = red_c[buf][win][1]; cz = red_c[buf][win][2];
   }
 }
 
@@ -245,9 +283,10 @@ extern "C" int cg_farthest_point_sample(const float* xyz, const long long* start
   if (!xyz || !start || !out) return CG_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((unsigned)B), block(1024);
-  if (N <= 1024 * 2) hipLaunchKernelGGL(fps_kernel<2>, grid, block, 0, s, xyz, start, N, npoint, out);
-  else if (N <= 1024 * 8) hipLaunchKernelGGL(fps_kernel<8>, grid, block, 0, s, xyz, start, N, npoint, out);
-  else if (N <= 1024 * 24) hipLaunchKernelGGL(fps_kernel<24>, grid, block, 0, s, xyz, start, N, npoint, out);
+  if (N <= 1024 * 2) hipLaunchKernelGGL((fps_kernel<1024, 2>), grid, block, 0, s, xyz, start, N, npoint, out);
+  else if (N <= 1024 * 8) hipLaunchKernelGGL((fps_kernel<1024, 8>), grid, block, 0, s, xyz, start, N, npoint, out);
+  else if (N <= 512 * 40) hipLaunchKernelGGL((fps_kernel<512, 40>), grid, dim3(512), 0, s, xyz, start, N, npoint, out);
+  else if (N <= 512 * 48) hipLaunchKernelGGL((fps_kernel<512, 48>), grid, dim3(512), 0, s, xyz, start, N, npoint, out);
   else {
     if (!dist_scratch) return CG_ERR_ARG;   // (B,N) floats needed for clouds beyond the register path
     hipLaunchKernelGGL(fps_kernel_global, grid, block, 0, s, xyz, start, N, npoint, dist_scratch, out);
