@@ -10,10 +10,11 @@
 // One wavefront owns one neighbourhood (b, s).  Its K neighbours are the 32 rows of an MFMA tile (K > 32: several row tiles,
 // K < 32: rows padded by repeating neighbour 0 -- the max is idempotent): the gathered, centred coordinates + features are
 // staged in a wave-private LDS strip, every layer is  act(W' x + b')  with BatchNorm folded on the host, evaluated as
-// v_mfma_f32_32x32x2_f32 (exact f32) with the neighbours as the M dimension and the channels as N, activations ping-pong between
-// two wave-private LDS strips, and the last layer's max over neighbours is a per-lane reduction over the 16 accumulator
-// registers + one lane^32 exchange -- no workgroup barrier anywhere in the kernel.  The strips are as wide as the widest STORED
-// activation, so e.g. the 64-64-128 layer runs 8 waves per workgroup (2 per SIMD) in 139 KB of LDS.
+// v_mfma_f32_32x32x2_f32 (exact f32) with the neighbours as the M dimension and the channels as N; a layer computes ALL its output
+// channel blocks before storing anything, so it overwrites its own input strip (no ping-pong pair), and the last layer's max over
+// neighbours is a per-lane reduction over the accumulator registers + one lane^32 exchange -- no workgroup barrier anywhere in the
+// kernel.  The strip is as wide as the widest STORED activation, so e.g. the 64-64-128 layer needs 8.7 KB per wave: 8 waves per
+// workgroup, two workgroups per CU.
 #include "cg_common.hpp"
 #include "../../include/catgrasp_amd.h"
 
@@ -35,25 +36,69 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 
-// CS: row stride (floats) of the wave-private activation strips = widest STORED activation (layer inputs; the last layer's output
+// One layer for the wave's 32-row tile: ALL NNB output channel blocks at once, so an activation fragment is read from LDS once per
+// k-step and feeds 4 x NNB MFMAs on NNB independent accumulators, and the NNB weight fragments of a k-step are requested
+// together.  Because every accumulator is complete before anything is stored, the layer writes its output over its own input: one
+// strip per wave instead of a ping-pong pair.  Last layer: the ReLU'd accumulators go straight into the running max.
+template <int NNB>
+__device__ __forceinline__ void sa_layer(float* strip, int CS, const float* __restrict__ w, const float* __restrict__ bias, int nks, bool last,
+                                         int lane, float* run) {
+  const int l31 = lane & 31, lhi = lane >> 5;
+  f32x16 c[NNB];
+#pragma unroll
+  for (int nb = 0; nb < NNB; ++nb) {
+    const float bv = bias[nb * 32 + l31];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) c[nb][r] = bv;
+  }
+  const float* arow = strip + l31 * CS + lhi * 4;
+  const f32x4* wp = (const f32x4*)w + lane;
+#pragma unroll(NNB > 4 ? 1 : 2)
+  for (int ks = 0; ks < nks; ++ks) {
+    const f32x4 av = *(const f32x4*)(arow + ks * 8);
+    f32x4 bv[NNB];
+#pragma unroll
+    for (int nb = 0; nb < NNB; ++nb) bv[nb] = wp[(size_t)(nb * nks + ks) * 64];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int nb = 0; nb < NNB; ++nb) c[nb] = mfma32(av[j], bv[nb][j], c[nb]);
+  }
+  wave_sync();                       // every lane's fragment reads of the strip are done before it is overwritten
+#pragma unroll
+  for (int nb = 0; nb < NNB; ++nb) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) c[nb][r] = fmaxf(c[nb][r], 0.f);
+    if (!last) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) strip[acc_row(r, lane) * CS + nb * 32 + l31] = c[nb][r];
+    } else {
+      float m = max16(c[nb]);
+      m = fmaxf(m, __shfl_xor(m, 32));
+      run[nb] = fmaxf(run[nb], m);
+    }
+  }
+  wave_sync();
+}
+
+// CS: row stride (floats) of the wave-private activation strip = widest STORED activation (layer inputs; the last layer's output
 // goes straight from the accumulators into the max) + 4 -> conflict-free 16-byte fragment reads.  A run-time value, so narrow
 // networks get small strips and therefore more resident waves (the chain inside a wave is latency bound: more waves = more overlap).
-template <int CMAX>
+template <int MAXNB>          // widest layer / 32: 4 (all widths <= 128; fits 128 registers, 4 waves per SIMD) or 8
 __global__ __launch_bounds__(512) void sa_group_mlp_max_kernel(SAArgs a, int CS, int WAVES) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int l31 = lane & 31, lhi = lane >> 5;
-  float* buf0 = smem + (size_t)wv * 2 * 32 * CS;
-  float* buf1 = buf0 + 32 * CS;
+  float* strip = smem + (size_t)wv * 32 * CS;
   const long g = (long)blockIdx.x * WAVES + wv;     // neighbourhood index b*S + s
   if (g >= (long)a.B * a.S) return;
   const int b = (int)(g / a.S), s = (int)(g - (long)b * a.S);
   const float cx = a.new_xyz[g * 3 + 0], cy = a.new_xyz[g * 3 + 1], cz = a.new_xyz[g * 3 + 2];
   const long long* idg = a.idx + g * a.K;
   const int c_last = a.cout[a.nlayers - 1];
-  float run[CMAX / 32];
+  float run[MAXNB];
 #pragma unroll
-  for (int q = 0; q < CMAX / 32; ++q) run[q] = -INFINITY;
+  for (int q = 0; q < MAXNB; ++q) run[q] = -INFINITY;
 
   for (int k0 = 0; k0 < a.K; k0 += 32) {
     // ---- gather + centre: lane (row r, half h) writes channels [8h, 8h+8) of neighbour k0 + r ----
@@ -72,58 +117,41 @@ __global__ __launch_bounds__(512) void sa_group_mlp_max_kernel(SAArgs a, int CS,
         else if (ch - 3 < a.D) x = pf[ch - 3];
         v[j] = x;
       }
-      *(f32x4*)(buf0 + l31 * CS + 8 * lhi) = f32x4{v[0], v[1], v[2], v[3]};
-      *(f32x4*)(buf0 + l31 * CS + 8 * lhi + 4) = f32x4{v[4], v[5], v[6], v[7]};
+      *(f32x4*)(strip + l31 * CS + 8 * lhi) = f32x4{v[0], v[1], v[2], v[3]};
+      *(f32x4*)(strip + l31 * CS + 8 * lhi + 4) = f32x4{v[4], v[5], v[6], v[7]};
     }
     wave_sync();
-    float* in = buf0; float* outb = buf1;
     for (int l = 0; l < a.nlayers; ++l) {
-      const int nks = a.cin[l] / 8, nnb = a.cout[l] / 32;
+      const int nks = a.cin[l] / 8;
       const bool last = (l == a.nlayers - 1);
-      const float* arow = in + l31 * CS + lhi * 4;
-      const f32x4* wp = (const f32x4*)a.w[l];
-      for (int nb = 0; nb < nnb; ++nb) {
-        const float bias = a.b[l][nb * 32 + l31];
-        f32x16 c;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) c[r] = bias;
-        for (int ks = 0; ks < nks; ++ks) {
-          const f32x4 av = *(const f32x4*)(arow + ks * 8);
-          const f32x4 bv = wp[(size_t)(nb * nks + ks) * 64 + lane];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) c = mfma32(av[j], bv[j], c);
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) c[r] = fmaxf(c[r], 0.f);
-        if (!last) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) outb[acc_row(r, lane) * CS + nb * 32 + l31] = c[r];
-        } else {
-          float m = max16(c);
-          m = fmaxf(m, __shfl_xor(m, 32));
-#pragma unroll
-          for (int q = 0; q < CMAX / 32; ++q) if (q == nb) run[q] = fmaxf(run[q], m);
-        }
+      const int nnb = a.cout[l] / 32;        // wave-uniform
+      if (nnb == 1) sa_layer<1>(strip, CS, a.w[l], a.b[l], nks, last, lane, run);
+      else if (nnb == 2) sa_layer<2>(strip, CS, a.w[l], a.b[l], nks, last, lane, run);
+      else if (nnb == 3) sa_layer<3>(strip, CS, a.w[l], a.b[l], nks, last, lane, run);
+      else if (nnb == 4) sa_layer<4>(strip, CS, a.w[l], a.b[l], nks, last, lane, run);
+      else if constexpr (MAXNB == 8) {
+        if (nnb == 5) sa_layer<5>(strip, CS, a.w[l], a.b[l], nks, last, lane, run);
+        else if (nnb == 6) sa_layer<6>(strip, CS, a.w[l], a.b[l], nks, last, lane, run);
+        else if (nnb == 7) sa_layer<7>(strip, CS, a.w[l], a.b[l], nks, last, lane, run);
+        else sa_layer<8>(strip, CS, a.w[l], a.b[l], nks, last, lane, run);
       }
-      wave_sync();
-      float* t = in; in = outb; outb = t;
     }
   }
   if (lane < 32) {
 #pragma unroll
-    for (int q = 0; q < CMAX / 32; ++q)
+    for (int q = 0; q < MAXNB; ++q)
       if (q * 32 < c_last) a.out[((size_t)b * c_last + q * 32 + lane) * a.S + s] = run[q];
   }
 }
 
-template <int CMAX>
+template <int MAXNB>
 int launch_sa(const SAArgs& a, int cs, hipStream_t s, int dev) {
-  const size_t per_wave = (size_t)2 * 32 * cs * 4;
-  int waves = (int)((size_t)(156 * 1024) / per_wave);
+  const size_t per_wave = (size_t)32 * cs * 4;
+  int waves = (int)((size_t)(78 * 1024) / per_wave);        // <= half a CU's LDS per workgroup: two workgroups co-reside
   if (waves > 8) waves = 8;
   if (waves < 1) return CG_ERR_UNSUPPORTED;
   const size_t lds = per_wave * waves;
-  auto kern = sa_group_mlp_max_kernel<CMAX>;
+  auto kern = sa_group_mlp_max_kernel<MAXNB>;
   static bool attr_set[CG_MAX_DEVICES] = {};
   if (dev < 0 || dev >= CG_MAX_DEVICES) return CG_ERR_UNSUPPORTED;
   if (!attr_set[dev]) {
@@ -160,7 +188,7 @@ extern "C" int cg_sa_group_mlp_max(const float* xyz, const float* points, const 
   }
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return CG_ERR_UNSUPPORTED;
-  if (cmax <= 128) return launch_sa<128>(a, cstore + 4, (hipStream_t)stream, dev);
-  if (cmax <= 256) return launch_sa<256>(a, cstore + 4, (hipStream_t)stream, dev);
-  return CG_ERR_UNSUPPORTED;
+  if (cmax > 256) return CG_ERR_UNSUPPORTED;
+  if (cmax <= 128) return launch_sa<4>(a, cstore + 4, (hipStream_t)stream, dev);
+  return launch_sa<8>(a, cstore + 4, (hipStream_t)stream, dev);
 }
