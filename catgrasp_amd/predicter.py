@@ -99,9 +99,18 @@ class GraspPredicter:
         return transforms.DeviceCloud(data['cloud_xyz'], data['cloud_normal'], self.device)
 
     def score_on_device(self, cloud_xyz, cloud_normal, ids, pose_inv):
-        """cloud_xyz/normal (M,3) f32 cuda; ids (G,n_pts) i32 cuda; pose_inv (G,12) f32 cuda.
+        """cloud_xyz/normal (M,3) f32 cuda; ids (G,n_pts) i32 cuda, or a callable ids(s, e) -> (e-s,n_pts) i32 cuda that is asked for
+        each chunk of candidates in order, exactly once; pose_inv (G,12) f32 cuda.
         -> probs (G,C), label (G) i32, confidence (G), p_G (G) cuda tensors."""
-        G = ids.shape[0]
+        G = pose_inv.shape[0]
+        id_chunks = {}
+
+        def ids_of(s, e):
+            if not callable(ids):
+                return ids[s:e]
+            if s not in id_chunks:
+                id_chunks[s] = ids(s, e)
+            return id_chunks[s]
         C = len(self.cfg['classes']) - 1
         logits = torch.empty((G, C), dtype=torch.float32, device=self.device)
         starts = list(range(0, G, self.chunk))
@@ -110,7 +119,7 @@ class GraspPredicter:
 
         def run(s, st):
             e = min(G, s + self.chunk)
-            x = ops.build_grasp_input(cloud_xyz, cloud_normal, ids[s:e], pose_inv[s:e], self._mean, self._inv_std)
+            x = ops.build_grasp_input(cloud_xyz, cloud_normal, ids_of(s, e), pose_inv[s:e], self._mean, self._inv_std)
             logits[s:e] = engine.cls_forward(self._W, x, st)[0]
         for k, s in enumerate(starts):
             run(s, status[k:k + 1] if guard else None)
@@ -123,14 +132,41 @@ class GraspPredicter:
                         run(starts[k], None)
         return ops.softmax_pg(logits)
 
+    def _numpy_id_chunks(self, n_valid, n_pts, G):
+        """ids(s, e) for score_on_device: numpy's global stream replayed in C (transforms.NumpyChoiceStream), one chunk ahead on a
+        worker thread -- the draw of chunk k+1 overlaps the device scoring chunk k (the C call releases the GIL)."""
+        from concurrent.futures import ThreadPoolExecutor
+        stream = transforms.NumpyChoiceStream(n_valid, n_pts)
+        pool = ThreadPoolExecutor(max_workers=1)
+        chunk, dev = self.chunk, self.device
+        pending = {}
+
+        def submit(s):
+            if s < G and s not in pending:
+                pending[s] = pool.submit(stream.draw, min(G, s + chunk) - s)
+
+        def ids(s, e):
+            submit(s)
+            host = pending.pop(s).result()
+            submit(e)                                   # the next chunk is drawn while this one is uploaded and scored
+            return torch.from_numpy(host).to(dev, non_blocking=True)
+
+        def close():
+            for f in pending.values():
+                f.result()
+            pool.shutdown(wait=True)
+            stream.close()
+        ids.close = close
+        return ids
+
     # ---- reference API ----
     def predict_batch(self, data, grasp_poses, ids=None, rng=None):
         """predicter.py:67-94.  Returns [[pred_label, confidence, probs(10,) float32], ...] per grasp pose.
         `ids` (G,n_pts): explicit resample indices into the z>=0.1 filtered cloud.  Without them the per-pose resampling
         draw of GraspDataset.transform (dataset_grasp.py:72-73) comes from
-          rng='numpy'  (default; $CATGRASP_AMD_RNG): numpy's GLOBAL generator, one np.random.choice per pose exactly like the
-                       reference's python loop -- seeding numpy reproduces the reference's draws, but the loop runs on the host
-                       (~75 us per pose: 13k poses/s);
+          rng='numpy'  (default; $CATGRASP_AMD_RNG): numpy's GLOBAL generator, consumed exactly like the reference's one
+                       np.random.choice per pose -- seeding numpy reproduces the reference's draws.  The stream is replayed in C one
+                       chunk ahead of the device (the draw is inherently sequential: ~15-25 us per pose on one host core);
           rng='device': the same distribution drawn by a counter-based generator on the device (cg_draw_resample_ids; seeded
                        from one draw of numpy's global generator, so it is still reproducible under np.random.seed) -- no
                        host loop and no 8 KB/pose upload."""
@@ -145,7 +181,7 @@ class GraspPredicter:
                 if rng == 'device':
                     ids_d = transforms.draw_ids_device(cloud.n, n_pts, G, self.device, seed=int(np.random.randint(0, 2 ** 31)))
                 elif rng == 'numpy':
-                    ids_d = torch.from_numpy(transforms.draw_ids_reference(cloud.n, n_pts, G)).to(self.device)
+                    ids_d = self._numpy_id_chunks(cloud.n, n_pts, G)
                 else:
                     raise ValueError(f"rng must be 'numpy' or 'device', not {rng!r}")
             else:
@@ -156,7 +192,11 @@ class GraspPredicter:
                     raise IndexError(f'resample index out of range for a cloud of {cloud.n} valid points')
                 ids_d = torch.from_numpy(ids).to(self.device)
             pinv = torch.from_numpy(transforms.pose_inverse_rows(grasp_poses, cloud.center)).to(self.device)
-            probs, label, conf, _ = self.score_on_device(cloud.xyz, cloud.normal, ids_d, pinv)
+            try:
+                probs, label, conf, _ = self.score_on_device(cloud.xyz, cloud.normal, ids_d, pinv)
+            finally:
+                if hasattr(ids_d, 'close'):
+                    ids_d.close()
             probs = probs.cpu().numpy(); label = label.cpu().numpy(); conf = conf.cpu().numpy()
         if not np.isfinite(probs).all():
             raise FloatingPointError('grasp-Q probabilities are not finite (non-finite weights or activations beyond float32)')

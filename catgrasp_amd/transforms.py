@@ -14,16 +14,50 @@ def valid_mask(cloud_xyz):
     return np.asarray(cloud_xyz)[:, 2] >= 0.1
 
 
+class NumpyChoiceStream:
+    """numpy's GLOBAL generator replayed in C (cg_host_numpy_choice_rows, csrc/nprng.hip): hands out, chunk by chunk, exactly the
+    rows `np.random.choice(np.arange(n_valid), n_pts, replace=n_valid<n_pts)` would return call after call, and puts the advanced
+    Mersenne-Twister state back into numpy on close().  The C call holds no GIL, so a worker thread can draw the next chunk while
+    the device scores the current one."""
+
+    def __init__(self, n_valid, n_pts):
+        import ctypes
+        from . import _lib as L
+        self._ct, self._fn = ctypes, L.lib().cg_host_numpy_choice_rows
+        self.n_valid, self.n_pts = int(n_valid), int(n_pts)
+        st = np.random.get_state()
+        if st[0] != 'MT19937':
+            raise RuntimeError(f'numpy global generator is {st[0]}, expected the legacy MT19937')
+        self._rest = (st[3], st[4])
+        self._key = np.ascontiguousarray(st[1], dtype=np.uint32).copy()
+        self._pos = ctypes.c_int(int(st[2]))
+        self._scratch = np.empty((max(self.n_valid, 1),), dtype=np.int32)
+
+    def draw(self, count, out=None):
+        ct = self._ct
+        if out is None:
+            out = np.empty((count, self.n_pts), dtype=np.int32)
+        assert out.shape == (count, self.n_pts) and out.dtype == np.int32 and out.flags.c_contiguous
+        rc = self._fn(self._key.ctypes.data_as(ct.c_void_p), ct.byref(self._pos), ct.c_int(self.n_valid), ct.c_int(self.n_pts),
+                      ct.c_long(count), self._scratch.ctypes.data_as(ct.c_void_p), out.ctypes.data_as(ct.c_void_p))
+        if rc != 0:
+            raise RuntimeError(f'cg_host_numpy_choice_rows failed with status {rc}')
+        return out
+
+    def close(self):
+        np.random.set_state(('MT19937', self._key, int(self._pos.value)) + self._rest)
+
+
 def draw_ids_reference(n_valid, n_pts, count):
     """Resample indices drawn exactly as the reference does: one `np.random.choice` per sample from
     numpy's GLOBAL generator (dataset_grasp.py:72-73), with replacement iff n_valid < n_pts.
-    Seeding numpy therefore reproduces the reference's draws.  -> (count, n_pts) int32."""
-    replace = n_valid < n_pts
-    base = np.arange(n_valid)
-    out = np.empty((count, n_pts), dtype=np.int32)
-    for i in range(count):
-        out[i] = np.random.choice(base, size=(n_pts), replace=replace)
-    return out
+    Seeding numpy therefore reproduces the reference's draws (the stream is replayed in C: same outputs, same generator state
+    afterwards, tests/test_cabi_and_host.py).  -> (count, n_pts) int32."""
+    st = NumpyChoiceStream(n_valid, n_pts)
+    try:
+        return st.draw(count)
+    finally:
+        st.close()
 
 
 _draw_counter = [0]

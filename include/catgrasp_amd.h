@@ -206,6 +206,14 @@ int cg_mesh_grid_fill(const float* vertices, const int* faces, int n_faces, cons
 int cg_draw_resample_ids(int n_valid, int n_pts, long count, unsigned long long seed, int base, long row_offset, int* out,
                          void* stream);
 
+/* HOST function (all pointers host memory; no device work): the same per-candidate draw REPLAYED FROM NUMPY'S OWN STREAM, for
+ * seeded parity with the reference.  h_mt_key624 / h_mt_pos: the Mersenne-Twister state of numpy's global RandomState as
+ * np.random.get_state() returns it (624 uint32 words, position 0..624); updated in place so the caller can np.random.set_state()
+ * it back.  Emits, for `count` candidates, exactly what `np.random.choice(np.arange(n_valid), n_pts, replace = n_valid < n_pts)`
+ * would have returned call after call (permutation(n_valid)[:n_pts], or randint(0, n_valid, n_pts)), ~3x faster than numpy and
+ * outside the GIL.  h_scratch: n_valid ints (replace=False branch).  h_out: (count, n_pts) int32. */
+int cg_host_numpy_choice_rows(unsigned int* h_mt_key624, int* h_mt_pos, int n_valid, int n_pts, long count, int* h_scratch, int* h_out);
+
 /* inv(grasp_pose) of dataset_grasp.py:69-70 for poses already on the device: poses (n,16) f32 row-major 4x4 with last
  * row 0 0 0 1 -> out (n,12) rows [R | t] with x_grasp = R x_centred + t, where x_centred = x_cam - h_center (HOST,
  * 3 doubles).  float64 arithmetic, rounded once (same contract as the host helper transforms.pose_inverse_rows). */

@@ -38,6 +38,9 @@ def test_argument_errors_are_reported_not_crashed():
     assert lib.cg_draw_resample_ids(2500, 2048, L(4), ctypes.c_ulonglong(1), 0, L(-1), one, null) == -1           # negative row offset
     assert lib.cg_draw_resample_ids(70000, 2048, L(4), ctypes.c_ulonglong(1), 0, L(0), one, null) == -2           # > 65535 without replacement
     assert lib.cg_draw_resample_ids(2500, 2048, L(0), ctypes.c_ulonglong(1), 0, L(0), null, null) == 0
+    bad_pos = ctypes.c_int(700)
+    assert lib.cg_host_numpy_choice_rows(one, ctypes.byref(bad_pos), 2500, 2048, L(1), one, one) == -1            # MT position > 624
+    assert lib.cg_host_numpy_choice_rows(None, ctypes.byref(bad_pos), 2500, 2048, L(1), one, one) == -1
     assert lib.cg_pose_inverse_rows(one, L(3), None, one, null) == -1                                             # no centre
     assert lib.cg_pose_inverse_rows(null, L(0), D3, null, null) == 0
     assert lib.cg_mesh_grid_count(one, one, 5, D3, ctypes.c_double(0.0), ctypes.c_double(0.001), I3, one, null) == -1      # cell size 0
@@ -144,6 +147,29 @@ def test_draw_ids_reference_consumes_numpy_global_rng_like_the_reference():
     np.random.seed(6)
     d = np.stack([tref.draw_ids(700, 2048) for _ in range(2)])
     assert np.array_equal(c, d) and c.max() < 700                          # with replacement when M < n_pts
+
+
+@pytest.mark.parametrize('n_valid,n_pts', [(2500, 2048), (2048, 2048), (700, 2048), (9000, 8192), (5000, 8192), (1, 4), (3, 2)])
+def test_numpy_stream_replay_is_bit_identical_to_numpy(n_valid, n_pts):
+    """The reference-exact resampling draw is numpy's global Mersenne Twister replayed in C (cg_host_numpy_choice_rows): the rows must
+    equal np.random.choice call after call AND numpy's generator must be left in the same state (so whatever draws next -- the RANSAC,
+    the next object's predict_batch -- sees the reference's stream), across state regenerations (624-word blocks), for both the
+    permutation (replace=False) and the randint (replace=True) branch, from arbitrary stream positions, in several chunks."""
+    for seed, burn in ((0, 0), (1, 17), (2 ** 31 - 1, 623), (77, 1250)):
+        np.random.seed(seed); np.random.randint(0, 10, burn)
+        want = np.stack([np.random.choice(np.arange(n_valid), size=(n_pts), replace=n_valid < n_pts) for _ in range(9)])
+        after_want = np.random.randint(0, 2 ** 31, 5); g_want = np.random.normal()
+        np.random.seed(seed); np.random.randint(0, 10, burn)
+        st = transforms.NumpyChoiceStream(n_valid, n_pts)
+        got = np.concatenate([st.draw(4), st.draw(0), st.draw(5)])
+        st.close()
+        after_got = np.random.randint(0, 2 ** 31, 5); g_got = np.random.normal()
+        assert np.array_equal(got, want) and np.array_equal(after_got, after_want) and g_got == g_want
+    # a cached gaussian in numpy's state survives the round trip
+    np.random.seed(4); np.random.normal(); a = transforms.draw_ids_reference(n_valid, n_pts, 2); x = np.random.normal()
+    np.random.seed(4); np.random.normal()
+    b = np.stack([np.random.choice(np.arange(n_valid), size=(n_pts), replace=n_valid < n_pts) for _ in range(2)]); y = np.random.normal()
+    assert np.array_equal(a, b) and x == y
 
 
 def test_device_cloud_applies_z_mask_and_centres():
