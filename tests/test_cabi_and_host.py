@@ -279,7 +279,7 @@ def test_committed_bench_line_honours_the_contract(name):
         assert d['config']['candidates_per_gpu'] == 50000 and d['config']['workload'].startswith('C3') and d['dtype'].startswith('f32 ')
         assert d['config']['evaluations_nocs_shape_adjust_true'] + d['config']['evaluations_cone_shape_adjust_false'] == 50000
         assert {x['precision'] for x in d['secondary']} == {'f16x3', 'bf16x3'} and all(x['codes_identical_to_primary'] for x in d['secondary'])
-        assert d['api']['predict_batch'][0]['poses'] == 50000 and d['api']['filterGraspPose']['gripper_triangles'][0] >= 5000
+        assert d['api']['predict_batch'][0]['poses'] == 50000 and d['api']['predict_batch'][0]['rng'] == 'device' and d['api']['filterGraspPose']['gripper_triangles'][0] >= 5000
         assert d['roofline']['frac'] > 0.85 and d['value'] > 50000
     for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype',
               'data', 'config', 'roofline', 'cpu_baseline'):
