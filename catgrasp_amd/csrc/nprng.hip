@@ -18,7 +18,17 @@ namespace {
 
 constexpr int MT_N = 624, MT_M = 397;
 
-struct MT { uint32_t* key; int pos; };
+// key: numpy's raw state words; tb: the same block after tempering (filled a whole block at a time, which the compiler vectorises,
+// so the hot loops only index it)
+struct MT { uint32_t* key; int pos; uint32_t tb[624]; };
+
+inline uint32_t temper(uint32_t y) {
+  y ^= (y >> 11);
+  y ^= (y << 7) & 0x9d2c5680u;
+  y ^= (y << 15) & 0xefc60000u;
+  y ^= (y >> 18);
+  return y;
+}
 
 inline void mt_gen(uint32_t* mt) {
   const uint32_t UPPER = 0x80000000u, LOWER = 0x7fffffffu, MATRIX_A = 0x9908b0dfu;
@@ -36,14 +46,13 @@ inline void mt_gen(uint32_t* mt) {
   mt[MT_N - 1] = mt[MT_M - 1] ^ (y >> 1) ^ (-(int32_t)(y & 1) & MATRIX_A);
 }
 
+inline void temper_block(MT& s) {
+  for (int i = 0; i < MT_N; ++i) s.tb[i] = temper(s.key[i]);
+}
+
 inline uint32_t mt_next(MT& s) {
-  if (s.pos == MT_N) { mt_gen(s.key); s.pos = 0; }
-  uint32_t y = s.key[s.pos++];
-  y ^= (y >> 11);
-  y ^= (y << 7) & 0x9d2c5680u;
-  y ^= (y << 15) & 0xefc60000u;
-  y ^= (y >> 18);
-  return y;
+  if (s.pos == MT_N) { mt_gen(s.key); temper_block(s); s.pos = 0; }
+  return s.tb[s.pos++];
 }
 
 inline uint32_t gen_mask(uint32_t max) {
@@ -66,7 +75,9 @@ extern "C" int cg_host_numpy_choice_rows(uint32_t* h_mt_key624, int* h_mt_pos, i
   if (!h_mt_key624 || !h_mt_pos || n_valid <= 0 || n_pts <= 0 || count < 0 || *h_mt_pos < 0 || *h_mt_pos > MT_N) return CG_ERR_ARG;
   if (count == 0) return CG_OK;
   if (!h_out) return CG_ERR_ARG;
-  MT s{h_mt_key624, *h_mt_pos};
+  MT s;
+  s.key = h_mt_key624; s.pos = *h_mt_pos;
+  temper_block(s);
   if (n_valid < n_pts) {                                  // replace=True: randint(0, n_valid, n_pts)
     const uint32_t rng = (uint32_t)n_valid - 1u, mask = gen_mask(rng);
     for (long r = 0; r < count; ++r) {
@@ -77,8 +88,10 @@ extern "C" int cg_host_numpy_choice_rows(uint32_t* h_mt_key624, int* h_mt_pos, i
     if (!h_scratch) return CG_ERR_ARG;                    // n_valid ints
     for (long r = 0; r < count; ++r) {
       for (int i = 0; i < n_valid; ++i) h_scratch[i] = i;
+      uint32_t mask = gen_mask((uint32_t)(n_valid - 1));
       for (int i = n_valid - 1; i > 0; --i) {
-        const uint32_t j = bounded(s, (uint32_t)i, gen_mask((uint32_t)i));
+        if ((uint32_t)i <= (mask >> 1)) mask >>= 1;          // = gen_mask(i): the smallest 2^k - 1 >= i
+        const uint32_t j = bounded(s, (uint32_t)i, mask);
         const int t = h_scratch[i]; h_scratch[i] = h_scratch[j]; h_scratch[j] = t;
       }
       int* o = h_out + r * n_pts;
