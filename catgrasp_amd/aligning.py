@@ -14,10 +14,10 @@ _c_int = ctypes.c_int
 def draw_hypothesis_ids(n_points, max_iter):
     """The reference's sampling (aligning.py:89-93): one `np.random.choice(n, size=4, replace=False)` per iteration from
     numpy's global generator, so a seeded run reproduces the reference's hypotheses.  -> (max_iter,4) int32."""
-    out = np.empty((max_iter, 4), dtype=np.int32)
-    for i in range(max_iter):
-        out[i] = np.random.choice(n_points, size=4, replace=False)
-    return out
+    from . import transforms
+    # np.random.choice(n, 4, replace=False) = permutation(n)[:4]: a full n-element shuffle per hypothesis.  Replayed in C from numpy's
+    # own generator state (transforms.NumpyChoiceStream: identical rows, identical state afterwards), ~2.5x faster than the python loop.
+    return transforms.draw_ids_reference(n_points, 4, max_iter)
 
 
 def draw_hypothesis_ids_fast(n_points, max_iter):
@@ -37,8 +37,8 @@ def estimate9DTransform(source, target, PassThreshold, max_iter=1000, use_kdtree
                         sampling='reference'):
     """-> (4x4 float64 transform, inlier index array) or (None, None), like aligning.py:83-119.
     `ids` (max_iter,4): explicit hypothesis samples; otherwise sampling='reference' reproduces the reference's
-    numpy-global-RNG draw call by call (slow: 10,000 python-level np.random.choice calls), sampling='fast' draws the same
-    distribution vectorised."""
+    numpy-global-RNG draw call by call (each draw is a full-cloud shuffle in numpy's stream: ~50 us per hypothesis even replayed in C),
+    sampling='fast' draws the same distribution vectorised."""
     if use_kdtree_for_eval:
         raise NotImplementedError('use_kdtree_for_eval=True is not built (the reference pipeline passes False, predicter.py:162)')
     if device is None:

@@ -165,6 +165,11 @@ def test_numpy_stream_replay_is_bit_identical_to_numpy(n_valid, n_pts):
         st.close()
         after_got = np.random.randint(0, 2 ** 31, 5); g_got = np.random.normal()
         assert np.array_equal(got, want) and np.array_equal(after_got, after_want) and g_got == g_want
+    # the RANSAC hypothesis draw of aligning.py:89-93 rides the same replay (np.random.choice(n, 4, replace=False) per hypothesis)
+    from catgrasp_amd import aligning
+    np.random.seed(9); h = aligning.draw_hypothesis_ids(max(n_valid, 4), 40); hx = np.random.rand()
+    np.random.seed(9); hw = np.stack([np.random.choice(max(n_valid, 4), size=4, replace=False) for _ in range(40)]); hy = np.random.rand()
+    assert np.array_equal(h, hw) and hx == hy
     # a cached gaussian in numpy's state survives the round trip
     np.random.seed(4); np.random.normal(); a = transforms.draw_ids_reference(n_valid, n_pts, 2); x = np.random.normal()
     np.random.seed(4); np.random.normal()
