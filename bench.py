@@ -42,9 +42,9 @@ PEAK_HBM_GBS = 8000.0                                   # MI355X_MICROARCH.md: H
 ALG_HBM_BYTES_PER_CANDIDATE = 49152 + 16384 + 4096
 # Measured HBM bytes per candidate of the same kernel: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, B = 4096),
 # 2*FETCH_SIZE (gfx950 correction, MI355X_MICROARCH.md §HBM) + WRITE_SIZE, / 4096 -- profiles/r2_pmc_hbm_pointmlp_f32.csv (f32 kernel
-# of this round) and profiles/r1_pmc_pointmlp.csv (split kernels, unchanged since).  CONSTANTS from those profiles, not counters read
+# of this round) and profiles/r2_pmc_hbm_pointmlp_split.csv (split kernels: same figures as round 1's r1_pmc_pointmlp.csv).  CONSTANTS from those profiles, not counters read
 # in this run (PMC collection needs its own rocprofv3 pass).
-PMC_HBM_BYTES_PER_CANDIDATE = {'bf16x3': (2 * 133760.3 + 16384.0) * 1024 / 4096, 'f16x3': (2 * 133762.0 + 16384.0) * 1024 / 4096,
+PMC_HBM_BYTES_PER_CANDIDATE = {'bf16x3': (2 * 133765.0 + 16384.0) * 1024 / 4096, 'f16x3': (2 * 133762.0 + 16384.0) * 1024 / 4096,
                                'f32': (2 * 133937.0 + 16384.0) * 1024 / 4096}
 DTYPE = {'f32': 'f32 (exact-f32 MFMA: every product and accumulation in float32, as the reference)',
          'f16x3': 'f32 in/out/accumulate; wide-layer products as 3x f16 MFMA on hi+lo half pieces (f16x3 split, 22 significant bits)',
@@ -303,7 +303,7 @@ def main():
         common = {'achieved': round(r['tflops'], 2), 'unit': 'TFLOP/s', 'avg_launch_ms': round(r['avg_ms'], 4), 'launches': r['launches'],
                   'candidates_per_launch': round(r['avg_cand'], 1), 'flop_per_candidate_launch': 2 * MAC_PER_POINT_ENC * 2048,
                   'traffic': int(per * r['avg_cand']),
-                  'traffic_source': 'constant from profiles/r2_pmc_hbm_pointmlp_f32.csv / r1_pmc_pointmlp.csv (2*FETCH_SIZE + WRITE_SIZE per candidate at B=4096) x candidates per '
+                  'traffic_source': 'constant from profiles/r2_pmc_hbm_pointmlp_f32.csv / r2_pmc_hbm_pointmlp_split.csv (2*FETCH_SIZE + WRITE_SIZE per candidate at B=4096) x candidates per '
                                     'launch -- not a counter read in this run; algorithmic bytes are 69,632 B/candidate',
                   'hbm_achieved_gbs': round(hbm_gbs, 1), 'hbm_frac': round(hbm_gbs / PEAK_HBM_GBS, 5)}
         if precision == 'f32':
