@@ -53,7 +53,6 @@ __device__ __forceinline__ void sa_layer(float* strip, int CS, const float* __re
   }
   const float* arow = strip + l31 * CS + lhi * 4;
   const f32x4* wp = (const f32x4*)w + lane;
-#pragma unroll(NNB > 4 ? 1 : 2)
   for (int ks = 0; ks < nks; ++ks) {
     const f32x4 av = *(const f32x4*)(arow + ks * 8);
     f32x4 bv[NNB];
