@@ -39,7 +39,13 @@ __device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned&
     amax = fmaxf(fmaxf(amax, fabsf(a)), fabsf(b));
     const f16x2 h = {(_Float16)a, (_Float16)b};
     hi = __builtin_bit_cast(unsigned, h);
-    const f16x2 l = {(_Float16)(a - (float)h[0]), (_Float16)(b - (float)h[1])};
+    // a - float(hi) as ONE mixed-precision FMA each: v_fma_mix_f32 reads the half operand straight out of the packed register
+    // (op_sel picks the low / high half), so the two v_cvt_f32_f16 per pair disappear -- a quarter of the split's VALU work.  The
+    // product float(hi) * -1 is exact, so this is the same correctly rounded difference.  (hipcc does not form the mix op itself.)
+    float la, lb;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(la) : "v"(hi), "v"(a));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(lb) : "v"(hi), "v"(b));
+    const f16x2 l = {(_Float16)la, (_Float16)lb};
     lo = __builtin_bit_cast(unsigned, l);
   } else {
     const bf16x2 h = {(__bf16)a, (__bf16)b};

@@ -207,6 +207,16 @@ __global__ __launch_bounds__(64 * RT, 2) void pointmlp_max_split_kernel(ArgsB a)
     wxh = p[0]; wxl = p[64];
   }
   __syncthreads();
+  // the lane's point of the NEXT tile travels from HBM while the current tile's 128 -> 1024 stream runs (6 registers across it)
+  f32x2 xn0 = {0.f, 0.f}, xn1 = xn0, xn2 = xn0;
+  auto fetch_point = [&](int tile) {
+    if (tile < t_end) {
+      const int q = tile * TP + w * 32 + l31;
+      const f32x2* src = (const f32x2*)(xb + (size_t)(q < a.N ? q : a.N - 1) * 6);       // replicate the last point: max-pool is idempotent
+      xn0 = src[0]; xn1 = src[1]; xn2 = src[2];
+    }
+  };
+  fetch_point(t_begin);
 
   for (int tile = t_begin; tile < t_end; ++tile) {
     // ================= front layers, wave-private and register-resident: points [32w, 32w+32) =================
@@ -216,9 +226,7 @@ __global__ __launch_bounds__(64 * RT, 2) void pointmlp_max_split_kernel(ArgsB a)
     const int pt = tile * TP + w * 32 + l31;
     frag fh[4], fl[4];          // the activation as B fragments (hi / lo), 4 chunks of 16 channels
     {
-      const int p = pt < a.N ? pt : a.N - 1;       // replicate the last point: max-pool is idempotent
-      const f32x2* src = (const f32x2*)(xb + (size_t)p * 6);
-      const f32x2 v0 = src[0], v1 = src[1], v2 = src[2];
+      const f32x2 v0 = xn0, v1 = xn1, v2 = xn2;
       float px = v0[0], py = v0[1], pz = v1[0];
       if (a.t3) {
         const float qx = px * t3r[0] + py * t3r[3] + pz * t3r[6];
@@ -296,6 +304,7 @@ __global__ __launch_bounds__(64 * RT, 2) void pointmlp_max_split_kernel(ArgsB a)
       }
     }
     fold(true);
+    fetch_point(tile + 1);
     __syncthreads();
     // ================= L3: 128 -> 1024 + running max.  wave w owns channel blocks [4w, 4w+4) =================
     // The 192-MFMA stream of one channel block is hand-scheduled assembly (gen_l3_asm.py -> l3_asm.inc): exact wait
