@@ -47,6 +47,32 @@ def build_augment(force=False):
     return AUG_OUT
 
 
+PG_SRC = '/root/reference/PointGroup/lib/pointgroup_ops/src'
+PG_OUT = os.path.join(_DIR, '_ref', 'libpointgroup_host_ref.so')
+PG_RANGES = {'pg_voxelize_extract.inc': ('voxelize/voxelize.cpp', 34, 152, 'template <Int dimension>'),      # voxelize_outputmap + voxelize_inputmap
+             'pg_bfs_extract.inc': ('bfs_cluster/bfs_cluster.cpp', 33, 91, 'ConnectedComponent find_cc')}   # find_cc, get_clusters, fill_cluster_idxs_
+
+
+def build_pointgroup_host(force=False):
+    """oracle/_ref/libpointgroup_host_ref.so = the reference's own host-side rule-book builder (voxelization_idx) and queue BFS
+    (bfs_cluster), compiled from the lines where they lie + its datatype.cpp; google-sparsehash -> oracle/pg_shim stand-in."""
+    if not os.path.isdir(PG_SRC):
+        raise FileNotFoundError(PG_SRC)
+    if os.path.exists(PG_OUT) and not force:
+        return PG_OUT
+    os.makedirs(os.path.dirname(PG_OUT), exist_ok=True)
+    for out, (rel, lo, hi, first) in PG_RANGES.items():
+        with open(os.path.join(PG_SRC, rel)) as f:
+            lines = f.readlines()[lo - 1:hi]
+        assert lines[0].startswith(first) and lines[-1].startswith('}'), f'reference layout changed: {rel}'
+        with open(os.path.join(_DIR, '_ref', out), 'w') as f:
+            f.writelines(lines)
+    subprocess.check_call(['g++', '-O2', '-fPIC', '-shared', '-std=c++14', '-w', '-I', os.path.join(_DIR, 'pg_shim'), '-I', PG_SRC, '-I', _DIR,
+                           os.path.join(_DIR, 'pg_wrap.cpp'), '-o', PG_OUT])
+    return PG_OUT
+
+
 if __name__ == '__main__':
     print(build(force=True))
     print(build_augment(force=True))
+    print(build_pointgroup_host(force=True))

@@ -2,8 +2,12 @@
 PointGroup/lib/pointgroup_ops/src (bfs_cluster.cu:15-62, sec_mean.cu:12-85, roipool.cu:12-40, get_iou.cu:12-37,
 voxelize.cu:10-34).  Sequential float32 accumulation in the kernels' loop order.
 
-PARITY UNPINNED: the originals are CUDA (no nvcc / NVIDIA device here) and the reference holds no test, fixture or golden
-vector for them; the semantics are restated line by line from the .cu sources."""
+PARITY: the CUDA kernels (ballquery_batch_p, sec_*, roipool, get_iou, voxelize_fp) are UNPINNED -- no nvcc / NVIDIA device here and
+the reference holds no test, fixture or golden vector for them; their semantics are restated line by line from the .cu sources.
+The two HOST-side ops at the end of this file (voxelization_idx, bfs_cluster) ARE pinned to the reference's own C++: oracle/build_ref.py:
+build_pointgroup_host compiles voxelize.cpp:34-152 and bfs_cluster.cpp:33-91 from the lines where they lie (+ datatype.cpp; the
+absent google-sparsehash container replaced by the stand-in oracle/pg_shim), tests/golden/make_golden_pointgroup.py commits its
+outputs (tests/golden/pointgroup_golden.npz) and tests/test_oracle_host_golden.py requires these restatements to reproduce them exactly."""
 import numpy as np
 
 

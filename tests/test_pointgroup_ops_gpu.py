@@ -111,3 +111,24 @@ def test_bfs_cluster_matches_the_host_bfs(cuda_device):
         for c in range(len(rco) - 1):
             assert np.array_equal(ci[rco[c]:rco[c + 1], 1], np.sort(rci[rco[c]:rco[c + 1], 1]))
     assert len(rco) - 1 >= 3
+
+
+def test_host_side_ops_against_the_reference_cpp_golden(cuda_device):
+    """The device formulations of voxelization_idx / bfs_cluster vs outputs of the REFERENCE's own host C++ (pointgroup_golden.npz):
+    the three voxelization tensors identical for every mode; the same clusters, numbering and offsets (members as sets: the
+    reference lists them in queue-visit order, the device in ascending index)."""
+    import os
+    from catgrasp_amd import pointgroup_ops as pg
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'pointgroup_golden.npz'))
+    for mode, coords in ((4, g['vox_coords']), (3, g['vox_coords']), (1, g['vox_coords']), (2, g['vox_coords']), (0, g['vox_unique_coords'])):
+        oc, im, om = pg.voxelization_idx(torch.from_numpy(coords).to(cuda_device), 3, mode)
+        assert np.array_equal(oc.cpu().numpy(), g[f'vox_mode{mode}_output_coords']) and np.array_equal(im.cpu().numpy(), g[f'vox_mode{mode}_input_map'])
+        assert np.array_equal(om.cpu().numpy(), g[f'vox_mode{mode}_output_map'])
+    t = lambda a: torch.from_numpy(a).to(cuda_device)
+    for thr in (1, 50):
+        ci, co_ = pg.bfs_cluster(t(g['bfs_label']), t(g['bfs_idx']), t(g['bfs_start_len']), thr)
+        rci, rco = g[f'bfs_thr{thr}_cluster_idxs'], g[f'bfs_thr{thr}_cluster_offsets']
+        ci, co_ = ci.cpu().numpy(), co_.cpu().numpy()
+        assert np.array_equal(co_, rco) and np.array_equal(ci[:, 0], rci[:, 0])
+        for c in range(len(rco) - 1):
+            assert np.array_equal(ci[rco[c]:rco[c + 1], 1], np.sort(rci[rco[c]:rco[c + 1], 1]))
