@@ -72,7 +72,37 @@ def build_pointgroup_host(force=False):
     return PG_OUT
 
 
+PGK_OUT = os.path.join(_DIR, '_ref', 'libpointgroup_kernels_ref.so')
+PGK_RANGES = {'pgk_ballquery.inc': ('bfs_cluster/bfs_cluster.cu', 15, 62), 'pgk_sec_mean.inc': ('sec_mean/sec_mean.cu', 12, 27),
+              'pgk_sec_min.inc': ('sec_mean/sec_mean.cu', 38, 53), 'pgk_sec_max.inc': ('sec_mean/sec_mean.cu', 64, 79),
+              'pgk_roipool_fp.inc': ('roipool/roipool.cu', 12, 31), 'pgk_get_iou.inc': ('get_iou/get_iou.cu', 12, 29),
+              'pgk_voxelize_fp.inc': ('voxelize/voxelize.cu', 9, 23)}
+
+
+def build_pointgroup_kernels(force=False):
+    """oracle/_ref/libpointgroup_kernels_ref.so = the reference's own PointGroup CUDA kernels (the __global__ functions, by line range,
+    from where they lie) compiled for gfx950 with hipcc behind oracle/pg_kernels_wrap.hip: the reference implementation itself runs
+    on the MI355X as the oracle of the N4 kernels.  Built here (the reference tree is only present in the build container); the
+    binary travels to the GPU box with the snapshot."""
+    if not os.path.isdir(PG_SRC):
+        raise FileNotFoundError(PG_SRC)
+    if os.path.exists(PGK_OUT) and not force:
+        return PGK_OUT
+    os.makedirs(os.path.dirname(PGK_OUT), exist_ok=True)
+    for out, (rel, lo, hi) in PGK_RANGES.items():
+        with open(os.path.join(PG_SRC, rel)) as f:
+            lines = f.readlines()[lo - 1:hi]
+        assert ('__global__' in lines[0] or '__global__' in lines[1]) and lines[-1].startswith('}'), f'reference layout changed: {rel}'
+        with open(os.path.join(_DIR, '_ref', out), 'w') as f:
+            f.writelines(lines)
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    subprocess.check_call([hipcc, '--offload-arch=gfx950', '-O2', '-fPIC', '-shared', '-std=c++17', '-w', '-ffp-contract=off', '-I', _DIR,
+                           os.path.join(_DIR, 'pg_kernels_wrap.hip'), '-o', PGK_OUT])
+    return PGK_OUT
+
+
 if __name__ == '__main__':
     print(build(force=True))
     print(build_augment(force=True))
     print(build_pointgroup_host(force=True))
+    print(build_pointgroup_kernels(force=True))

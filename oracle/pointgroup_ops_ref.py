@@ -2,8 +2,11 @@
 PointGroup/lib/pointgroup_ops/src (bfs_cluster.cu:15-62, sec_mean.cu:12-85, roipool.cu:12-40, get_iou.cu:12-37,
 voxelize.cu:10-34).  Sequential float32 accumulation in the kernels' loop order.
 
-PARITY: the CUDA kernels (ballquery_batch_p, sec_*, roipool, get_iou, voxelize_fp) are UNPINNED -- no nvcc / NVIDIA device here and
-the reference holds no test, fixture or golden vector for them; their semantics are restated line by line from the .cu sources.
+PARITY: the reference holds no test, fixture or golden vector for its CUDA kernels (ballquery_batch_p, sec_*, roipool, get_iou,
+voxelize_fp) and there is no nvcc / NVIDIA device here; this file restates their semantics line by line from the .cu sources.  The
+PRODUCT kernels are additionally pinned to the reference kernels THEMSELVES: they are plain CUDA C, so oracle/build_ref.py:
+build_pointgroup_kernels compiles their text (from where it lies) for gfx950 with hipcc, and
+tests/test_pointgroup_ops_gpu.py::test_product_equals_the_reference_cuda_kernels_running_on_this_gpu runs both on the MI355X.
 The two HOST-side ops at the end of this file (voxelization_idx, bfs_cluster) ARE pinned to the reference's own C++: oracle/build_ref.py:
 build_pointgroup_host compiles voxelize.cpp:34-152 and bfs_cluster.cpp:33-91 from the lines where they lie (+ datatype.cpp; the
 absent google-sparsehash container replaced by the stand-in oracle/pg_shim), tests/golden/make_golden_pointgroup.py commits its

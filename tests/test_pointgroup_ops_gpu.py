@@ -132,3 +132,70 @@ def test_host_side_ops_against_the_reference_cpp_golden(cuda_device):
         assert np.array_equal(co_, rco) and np.array_equal(ci[:, 0], rci[:, 0])
         for c in range(len(rco) - 1):
             assert np.array_equal(ci[rco[c]:rco[c + 1], 1], np.sort(rci[rco[c]:rco[c + 1], 1]))
+
+
+def test_product_equals_the_reference_cuda_kernels_running_on_this_gpu(cuda_device):
+    """Row N4 pinned to the reference implementation itself: oracle/_ref/libpointgroup_kernels_ref.so holds the reference's OWN
+    PointGroup CUDA kernels (bfs_cluster.cu:15-62, sec_mean.cu, roipool.cu:12-31, get_iou.cu:12-29, voxelize.cu:9-23), compiled for
+    gfx950 by oracle/build_ref.py:build_pointgroup_kernels from the text where it lies and launched with the reference's geometry.
+    The product kernels must return the same tensors on the same device inputs: bitwise for the segmented reductions, the arg-max
+    pool, the IoU table and the rule-book pooling; per-point neighbour lists and counts for the ball query (the reference hands out
+    its CSR start positions with an atomicAdd, i.e. in thread-arrival order)."""
+    import ctypes
+    import os
+    from catgrasp_amd import pointgroup_ops as pg
+    so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'oracle', '_ref', 'libpointgroup_kernels_ref.so')
+    if not os.path.exists(so):
+        pytest.skip('oracle/_ref/libpointgroup_kernels_ref.so not built (python oracle/build_ref.py in the build container)')
+    lib = ctypes.CDLL(so)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    dev = cuda_device
+    g = torch.Generator(device=dev); g.manual_seed(3)
+    # ---- segmented reductions + RoI pool
+    N, C = 3000, 80
+    inp = torch.randn(N, C, device=dev, generator=g)
+    cuts = torch.sort(torch.randperm(N - 1, device=dev, generator=g)[:40] + 1).values
+    offsets = torch.cat([torch.zeros(1, device=dev, dtype=torch.long), cuts, torch.tensor([N], device=dev)]).int().contiguous()
+    nseg = offsets.numel() - 1
+    for which, fn in ((0, pg.sec_mean), (1, pg.sec_min), (2, pg.sec_max)):
+        ref_out = torch.zeros(nseg, C, device=dev)
+        assert lib.ref_sec(which, nseg, C, P(inp), P(offsets), P(ref_out), st) == 0
+        assert torch.equal(fn(inp, offsets), ref_out)
+    ref_feats = torch.zeros(nseg, C, device=dev); ref_idx = torch.zeros(nseg, C, device=dev, dtype=torch.int32)
+    assert lib.ref_roipool_fp(nseg, C, P(inp), P(offsets), P(ref_feats), P(ref_idx), st) == 0
+    of, am = pg.roipool(inp, offsets)
+    assert torch.equal(of, ref_feats) and torch.equal(am, ref_idx)
+    # ---- IoU of proposals vs instances
+    nI = 37
+    labels = torch.randint(-1, nI, (N,), device=dev, generator=g).long(); labels[labels < 0] = -100
+    pidx = torch.randint(0, N, (5000,), device=dev, generator=g).int()
+    poff = torch.tensor([0, 100, 100, 900, 2500, 5000], device=dev, dtype=torch.int32)
+    pnum = torch.bincount(labels[labels >= 0], minlength=nI).int()
+    ref_iou = torch.zeros(5, nI, device=dev)
+    assert lib.ref_get_iou(nI, 5, P(pidx), P(poff), P(labels), P(pnum), P(ref_iou), st) == 0
+    assert torch.equal(pg.get_iou(pidx, poff, labels, pnum), ref_iou)
+    # ---- rule-book pooling (mean and sum) through the product's own voxelization_idx maps
+    coords = torch.cat([torch.zeros(N, 1, dtype=torch.long, device=dev), torch.randint(0, 9, (N, 3), device=dev, generator=g)], 1)
+    _, _, om = pg.voxelization_idx(coords, 1, 4)
+    feats = torch.randn(N, 19, device=dev, generator=g)
+    for mode in (4, 3):
+        ref_v = torch.zeros(om.shape[0], 19, device=dev)
+        assert lib.ref_voxelize_fp(om.shape[0], om.shape[1] - 1, 19, P(feats), P(ref_v), P(om), int(mode == 4), st) == 0
+        assert torch.equal(pg.voxelization(feats, om, mode), ref_v)
+    # ---- ball query inside batches
+    sizes = [700, 1200, 300]
+    xyz = torch.cat([torch.rand(s, 3, device=dev, generator=g) * 0.3 for s in sizes]).contiguous()
+    bidx = torch.cat([torch.full((s,), i, dtype=torch.int32, device=dev) for i, s in enumerate(sizes)])
+    boff = torch.tensor([0, 700, 1900, 2200], dtype=torch.int32, device=dev)
+    n, mean_active, radius = xyz.shape[0], 60, 0.04
+    ref_idx = torch.zeros(n * mean_active, dtype=torch.int32, device=dev); ref_sl = torch.zeros(n, 2, dtype=torch.int32, device=dev)
+    cumsum = torch.zeros(1, dtype=torch.int32, device=dev)
+    assert lib.ref_ballquery_batch_p(n, mean_active, ctypes.c_float(radius), P(xyz), P(bidx), P(boff), P(ref_idx), P(ref_sl), P(cumsum), st) == 0
+    idx, sl = pg.ballquery_batch_p(xyz, bidx, boff, radius, mean_active)
+    total = int(cumsum.item())
+    assert total == idx.numel() < n * mean_active and torch.equal(sl[:, 1], ref_sl[:, 1])
+    ri, rs, mi, ms = ref_idx.cpu().numpy(), ref_sl.cpu().numpy(), idx.cpu().numpy(), sl.cpu().numpy()
+    assert sorted(rs[:, 0].tolist()) == sorted(ms[:, 0].tolist())          # a permutation of the same CSR layout
+    for p in range(n):
+        assert np.array_equal(ri[rs[p, 0]:rs[p, 0] + rs[p, 1]], mi[ms[p, 0]:ms[p, 0] + ms[p, 1]])
