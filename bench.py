@@ -16,7 +16,7 @@ Workloads (config.workload):
       candidates in TOTAL cut into contiguous slices over the ranks.
 All inputs are resident in HBM before the timed region; weights are seeded random (the reference ships no checkpoints).
 `value` is measured under --precision (default f32: exact-f32 MFMA, the reference's arithmetic); the split-precision modes of
-the product (f16x3 -- its default --, bf16x3) are measured in the same run and reported under `secondary`.
+the product (f16x3, bf16x3; opt-in via CATGRASP_AMD_PRECISION) are measured in the same run and reported under `secondary`.
 
 Launch: python bench.py --gpus 1 --steps K --warmup W
         python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
