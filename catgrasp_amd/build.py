@@ -27,7 +27,7 @@ def _stale(target, deps):
 
 def build(force=False, verbose=True):
     srcs = sources()
-    for g, i in (('gen_l3_asm.py', 'l3_asm.inc'), ('gen_l3_f32_asm.py', 'l3_f32_asm.inc')):
+    for g, i in (('gen_l3_asm.py', 'l3_asm.inc'), ('gen_l3_f32_asm.py', 'l3_f32_asm.inc'), ('gen_l3_mx_asm.py', 'l3_mx_asm.inc')):
         gen, inc = os.path.join(CSRC, g), os.path.join(CSRC, i)
         if _stale(inc, [gen]):      # the hand-scheduled instruction streams of pointmlp_split.hip / pointmlp.hip are generated text
             subprocess.check_call([sys.executable, gen])

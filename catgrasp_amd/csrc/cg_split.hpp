@@ -55,3 +55,25 @@ __device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned&
     lo = __builtin_bit_cast(unsigned, l);
   }
 }
+
+// f16fp8x2 mode: four floats of one MX unit -> the two packed half hi pairs (for the f16 image) and, returned / through d_lo, one dword
+// each of the e4m3 images of the hi pieces and of the residuals: fp8(a / sc_hi) and fp8((a - half(a)) / sc_lo), sc_* powers of two
+// (v_cvt_scalef32_pk_fp8_f32 divides by its scale operand and rounds to nearest even; measured, scripts/probe/mx_probe.hip).
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned split_mx(float a0, float a1, float a2, float a3, float sc_hi, float sc_lo, unsigned& h01, unsigned& h23,
+                                             unsigned& d_lo) {
+  const f16x2 p01 = {(_Float16)a0, (_Float16)a1}, p23 = {(_Float16)a2, (_Float16)a3};
+  h01 = __builtin_bit_cast(unsigned, p01); h23 = __builtin_bit_cast(unsigned, p23);
+  float l0, l1, l2, l3;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(h01), "v"(a0));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(h01), "v"(a1));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l2) : "v"(h23), "v"(a2));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l3) : "v"(h23), "v"(a3));
+  s16x2 dh = {0, 0}, dl = {0, 0};
+  dh = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(dh, a0, a1, sc_hi, false);
+  dh = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(dh, a2, a3, sc_hi, true);
+  dl = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(dl, l0, l1, sc_lo, false);
+  dl = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(dl, l2, l3, sc_lo, true);
+  d_lo = __builtin_bit_cast(unsigned, dl);
+  return __builtin_bit_cast(unsigned, dh);
+}

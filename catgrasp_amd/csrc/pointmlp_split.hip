@@ -28,16 +28,21 @@
 #include "cg_split.hpp"
 #include "../../include/catgrasp_amd.h"
 #include "l3_asm.inc"
+#include "l3_mx_asm.inc"
 
 namespace {
 
 constexpr int SH = 136;        // 16-bit elements per row of the h2 hi / lo images
-template <int RT> struct Geo {
+constexpr int S8 = 144;        // bytes per row of the fp8 images of the f16fp8x2 mode: 128 data + 16 pad (holds the row's 8 scale bytes)
+constexpr int MX_NB_BYTES = 16640;   // one packed channel block of the f16fp8x2 weights (folding.pack_b_f16fp8x2; gen_l3_mx_asm.py)
+template <int RT, bool MX = false> struct Geo {
   static constexpr int TP = 32 * RT;        // points per tile, one wave per 32-point row tile
   static constexpr int NT = 64 * RT;
   static constexpr int NBW = 32 / RT;       // 32-channel blocks of the 1024-wide layer owned by each wave
   // h2 hi/lo images + running max + first-layer fragments [2][2][64] + mid-layer fragments [2][4][2][64] (16 B each)
-  static constexpr size_t LDS_BYTES = (size_t)2 * TP * SH * 2 + 1024 * 4 + 256 * 16 + 1024 * 16;
+  // MX: h2 hi image (f16) + hi8 / lo8 images (e4m3); the running max lives in registers
+  static constexpr size_t IMG_BYTES = MX ? (size_t)TP * SH * 2 + (size_t)2 * TP * S8 : (size_t)2 * TP * SH * 2 + 1024 * 4;
+  static constexpr size_t LDS_BYTES = IMG_BYTES + 256 * 16 + 1024 * 16;
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
 
@@ -126,20 +131,24 @@ __device__ __forceinline__ void load_b(const unsigned short* wp, int nb, int kc,
 // An opaque zero: added to the (tile-invariant) front-layer weight pointers inside the tile loop so the compiler
 // does not hoist 32 KB of weight-fragment loads out of the loop and spill them.
 __device__ __forceinline__ int opaque_zero() { int z; asm volatile("s_mov_b32 %0, 0" : "=s"(z)); return z; }
+__device__ __forceinline__ int opaque_copy(int v) { int r; asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(v)); return r; }
 
-template <int MID, int RT, bool F16>
+template <int MID, int RT, bool F16, bool MX>
 __global__ __launch_bounds__(64 * RT, 2) void pointmlp_max_split_kernel(ArgsB a) {
+  static_assert(!MX || (F16 && RT == 8), "the f16fp8x2 stream is written for half pieces and 256-point tiles");
   constexpr int TP = Geo<RT>::TP, NT = Geo<RT>::NT, NBW = Geo<RT>::NBW;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   unsigned short* h2hi = (unsigned short*)smem_raw;      // 16-bit elements (bf16 or half bit patterns)
-  unsigned short* h2lo = h2hi + TP * SH;
-  float* rmax = (float*)(h2lo + TP * SH);
-  frag* w1f = (frag*)(rmax + 1024);     // [nb 2][hi|lo][lane]
+  unsigned short* h2lo = h2hi + TP * SH;                 // (!MX)
+  unsigned char* h8hi = (unsigned char*)(h2hi + TP * SH);   // (MX) e4m3 images of the hi / lo pieces, one power-of-two scale per
+  unsigned char* h8lo = h8hi + TP * S8;                     //      32 channels of a point; the row's scale bytes sit in its pad
+  float* rmax = (float*)(h2lo + TP * SH);                // (!MX)
+  frag* w1f = (frag*)(smem_raw + Geo<RT, MX>::IMG_BYTES);     // [nb 2][hi|lo][lane]
   frag* wmf = w1f + 256;                  // [nb 2][kc 4][hi|lo][lane]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int w = tid >> 6;
+  const int w = MX ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6);
   const int l31 = lane & 31, lhi = lane >> 5;
   int b, split, nsp;
   if ((int)blockIdx.x < a.n_main * a.nsplit) {
@@ -164,7 +173,8 @@ __global__ __launch_bounds__(64 * RT, 2) void pointmlp_max_split_kernel(ArgsB a)
     }
   };
   // ---- once per workgroup: running max, first-layer fragments (W1 | b1 as the k = 6 column), mid-layer fragments
-  for (int i = tid; i < 1024; i += NT) rmax[i] = -INFINITY;
+  if constexpr (!MX) { for (int i = tid; i < 1024; i += NT) rmax[i] = -INFINITY; }
+  float rm[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};      // (MX) running max of the wave's 4 channel blocks, channel = lane & 31
   for (int i = tid; i < 128; i += NT) {
     const int nb = i >> 6, ln = i & 63, row = nb * 32 + (ln & 31);
     f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
@@ -195,35 +205,45 @@ __global__ __launch_bounds__(64 * RT, 2) void pointmlp_max_split_kernel(ArgsB a)
   float t3r[9];
   if (a.t3) {
 #pragma unroll
-    for (int j = 0; j < 9; ++j) t3r[j] = a.t3[b * 9 + j];
+    for (int j = 0; j < 9; ++j) {
+      t3r[j] = a.t3[b * 9 + j];
+      if constexpr (MX) t3r[j] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(t3r[j])));     // scalar registers: nothing of it lives in v0..v61
+    }
   }
   const float* xb = a.x + (size_t)b * a.N * 6;
   // LDS byte addresses of this lane's A-fragment row in the hi / lo images (generic -> LDS address = low 32 bits)
   const unsigned ahi_addr = (unsigned)(uintptr_t)(h2hi + l31 * SH + lhi * 8);
   const unsigned alo_addr = (unsigned)(uintptr_t)(h2lo + l31 * SH + lhi * 8);
   u32x4 wxh, wxl;          // weight fragments (hi / lo) of the wave's next channel block, k chunk 0
-  {
+  if constexpr (!MX) {
     const u32x4* p = (const u32x4*)a.w3 + (size_t)((w * NBW * 8) * 2) * 64 + lane;
     wxh = p[0]; wxl = p[64];
   }
   __syncthreads();
   // the lane's point of the NEXT tile travels from HBM while the current tile's 128 -> 1024 stream runs (6 registers across it)
   f32x2 xn0 = {0.f, 0.f}, xn1 = xn0, xn2 = xn0;
-  auto fetch_point = [&](int tile) {
+  auto fetch_point = [&](int tile, int l31) {
     if (tile < t_end) {
       const int q = tile * TP + w * 32 + l31;
       const f32x2* src = (const f32x2*)(xb + (size_t)(q < a.N ? q : a.N - 1) * 6);       // replicate the last point: max-pool is idempotent
       xn0 = src[0]; xn1 = src[1]; xn2 = src[2];
     }
   };
-  fetch_point(t_begin);
+  fetch_point(t_begin, l31);
 
   for (int tile = t_begin; tile < t_end; ++tile) {
+    // (MX) every lane-dependent index / LDS address of the tile body is re-derived from an opaque copy of the lane id, so that the id alone --
+    // not the two dozen values derived from it -- is live across the L3 asm block, which leaves the compiler only v0..v61
+    const int ln = MX ? opaque_copy(lane) : lane;
+    const int r31 = ln & 31, hh = ln >> 5;
+    const unsigned ahi_t = MX ? (unsigned)(uintptr_t)(h2hi + r31 * SH + hh * 8) : ahi_addr, alo_t = alo_addr;
+    const unsigned a8h_t = (unsigned)(uintptr_t)(h8hi + r31 * S8 + hh * 32), a8l_t = (unsigned)(uintptr_t)(h8lo + r31 * S8 + hh * 32);
+    const unsigned asc_t = (unsigned)(uintptr_t)(h8hi + r31 * S8 + 128 + hh * 2);
     // ================= front layers, wave-private and register-resident: points [32w, 32w+32) =================
     const int oz = opaque_zero();
     const unsigned short* w2_t = a.w2 + oz;
     const float* b2_t = a.b2 + oz;
-    const int pt = tile * TP + w * 32 + l31;
+    const int pt = tile * TP + w * 32 + r31;
     frag fh[4], fl[4];          // the activation as B fragments (hi / lo), 4 chunks of 16 channels
     {
       const f32x2 v0 = xn0, v1 = xn1, v2 = xn2;
@@ -235,26 +255,26 @@ __global__ __launch_bounds__(64 * RT, 2) void pointmlp_max_split_kernel(ArgsB a)
         px = qx; py = qy; pz = qz;
       }
       f32x4 q0 = {px, py, pz, v1[1]}, q1 = {v2[0], v2[1], 1.f, 0.f};     // k = 6 carries the bias
-      if (lhi) { q0 = f32x4{0.f, 0.f, 0.f, 0.f}; q1 = q0; }              // k = 8..15: padding
+      if (hh) { q0 = f32x4{0.f, 0.f, 0.f, 0.f}; q1 = q0; }              // k = 8..15: padding
       frag xh, xl;
       split8<F16>(q0, q1, xh, xl, amax);
       fold(false);
       // L0: 6(+1) -> 64
       const f32x16 z = {0};
-      f32x16 c0 = mfma3<F16>(w1f[lane], w1f[64 + lane], xh, xl, z);
-      f32x16 c1 = mfma3<F16>(w1f[128 + lane], w1f[192 + lane], xh, xl, z);
+      f32x16 c0 = mfma3<F16>(w1f[ln], w1f[64 + ln], xh, xl, z);
+      f32x16 c1 = mfma3<F16>(w1f[128 + ln], w1f[192 + ln], xh, xl, z);
       acts_to_frags<F16>(relu16(c0), fh[0], fl[0], fh[1], fl[1], amax);
       acts_to_frags<F16>(relu16(c1), fh[2], fl[2], fh[3], fl[3], amax);
       fold(true);
     }
     if (MID != 0) {  // mid: 64 -> 64 (shared conv+BN+ReLU, or the per-sample 64x64 feature transform)
       f32x16 c0, c1;
-      if (MID == 1) { c0 = bias_tile(a.bm + oz, 0, lhi); c1 = bias_tile(a.bm + oz, 1, lhi); }
+      if (MID == 1) { c0 = bias_tile(a.bm + oz, 0, hh); c1 = bias_tile(a.bm + oz, 1, hh); }
       else { c0 = f32x16{0}; c1 = f32x16{0}; }
 #pragma unroll
       for (int kc = 0; kc < 4; ++kc) {
-        const frag* f0 = wmf + (kc * 2) * 64 + lane;
-        const frag* f1 = wmf + ((4 + kc) * 2) * 64 + lane;
+        const frag* f0 = wmf + (kc * 2) * 64 + ln;
+        const frag* f1 = wmf + ((4 + kc) * 2) * 64 + ln;
         const frag a0h = f0[0], a0l = f0[64], a1h = f1[0], a1l = f1[64];
         c0 = mfma_x<F16>(a0h, fl[kc], c0); c1 = mfma_x<F16>(a1h, fl[kc], c1);
         c0 = mfma_x<F16>(a0l, fh[kc], c0); c1 = mfma_x<F16>(a1l, fh[kc], c1);
@@ -262,7 +282,7 @@ __global__ __launch_bounds__(64 * RT, 2) void pointmlp_max_split_kernel(ArgsB a)
       }
       if (MID == 1) { c0 = relu16(c0); c1 = relu16(c1); }
       if (MID == 2 && a.pointfeat && pt < a.N) {
-        float* pf = a.pointfeat + ((size_t)b * a.N + pt) * 64 + 4 * lhi;
+        float* pf = a.pointfeat + ((size_t)b * a.N + pt) * 64 + 4 * hh;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           *(f32x4*)(pf + 8 * q) = f32x4{c0[4 * q], c0[4 * q + 1], c0[4 * q + 2], c0[4 * q + 3]};
@@ -275,15 +295,16 @@ __global__ __launch_bounds__(64 * RT, 2) void pointmlp_max_split_kernel(ArgsB a)
     }
     __syncthreads();   // the previous tile's L3 reads of the h2 images are complete
     {  // L2: 64 -> 128, two channel blocks at a time, written split into the hi / lo images
-      const int row = w * 32 + l31;
+      const int row = w * 32 + r31;
+      unsigned sc_word_hi = 0, sc_word_lo = 0;
 #pragma unroll
       for (int np = 0; np < 2; ++np) {
-        f32x16 c0 = bias_tile(b2_t, np * 2, lhi), c1 = bias_tile(b2_t, np * 2 + 1, lhi);
+        f32x16 c0 = bias_tile(b2_t, np * 2, hh), c1 = bias_tile(b2_t, np * 2 + 1, hh);
 #pragma unroll
         for (int kc = 0; kc < 4; ++kc) {
           frag a0h, a0l, a1h, a1l;
-          load_b(w2_t, np * 2, kc, 4, lane, a0h, a0l);
-          load_b(w2_t, np * 2 + 1, kc, 4, lane, a1h, a1l);
+          load_b(w2_t, np * 2, kc, 4, ln, a0h, a0l);
+          load_b(w2_t, np * 2 + 1, kc, 4, ln, a1h, a1l);
           c0 = mfma_x<F16>(a0h, fl[kc], c0); c1 = mfma_x<F16>(a1h, fl[kc], c1);
           c0 = mfma_x<F16>(a0l, fh[kc], c0); c1 = mfma_x<F16>(a1l, fh[kc], c1);
           c0 = mfma_x<F16>(a0h, fh[kc], c0); c1 = mfma_x<F16>(a1h, fh[kc], c1);
@@ -291,31 +312,68 @@ __global__ __launch_bounds__(64 * RT, 2) void pointmlp_max_split_kernel(ArgsB a)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const f32x16 c = relu16(h ? c1 : c0);
+          if constexpr (!MX) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            unsigned h0, l0, h1, l1;
-            split2<F16>(c[4 * q], c[4 * q + 1], h0, l0, amax);
-            split2<F16>(c[4 * q + 2], c[4 * q + 3], h1, l1, amax);
-            const int off = row * SH + (np * 2 + h) * 32 + 8 * q + 4 * lhi;
-            *(u32x2*)(h2hi + off) = u32x2{h0, h1};
-            *(u32x2*)(h2lo + off) = u32x2{l0, l1};
+            for (int q = 0; q < 4; ++q) {
+              unsigned h0, l0, h1, l1;
+              split2<F16>(c[4 * q], c[4 * q + 1], h0, l0, amax);
+              split2<F16>(c[4 * q + 2], c[4 * q + 3], h1, l1, amax);
+              const int off = row * SH + (np * 2 + h) * 32 + 8 * q + 4 * hh;
+              *(u32x2*)(h2hi + off) = u32x2{h0, h1};
+              *(u32x2*)(h2lo + off) = u32x2{l0, l1};
+            }
+          } else {
+            // channel block np*2+h of this point = one MX unit: the ln pair (p, 0) / (p, 1) holds its 16 + 16 values.  Scale: the
+            // unit's largest value lands in [128, 256) of e4m3 (max 448); its residuals (<= 2^-12 of that) in (0, 128].
+            float m = fmaxf(max16(c), 0.f);
+            const u32x2 sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+            m = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+            amax = fmaxf(amax, m);
+            int e = __builtin_amdgcn_frexp_expf(m);           // m = f * 2^e, f in [0.5, 1); 0 for m = 0
+            e = e < -100 ? -100 : (e > 100 ? 100 : e);
+            const float sc_hi = __uint_as_float((unsigned)(e - 8 + 127) << 23), sc_lo = __uint_as_float((unsigned)(e - 19 + 127) << 23);
+            u32x4 d_hi, d_lo;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              unsigned h0, h1, dl;
+              d_hi[q] = split_mx(c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3], sc_hi, sc_lo, h0, h1, dl);
+              d_lo[q] = dl;
+              *(u32x2*)(h2hi + row * SH + (np * 2 + h) * 32 + 8 * q + 4 * hh) = u32x2{h0, h1};
+            }
+            // unit u = h of k-half kh = np: bytes [16u, 16u+16) of the 32 the reading ln-half hh fetches for that k-half
+            *(u32x4*)(h8hi + row * S8 + np * 64 + hh * 32 + h * 16) = d_hi;
+            *(u32x4*)(h8lo + row * S8 + np * 64 + hh * 32 + h * 16) = d_lo;
+            sc_word_hi |= (unsigned)(119 + e) << (8 * (2 * h + np));      // E8M0 of 2^(e-8); reader ln-half u reads bytes [2u, 2u+1] = k-halves 0, 1
+            sc_word_lo |= (unsigned)(108 + e) << (8 * (2 * h + np));      // E8M0 of 2^(e-19)
           }
         }
       }
+      if constexpr (MX) {
+        if (hh == 0) *(u32x2*)(h8hi + row * S8 + 128) = u32x2{sc_word_hi, sc_word_lo};
+      }
     }
     fold(true);
-    fetch_point(tile + 1);
+    fetch_point(tile + 1, r31);
     __syncthreads();
     // ================= L3: 128 -> 1024 + running max.  wave w owns channel blocks [4w, 4w+4) =================
     // The 192-MFMA stream of one channel block is hand-scheduled assembly (gen_l3_asm.py -> l3_asm.inc): exact wait
     // counts, A fragments through a 3-deep register ring, weight fragments double buffered with the next block's first
     // fragments (wxh / wxl) already in flight when the block ends.
+    if constexpr (MX) {
+      // one asm block = the wave's 4 channel blocks of this tile (gen_l3_mx_asm.py -> l3_mx_asm.inc); it folds the tile into the running per-lane maxima rm[0..3]
+      float t0; unsigned vo;
+      const unsigned vw = (unsigned)(w * NBW * MX_NB_BYTES + ln * 16), vs = (unsigned)(w * NBW * MX_NB_BYTES + 16384 + ln * 4);
+      asm volatile(CG_L3_MX_ASM
+                   : [m0] "+v"(rm[0]), [m1] "+v"(rm[1]), [m2] "+v"(rm[2]), [m3] "+v"(rm[3]), [t0] "=&v"(t0), [vo] "=&v"(vo)
+                   : [a16] "v"(ahi_t), [a8h] "v"(a8h_t), [a8l] "v"(a8l_t), [asc] "v"(asc_t), [vw] "v"(vw), [vs] "v"(vs), [wb] "s"(a.w3)
+                   : "memory", CG_L3_MX_CLOBBERS);
+    } else {
 #pragma unroll 1
     for (int q = 0; q < NBW; ++q) {
       const int nb = w * NBW + q;
       const int nb_next = (q + 1 < NBW) ? nb + 1 : w * NBW;
-      unsigned voff = (unsigned)((nb * 8 * 2) * 64 + lane) * 16u;
-      const unsigned vnext = (unsigned)((nb_next * 8 * 2) * 64 + lane) * 16u;
+      unsigned voff = (unsigned)((nb * 8 * 2) * 64 + ln) * 16u;
+      const unsigned vnext = (unsigned)((nb_next * 8 * 2) * 64 + ln) * 16u;
       f32x16 c0, c1, c2, c3, c4, c5, c6, c7;
       u32x4 r0ah, r0al, r0bh, r0bl, r1ah, r1al, r1bh, r1bl, r2ah, r2al, r2bh, r2bl, wyh, wyl;
 #define CG_L3_OPERANDS \
@@ -324,7 +382,7 @@ __global__ __launch_bounds__(64 * RT, 2) void pointmlp_max_split_kernel(ArgsB a)
                      [r0bl] "=&v"(r0bl), [r1ah] "=&v"(r1ah), [r1al] "=&v"(r1al), [r1bh] "=&v"(r1bh), [r1bl] "=&v"(r1bl),\
                      [r2ah] "=&v"(r2ah), [r2al] "=&v"(r2al), [r2bh] "=&v"(r2bh), [r2bl] "=&v"(r2bl), [yh] "=&v"(wyh),\
                      [yl] "=&v"(wyl), [xh] "+v"(wxh), [xl] "+v"(wxl), [voff] "+v"(voff)\
-                   : [vnext] "v"(vnext), [ahi] "v"(ahi_addr), [alo] "v"(alo_addr), [wbase] "s"(a.w3) \
+                   : [vnext] "v"(vnext), [ahi] "v"(ahi_t), [alo] "v"(alo_t), [wbase] "s"(a.w3) \
                    : "memory"
       if constexpr (F16) { asm volatile(CG_L3_BLOCK_ASM_F16 CG_L3_OPERANDS); }
       else { asm volatile(CG_L3_BLOCK_ASM_BF16 CG_L3_OPERANDS); }
@@ -334,20 +392,36 @@ __global__ __launch_bounds__(64 * RT, 2) void pointmlp_max_split_kernel(ArgsB a)
       m = fmaxf(fmaxf(m, max16(c5)), max16(c6));
       m = fmaxf(m, max16(c7));
       m = fmaxf(m, __shfl_xor(m, 32));
-      if (lane < 32) {
-        const int ch = nb * 32 + lane;
+      if (ln < 32) {
+        const int ch = nb * 32 + ln;
         rmax[ch] = fmaxf(rmax[ch], m);
       }
+    }
     }
   }
   if (F16 && flags && lane == 0 && a.status) atomicOr(a.status, flags);
   __syncthreads();
   if (t_end > t_begin) {
-    for (int ch = tid; ch < 1024; ch += NT) {
-      float v = rmax[ch] + a.b3[ch];
-      if (a.relu3) v = fmaxf(v, 0.f);
-      if (nsp == 1) a.out[(size_t)b * 1024 + ch] = v;
-      else atomic_max_f32(a.out + (size_t)b * 1024 + ch, v);
+    if constexpr (MX) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) rm[q] = fmaxf(rm[q], __shfl_xor(rm[q], 32));
+      if (lane < 32) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int ch = (w * NBW + q) * 32 + lane;
+          float v = rm[q] + a.b3[ch];
+          if (a.relu3) v = fmaxf(v, 0.f);
+          if (nsp == 1) a.out[(size_t)b * 1024 + ch] = v;
+          else atomic_max_f32(a.out + (size_t)b * 1024 + ch, v);
+        }
+      }
+    } else {
+      for (int ch = tid; ch < 1024; ch += NT) {
+        float v = rmax[ch] + a.b3[ch];
+        if (a.relu3) v = fmaxf(v, 0.f);
+        if (nsp == 1) a.out[(size_t)b * 1024 + ch] = v;
+        else atomic_max_f32(a.out + (size_t)b * 1024 + ch, v);
+      }
     }
   }
 }
@@ -357,11 +431,11 @@ __global__ void fill_kernel_b(float* p, size_t n, float v) {
   if (i < n) p[i] = v;
 }
 
-template <int MID, int RT, bool F16>
+template <int MID, int RT, bool F16, bool MX = false>
 int launch(const ArgsB& a, hipStream_t s, int dev) {
   constexpr int NT = Geo<RT>::NT;
-  constexpr size_t LDS_BYTES = Geo<RT>::LDS_BYTES;
-  auto kern = pointmlp_max_split_kernel<MID, RT, F16>;
+  constexpr size_t LDS_BYTES = Geo<RT, MX>::LDS_BYTES;
+  auto kern = pointmlp_max_split_kernel<MID, RT, F16, MX>;
   static bool attr_set[CG_MAX_DEVICES] = {};     // per instantiation and per device (the attribute is per device)
   if (dev < 0 || dev >= CG_MAX_DEVICES) return CG_ERR_UNSUPPORTED;
   if (!attr_set[dev]) {
@@ -375,7 +449,7 @@ int launch(const ArgsB& a, hipStream_t s, int dev) {
 
 }  // namespace
 
-template <bool F16>
+template <bool F16, bool MX = false>
 static int pointmlp_max_split(const float* x, int B, int N, const float* t3, const float* w1, const float* b1,
                               int mid_mode, const unsigned short* wm_split, const float* bm, const float* t64,
                               const unsigned short* w2_split, const float* b2, const unsigned short* w3_split,
@@ -409,9 +483,9 @@ static int pointmlp_max_split(const float* x, int B, int N, const float* t3, con
     hipLaunchKernelGGL(fill_kernel_b, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, out + (size_t)first * 1024, n, -INFINITY);
   }
   ArgsB a{x, B, N, t3, w1, b1, wm_split, bm, t64, w2_split, b2, w3_split, b3, relu3, nsplit, n_main, tail_split, out, pointfeat, F16 ? status : nullptr};
-  if (mid_mode == 0) return launch<0, 8, F16>(a, s, dev);
-  if (mid_mode == 1) return launch<1, 8, F16>(a, s, dev);
-  return launch<2, 8, F16>(a, s, dev);
+  if (mid_mode == 0) return launch<0, 8, F16, MX>(a, s, dev);
+  if (mid_mode == 1) return launch<1, 8, F16, MX>(a, s, dev);
+  return launch<2, 8, F16, MX>(a, s, dev);
 }
 
 extern "C" int cg_pointmlp_max_bf16x3(const float* x, int B, int N, const float* t3, const float* w1, const float* b1,
@@ -428,4 +502,15 @@ extern "C" int cg_pointmlp_max_f16x3(const float* x, int B, int N, const float* 
                                       const float* b3, int relu3, int nsplit, int tile_points, float* out, float* pointfeat,
                                       int* status, void* stream) {
   return pointmlp_max_split<true>(x, B, N, t3, w1, b1, mid_mode, wm_split, bm, t64, w2_split, b2, w3_split, b3, relu3, nsplit, tile_points, out, pointfeat, status, stream);
+}
+
+// f16fp8x2: as cg_pointmlp_max_f16x3 except that the 128 -> 1024 layer adds its two correction terms with block-scaled e4m3 operands;
+// w3_mx is that layer's weight image in the packed format of folding.pack_b_f16fp8x2 (16,640 B per 32 output channels).
+extern "C" int cg_pointmlp_max_f16fp8x2(const float* x, int B, int N, const float* t3, const float* w1, const float* b1,
+                                         int mid_mode, const unsigned short* wm_split, const float* bm, const float* t64,
+                                         const unsigned short* w2_split, const float* b2, const void* w3_mx,
+                                         const float* b3, int relu3, int nsplit, int tile_points, float* out, float* pointfeat,
+                                         int* status, void* stream) {
+  return pointmlp_max_split<true, true>(x, B, N, t3, w1, b1, mid_mode, wm_split, bm, t64, w2_split, b2, (const unsigned short*)w3_mx, b3, relu3, nsplit, tile_points, out,
+                                        pointfeat, status, stream);
 }

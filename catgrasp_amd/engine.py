@@ -19,6 +19,10 @@ from . import ops
 #           for every wide layer: logits within ~2e-6 of the float64 evaluation -- float32's own distance -- at 3.2x the f32 rate.  Half
 #           has a narrow exponent range: the kernels report range excursions per call and the engine re-runs such batches with bf16
 #           pieces (run_guarded), so a valid checkpoint never fails.
+# 'f16fp8x2': opt-in, the fastest mode: 'f16x3' everywhere except the 128 -> 1024 per-point layers (91 % of the matrix work), whose two
+#           correction terms run on the block-scaled e4m3 matrix instruction (x_hi8.w_lo8 + x_lo8.w_hi8, one power-of-two scale per 32
+#           channels) -- 2 instead of 3 units of matrix time per product block.  Logits within ~5e-5 of the float64 evaluation (the bar is
+#           1e-4); same range guard and bf16x3 re-run as 'f16x3'.
 # 'bf16x3': the same with bf16 pieces (8 + 8 bits; ~2e-5): float32's exponent range, per-point layers + segmentation head only.
 # For scale: the reference's own GPU path runs its Conv1d layers through cuDNN, where TF32 (10-bit mantissa) is PyTorch's default
 # on Ampere and later.
@@ -28,11 +32,12 @@ TILE_POINTS = 256   # bf16x3 kernel geometry: points per workgroup tile (8 waves
 
 def set_precision(p):
     global PRECISION
-    assert p in ('f32', 'bf16x3', 'f16x3'), p
+    assert p in ('f32', 'bf16x3', 'f16x3', 'f16fp8x2'), p
     PRECISION = p
 
 
 HALF_OVERFLOW, HALF_UNDERFLOW = 1, 2        # CG_STATUS_HALF_* bits of include/catgrasp_amd.h
+HALF_MODES = ('f16x3', 'f16fp8x2')         # modes built on IEEE-half pieces: range-guarded, re-run under bf16x3 when the guard trips
 _warned = set()
 
 
@@ -74,7 +79,7 @@ def run_guarded(forward, W, x):
     (or layer outputs that sank into the half subnormals) in a per-call status word; such a batch is evaluated again with bf16
     pieces -- float32's exponent range, ~2e-5 instead of ~2e-6 logits error, still inside the 1e-4 bar -- so a valid checkpoint
     never raises and never returns range-damaged numbers.  Costs one 4-byte read-back per call."""
-    if PRECISION != 'f16x3':
+    if PRECISION not in HALF_MODES:
         return forward(W, x, None)
     st = new_status(x.device)
     out = forward(W, x, st)
@@ -99,7 +104,7 @@ def _dense(W, name, x, n_out, bias, status=None, **kw):
     image (FC tails and segmentation head; the 9- and 10-wide output layers stay exact f32).  'bf16x3': only the per-point
     segmentation head -- measured, splitting the per-candidate FC tails with bf16 pieces buys 3 % of the step and raises the
     logits error from ~2e-5 to ~6e-5 of the 1e-4 bar."""
-    if PRECISION == 'f16x3' and W.half_ok.get(name + '.h', False):       # a layer whose weights do not fit the half pieces stays f32
+    if PRECISION in HALF_MODES and W.half_ok.get(name + '.h', False):       # a layer whose weights do not fit the half pieces stays f32
         return ops.gemm_bias_act(x, W[name + '.h'], n_out, bias, split='f16', status=status, **kw)
     if PRECISION == 'bf16x3' and (name + '.s') in W:
         return ops.gemm_bias_act(x, W[name + '.s'], n_out, bias, split='bf16', **kw)
@@ -138,11 +143,12 @@ def _encoder_forward_split(W, x, want_pointfeat=False, status=None):
 
     def point_pass(w1, tag, relu3, mid=None, **kw):
         names = [tag + '.w2', tag + '.w3'] + ([mid] if mid else [])
-        half = PRECISION == 'f16x3' and all(W.half_ok.get(n + '.h', False) for n in names)
+        half = PRECISION in HALF_MODES and all(W.half_ok.get(n + '.h', False) for n in names)
         sfx = '.h' if half else '.s'
+        mx = half and PRECISION == 'f16fp8x2'
         extra = dict(wm=W[mid + sfx], bm=W[mid[:-3] + '.bm']) if mid else {}
-        return ops.pointmlp_max(x, W[w1 + '.w1'], W[w1 + '.b1'], W[tag + '.w2' + sfx], W[tag + '.b2'], W[tag + '.w3' + sfx], W[tag + '.b3'],
-                                relu3, nsplit=ns, split='f16' if half else 'bf16', tile_points=TILE_POINTS,
+        return ops.pointmlp_max(x, W[w1 + '.w1'], W[w1 + '.b1'], W[tag + '.w2' + sfx], W[tag + '.b2'], W[tag + '.w3' + ('.q' if mx else sfx)], W[tag + '.b3'],
+                                relu3, nsplit=ns, split=('f16fp8' if mx else 'f16') if half else 'bf16', tile_points=TILE_POINTS,
                                 status=status if half else None, **extra, **kw)
 
     g = point_pass('stn', 'stn', True)
@@ -165,10 +171,11 @@ def stn3d_forward(W, x, status=None):
     if PRECISION == 'f32':
         g = ops.pointmlp_max(x, W['stn.w1'], W['stn.b1'], W['stn.w2'], W['stn.b2'], W['stn.w3'], W['stn.b3'], True, nsplit=_nsplit(B, N))
     else:
-        half = PRECISION == 'f16x3' and all(W.half_ok.get(n + '.h', False) for n in ('stn.w2', 'stn.w3'))
+        half = PRECISION in HALF_MODES and all(W.half_ok.get(n + '.h', False) for n in ('stn.w2', 'stn.w3'))
         sfx = '.h' if half else '.s'
-        g = ops.pointmlp_max(x, W['stn.w1'], W['stn.b1'], W['stn.w2' + sfx], W['stn.b2'], W['stn.w3' + sfx], W['stn.b3'], True,
-                             nsplit=_nsplit(B, N, TILE_POINTS), split='f16' if half else 'bf16', tile_points=TILE_POINTS,
+        mx = half and PRECISION == 'f16fp8x2'
+        g = ops.pointmlp_max(x, W['stn.w1'], W['stn.b1'], W['stn.w2' + sfx], W['stn.b2'], W['stn.w3' + ('.q' if mx else sfx)], W['stn.b3'], True,
+                             nsplit=_nsplit(B, N, TILE_POINTS), split=('f16fp8' if mx else 'f16') if half else 'bf16', tile_points=TILE_POINTS,
                              status=status if half else None)
     h = _dense(W, 'stn.fc1', g, 512, W['stn.fc1b'], relu=True, status=status)
     h = _dense(W, 'stn.fc2', h, 256, W['stn.fc2b'], relu=True, status=status)

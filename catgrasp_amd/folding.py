@@ -76,6 +76,54 @@ def pack_b_split(w, elem='bf16'):
     return np.ascontiguousarray(out).reshape(-1)
 
 
+MX_NB_BYTES = 16640        # csrc/gen_l3_mx_asm.py: f16 fragments 8192 | lo8 4096 | hi8 4096 | scales 256
+
+
+def _e4m3_bits(x):
+    """float32 array -> uint8 OCP e4m3 bit patterns, round-to-nearest-even (|x| <= 448 by construction of the scales)."""
+    return torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(torch.float8_e4m3fn).view(torch.uint8).numpy()
+
+
+def pack_b_f16fp8x2(w):
+    """W:(N,128) -> flat uint8 image of the 128 -> 1024 layer for the f16fp8x2 mode (csrc/pointmlp_split.hip, gen_l3_mx_asm.py).
+    Per 32 output channels (16,640 B):
+      [0,8192)       f16 hi pieces,   [kc 8][lane 64][8]: element e of lane l = half(W[nb*32 + (l&31)][kc*16 + (l>>5)*8 + e])
+      [8192,12288)   lo8 = e4m3((W - half(W)) / 2^(e-19)),  [kh 2][u 2][lane 64][16 B]
+      [12288,16384)  hi8 = e4m3(W / 2^(e-8)),               same layout
+      [16384,16640)  scales, [lane 64][4 B] = E8M0 of (hi8 kh0, hi8 kh1, lo8 kh0, lo8 kh1) of unit u = l>>5
+    One MX unit = 32 consecutive input channels of one output channel: unit u of k-half kh = channels [32*(2kh+u), +32); e = its
+    frexp exponent (largest |w| in [2^(e-1), 2^e)), so the largest hi8 value lies in [128, 256) and every residual in (0, 128].
+    Byte 4q+i of lane-half g = l>>5 within the unit holds channel 32*(2kh+u) + 8q + 4g + i (the order the producing layer's lanes
+    hold them; the matrix instruction only needs both operands to agree)."""
+    w = np.asarray(w, dtype=np.float32)
+    n, k = w.shape
+    assert k == 128 and n % 32 == 0, (n, k)
+    nb = n // 32
+    with np.errstate(over='ignore'):
+        hi = w.astype(np.float16)
+    lo = w - hi.astype(np.float32)
+    blk = np.abs(w).reshape(n, 4, 32).max(axis=2)                       # (n, 4) unit maxima, unit index = 2*kh + u
+    e = np.clip(np.frexp(blk)[1], -100, 100).astype(np.int32)           # frexp(0) = (0, 0)
+    sc_hi = np.ldexp(np.float32(1), e - 8)[:, :, None]
+    sc_lo = np.ldexp(np.float32(1), e - 19)[:, :, None]
+    hi8 = _e4m3_bits((w.reshape(n, 4, 32) / sc_hi).reshape(n, 128))
+    lo8 = _e4m3_bits((lo.reshape(n, 4, 32) / sc_lo).reshape(n, 128))
+
+    def frag8(img):
+        # channel index c = 32*(2kh+u) + 8q + 4g + i  ->  [nb, j, kh, u, q, g, i] -> [nb, kh, u, g, j, q, i]
+        v = img.reshape(nb, 32, 2, 2, 4, 2, 4).transpose(0, 2, 3, 5, 1, 4, 6)
+        return np.ascontiguousarray(v).reshape(nb, 4096)
+    # f16 fragments: [nb, j, kc, g, e] -> [nb, kc, g, j, e]
+    f16 = np.ascontiguousarray(hi.view(np.uint16).reshape(nb, 32, 8, 2, 8).transpose(0, 2, 3, 1, 4)).reshape(nb, 4096).view(np.uint8)
+    # scales: lane (g, j): bytes (hi8 kh0, hi8 kh1, lo8 kh0, lo8 kh1) of unit u = g
+    eb = e.reshape(nb, 32, 2, 2)                                       # [nb, j, kh, u]
+    sc = np.stack([119 + eb[:, :, 0, :], 119 + eb[:, :, 1, :], 108 + eb[:, :, 0, :], 108 + eb[:, :, 1, :]], axis=-1)   # [nb, j, u, 4]
+    sc = np.ascontiguousarray(sc.transpose(0, 2, 1, 3)).astype(np.uint8).reshape(nb, 256)
+    out = np.concatenate([f16, frag8(lo8), frag8(hi8), sc], axis=1)
+    assert out.shape == (nb, MX_NB_BYTES)
+    return np.ascontiguousarray(out).reshape(-1)
+
+
 def _get(sd, name):
     return sd[name].detach().cpu().double().numpy()
 
@@ -120,6 +168,10 @@ class DeviceWeights:
         with np.errstate(over='ignore'):
             self.t[name] = torch.from_numpy(pack_b_split(w, 'f16').view(np.int16)).to(self.device)
 
+    def put_mx(self, name, w):
+        """f16fp8x2 image ('....q') of a 128 -> 1024 per-point layer; usable under the same range screen as its half image."""
+        self.t[name] = torch.from_numpy(pack_b_f16fp8x2(w)).to(self.device)
+
     def __contains__(self, k):
         return k in self.t
 
@@ -138,7 +190,7 @@ def _prepare_tnet(W, sd, q, tag, k):
     w, b = fold_bn(*_conv(sd, q + 'conv2'), _bn(sd, q + 'bn2'))
     W.put(tag + '.w2', pack_b(w)); W.put(tag + '.b2', b); W.put_split(tag + '.w2.s', w)
     w, b = fold_bn(*_conv(sd, q + 'conv3'), _bn(sd, q + 'bn3'))
-    W.put(tag + '.w3', pack_b(w)); W.put(tag + '.b3', b); W.put_split(tag + '.w3.s', w)
+    W.put(tag + '.w3', pack_b(w)); W.put(tag + '.b3', b); W.put_split(tag + '.w3.s', w); W.put_mx(tag + '.w3.q', w)
     w, b = fold_bn(_get(sd, q + 'fc1.weight'), _get(sd, q + 'fc1.bias'), _bn(sd, q + 'bn4'))
     W.put(tag + '.fc1', pack_b(w)); W.put(tag + '.fc1b', b); W.put_half(tag + '.fc1.h', w)
     w, b = fold_bn(_get(sd, q + 'fc2.weight'), _get(sd, q + 'fc2.bias'), _bn(sd, q + 'bn5'))
@@ -174,7 +226,7 @@ def prepare_encoder(sd, prefix, device, out=None):
     w, b = fold_bn(*_conv(sd, p + 'conv2'), _bn(sd, p + 'bn2'))
     W.put('enc.w2', pack_b(w)); W.put('enc.b2', b); W.put_split('enc.w2.s', w)
     w, b = fold_bn(*_conv(sd, p + 'conv3'), _bn(sd, p + 'bn3'))
-    W.put('enc.w3', pack_b(w)); W.put('enc.b3', b); W.put_split('enc.w3.s', w)
+    W.put('enc.w3', pack_b(w)); W.put('enc.b3', b); W.put_split('enc.w3.s', w); W.put_mx('enc.w3.q', w)
     return W
 
 

@@ -18,7 +18,8 @@ KERNEL_TIMER = None
 def pointmlp_max(x, w1, b1, w2p, b2, w3p, b3, relu3, t3=None, mid_mode=0, wm=None, bm=None, t64=None,
                  nsplit=1, pointfeat=False, split=False, tile_points=256, status=None):
     """x:(B,N,6) -> (B,1024) [, pointfeat (B,N,64)].  See cg_pointmlp_max / cg_pointmlp_max_bf16x3 in
-    include/catgrasp_amd.h.  split='f16' / 'bf16': w2p/w3p/wm are the split images of that element type (folding.pack_b_split)."""
+    include/catgrasp_amd.h.  split='f16' / 'bf16': w2p/w3p/wm are the split images of that element type (folding.pack_b_split);
+    split='f16fp8': as 'f16' except that w3p is the f16fp8x2 image of the 128 -> 1024 layer (folding.pack_b_f16fp8x2)."""
     require_cuda(x)
     f32c(x)
     B, N, D = x.shape
@@ -35,12 +36,14 @@ def pointmlp_max(x, w1, b1, w2p, b2, w3p, b3, relu3, t3=None, mid_mode=0, wm=Non
                 _c_int(tile_points), _p(out), _p(pf))
         if split == 'f16':      # status: caller-owned device int that collects the half range bits (None: not tracked)
             st = L.lib().cg_pointmlp_max_f16x3(*args, _p(status), _stream())
+        elif split == 'f16fp8':
+            st = L.lib().cg_pointmlp_max_f16fp8x2(*args, _p(status), _stream())
         else:
             st = L.lib().cg_pointmlp_max_bf16x3(*args, _stream())
         if timer is not None:
             ev1.record()
             timer['events'].append((ev0, ev1, (B, N)))
-        check(st, 'cg_pointmlp_max_f16x3' if split == 'f16' else 'cg_pointmlp_max_bf16x3')
+        check(st, {'f16': 'cg_pointmlp_max_f16x3', 'f16fp8': 'cg_pointmlp_max_f16fp8x2'}.get(split, 'cg_pointmlp_max_bf16x3'))
         return (out, pf) if pointfeat else out
     timer = KERNEL_TIMER if (KERNEL_TIMER is not None and KERNEL_TIMER['mid_mode'] == mid_mode) else None
     if timer is not None:

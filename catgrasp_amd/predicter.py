@@ -114,7 +114,7 @@ class GraspPredicter:
         C = len(self.cfg['classes']) - 1
         logits = torch.empty((G, C), dtype=torch.float32, device=self.device)
         starts = list(range(0, G, self.chunk))
-        guard = engine.PRECISION == 'f16x3'
+        guard = engine.PRECISION in engine.HALF_MODES
         status = engine.new_status(self.device, len(starts)) if guard else None      # one range word per chunk
 
         def run(s, st):

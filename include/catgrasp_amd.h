@@ -69,6 +69,18 @@ int cg_pointmlp_max_f16x3(const float* x, int B, int N, const float* t3, const f
                            const unsigned short* w2_split, const float* b2, const unsigned short* w3_split,
                            const float* b3, int relu3, int nsplit, int tile_points, float* out, float* pointfeat,
                            int* status, void* stream);
+/* "f16fp8x2": cg_pointmlp_max_f16x3 with a cheaper 128 -> 1024 layer (91 % of the pass's matrix work): its main term stays one f16 MFMA
+ * per 16 input channels, its two correction terms x_hi.w_lo + x_lo.w_hi run on the block-scaled e4m3 matrix instruction of gfx950
+ * (v_mfma_scale_f32_32x32x64_f8f6f4; one power-of-two scale per 32 input channels of a point / of an output channel, applied by the
+ * instruction, f32 accumulation into the same registers) -- 128 instead of 192 matrix passes per 32x32x128 product block.  The e4m3
+ * rounding of the OTHER factor of each correction term (2^-4 relative, on a term that is 2^-11 of the product) puts the logits within
+ * ~5e-5 of the float64 evaluation (parity bar 1e-4).  w3_mx: folding.pack_b_f16fp8x2 (16,640 B per 32 output channels); every
+ * other argument, the front layers (f16x3) and `status` as cg_pointmlp_max_f16x3.  Opt-in: CATGRASP_AMD_PRECISION=f16fp8x2. */
+int cg_pointmlp_max_f16fp8x2(const float* x, int B, int N, const float* t3, const float* w1, const float* b1,
+                             int mid_mode, const unsigned short* wm_split, const float* bm, const float* t64,
+                             const unsigned short* w2_split, const float* b2, const void* w3_mx,
+                             const float* b3, int relu3, int nsplit, int tile_points, float* out, float* pointfeat,
+                             int* status, void* stream);
 
 /* Y[M,N] = act(X[M,K] . W^T + bias + row_bias[row / rows_per_group]) (+ flattened identity k x k):
  * replaces Linear->BN->ReLU tails (pointnet2.py:178-185, :216-223, :295-298) and the Conv1d(k=1)

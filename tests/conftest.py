@@ -21,13 +21,13 @@ def cuda_device():
 
 
 # Every GPU test module that runs the PointNet kernels is executed under ALL arithmetic modes of the engine (exact-f32 MFMA, the
-# split-half "f16x3" MFMA path that is the default and that bench.py times, and its bf16 sibling), against the same oracle and bar.
+# split-half "f16x3" MFMA path, its bf16 sibling, and the 2-unit "f16fp8x2" mode), against the same oracle and bar.
 _NET_MODULES = ('test_pointnet_gpu', 'test_predicter_gpu', 'test_pipeline_gpu', 'test_fullsize_properties_gpu', 'test_workload_gpu')
 
 
 def pytest_generate_tests(metafunc):
     if metafunc.module.__name__.split('.')[-1] in _NET_MODULES and 'mlp_precision' in metafunc.fixturenames:
-        metafunc.parametrize('mlp_precision', ['f32', 'bf16x3', 'f16x3'], indirect=True)
+        metafunc.parametrize('mlp_precision', ['f32', 'bf16x3', 'f16x3', 'f16fp8x2'], indirect=True)
 
 
 @pytest.fixture(autouse=True)

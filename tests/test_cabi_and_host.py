@@ -324,3 +324,63 @@ def test_split_packing_half_and_bf16():
         small = np.abs(full).max() * 2.0 ** -24 if elem == 'f16' else 0.0           # half residuals below 2^-24 flush toward zero
         assert np.all(np.abs(rec - exp) <= np.abs(exp) * 2.0 ** -bits + small + 1e-30)
     assert np.array_equal(folding.pack_b_bf16x3(w), folding.pack_b_split(w, 'bf16'))
+
+
+def _e4m3(b):
+    b = np.asarray(b, dtype=np.uint8).astype(np.int32)
+    s, e, m = b >> 7, (b >> 3) & 15, b & 7
+    v = np.where(e == 0, np.ldexp(m / 8.0, -6), np.ldexp(1.0 + m / 8.0, e - 7))
+    return np.where(s == 1, -v, v)
+
+
+def test_f16fp8x2_weight_image_layout_and_arithmetic():
+    """folding.pack_b_f16fp8x2 against an independent per-byte decoder that follows the MEASURED operand layout of
+    v_mfma_scale_f32_32x32x64_f8f6f4 (scripts/probe/mx_probe2.hip: byte p of lane-half g pairs with byte p of lane-half g on the other
+    side; the scale of lane i + 32u covers bytes [16u, 16u+16) of both lanes of row i): every weight is recovered to e4m3 / half + e4m3
+    accuracy at the K index the kernel's activation images use, and the 2-unit product x_hi8.w_lo8 + x_lo8.w_hi8 + x_hi.w_hi built from
+    the decoded image reproduces W.x to the accuracy class the mode claims."""
+    from catgrasp_amd import folding
+    rng = np.random.default_rng(3)
+    w = (rng.normal(0, 0.1, (64, 128)) * np.exp2(rng.integers(-6, 3, (64, 1)))).astype(np.float32)
+    w[5, 32:64] = 0.0                                              # an all-zero unit
+    img = folding.pack_b_f16fp8x2(w).reshape(2, folding.MX_NB_BYTES)
+    w_hi = np.zeros_like(w); w_hi8 = np.zeros_like(w); w_lo8 = np.zeros_like(w)
+    for nb in range(2):
+        blk = img[nb]
+        f16 = blk[:8192].view(np.float16).reshape(8, 64, 8)
+        sc = blk[16384:].reshape(64, 4).astype(np.int32)
+        for l in range(64):
+            j, g = l & 31, l >> 5
+            ch = nb * 32 + j
+            for kc in range(8):
+                w_hi[ch, kc * 16 + g * 8:kc * 16 + g * 8 + 8] = f16[kc, l]
+            for name, off, dst, sbyte in (('lo8', 8192, w_lo8, 2), ('hi8', 12288, w_hi8, 0)):
+                for kh in range(2):
+                    for u in range(2):
+                        raw = blk[off + kh * 2048 + u * 1024 + l * 16: off + kh * 2048 + u * 1024 + l * 16 + 16]
+                        # the hardware scales unit u with the byte supplied by lane j + 32u
+                        e8 = int(blk[16384 + (j + 32 * u) * 4 + sbyte + kh])
+                        for p in range(16):
+                            q, i = divmod(p, 4)
+                            k = 32 * (2 * kh + u) + 8 * q + 4 * g + i
+                            dst[ch, k] = _e4m3(raw[p]) * 2.0 ** (e8 - 127)
+    assert np.array_equal(w_hi, w.astype(np.float16).astype(np.float32))
+    unit_max = np.abs(w).reshape(64, 4, 32).max(2).repeat(32, axis=1)
+    assert np.all(np.abs(w_hi8 - w) <= np.maximum(np.abs(w) * 2.0 ** -4, unit_max * 2.0 ** -17))
+    assert np.all(np.abs(w_hi + w_lo8 - w) <= np.abs(w) * 2.0 ** -15 + unit_max * 2.0 ** -26 + 2.0 ** -29)     # e4m3 rounding of the residual, its subnormal step, half subnormals
+    assert np.all(w_hi8[5, 32:64] == 0) and np.all(w_lo8[5, 32:64] == 0)
+    # the layer: activations quantised by the kernel's rule (one scale per 32 channels of a point, from the unit maximum)
+    x = np.maximum(rng.normal(0.2, 1.0, (128, 300)), 0).astype(np.float32)
+    xb = x.T.reshape(300, 4, 32)
+    e = np.frexp(xb.max(2, keepdims=True))[1]
+    import torch
+    q8 = lambda v, s: (torch.from_numpy((v / s).astype(np.float32)).to(torch.float8_e4m3fn).to(torch.float32).numpy() * s)
+    x_hi = xb.astype(np.float16).astype(np.float32)
+    x_hi8 = q8(xb, np.exp2(e - 8.0)).reshape(300, 128).T
+    x_lo8 = q8(xb - x_hi, np.exp2(e - 19.0)).reshape(300, 128).T
+    y = w_lo8.astype(np.float64) @ x_hi8 + w_hi8.astype(np.float64) @ x_lo8 + w_hi.astype(np.float64) @ x_hi.reshape(300, 128).T
+    ref = w.astype(np.float64) @ x.astype(np.float64)
+    scale = np.abs(w).astype(np.float64) @ np.abs(x)
+    assert np.max(np.abs(y - ref) / scale) < 2.0 ** -15          # vs 2^-12 for the bare f16 product: the corrections are in place
+    y_main = w_hi.astype(np.float64) @ x_hi.reshape(300, 128).T
+    assert np.max(np.abs(y_main - ref) / scale) > 2 * np.max(np.abs(y - ref) / scale)
