@@ -16,7 +16,7 @@ Workloads (config.workload):
       candidates in TOTAL cut into contiguous slices over the ranks.
 All inputs are resident in HBM before the timed region; weights are seeded random (the reference ships no checkpoints).
 `value` is measured under --precision (default f32: exact-f32 MFMA, the reference's arithmetic); the split-precision modes of
-the product (f16x3, bf16x3; opt-in via CATGRASP_AMD_PRECISION) are measured in the same run and reported under `secondary`.
+the product (f16x3, f16fp8x2, bf16x3; opt-in via CATGRASP_AMD_PRECISION) are measured in the same run and reported under `secondary`.
 
 Launch: python bench.py --gpus 1 --steps K --warmup W
         python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
@@ -46,9 +46,13 @@ ALG_HBM_BYTES_PER_CANDIDATE = 49152 + 16384 + 4096
 # in this run (PMC collection needs its own rocprofv3 pass).
 PMC_HBM_BYTES_PER_CANDIDATE = {'bf16x3': (2 * 133765.0 + 16384.0) * 1024 / 4096, 'f16x3': (2 * 133762.0 + 16384.0) * 1024 / 4096,
                                'f32': (2 * 133937.0 + 16384.0) * 1024 / 4096}
+PMC_HBM_BYTES_PER_CANDIDATE['f16fp8x2'] = PMC_HBM_BYTES_PER_CANDIDATE['f16x3']      # same inputs / outputs; the weight image (532 KB) is L2 resident
+L3_SHARE = 131072.0 / MAC_PER_POINT_ENC                 # share of the pass's MACs in the 128 -> 1024 layer
 DTYPE = {'f32': 'f32 (exact-f32 MFMA: every product and accumulation in float32, as the reference)',
          'f16x3': 'f32 in/out/accumulate; wide-layer products as 3x f16 MFMA on hi+lo half pieces (f16x3 split, 22 significant bits)',
-         'bf16x3': 'f32 in/out/accumulate; wide-layer products as 3x bf16 MFMA on hi+lo bf16 pieces (bf16x3 split, 16 significant bits)'}
+         'bf16x3': 'f32 in/out/accumulate; wide-layer products as 3x bf16 MFMA on hi+lo bf16 pieces (bf16x3 split, 16 significant bits)',
+         'f16fp8x2': 'f32 in/out/accumulate; 128->1024 layers as 1 f16 MFMA + 2 block-scaled e4m3 MFMAs (half cost each) per product block, '
+                     'all other wide layers f16x3'}
 
 
 def subdivide(V, F, times):
@@ -202,10 +206,10 @@ def main():
     ap.add_argument('--scaling', choices=['weak', 'strong'], default='weak')
     ap.add_argument('--candidates', type=int, default=50000, help='weak scaling: grasp candidates per GPU per step (C3: 50,000)')
     ap.add_argument('--candidates-total', type=int, default=200000, help='strong scaling: candidates per step over ALL GPUs (C4: 200,000)')
-    ap.add_argument('--precision', choices=['f32', 'f16x3', 'bf16x3'], default='f32',
+    ap.add_argument('--precision', choices=['f32', 'f16x3', 'bf16x3', 'f16fp8x2'], default='f32',
                     help='arithmetic of the timed path (`value`): f32 = exact-f32 MFMA (the reference\'s arithmetic); f16x3 / bf16x3 = split MFMA '
                          'products (3 MFMAs on hi+lo 16-bit pieces, f32 accumulation; logits within ~2e-6 / ~2e-5 of the float64 evaluation)')
-    ap.add_argument('--secondary', default='f16x3,bf16x3', help='comma list of further precisions measured in the same run ("" = none)')
+    ap.add_argument('--secondary', default='f16x3,bf16x3,f16fp8x2', help='comma list of further precisions measured in the same run ("" = none)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-api', action='store_true', help='skip the reference-API wall-clock block')
     args = ap.parse_args()
@@ -309,6 +313,16 @@ def main():
         if precision == 'f32':
             return dict({'bound': 'mfma', 'kernel': 'pointmlp_max_kernel<2> (encoder pass: conv1, x.T64, conv2, conv3, max; exact-f32 MFMA)',
                          'peak': PEAK_F32_MFMA_TFLOPS, 'frac': round(r['tflops'] / PEAK_F32_MFMA_TFLOPS, 4)}, **common)
+        if precision == 'f16fp8x2':
+            units = 2.0 * L3_SHARE + 3.0 * (1.0 - L3_SHARE)          # matrix-pipe time per algorithmic flop, in 16-bit-MFMA flop equivalents
+            return dict({'bound': 'mfma',
+                         'kernel': 'pointmlp_max_split_kernel<2, 8, true, true> (encoder pass; 128->1024 layer = 1 f16 MFMA + 2 block-scaled e4m3 MFMAs '
+                                   'at half cost each per product block; front layers 3 f16 MFMAs)',
+                         'peak': PEAK_16BIT_MFMA_TFLOPS, 'frac': round(r['tflops'] / PEAK_16BIT_MFMA_TFLOPS, 4),
+                         'issued_mfma_tflops': round(units * r['tflops'], 1), 'issued_frac': round(units * r['tflops'] / PEAK_16BIT_MFMA_TFLOPS, 4),
+                         'note': f'achieved counts ALGORITHMIC flops; the matrix pipe spends {units:.3f} 16-bit-MFMA flop equivalents per algorithmic flop '
+                                 '(an e4m3 MX MFMA does 2x the flops per pass), so the ceiling for algorithmic flops is peak/'
+                                 f'{units:.3f} = {PEAK_16BIT_MFMA_TFLOPS / units:.0f} TFLOP/s'}, **common)
         el = 'f16' if precision == 'f16x3' else 'bf16'
         return dict({'bound': 'mfma',
                      'kernel': f'pointmlp_max_split_kernel<2, 8, {"true" if el == "f16" else "false"}> (encoder pass; 3 {el} MFMAs per algorithmic product block)',

@@ -16,12 +16,12 @@ ds_write_b128.
 
 Registers are PHYSICAL (declared as clobbers): operand tuples of 8 registers cannot be sub-addressed through inline-asm operands.
     v[128:255]  accumulators c0..c7 (row tiles)          v[80:111]  A ring, 4 slots x 8 (an fp8 fragment or two f16 fragments)
-    v[112:123]  f16 weight fragments, ring of 3          v[62:69], v[70:77]  fp8 weight fragments U, V
-    v[124:127]  A scale ring                             v78  weight scales (4 bytes: hi8 kh0, hi8 kh1, lo8 kh0, lo8 kh1)
+    v[112:123]  f16 weight fragments, ring of 3          v[58:65], v[66:73]  fp8 weight fragments U, V
+    v[76:79], v[124:127]  A scales, one per row tile     v74  weight scales (4 bytes: hi8 kh0, hi8 kh1, lo8 kh0, lo8 kh1)
 Step = 64 cycles of the matrix pipe: one scaled MFMA (row tile rt) or two f16 MFMAs (row tiles 2P, 2P+1 at k chunk kc).  Per channel block:
     s  0.. 7  x_hi8[rt][kh0] . U = w_lo8[kh0]        s  8..15  x_hi8[rt][kh1] . V = w_lo8[kh1]       s 16..31  f16 kc 0..3
     s 32..39  x_lo8[rt][kh0] . U = w_hi8[kh0]        s 40..47  x_lo8[rt][kh1] . V = w_hi8[kh1]       s 48..63  f16 kc 4..7
-Every A fill (2 ds_read_b128 [+ the ds_read_u16 of the scale]) is issued 3 steps ahead, every weight fragment >= 8 steps ahead (the
+Every A fill (2 ds_read_b128 [+ the ds_read_u16 of the row tile's scale pair, k-half 0 only]) is issued 3 steps ahead, every weight fragment >= 8 steps ahead (the
 next block's first fragments during the current block's tail), all wait counts are exact.  The max over the 128 accumulator
 registers of block q is interleaved, row tile by row tile, with the first 8 steps of block q+1 (which overwrite them in that order), and
 folds straight into the wave's running per-lane maxima %[m0..3] (in/out operands; the lane^32 exchange happens once, after the last tile).
@@ -31,10 +31,10 @@ import os
 ACC0 = 128
 RING0, NRING = 80, 4
 M0, NM = 112, 3
-U, V = 62, 70
-SC0, NSC = 124, 4
-BSC = 78
-CLOBBER_LO, CLOBBER_HI = 62, 255
+U, V = 58, 66
+SCR = [76, 77, 78, 79, 124, 125, 126, 127]      # A scale registers, one per row tile
+BSC = 74
+CLOBBER_LO, CLOBBER_HI = 58, 255
 
 NB_BYTES = 16640                   # one channel block of the packed weights: f16 8192 | lo8 4096 | hi8 4096 | scales 256
 OFF_LO8, OFF_HI8 = 8192, 12288
@@ -76,7 +76,8 @@ class Gen:
             off = rt * RT8 + kh * 64
             out.append((f'ds_read_b128 {vr(slot, 4)}, {base} offset:{off}', tag))
             out.append((f'ds_read_b128 {vr(slot + 4, 4)}, {base} offset:{off + 16}', tag))
-            out.append((f'ds_read_u16 v{SC0 + s % NSC}, %[asc] offset:{rt * RT8 + (4 if lo else 0)}', tag))
+            if kh == 0:      # the row tile's scale pair (bytes: unit lhi of k-half 0, of k-half 1) serves both k-halves: steps s and s + 8
+                out.append((f'ds_read_u16 v{SCR[rt]}, %[asc] offset:{rt * RT8 + (8 * 144 if lo else 0)}', tag))
         else:
             t = s - 16 if s < 32 else s - 48 + 16
             kc, P = divmod(t, 4)
@@ -109,8 +110,10 @@ class Gen:
         return out
 
     def issue(self, items):
+        abl = os.environ.get('MX_ABL', '')        # dev ablations: drop the LDS reads / the weight loads from the stream (results garbage)
         for ins, tag in items:
-            self.emit(ins)
+            if not ((abl == 'nods' and ins.startswith('ds_')) or (abl == 'novm' and ins.startswith('global_'))):
+                self.emit(ins)
             if tag is not None:
                 (self.ds if ins.startswith('ds_') else self.vm).append(tag)
 
@@ -151,6 +154,11 @@ class Gen:
         # prologue: the first block's weight fragments of the first phases, the A fills of steps 0..2
         for what in (('lo8', 0), ('lo8', 1), ('sc',), ('m', 0), ('m', 1)):
             self.issue(self.wload(0, what))
+        # the workgroup barrier between the 64 -> 128 layer's LDS writes and these reads sits HERE, after the weight loads have been
+        # issued: their L2 latency (the only wait of the stream that cannot be covered by earlier MFMAs) elapses while the wave waits for
+        # its siblings.  lgkmcnt(0): this wave's own LDS writes have landed.
+        self.emit('s_waitcnt lgkmcnt(0)')
+        self.emit('s_barrier')
         for s in range(NRING - 1):
             self.issue(self.fill(0, s))
         for q in range(nb):
@@ -189,7 +197,7 @@ class Gen:
                 if s == 49:
                     w += self.wload(q + 1, ('lo8', 1))
                 if s == 50:
-                    w += self.wload(q + 1, ('sc',))          # v78 was last read by step 47
+                    w += self.wload(q + 1, ('sc',))          # the weight-scale register was last read by step 47
                 # ---- MFMAs
                 slot = RING0 + 8 * (s % NRING)
                 if not main:
@@ -200,7 +208,7 @@ class Gen:
                     osa = kh                                 # A scale register: bytes [unit lhi of kh0, of kh1]
                     osb = kh if lo else 2 + kh               # weight scale register: hi8 kh0, hi8 kh1, lo8 kh0, lo8 kh1
                     c_in = '0' if s < 8 else acc(rt)
-                    self.emit(f'v_mfma_scale_f32_32x32x64_f8f6f4 {acc(rt)}, {vr(slot, 8)}, {vr(b, 8)}, {c_in}, v{SC0 + s % NSC}, v{BSC} '
+                    self.emit(f'v_mfma_scale_f32_32x32x64_f8f6f4 {acc(rt)}, {vr(slot, 8)}, {vr(b, 8)}, {c_in}, v{SCR[rt]}, v{BSC} '
                               f'op_sel:[{osa & 1},{osb & 1},0] op_sel_hi:[{osa >> 1},{osb >> 1},0]')
                     self.issue(fillers + w)
                 else:

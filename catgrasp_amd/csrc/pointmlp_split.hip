@@ -33,7 +33,7 @@
 namespace {
 
 constexpr int SH = 136;        // 16-bit elements per row of the h2 hi / lo images
-constexpr int S8 = 144;        // bytes per row of the fp8 images of the f16fp8x2 mode: 128 data + 16 pad (holds the row's 8 scale bytes)
+constexpr int S8 = 144;        // bytes per row of the fp8 images of the f16fp8x2 mode: 128 data + 16 pad (the pads of a row tile hold its scale bytes)
 constexpr int MX_NB_BYTES = 16640;   // one packed channel block of the f16fp8x2 weights (folding.pack_b_f16fp8x2; gen_l3_mx_asm.py)
 template <int RT, bool MX = false> struct Geo {
   static constexpr int TP = 32 * RT;        // points per tile, one wave per 32-point row tile
@@ -148,8 +148,8 @@ __global__ __launch_bounds__(64 * RT, 2) void pointmlp_max_split_kernel(ArgsB a)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int w = MX ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6);
-  const int l31 = lane & 31, lhi = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31;
   int b, split, nsp;
   if ((int)blockIdx.x < a.n_main * a.nsplit) {
     nsp = a.nsplit; b = blockIdx.x / nsp; split = blockIdx.x - b * nsp;
@@ -207,13 +207,10 @@ __global__ __launch_bounds__(64 * RT, 2) void pointmlp_max_split_kernel(ArgsB a)
 #pragma unroll
     for (int j = 0; j < 9; ++j) {
       t3r[j] = a.t3[b * 9 + j];
-      if constexpr (MX) t3r[j] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(t3r[j])));     // scalar registers: nothing of it lives in v0..v61
+      t3r[j] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(t3r[j])));     // scalar registers: nothing of it lives across the L3 asm block
     }
   }
   const float* xb = a.x + (size_t)b * a.N * 6;
-  // LDS byte addresses of this lane's A-fragment row in the hi / lo images (generic -> LDS address = low 32 bits)
-  const unsigned ahi_addr = (unsigned)(uintptr_t)(h2hi + l31 * SH + lhi * 8);
-  const unsigned alo_addr = (unsigned)(uintptr_t)(h2lo + l31 * SH + lhi * 8);
   u32x4 wxh, wxl;          // weight fragments (hi / lo) of the wave's next channel block, k chunk 0
   if constexpr (!MX) {
     const u32x4* p = (const u32x4*)a.w3 + (size_t)((w * NBW * 8) * 2) * 64 + lane;
@@ -232,18 +229,37 @@ __global__ __launch_bounds__(64 * RT, 2) void pointmlp_max_split_kernel(ArgsB a)
   fetch_point(t_begin, l31);
 
   for (int tile = t_begin; tile < t_end; ++tile) {
-    // (MX) every lane-dependent index / LDS address of the tile body is re-derived from an opaque copy of the lane id, so that the id alone --
-    // not the two dozen values derived from it -- is live across the L3 asm block, which leaves the compiler only v0..v61
-    const int ln = MX ? opaque_copy(lane) : lane;
+    // every lane-dependent index / LDS address of the tile body is re-derived from an opaque copy of the lane id, so that the id alone -- not
+    // the two dozen values derived from it -- is live across the L3 asm block (MX: it leaves the compiler only v0..v57)
+    const int ln = opaque_copy(lane);
     const int r31 = ln & 31, hh = ln >> 5;
-    const unsigned ahi_t = MX ? (unsigned)(uintptr_t)(h2hi + r31 * SH + hh * 8) : ahi_addr, alo_t = alo_addr;
+    // LDS byte addresses of this lane's A-fragment row in the hi / lo images (generic -> LDS address = low 32 bits)
+    const unsigned ahi_t = (unsigned)(uintptr_t)(h2hi + r31 * SH + hh * 8), alo_t = (unsigned)(uintptr_t)(h2lo + r31 * SH + hh * 8);
     const unsigned a8h_t = (unsigned)(uintptr_t)(h8hi + r31 * S8 + hh * 32), a8l_t = (unsigned)(uintptr_t)(h8lo + r31 * S8 + hh * 32);
-    const unsigned asc_t = (unsigned)(uintptr_t)(h8hi + r31 * S8 + 128 + hh * 2);
+    // scale pairs of a 32-row tile: row r's hi-piece dword sits in the pad of row r>>2, slot r&3 (its lo-piece dword 8 rows further), so the
+    // 32 rows of a tile fall into 32 different banks (in the row's own pad -- stride 36 dwords -- they fell 4-way into 8)
+    const unsigned asc_t = (unsigned)(uintptr_t)(h8hi + (r31 >> 2) * S8 + 128 + (r31 & 3) * 4 + hh * 2);
     // ================= front layers, wave-private and register-resident: points [32w, 32w+32) =================
     const int oz = opaque_zero();
     const unsigned short* w2_t = a.w2 + oz;
     const float* b2_t = a.b2 + oz;
     const int pt = tile * TP + w * 32 + r31;
+    // The 64 -> 128 layer's weight fragments come from L2 (tile-invariant, but 128 registers: they cannot stay resident).  Left to the
+    // compiler they are fetched "4 fragments, wait, 6 MFMAs" -- eight exposed L2 latencies per tile with the matrix pipe idle.  So the
+    // first channel-block pair (+ its biases, straight into the accumulators) is requested HERE, a whole layer or two ahead, and the
+    // second pair when the layer starts, i.e. one pair (24 MFMAs + the split epilogue) ahead.
+    frag w2h[2][2][4], w2l[2][2][4];          // [pair][block of the pair][k chunk]
+    f32x16 cb[2][2];
+    auto fetch_w2 = [&](int np) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) load_b(w2_t, np * 2 + j, kc, 4, ln, w2h[np][j][kc], w2l[np][j][kc]);
+        cb[np][j] = bias_tile(b2_t, np * 2 + j, hh);
+      }
+    };
+    fetch_w2(0);
+    __builtin_amdgcn_sched_barrier(0);
     frag fh[4], fl[4];          // the activation as B fragments (hi / lo), 4 chunks of 16 channels
     {
       const f32x2 v0 = xn0, v1 = xn1, v2 = xn2;
@@ -297,14 +313,14 @@ __global__ __launch_bounds__(64 * RT, 2) void pointmlp_max_split_kernel(ArgsB a)
     {  // L2: 64 -> 128, two channel blocks at a time, written split into the hi / lo images
       const int row = w * 32 + r31;
       unsigned sc_word_hi = 0, sc_word_lo = 0;
+      fetch_w2(1);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int np = 0; np < 2; ++np) {
-        f32x16 c0 = bias_tile(b2_t, np * 2, hh), c1 = bias_tile(b2_t, np * 2 + 1, hh);
+        f32x16 c0 = cb[np][0], c1 = cb[np][1];
 #pragma unroll
         for (int kc = 0; kc < 4; ++kc) {
-          frag a0h, a0l, a1h, a1l;
-          load_b(w2_t, np * 2, kc, 4, ln, a0h, a0l);
-          load_b(w2_t, np * 2 + 1, kc, 4, ln, a1h, a1l);
+          const frag a0h = w2h[np][0][kc], a0l = w2l[np][0][kc], a1h = w2h[np][1][kc], a1l = w2l[np][1][kc];
           c0 = mfma_x<F16>(a0h, fl[kc], c0); c1 = mfma_x<F16>(a1h, fl[kc], c1);
           c0 = mfma_x<F16>(a0l, fh[kc], c0); c1 = mfma_x<F16>(a1l, fh[kc], c1);
           c0 = mfma_x<F16>(a0h, fh[kc], c0); c1 = mfma_x<F16>(a1h, fh[kc], c1);
@@ -349,12 +365,16 @@ __global__ __launch_bounds__(64 * RT, 2) void pointmlp_max_split_kernel(ArgsB a)
         }
       }
       if constexpr (MX) {
-        if (hh == 0) *(u32x2*)(h8hi + row * S8 + 128) = u32x2{sc_word_hi, sc_word_lo};
+        if (hh == 0) {
+          unsigned char* sp = h8hi + (w * 32 + (r31 >> 2)) * S8 + 128 + (r31 & 3) * 4;
+          *(unsigned*)sp = sc_word_hi;
+          *(unsigned*)(sp + 8 * S8) = sc_word_lo;
+        }
       }
     }
     fold(true);
     fetch_point(tile + 1, r31);
-    __syncthreads();
+    if constexpr (!MX) __syncthreads();        // MX: the barrier is inside the asm block, behind its first weight loads
     // ================= L3: 128 -> 1024 + running max.  wave w owns channel blocks [4w, 4w+4) =================
     // The 192-MFMA stream of one channel block is hand-scheduled assembly (gen_l3_asm.py -> l3_asm.inc): exact wait
     // counts, A fragments through a 3-deep register ring, weight fragments double buffered with the next block's first

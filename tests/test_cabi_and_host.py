@@ -56,6 +56,8 @@ def test_argument_errors_are_reported_not_crashed():
     assert lib.cg_pg_voxel_fill_maps(one, one, one, one, 5, 1, 4, one, one, null) == -1                           # width < 2
     assert lib.cg_pg_cc_propagate(one, one, one, 5, null, one, null) == -1
     assert lib.cg_pointmlp_max_f16x3(null, 1, 64, null, null, null, 0, null, null, null, null, null, null, null, 0, 1, 256, null, null, null, null) == -1
+    assert lib.cg_pointmlp_max_f16fp8x2(null, 1, 64, null, null, null, 0, null, null, null, null, null, null, null, 0, 1, 256, null, null, null, null) == -1
+    assert lib.cg_pointmlp_max_f16fp8x2(one, 1, 64, null, one, one, 0, null, null, null, one, one, one, one, 0, 1, 64, one, null, null, null) == -2   # 256-point tiles only
     # zero-sized work is a successful no-op
     assert lib.cg_softmax_pg(one, 0, 10, one, one, one, one, null) == 0
     assert lib.cg_voxel_keys(null, ctypes.c_long(0), ctypes.c_float(0.001), null, null) == 0
@@ -283,7 +285,7 @@ def test_committed_bench_line_honours_the_contract(name):
     if name.startswith('r2'):
         assert d['config']['candidates_per_gpu'] == 50000 and d['config']['workload'].startswith('C3') and d['dtype'].startswith('f32 ')
         assert d['config']['evaluations_nocs_shape_adjust_true'] + d['config']['evaluations_cone_shape_adjust_false'] == 50000
-        assert {x['precision'] for x in d['secondary']} == {'f16x3', 'bf16x3'} and all(x['codes_identical_to_primary'] for x in d['secondary'])
+        assert {x['precision'] for x in d['secondary']} >= {'f16x3', 'bf16x3'} and all(x['codes_identical_to_primary'] for x in d['secondary'])
         assert d['api']['predict_batch'][0]['poses'] == 50000 and d['api']['predict_batch'][0]['rng'] == 'device' and d['api']['filterGraspPose']['gripper_triangles'][0] >= 5000
         assert d['roofline']['frac'] > 0.85 and d['value'] > 50000
     for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype',
