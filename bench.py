@@ -46,7 +46,7 @@ ALG_HBM_BYTES_PER_CANDIDATE = 49152 + 16384 + 4096
 # in this run (PMC collection needs its own rocprofv3 pass).
 PMC_HBM_BYTES_PER_CANDIDATE = {'bf16x3': (2 * 133765.0 + 16384.0) * 1024 / 4096, 'f16x3': (2 * 133762.0 + 16384.0) * 1024 / 4096,
                                'f32': (2 * 133937.0 + 16384.0) * 1024 / 4096}
-PMC_HBM_BYTES_PER_CANDIDATE['f16fp8x2'] = PMC_HBM_BYTES_PER_CANDIDATE['f16x3']      # same inputs / outputs; the weight image (532 KB) is L2 resident
+PMC_HBM_BYTES_PER_CANDIDATE['f16fp8x2'] = (2 * 134646.0 + 18420.0) * 1024 / 4096         # profiles/r2_pmc_hbm_pointmlp_f16fp8x2.csv
 L3_SHARE = 131072.0 / MAC_PER_POINT_ENC                 # share of the pass's MACs in the 128 -> 1024 layer
 DTYPE = {'f32': 'f32 (exact-f32 MFMA: every product and accumulation in float32, as the reference)',
          'f16x3': 'f32 in/out/accumulate; wide-layer products as 3x f16 MFMA on hi+lo half pieces (f16x3 split, 22 significant bits)',
@@ -307,7 +307,7 @@ def main():
         common = {'achieved': round(r['tflops'], 2), 'unit': 'TFLOP/s', 'avg_launch_ms': round(r['avg_ms'], 4), 'launches': r['launches'],
                   'candidates_per_launch': round(r['avg_cand'], 1), 'flop_per_candidate_launch': 2 * MAC_PER_POINT_ENC * 2048,
                   'traffic': int(per * r['avg_cand']),
-                  'traffic_source': 'constant from profiles/r2_pmc_hbm_pointmlp_f32.csv / r2_pmc_hbm_pointmlp_split.csv (2*FETCH_SIZE + WRITE_SIZE per candidate at B=4096) x candidates per '
+                  'traffic_source': 'constant from profiles/r2_pmc_hbm_pointmlp_{f32,split,f16fp8x2}.csv (2*FETCH_SIZE + WRITE_SIZE per candidate at B=4096) x candidates per '
                                     'launch -- not a counter read in this run; algorithmic bytes are 69,632 B/candidate',
                   'hbm_achieved_gbs': round(hbm_gbs, 1), 'hbm_frac': round(hbm_gbs / PEAK_HBM_GBS, 5)}
         if precision == 'f32':

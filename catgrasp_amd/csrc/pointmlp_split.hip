@@ -244,22 +244,6 @@ __global__ __launch_bounds__(64 * RT, 2) void pointmlp_max_split_kernel(ArgsB a)
     const unsigned short* w2_t = a.w2 + oz;
     const float* b2_t = a.b2 + oz;
     const int pt = tile * TP + w * 32 + r31;
-    // The 64 -> 128 layer's weight fragments come from L2 (tile-invariant, but 128 registers: they cannot stay resident).  Left to the
-    // compiler they are fetched "4 fragments, wait, 6 MFMAs" -- eight exposed L2 latencies per tile with the matrix pipe idle.  So the
-    // first channel-block pair (+ its biases, straight into the accumulators) is requested HERE, a whole layer or two ahead, and the
-    // second pair when the layer starts, i.e. one pair (24 MFMAs + the split epilogue) ahead.
-    frag w2h[2][2][4], w2l[2][2][4];          // [pair][block of the pair][k chunk]
-    f32x16 cb[2][2];
-    auto fetch_w2 = [&](int np) {
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-#pragma unroll
-        for (int kc = 0; kc < 4; ++kc) load_b(w2_t, np * 2 + j, kc, 4, ln, w2h[np][j][kc], w2l[np][j][kc]);
-        cb[np][j] = bias_tile(b2_t, np * 2 + j, hh);
-      }
-    };
-    fetch_w2(0);
-    __builtin_amdgcn_sched_barrier(0);
     frag fh[4], fl[4];          // the activation as B fragments (hi / lo), 4 chunks of 16 channels
     {
       const f32x2 v0 = xn0, v1 = xn1, v2 = xn2;
@@ -313,14 +297,14 @@ __global__ __launch_bounds__(64 * RT, 2) void pointmlp_max_split_kernel(ArgsB a)
     {  // L2: 64 -> 128, two channel blocks at a time, written split into the hi / lo images
       const int row = w * 32 + r31;
       unsigned sc_word_hi = 0, sc_word_lo = 0;
-      fetch_w2(1);
-      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int np = 0; np < 2; ++np) {
-        f32x16 c0 = cb[np][0], c1 = cb[np][1];
+        f32x16 c0 = bias_tile(b2_t, np * 2, hh), c1 = bias_tile(b2_t, np * 2 + 1, hh);
 #pragma unroll
         for (int kc = 0; kc < 4; ++kc) {
-          const frag a0h = w2h[np][0][kc], a0l = w2l[np][0][kc], a1h = w2h[np][1][kc], a1l = w2l[np][1][kc];
+          frag a0h, a0l, a1h, a1l;
+          load_b(w2_t, np * 2, kc, 4, ln, a0h, a0l);
+          load_b(w2_t, np * 2 + 1, kc, 4, ln, a1h, a1l);
           c0 = mfma_x<F16>(a0h, fl[kc], c0); c1 = mfma_x<F16>(a1h, fl[kc], c1);
           c0 = mfma_x<F16>(a0l, fh[kc], c0); c1 = mfma_x<F16>(a1l, fh[kc], c1);
           c0 = mfma_x<F16>(a0h, fh[kc], c0); c1 = mfma_x<F16>(a1h, fh[kc], c1);

@@ -91,6 +91,17 @@ def run_guarded(forward, W, x):
     return out
 
 
+def run_guarded_features(forward, W, x):
+    """run_guarded for the standalone building blocks (STN3d, PointNetEncoder), whose OUTPUT is the raw 1024-wide feature / the
+    transform itself rather than logits behind FC layers and a softmax.  The 2-unit mode's e4m3 correction terms reach ~1e-4 of the
+    feature scale there (measured 1.1e-4 on tests/test_predicter_gpu.py's encoder case) -- the mode is specified on the nets' logits --
+    so under 'f16fp8x2' these blocks run 'f16x3'."""
+    if PRECISION == 'f16fp8x2':
+        with precision('f16x3'):
+            return run_guarded(forward, W, x)
+    return run_guarded(forward, W, x)
+
+
 def _nsplit(B, N, tp=64):
     """Workgroups per sample: keep >= ~1024 workgroups in flight for small batches."""
     ntiles = (N + tp - 1) // tp

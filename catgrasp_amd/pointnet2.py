@@ -97,7 +97,7 @@ class STN3d(_TNet):
         if self._channel != 6:
             raise NotImplementedError('HIP path is built for the 6-channel (xyz+normal) input')
         W = _cached_weights(self, x.device, folding.prepare_stn3d)
-        return engine.run_guarded(engine.stn3d_forward, W, x.float().transpose(1, 2).contiguous()).view(-1, 3, 3)
+        return engine.run_guarded_features(engine.stn3d_forward, W, x.float().transpose(1, 2).contiguous()).view(-1, 3, 3)
 
 
 class STNkd(_TNet):
@@ -137,7 +137,7 @@ class PointNetEncoder(nn.Module):
             W = _cached_weights(self, x.device, lambda sd, dev: folding.prepare_encoder(sd, '', dev))
             xt = x.float().transpose(1, 2).contiguous()
             gf = self.global_feat
-            return engine.run_guarded(lambda w, xx, st: engine.encoder_module_forward(w, xx, gf, st), W, xt)
+            return engine.run_guarded_features(lambda w, xx, st: engine.encoder_module_forward(w, xx, gf, st), W, xt)
         return self._torch_forward(x)
 
     def _torch_forward(self, x):
