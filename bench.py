@@ -14,6 +14,9 @@ Workloads (config.workload):
       50,000 candidates PER GPU; --gpus N is weak scaling (every rank scores its own 50k candidates of the same scene).
   C4 (--scaling strong; configs[3]): screw category, 40k-pt scene (16 x 2500), 72 symmetries, --candidates-total (200,000)
       candidates in TOTAL cut into contiguous slices over the ranks.
+  C5 (--workload C5; configs[4]): mixed-category bin, 60k-pt scene (24 x 2500: nut / hnm / screw in turn, 12 / 2 / 72 symmetries, one
+      GraspPredicter + NunocsPredicter per category with its own weights), --candidates-total (500,000) candidates in TOTAL cut into
+      contiguous slices over the ranks (strong scaling), split-bf16 MFMA arithmetic (--precision bf16x3) unless told otherwise.
 All inputs are resident in HBM before the timed region; weights are seeded random (the reference ships no checkpoints).
 `value` is measured under --precision (default f32: exact-f32 MFMA, the reference's arithmetic); the split-precision modes of
 the product (f16x3, f16fp8x2, bf16x3; opt-in via CATGRASP_AMD_PRECISION) are measured in the same run and reported under `secondary`.
@@ -21,6 +24,7 @@ the product (f16x3, f16fp8x2, bf16x3; opt-in via CATGRASP_AMD_PRECISION) are mea
 Launch: python bench.py --gpus 1 --steps K --warmup W
         python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
         ... bench.py --gpus 8 --scaling strong --candidates-total 200000        (C4)
+        ... bench.py --gpus 8 --workload C5                                     (C5)
 """
 import argparse
 import json
@@ -167,7 +171,7 @@ def cpu_baseline(batch, sd_cls, sd_seg, n_score=100, n_coll=4096):
     bg = __import__('catgrasp_amd.synth', fromlist=['x']).background_points(batch.objs, 0, g['diameter'])
     I4 = np.eye(4)
     from catgrasp_amd import transforms
-    sym = transforms.get_symmetry_tfs('nut' if batch.kind == 'nut' else 'screw')
+    sym = transforms.get_symmetry_tfs(batch.cats[0])
     n_can = max(1, (n_coll // 2) // len(sym))
     can = batch.host_poses(seg_nocs)[:n_can]
     t0 = time.perf_counter()
@@ -203,16 +207,30 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--scaling', choices=['weak', 'strong'], default='weak')
+    ap.add_argument('--scaling', choices=['weak', 'strong'], default=None, help='default: weak (C3); C4 and C5 are strong-scaling workloads')
+    ap.add_argument('--workload', choices=['C3', 'C4', 'C5'], default=None,
+                    help='BASELINE.json configs[2] / [3] / [4]; default C3, or C4 under --scaling strong')
     ap.add_argument('--candidates', type=int, default=50000, help='weak scaling: grasp candidates per GPU per step (C3: 50,000)')
-    ap.add_argument('--candidates-total', type=int, default=200000, help='strong scaling: candidates per step over ALL GPUs (C4: 200,000)')
-    ap.add_argument('--precision', choices=['f32', 'f16x3', 'bf16x3', 'f16fp8x2'], default='f32',
+    ap.add_argument('--candidates-total', type=int, default=None,
+                    help='strong scaling: candidates per step over ALL GPUs (default C4: 200,000; C5: 500,000)')
+    ap.add_argument('--precision', choices=['f32', 'f16x3', 'bf16x3', 'f16fp8x2'], default=None,
                     help='arithmetic of the timed path (`value`): f32 = exact-f32 MFMA (the reference\'s arithmetic); f16x3 / bf16x3 = split MFMA '
-                         'products (3 MFMAs on hi+lo 16-bit pieces, f32 accumulation; logits within ~2e-6 / ~2e-5 of the float64 evaluation)')
+                         'products (3 MFMAs on hi+lo 16-bit pieces, f32 accumulation; logits within ~2e-6 / ~2e-5 of the float64 evaluation).  '
+                         'Default f32; bf16x3 for C5 (configs[4] names the bf16 MFMA path)')
     ap.add_argument('--secondary', default='f16x3,bf16x3,f16fp8x2', help='comma list of further precisions measured in the same run ("" = none)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-api', action='store_true', help='skip the reference-API wall-clock block')
     args = ap.parse_args()
+    if args.workload is None:
+        args.workload = 'C4' if args.scaling == 'strong' else 'C3'
+    want = 'weak' if args.workload == 'C3' else 'strong'
+    if args.scaling not in (None, want):
+        ap.error(f'--workload {args.workload} is a {want}-scaling workload')
+    args.scaling = want
+    if args.precision is None:
+        args.precision = 'bf16x3' if args.workload == 'C5' else 'f32'
+    if args.candidates_total is None:
+        args.candidates_total = 500000 if args.workload == 'C5' else 200000
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -237,19 +255,21 @@ def main():
     from catgrasp_amd.predicter import DEFAULT_GRASP_CFG, DEFAULT_NUNOCS_CFG, GraspPredicter, NunocsPredicter
     from catgrasp_amd.workload import SceneBatch
     strong = args.scaling == 'strong'
-    cat = 'screw' if strong else 'nut'
-    sd_cls = synth.make_state_dict('cls', 6, 10, seed=0)
-    sd_seg = synth.make_state_dict('seg', 6, 300, seed=1)
-    gp = GraspPredicter(cat, cfg=DEFAULT_GRASP_CFG, state_dict=sd_cls, device=device)
-    npred = NunocsPredicter(cat, cfg=DEFAULT_NUNOCS_CFG, state_dict=sd_seg, device=device)
-    if strong:      # C4: one fixed batch cut into `world` contiguous slices
+    cats = {'C3': ['nut'], 'C4': ['screw'], 'C5': ['nut', 'hnm', 'screw']}[args.workload]
+    # one GraspPredicter / NunocsPredicter per category, each with its own seeded random-init weights (run_grasp_simulation.py:701-702)
+    sds = {c: (synth.make_state_dict('cls', 6, 10, seed=2 * i), synth.make_state_dict('seg', 6, 300, seed=2 * i + 1)) for i, c in enumerate(cats)}
+    sd_cls, sd_seg = sds[cats[0]]
+    gps = {c: GraspPredicter(c, cfg=DEFAULT_GRASP_CFG, state_dict=sds[c][0], device=device) for c in cats}
+    npreds = {c: NunocsPredicter(c, cfg=DEFAULT_NUNOCS_CFG, state_dict=sds[c][1], device=device) for c in cats}
+    gp = gps[cats[0]]
+    if strong:      # C4 / C5: one fixed batch cut into `world` contiguous slices
         n_total = args.candidates_total
         per, bounds = cgd.shard_bounds(n_total, world)
-        batch = SceneBatch(device, gp, npred, kind='screw', n_objects=16, pts_per_object=2500, per_replica=n_total, replicas=1,
-                           materialize=bounds[rank])
+        batch = SceneBatch(device, gps, npreds, kind='screw' if args.workload == 'C4' else 'bin', n_objects=16 if args.workload == 'C4' else 24,
+                           pts_per_object=2500, per_replica=n_total, replicas=1, materialize=bounds[rank])
     else:           # C3: every rank scores its own replica of the candidate set (global order is replica-major: slice r == replica r)
         n_total = args.candidates * world
-        batch = SceneBatch(device, gp, npred, kind='nut', n_objects=8, pts_per_object=2500, per_replica=args.candidates, replicas=world,
+        batch = SceneBatch(device, gps, npreds, kind='nut', n_objects=8, pts_per_object=2500, per_replica=args.candidates, replicas=world,
                            materialize=(rank * args.candidates, (rank + 1) * args.candidates))
     assert batch.n_total == n_total
 
@@ -343,24 +363,30 @@ def main():
     engine.set_precision(args.precision)
 
     if rank == 0:
+        from catgrasp_amd.workload import SYMMETRY_COUNT
+        sym_txt = ' / '.join(str(SYMMETRY_COUNT[c]) for c in cats)
         dt = prim['dt']
         codes = ref_out[:, 1].long()
         line = {
-            'metric': 'grasp candidates scored+collision-checked /sec, 20k-pt clutter scene' if not strong else
-                      'grasp candidates scored+collision-checked /sec, 40k-pt scene, candidates sharded over the GPUs',
+            'metric': {'C3': 'grasp candidates scored+collision-checked /sec, 20k-pt clutter scene',
+                       'C4': 'grasp candidates scored+collision-checked /sec, 40k-pt scene, candidates sharded over the GPUs',
+                       'C5': 'grasp candidates scored+collision-checked /sec, 60k-pt mixed-category bin, candidates sharded over the GPUs'}[args.workload],
             'value': round(n_total * args.steps / dt, 1), 'unit': 'candidates/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None,
             'dtype': DTYPE[args.precision],
             'data': 'synthetic (seeded clouds/candidates/gripper, random-init weights)',
-            'config': {'workload': ('C4 (BASELINE.json configs[3]): screw category, 40k-pt scene (16 objects x 2500 pts), '
-                                    f'{n_total} candidates in total over {world} GPU(s)' if strong else
-                                    'C3 (BASELINE.json configs[2]): nut clutter pile, 20k-pt scene (8 objects x 2500 pts), '
-                                    f'{args.candidates} candidates/GPU') +
-                                   f': NUNOCS PointNetSeg(8192x6) per object + filterGraspPose [canonical grasps x {batch.n_sym} symmetries with '
+            'config': {'workload': {'C3': 'C3 (BASELINE.json configs[2]): nut clutter pile, 20k-pt scene (8 objects x 2500 pts), '
+                                          f'{args.candidates} candidates/GPU',
+                                    'C4': 'C4 (BASELINE.json configs[3]): screw category, 40k-pt scene (16 objects x 2500 pts), '
+                                          f'{n_total} candidates in total over {world} GPU(s)',
+                                    'C5': 'C5 (BASELINE.json configs[4]): mixed-category bin, 60k-pt scene (24 objects x 2500 pts: nut / hnm / screw '
+                                          'in turn, one GraspPredicter + NunocsPredicter per category), '
+                                          f'{n_total} candidates in total over {world} GPU(s)'}[args.workload] +
+                                   f': NUNOCS PointNetSeg(8192x6) per object + filterGraspPose [canonical grasps x {sym_txt} symmetries with '
                                    'adjust_collision_pose=True (grasp_sampler.py:345) and cone poses with symmetry=[I] (grasp_sampler.py:216)] + '
                                    'device pose inverse + per-candidate resampling draw + grasp-Q PointNetCls(2048x6) + softmax/p_G for EVERY candidate',
                        'candidates_per_gpu': n_total // world, 'candidates_total': n_total, 'scene_points': int(batch.cloud_xyz.shape[0]),
-                       'symmetries': batch.n_sym,
+                       'symmetries': {c: SYMMETRY_COUNT[c] for c in cats} if len(cats) > 1 else batch.n_sym,
                        'evaluations_nocs_shape_adjust_true': int(sum(s.count for s in batch.segs if s.kind == 'nocs')),
                        'evaluations_cone_shape_adjust_false': int(sum(s.count for s in batch.segs if s.kind == 'cone')),
                        'reject_code_histogram_0keep_1dir_2ik_3open_4enclosed': torch.bincount(codes, minlength=5).tolist(),

@@ -117,13 +117,18 @@ def screw_surface(n, rng, r=0.0025, length=0.04, head_r=0.005, head_len=0.01):
     return pts, nrm
 
 
+# mixed-category bins: object k belongs to category MIXED_BINS[kind][k % 3] ('hnm' and 'screw' share the synthetic bolt geometry,
+# SURVEY.md §8(d); they differ in symmetry count and in the weights of their predicters)
+MIXED_BINS = {'mixed': ['nut', 'screw', 'screw'], 'bin': ['nut', 'hnm', 'screw']}
+
+
 def make_scene(n_objects, pts_per_object, seed=0, kind='nut'):
     """Clutter pile in the camera frame: objects at random SE(3) poses inside a 10x10x4 cm box at
     z in [0.55,0.75] m.  Returns list of dict(xyz (M,3) f64, normal (M,3) f64, pose 4x4)."""
     rng = np.random.default_rng(seed)
     objs = []
     for k in range(n_objects):
-        kk = kind if kind != 'mixed' else ['nut', 'screw', 'screw'][k % 3]
+        kk = MIXED_BINS[kind][k % 3] if kind in MIXED_BINS else kind
         p, n = (nut_surface if kk == 'nut' else screw_surface)(pts_per_object, rng)
         R = random_rotation(rng)
         t = np.array([rng.uniform(-0.05, 0.05), rng.uniform(-0.05, 0.05), rng.uniform(0.55, 0.59) + 0.16 * rng.uniform()])

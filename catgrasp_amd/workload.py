@@ -38,10 +38,14 @@ class Segment:
 def plan_segments(n_objects, per_replica, n_sym, replicas=1, nocs_fraction=0.5):
     """Global evaluation order: replica-major, then object, then [nocs segment, cone segment].  `per_replica` evaluations are
     split evenly over the objects (remainder to the first ones); within an object ~nocs_fraction of them come from canonical
-    grasps x n_sym symmetries (adjust=True) and the rest from cone poses (adjust=False).  -> (segments, n_total)."""
+    grasps x n_sym symmetries (adjust=True) and the rest from cone poses (adjust=False).  n_sym: the category's symmetry count, or
+    one count per object for a mixed-category bin.  -> (segments, n_total)."""
+    per_obj_sym = [int(n_sym)] * n_objects if np.ndim(n_sym) == 0 else [int(v) for v in n_sym]
+    assert len(per_obj_sym) == n_objects and all(v >= 1 for v in per_obj_sym)
     segs, start = [], 0
     for r in range(replicas):
         for k in range(n_objects):
+            n_sym = per_obj_sym[k]
             per = per_replica // n_objects + (1 if k < per_replica % n_objects else 0)
             n_can = int(round(per * nocs_fraction / n_sym))
             n_cone = per - n_can * n_sym
@@ -98,15 +102,27 @@ class SceneBatch:
     def __init__(self, device, grasp_predicter, nunocs_predicter, kind='nut', n_objects=8, pts_per_object=2500, per_replica=50000,
                  replicas=1, scene_seed=0, nocs_scale=0.02, materialize=None):
         # materialize: (lo, hi) global evaluation range whose candidate poses are generated up front (default: all)
+        # kind: one category ('nut' | 'hnm' | 'screw'), or a mixed bin of synth.MIXED_BINS ('bin' = nut + hnm + screw, BASELINE.json
+        # configs[4]); for a mixed bin the two predicters are dicts {category: predicter} -- the reference keeps one GraspPredicter /
+        # NunocsPredicter per class (run_grasp_simulation.py:701-702), each with its own weights.
         import torch
         from . import my_cpp, synth, transforms
-        self.device, self.gp, self.npred, self.kind = device, grasp_predicter, nunocs_predicter, kind
+        self.device, self.kind = device, kind
         self.objs = synth.make_scene(n_objects, pts_per_object, seed=scene_seed, kind=kind)       # same scene on every rank
         self.gripper = synth.make_gripper()
-        cat = 'nut' if kind == 'nut' else 'screw'
-        self.n_sym = SYMMETRY_COUNT[cat]
-        self.segs, self.n_total = plan_segments(n_objects, per_replica, self.n_sym, replicas)
-        self.sym = torch.from_numpy(np.stack(transforms.get_symmetry_tfs(cat)).astype(np.float32).reshape(-1, 16)).to(device)
+        self.cats = [ob['kind'] for ob in self.objs]                                               # category of every object
+        self.gps = grasp_predicter if isinstance(grasp_predicter, dict) else {c: grasp_predicter for c in set(self.cats)}
+        self.npreds = nunocs_predicter if isinstance(nunocs_predicter, dict) else {c: nunocs_predicter for c in set(self.cats)}
+        missing = set(self.cats) - set(self.gps) | set(self.cats) - set(self.npreds)
+        if missing:
+            raise KeyError(f'no predicter for categories {sorted(missing)}')
+        self.gp, self.npred = self.gps[self.cats[0]], self.npreds[self.cats[0]]
+        if len({g.cfg['n_pts'] for g in self.gps.values()}) != 1:
+            raise ValueError('the grasp predicters of one bin must resample to the same n_pts')
+        self.n_sym = max(SYMMETRY_COUNT[c] for c in self.cats)
+        self.segs, self.n_total = plan_segments(n_objects, per_replica, [SYMMETRY_COUNT[c] for c in self.cats], replicas)
+        self.syms = {c: torch.from_numpy(np.stack(transforms.get_symmetry_tfs(c)).astype(np.float32).reshape(-1, 16)).to(device)
+                     for c in set(self.cats)}
         self.eye = torch.eye(4, device=device).reshape(1, 16).contiguous()
         self.clouds, self.offsets, self.scenes, self.nocs_pose = [], [], [], []
         off = 0
@@ -121,7 +137,7 @@ class SceneBatch:
         self.cloud_xyz = torch.cat([c.xyz for c in self.clouds]).contiguous()
         self.cloud_normal = torch.cat([c.normal for c in self.clouds]).contiguous()
         gen = torch.Generator(device=device); gen.manual_seed(1234)
-        n_n = nunocs_predicter.cfg['n_pts'] if nunocs_predicter is not None else 8192
+        n_n = self.npred.cfg['n_pts'] if self.npred is not None else 8192
         self.nunocs_ids = torch.stack([transforms.draw_ids_device(c.n, n_n, 1, device, gen, base=o)[0]
                                        for c, o in zip(self.clouds, self.offsets)]).contiguous()
         self._poses = {}
@@ -149,9 +165,14 @@ class SceneBatch:
 
     # ---- device stages (replaced at the tensor level by the CPU control-flow test)
     def run_nunocs(self, obj_ids):
+        """NUNOCS net over the given objects, one batched forward per category present (each category has its own weights)."""
         import torch
-        ids = self.nunocs_ids[torch.as_tensor(obj_ids, device=self.device)]
-        return self.npred.nocs_on_device(self.cloud_xyz, self.cloud_normal, ids)
+        out = {}
+        for cat in dict.fromkeys(self.cats[k] for k in obj_ids):
+            ks = [k for k in obj_ids if self.cats[k] == cat]
+            ids = self.nunocs_ids[torch.as_tensor(ks, device=self.device)]
+            out[cat] = (ks, self.npreds[cat].nocs_on_device(self.cloud_xyz, self.cloud_normal, ids))
+        return out
 
     def run_filter(self, seg, i0, i1, j0, j1):
         """-> codes (E) int8, grasp_in_cam (E,16) f32 (rejected evaluations keep their composed pose) for poses [i0,i1) x syms [j0,j1)."""
@@ -159,7 +180,7 @@ class SceneBatch:
         I4 = np.eye(4, dtype=np.float32)
         g = self.gripper
         if seg.kind == 'nocs':
-            sym, nocs = self.sym[j0:j1], self.nocs_pose[seg.obj]
+            sym, nocs = self.syms[self.cats[seg.obj]][j0:j1], self.nocs_pose[seg.obj]
         else:
             sym, nocs = self.eye, I4
         codes, poses, _ = my_cpp.filter_on_device(self.scenes[seg.obj], self.segment_poses(seg)[i0:i1], sym, nocs, I4, I4, I4,
@@ -175,9 +196,11 @@ class SceneBatch:
         transforms.draw_ids_device(dc.n, self.gp.cfg['n_pts'], poses.shape[0], self.device, seed=self.draw_seed,
                                    base=self.offsets[obj], row_offset=row_offset, out=ids_out)
 
-    def run_net(self, ids, pinv):
-        """-> p_G (E): input transform + PointNetCls + softmax + p_G for every candidate of the slice in one batch."""
-        return self.gp.score_on_device(self.cloud_xyz, self.cloud_normal, ids, pinv)[3]
+    def run_net(self, ids, pinv, cat=None):
+        """-> p_G (E): input transform + PointNetCls + softmax + p_G for every candidate of the rows in one batch, under the
+        weights of category `cat` (None: the bin's only category)."""
+        gp = self.gp if cat is None else self.gps[cat]
+        return gp.score_on_device(self.cloud_xyz, self.cloud_normal, ids, pinv)[3]
 
     def alloc(self, n):
         import torch
@@ -223,7 +246,20 @@ class SceneBatch:
         for obj, g0, n in runs:
             self.run_prep(obj, poses[pos:pos + n], g0, pinv[pos:pos + n], ids[pos:pos + n])
             pos += n
-        return pack_records(self.run_net(ids, pinv), codes)
+        # scoring: one batch per run of consecutive rows of the same category (a single-category bin: the whole slice at once)
+        spans = []
+        pos = 0
+        for obj, _, n in runs:
+            if spans and spans[-1][0] == self.cats[obj]:
+                spans[-1][2] += n
+            else:
+                spans.append([self.cats[obj], pos, n])
+            pos += n
+        if len(spans) == 1:
+            p_g = self.run_net(ids, pinv, spans[0][0])
+        else:
+            p_g = torch.cat([self.run_net(ids[a:a + n], pinv[a:a + n], cat) for cat, a, n in spans])
+        return pack_records(p_g, codes)
 
 
 def build_flat_workload(device, G, seed, n_objects=8, pts_per_object=2500, kind='nut'):

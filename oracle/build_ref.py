@@ -4,6 +4,16 @@ which is git-ignored but travels to the GPU box).  my_cpp itself cannot be built
 import os
 import subprocess
 
+
+def _drop_extracts(names):
+    """The line ranges extracted from the reference are compile inputs only: remove them once the binary is linked, so that
+    oracle/_ref/ holds binaries and nothing else (no reference text travels to the GPU box or lingers in the tree)."""
+    for n in names:
+        try:
+            os.remove(os.path.join(_DIR, '_ref', n))
+        except FileNotFoundError:
+            pass
+
 _DIR = os.path.dirname(os.path.abspath(__file__))
 REF = '/root/reference/ikfast_pybind/src/kuka_iiwa14'
 OUT = os.path.join(_DIR, '_ref', 'libikfast_ref.so')
@@ -42,8 +52,11 @@ def build_augment(force=False):
     assert lines[0].startswith('Eigen::Matrix3f directionVecToRotation') and lines[-1].startswith('}'), 'reference layout changed'
     with open(os.path.join(_DIR, '_ref', 'augment_extract.inc'), 'w') as f:
         f.writelines(lines)
-    subprocess.check_call(['g++', '-O2', '-DNDEBUG', '-fPIC', '-shared', '-std=c++14', '-w', '-I', AUG_EIGEN, '-I', _DIR,
-                           os.path.join(_DIR, 'augment_wrap.cpp'), '-o', AUG_OUT])
+    try:
+        subprocess.check_call(['g++', '-O2', '-DNDEBUG', '-fPIC', '-shared', '-std=c++14', '-w', '-I', AUG_EIGEN, '-I', _DIR,
+                               os.path.join(_DIR, 'augment_wrap.cpp'), '-o', AUG_OUT])
+    finally:
+        _drop_extracts(['augment_extract.inc'])
     return AUG_OUT
 
 
@@ -67,8 +80,11 @@ def build_pointgroup_host(force=False):
         assert lines[0].startswith(first) and lines[-1].startswith('}'), f'reference layout changed: {rel}'
         with open(os.path.join(_DIR, '_ref', out), 'w') as f:
             f.writelines(lines)
-    subprocess.check_call(['g++', '-O2', '-fPIC', '-shared', '-std=c++14', '-w', '-I', os.path.join(_DIR, 'pg_shim'), '-I', PG_SRC, '-I', _DIR,
-                           os.path.join(_DIR, 'pg_wrap.cpp'), '-o', PG_OUT])
+    try:
+        subprocess.check_call(['g++', '-O2', '-fPIC', '-shared', '-std=c++14', '-w', '-I', os.path.join(_DIR, 'pg_shim'), '-I', PG_SRC, '-I', _DIR,
+                               os.path.join(_DIR, 'pg_wrap.cpp'), '-o', PG_OUT])
+    finally:
+        _drop_extracts(PG_RANGES)
     return PG_OUT
 
 
@@ -96,8 +112,11 @@ def build_pointgroup_kernels(force=False):
         with open(os.path.join(_DIR, '_ref', out), 'w') as f:
             f.writelines(lines)
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    subprocess.check_call([hipcc, '--offload-arch=gfx950', '-O2', '-fPIC', '-shared', '-std=c++17', '-w', '-ffp-contract=off', '-I', _DIR,
-                           os.path.join(_DIR, 'pg_kernels_wrap.hip'), '-o', PGK_OUT])
+    try:
+        subprocess.check_call([hipcc, '--offload-arch=gfx950', '-O2', '-fPIC', '-shared', '-std=c++17', '-w', '-ffp-contract=off', '-I', _DIR,
+                               os.path.join(_DIR, 'pg_kernels_wrap.hip'), '-o', PGK_OUT])
+    finally:
+        _drop_extracts(PGK_RANGES)
     return PGK_OUT
 
 

@@ -11,7 +11,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from catgrasp_amd import distributed as cgd
-from catgrasp_amd import workload
+from catgrasp_amd import synth, workload
 
 
 def _free_port():
@@ -24,9 +24,14 @@ class HostBatch(workload.SceneBatch):
 
     def __init__(self, n_objects, per_replica, n_sym, replicas):
         self.device = torch.device('cpu')
-        self.n_sym = n_sym
-        self.segs, self.n_total = workload.plan_segments(n_objects, per_replica, n_sym, replicas)
-        self.nunocs_calls = []
+        if isinstance(n_sym, str):      # a mixed-category bin of synth.MIXED_BINS: per-object category, symmetry count and weights
+            self.cats = [synth.MIXED_BINS[n_sym][k % 3] for k in range(n_objects)]
+        else:
+            self.cats = [{12: 'nut', 2: 'hnm', 72: 'screw'}[n_sym]] * n_objects
+        per_obj = [workload.SYMMETRY_COUNT[c] for c in self.cats]
+        self.n_sym = max(per_obj)
+        self.segs, self.n_total = workload.plan_segments(n_objects, per_replica, per_obj, replicas)
+        self.nunocs_calls, self.net_calls = [], []
 
     def run_nunocs(self, obj_ids):
         self.nunocs_calls.append(list(obj_ids))
@@ -39,14 +44,19 @@ class HostBatch(workload.SceneBatch):
         return codes, poses
 
     def alloc(self, n):
-        return torch.empty((n, 12)), torch.empty((n, 4), dtype=torch.int32)
+        return torch.empty((n, 12)), torch.empty((n, 5), dtype=torch.int32)
 
     def run_prep(self, obj, poses, row_offset, pinv_out, ids_out):
         pinv_out.copy_(poses[:, :12] + 1000.0 * obj)
-        ids_out.copy_((row_offset + torch.arange(poses.shape[0])).view(-1, 1).to(torch.int32) * 4 + torch.arange(4, dtype=torch.int32))
+        ids_out[:, :4] = (row_offset + torch.arange(poses.shape[0])).view(-1, 1).to(torch.int32) * 4 + torch.arange(4, dtype=torch.int32)
+        ids_out[:, 4] = obj
 
-    def run_net(self, ids, pinv):
-        return torch.sin(ids[:, 1].float() * 0.37) * 0.25 + pinv[:, 3] * 1e-6
+    def run_net(self, ids, pinv, cat=None):
+        # every row must arrive under the weights of its own object's category (the object id rides in ids[:, 4], see run_prep)
+        assert all(self.cats[k] == cat for k in ids[:, 4].unique().tolist())
+        self.net_calls.append((cat, int(ids.shape[0])))
+        w = {'nut': 1.0, 'hnm': 2.0, 'screw': 3.0}[cat]
+        return torch.sin(ids[:, 1].float() * 0.37) * 0.25 * w + pinv[:, 3] * 1e-6
 
 
 def _worker(rank, world, port, cfg, q):
@@ -55,7 +65,7 @@ def _worker(rank, world, port, cfg, q):
     try:
         b = HostBatch(*cfg)
         out = cgd.score_sharded(b.score_slice, b.n_total)
-        q.put((rank, out.clone(), b.nunocs_calls))
+        q.put((rank, out.numpy().copy(), b.nunocs_calls))      # by value: a shared-memory tensor could outlive its producer
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -72,13 +82,15 @@ def _run(cfg, world=2):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    return {r: (o, c) for r, o, c in got}
+    return {r: (torch.from_numpy(o), c) for r, o, c in got}
 
 
 def test_sharded_step_equals_unsharded_world2():
     for cfg in ((3, 101, 12, 2),        # weak layout: 2 replicas x 101 candidates, slice r == replica r
                 (4, 1001, 12, 1),       # strong: odd total, the cut falls inside a symmetry group
                 (16, 2000, 72, 1),      # C4 shape in small: 16 objects, 72 symmetries
+                (24, 5003, 'bin', 1),   # C5 shape in small: mixed nut + hnm + screw bin (12 / 2 / 72 symmetries, per-category weights)
+                (5, 600, 'bin', 2),     # the same bin under the weak layout
                 (2, 3, 12, 1), (1, 1, 12, 1)):     # fewer candidates than ranks
         whole = HostBatch(*cfg)
         ref = whole.score_slice(0, whole.n_total)
@@ -88,6 +100,9 @@ def test_sharded_step_equals_unsharded_world2():
             assert res[r][0].shape == ref.shape and torch.equal(res[r][0], ref), cfg
         if cfg[3] == 2:                 # weak scaling: every rank ran the NUNOCS stage over all objects of its replica
             assert res[0][1] == [list(range(cfg[0]))] and res[1][1] == [list(range(cfg[0]))]
+        if cfg[2] == 'bin':             # one scoring batch per run of same-category rows, all categories present
+            assert {c for c, _ in whole.net_calls} == {'nut', 'hnm', 'screw'}
+            assert sum(n for _, n in whole.net_calls) == whole.n_total and len(whole.net_calls) == cfg[0] * cfg[3]
 
 
 def test_slicing_arithmetic():
@@ -101,6 +116,20 @@ def test_slicing_arithmetic():
     per, bounds = cgd.shard_bounds(200000, 8)
     assert per == 25000 and bounds[7] == (175000, 200000)
     assert cgd.shard_bounds(10, 4)[1] == [(0, 3), (3, 6), (6, 9), (9, 10)] and cgd.shard_bounds(2, 4)[1][3] == (2, 2)
+
+
+def test_mixed_bin_plan():
+    """Per-object symmetry counts: each object's 'nocs' segment uses its own category's count; totals are exact."""
+    cats = [synth.MIXED_BINS['bin'][k % 3] for k in range(24)]
+    segs, n = workload.plan_segments(24, 500000, [workload.SYMMETRY_COUNT[c] for c in cats], 1)
+    assert n == 500000 and sum(s.count for s in segs) == n
+    for s in segs:
+        assert s.n_sym == (workload.SYMMETRY_COUNT[cats[s.obj]] if s.kind == 'nocs' else 1)
+    assert all(a.start + a.count == b.start for a, b in zip(segs[:-1], segs[1:]))
+    per_obj = {}
+    for s in segs:
+        per_obj[s.obj] = per_obj.get(s.obj, 0) + s.count
+    assert sorted(set(per_obj.values())) == [20833, 20834]
 
 
 def test_single_process_path():

@@ -64,3 +64,53 @@ def test_records_match_the_oracle_on_a_sample(batch, mlp_precision):
         probs = torch.softmax(logits, 1).numpy()
         pg = (probs * np.arange(10)).sum(1) / 10
         assert np.abs(rec[seg.start + keep, 0] - pg).max() <= 1e-4
+
+
+@pytest.fixture(scope='module')
+def bin_batch(cuda_device):
+    """BASELINE.json configs[4] in small: nut + hnm + screw objects in one bin, one predicter pair per category (own weights)."""
+    from catgrasp_amd.predicter import DEFAULT_GRASP_CFG, DEFAULT_NUNOCS_CFG, GraspPredicter, NunocsPredicter
+    cats = ['nut', 'hnm', 'screw']
+    sds = {c: synth.make_state_dict('cls', 6, 10, seed=20 + i) for i, c in enumerate(cats)}
+    gps = {c: GraspPredicter(c, cfg=DEFAULT_GRASP_CFG, state_dict=sds[c], device=cuda_device) for c in cats}
+    nps = {c: NunocsPredicter(c, cfg=DEFAULT_NUNOCS_CFG, state_dict=synth.make_state_dict('seg', 6, 300, seed=30 + i), device=cuda_device)
+           for i, c in enumerate(cats)}
+    b = workload.SceneBatch(cuda_device, gps, nps, kind='bin', n_objects=4, pts_per_object=2100, per_replica=1500, replicas=1)
+    b.sds = sds
+    return b
+
+
+def test_mixed_category_bin(bin_batch, mlp_precision):
+    """Every object is filtered with its own category's symmetry set and scored under its own category's weights; the result does
+    not depend on how the bin is cut (cuts through symmetry groups, objects and category changes)."""
+    from catgrasp_amd import transforms
+    b = bin_batch
+    n = b.n_total
+    assert n == 1500 and b.cats == ['nut', 'hnm', 'screw', 'nut']
+    assert [s.n_sym for s in b.segs if s.kind == 'nocs'] == [12, 2, 72, 12]
+    with torch.no_grad():
+        whole = b.score_slice(0, n)
+        for cuts in ([0, 375, 750, 1125, n], [0, 3, 380, 381, 760, 801, 1400, n]):
+            assert torch.equal(torch.cat([b.score_slice(lo, hi) for lo, hi in zip(cuts[:-1], cuts[1:])]), whole)
+    rec = whole.cpu().numpy()
+    g = b.gripper
+    for seg in b.segs:
+        cat = b.cats[seg.obj]
+        P = b.host_poses(seg)
+        ob = b.objs[seg.obj]
+        bg = synth.background_points(b.objs, seg.obj, g['diameter'])
+        sym = transforms.get_symmetry_tfs(cat) if seg.kind == 'nocs' else [I4]
+        nocs = b.nocs_pose[seg.obj] if seg.kind == 'nocs' else I4
+        oc, op, _ = co.filter_grasp_pose(P, sym, nocs, I4, I4, I4, g['gripper_in_grasp'], 1, 0, int(seg.adjust), g['vertices'], g['faces'],
+                                         g['enclosed_vertices'], g['enclosed_faces'], ob['xyz'], bg, 0.0005)
+        assert np.array_equal(rec[seg.start:seg.start + seg.count, 1].astype(np.int8), oc)
+        keep = np.nonzero(oc == 0)[0][:3]
+        if len(keep) == 0:
+            continue
+        dc = b.clouds[seg.obj]
+        xs = []
+        for e in keep:
+            ids = transforms.draw_ids_device(dc.n, 2048, 1, b.device, seed=b.draw_seed, row_offset=seg.start + int(e)).cpu().numpy()[0]
+            xs.append(tref.grasp_transform(ob['xyz'].copy(), ob['normal'].copy(), op[e].astype(np.float64), ids)['input'])
+        probs = torch.softmax(oref.pointnet_cls_forward(b.sds[cat], torch.from_numpy(np.stack(xs)).float())[0], 1).numpy()
+        assert np.abs(rec[seg.start + keep, 0] - (probs * np.arange(10)).sum(1) / 10).max() <= 1e-4
