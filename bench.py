@@ -96,11 +96,14 @@ def api_block(batch, gp, device, n=50000):
             t, ret = wall(lambda: gp.predict_batch(data, poses, rng='device'), 3)
         assert len(ret) == n and len(ret[0]) == 3 and ret[0][2].shape == (10,)
         pb.append({'poses': n, 'rng': 'device', 'precision': prec, 'wall_s': round(t, 4), 'candidates_per_s': round(n / t, 1)})
-    np.random.seed(0)
-    t, _ = wall(lambda: gp.predict_batch(data, poses, rng='numpy'), 1)
-    pb.append({'poses': n, 'rng': 'numpy (the default: the reference\'s global-generator stream, bit-identical draws and generator state; '
-                                  'replayed in C one chunk ahead of the device, sequential on one host core)',
-               'precision': engine.PRECISION, 'wall_s': round(t, 4), 'candidates_per_s': round(n / t, 1)})
+    for prec in dict.fromkeys([engine.PRECISION, 'f16x3']):
+        with engine.precision(prec):
+            np.random.seed(0)
+            t, _ = wall(lambda: gp.predict_batch(data, poses, rng='numpy'), 1)
+        pb.append({'poses': n, 'rng': 'numpy (the default: the reference\'s global-generator stream, bit-identical draws and generator state; the '
+                                      'sequential rejection sampling of the stream replayed in C on one host core one chunk ahead of the device, '
+                                      'the permutation swap chains on the device)',
+                   'precision': prec, 'wall_s': round(t, 4), 'candidates_per_s': round(n / t, 1)})
     out['predict_batch'] = pb
     # filterGraspPose, 20 positional arguments, >= 5k-triangle gripper meshes, nut symmetries, pose nudging on
     g = batch.gripper

@@ -100,6 +100,48 @@ __global__ __launch_bounds__(64) void draw_ids_perm_kernel(int n_valid, int n_pt
   }
 }
 
+// The swap chain of numpy's permutation(n_valid) for `count` rows whose swap partners the host extracted from numpy's generator
+// (cg_host_numpy_shuffle_partners): a[i] <-> a[j(i)] for i = n_valid-1 .. 1 on a = arange(n_valid), out = a[:n_pts] + base.
+// One lane per row, the row's array in LDS as u16, rows interleaved like draw_ids_perm_kernel (the LDS operations of a lane
+// execute in program order, so the chain needs no other synchronisation); partners arrive 8 steps per 16-byte load, one load
+// ahead of the chain; the finished rows leave through coalesced stores by the whole wave.
+__global__ __launch_bounds__(64) void apply_shuffle_rows_kernel(const unsigned short* __restrict__ partners, long row_stride,
+                                                                int n_valid, int n_pts, long count, int base, int R,
+                                                                int* __restrict__ out) {
+  extern __shared__ unsigned short perm[];
+  const int r = threadIdx.x;
+  const long row0 = (long)blockIdx.x * R, row = row0 + r;
+  if (r < R && row < count) {
+    for (int k = 0; k < n_valid; ++k) perm[k * R + r] = (unsigned short)k;
+    const uint4* js = (const uint4*)(partners + row * row_stride);
+    const int steps = n_valid - 1;
+    int i = n_valid - 1;
+    uint4 nxt = js[0];
+    for (int s0 = 0; s0 < steps; s0 += 8) {
+      const uint4 cur = nxt;
+      if (s0 + 8 < steps) nxt = js[(s0 >> 3) + 1];
+      const unsigned w[4] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        if (s0 + t < steps) {
+          const int j = (int)((w[t >> 1] >> ((t & 1) * 16)) & 0xffffu);
+          const unsigned short pa = perm[i * R + r], pb = perm[j * R + r];
+          perm[i * R + r] = pb;
+          perm[j * R + r] = pa;
+          --i;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const long left = count - row0;
+  const int nrows = left < (long)R ? (int)left : R;
+  for (int rr = 0; rr < nrows; ++rr) {
+    int* o = out + (row0 + rr) * n_pts;
+    for (int k = threadIdx.x; k < n_pts; k += 64) o[k] = (int)perm[k * R + rr] + base;
+  }
+}
+
 // n_valid < n_pts (or a cloud too large for the LDS permutation): iid uniform indices = np.random.choice(replace=True)
 __global__ __launch_bounds__(256) void draw_ids_iid_kernel(int n_valid, int n_pts, long count, unsigned k0, unsigned k1,
                                                            int base, long row_offset, int* __restrict__ out) {
@@ -226,6 +268,26 @@ extern "C" int cg_draw_resample_ids(int n_valid, int n_pts, long count, unsigned
   if ((n_pts & 3) != 0) return CG_ERR_UNSUPPORTED;
   const long total = count * n_pts;
   hipLaunchKernelGGL(draw_ids_iid_kernel, dim3((unsigned)((total + 1023) / 1024)), dim3(256), 0, s, n_valid, n_pts, count, k0, k1, base, row_offset, out);
+  return cg_hip_status(hipGetLastError());
+}
+
+extern "C" int cg_apply_shuffle_rows(const unsigned short* partners, long row_stride, int n_valid, int n_pts, long count, int base,
+                                     int* out, void* stream) {
+  if (n_valid < 2 || n_valid > 65536 || n_pts <= 0 || n_pts > n_valid || count < 0 || row_stride < n_valid - 1 || (row_stride & 7))
+    return CG_ERR_ARG;
+  if (count == 0) return CG_OK;
+  if (!partners || !out || ((uintptr_t)partners & 15)) return CG_ERR_ARG;
+  constexpr size_t LDS = 128 * 1024;
+  int R = (int)(LDS / ((size_t)n_valid * 2));
+  if (R > 64) R = 64;
+  const size_t bytes = (size_t)R * n_valid * 2;
+  auto kern = apply_shuffle_rows_kernel;
+  if (bytes > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)((count + R - 1) / R)), dim3(64), bytes, (hipStream_t)stream, partners, row_stride, n_valid,
+                     n_pts, count, base, R, out);
   return cg_hip_status(hipGetLastError());
 }
 

@@ -91,6 +91,20 @@ def softmax_pg(logits):
     return probs, label, conf, pg
 
 
+def apply_shuffle_rows(partners, n_valid, n_pts, base=0, out=None):
+    """partners: (count, stride) uint16 cuda -- the Fisher-Yates swap partners of `count` numpy permutation(n_valid) draws
+    (transforms.NumpyChoiceStream.draw_partners) -> (count, n_pts) int32 = base + permutation[:n_pts] of every row."""
+    require_cuda(partners)
+    if partners.dtype != torch.uint16 or partners.dim() != 2 or not partners.is_contiguous():
+        raise TypeError('partners must be a contiguous (count, stride) uint16 tensor')
+    count, stride = partners.shape
+    if out is None:
+        out = torch.empty((count, n_pts), dtype=torch.int32, device=partners.device)
+    check(L.lib().cg_apply_shuffle_rows(_p(partners), _c_long(stride), _c_int(n_valid), _c_int(n_pts), _c_long(count), _c_int(base), _p(out),
+                                        _stream()), 'cg_apply_shuffle_rows')
+    return out
+
+
 def nunocs_decode(logits, nbins):
     """logits:(P,3*nbins) -> coords (P,3), conf_z (P)."""
     require_cuda(logits)

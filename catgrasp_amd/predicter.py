@@ -134,22 +134,27 @@ class GraspPredicter:
 
     def _numpy_id_chunks(self, n_valid, n_pts, G):
         """ids(s, e) for score_on_device: numpy's global stream replayed in C (transforms.NumpyChoiceStream), one chunk ahead on a
-        worker thread -- the draw of chunk k+1 overlaps the device scoring chunk k (the C call releases the GIL)."""
+        worker thread -- the draw of chunk k+1 overlaps the device scoring chunk k (the C call releases the GIL).  For the usual
+        replace=False draw the host only extracts the swap partners from the stream (the part that is sequential) and the
+        permutation's swap chain runs on the device (ops.apply_shuffle_rows): same rows, same generator state afterwards."""
         from concurrent.futures import ThreadPoolExecutor
         stream = transforms.NumpyChoiceStream(n_valid, n_pts)
         pool = ThreadPoolExecutor(max_workers=1)
         chunk, dev = self.chunk, self.device
         pending = {}
+        on_device = stream.on_device_chain
+        draw = stream.draw_partners if on_device else stream.draw
 
         def submit(s):
             if s < G and s not in pending:
-                pending[s] = pool.submit(stream.draw, min(G, s + chunk) - s)
+                pending[s] = pool.submit(draw, min(G, s + chunk) - s)
 
         def ids(s, e):
             submit(s)
             host = pending.pop(s).result()
             submit(e)                                   # the next chunk is drawn while this one is uploaded and scored
-            return torch.from_numpy(host).to(dev, non_blocking=True)
+            up = torch.from_numpy(host).to(dev, non_blocking=True)
+            return ops.apply_shuffle_rows(up, n_valid, n_pts) if on_device else up
 
         def close():
             for f in pending.values():

@@ -44,6 +44,26 @@ class NumpyChoiceStream:
             raise RuntimeError(f'cg_host_numpy_choice_rows failed with status {rc}')
         return out
 
+    @property
+    def on_device_chain(self):
+        """True when the swap chain of the draw can run on the device (replace=False rows of a cloud that fits the u16 LDS
+        permutation): the host then only extracts the swap partners from the stream (draw_partners)."""
+        return self.n_pts <= self.n_valid <= 65536 and self.n_valid >= 2
+
+    def draw_partners(self, count):
+        """The sequential part of `count` permutation(n_valid) draws alone (cg_host_numpy_shuffle_partners): the Fisher-Yates swap
+        partners as a (count, stride) uint16 array, stride = n_valid-1 rounded up to 8; ops.apply_shuffle_rows turns them into the
+        rows draw() would have returned.  Advances the generator exactly like draw()."""
+        ct = self._ct
+        from . import _lib as L
+        stride = (self.n_valid - 1 + 7) & ~7
+        out = np.empty((count, stride), dtype=np.uint16)
+        rc = L.lib().cg_host_numpy_shuffle_partners(self._key.ctypes.data_as(ct.c_void_p), ct.byref(self._pos), ct.c_int(self.n_valid),
+                                                    ct.c_long(count), ct.c_long(stride), out.ctypes.data_as(ct.c_void_p))
+        if rc != 0:
+            raise RuntimeError(f'cg_host_numpy_shuffle_partners failed with status {rc}')
+        return out
+
     def close(self):
         np.random.set_state(('MT19937', self._key, int(self._pos.value)) + self._rest)
 

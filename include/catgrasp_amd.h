@@ -226,6 +226,17 @@ int cg_draw_resample_ids(int n_valid, int n_pts, long count, unsigned long long 
  * outside the GIL.  h_scratch: n_valid ints (replace=False branch).  h_out: (count, n_pts) int32. */
 int cg_host_numpy_choice_rows(unsigned int* h_mt_key624, int* h_mt_pos, int n_valid, int n_pts, long count, int* h_scratch, int* h_out);
 
+/* The same draw with the swap chain on the device (n_pts <= n_valid <= 65536, the replace=False branch): the HOST part is only
+ * what makes numpy's stream sequential -- the rejection-sampled Fisher-Yates swap partners j(i), i = n_valid-1 .. 1, of `count`
+ * consecutive permutation(n_valid) calls, written as u16 at h_partners + r*row_stride + (n_valid-1-i) (row_stride >= n_valid-1,
+ * tail zero-filled); the generator state advances exactly as under cg_host_numpy_choice_rows.  HOST pointers. */
+int cg_host_numpy_shuffle_partners(unsigned int* h_mt_key624, int* h_mt_pos, int n_valid, long count, long row_stride,
+                                   unsigned short* h_partners);
+/* ... and the DEVICE part: out (count,n_pts) i32 = base + permutation[:n_pts] of every row, the swap chain a[i] <-> a[j(i)] run
+ * one row per lane in LDS.  partners: DEVICE copy of the host array above, 16-byte aligned, row_stride a multiple of 8. */
+int cg_apply_shuffle_rows(const unsigned short* partners, long row_stride, int n_valid, int n_pts, long count, int base, int* out,
+                          void* stream);
+
 /* inv(grasp_pose) of dataset_grasp.py:69-70 for poses already on the device: poses (n,16) f32 row-major 4x4 with last
  * row 0 0 0 1 -> out (n,12) rows [R | t] with x_grasp = R x_centred + t, where x_centred = x_cam - h_center (HOST,
  * 3 doubles).  float64 arithmetic, rounded once (same contract as the host helper transforms.pose_inverse_rows). */

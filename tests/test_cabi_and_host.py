@@ -41,6 +41,16 @@ def test_argument_errors_are_reported_not_crashed():
     bad_pos = ctypes.c_int(700)
     assert lib.cg_host_numpy_choice_rows(one, ctypes.byref(bad_pos), 2500, 2048, L(1), one, one) == -1            # MT position > 624
     assert lib.cg_host_numpy_choice_rows(None, ctypes.byref(bad_pos), 2500, 2048, L(1), one, one) == -1
+    ok_pos = ctypes.c_int(0)
+    assert lib.cg_host_numpy_shuffle_partners(one, ctypes.byref(bad_pos), 2500, L(1), L(2504), one) == -1         # MT position > 624
+    assert lib.cg_host_numpy_shuffle_partners(one, ctypes.byref(ok_pos), 70000, L(1), L(70000), one) == -1        # > 65536: u16 partners
+    assert lib.cg_host_numpy_shuffle_partners(one, ctypes.byref(ok_pos), 2500, L(1), L(2000), one) == -1          # stride < n_valid - 1
+    assert lib.cg_host_numpy_shuffle_partners(one, ctypes.byref(ok_pos), 2500, L(0), L(2504), None) == 0
+    assert lib.cg_apply_shuffle_rows(one, L(2504), 2500, 2048, L(-1), 0, one, null) == -1
+    assert lib.cg_apply_shuffle_rows(one, L(2501), 2500, 2048, L(1), 0, one, null) == -1                          # stride not a multiple of 8
+    assert lib.cg_apply_shuffle_rows(one, L(2504), 2500, 4096, L(1), 0, one, null) == -1                          # n_pts > n_valid
+    assert lib.cg_apply_shuffle_rows(None, L(2504), 2500, 2048, L(1), 0, one, null) == -1
+    assert lib.cg_apply_shuffle_rows(None, L(2504), 2500, 2048, L(0), 0, None, null) == 0
     assert lib.cg_pose_inverse_rows(one, L(3), None, one, null) == -1                                             # no centre
     assert lib.cg_pose_inverse_rows(null, L(0), D3, null, null) == 0
     assert lib.cg_mesh_grid_count(one, one, 5, D3, ctypes.c_double(0.0), ctypes.c_double(0.001), I3, one, null) == -1      # cell size 0
@@ -177,6 +187,38 @@ def test_numpy_stream_replay_is_bit_identical_to_numpy(n_valid, n_pts):
     np.random.seed(4); np.random.normal()
     b = np.stack([np.random.choice(np.arange(n_valid), size=(n_pts), replace=n_valid < n_pts) for _ in range(2)]); y = np.random.normal()
     assert np.array_equal(a, b) and x == y
+
+
+@pytest.mark.parametrize('n_valid,n_pts', [(2500, 2048), (2048, 2048), (9000, 8192), (2, 1), (65536, 2048), (3, 2)])
+def test_numpy_shuffle_partners_replay(n_valid, n_pts):
+    """The split form of the same draw (cg_host_numpy_shuffle_partners): the host extracts only the swap partners of numpy's
+    permutation(n_valid) -- applying them to arange(n_valid) (what cg_apply_shuffle_rows does on the device, here in numpy) must
+    give np.random.choice's rows, the generator must end in the same state, chunking must not matter, and a stream may mix
+    draw() and draw_partners() calls."""
+    for seed, burn in ((0, 0), (5, 623), (2 ** 31 - 1, 1250)):
+        np.random.seed(seed); np.random.randint(0, 10, burn)
+        want = np.stack([np.random.choice(np.arange(n_valid), size=(n_pts), replace=False) for _ in range(7)])
+        after_want = np.random.randint(0, 2 ** 31, 5)
+        np.random.seed(seed); np.random.randint(0, 10, burn)
+        st = transforms.NumpyChoiceStream(n_valid, n_pts)
+        assert st.on_device_chain
+        parts = [st.draw_partners(3), st.draw_partners(0), st.draw(1), st.draw_partners(3)]
+        st.close()
+        after_got = np.random.randint(0, 2 ** 31, 5)
+        rows = []
+        for p in parts:
+            if p.dtype == np.int32:
+                rows.extend(p)
+                continue
+            assert p.dtype == np.uint16 and p.shape[1] % 8 == 0 and p.shape[1] >= n_valid - 1 and not p[:, n_valid - 1:].any()
+            for js in p:
+                a = np.arange(n_valid)
+                for s_, j in enumerate(js[:n_valid - 1]):
+                    i = n_valid - 1 - s_
+                    a[i], a[j] = a[j], a[i]
+                rows.append(a[:n_pts])
+        assert np.array_equal(np.stack(rows), want) and np.array_equal(after_got, after_want)
+    assert not transforms.NumpyChoiceStream(700, 2048).on_device_chain and not transforms.NumpyChoiceStream(70000, 2048).on_device_chain
 
 
 def test_device_cloud_applies_z_mask_and_centres():

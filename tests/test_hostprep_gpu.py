@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from catgrasp_amd import synth
+from catgrasp_amd import synth, transforms
 
 pytestmark = pytest.mark.gpu
 I4 = np.eye(4)
@@ -80,3 +80,43 @@ def test_scene_cache_and_keep_rejected_pose(cuda_device):
     c, p, _ = my_cpp.filterGraspPoseDetailed(P, [I4], I4, I4, I4, I4, g['gripper_in_grasp'], True, False, False, [0] * 7, [0] * 7, *args)
     assert len(surv) == int((c == 0).sum()) and all(a.shape == (4, 4) and a.dtype == np.float32 for a in surv)
     assert np.array_equal(np.stack(surv), p[c == 0])
+
+
+@pytest.mark.parametrize('n_valid,n_pts', [(2500, 2048), (2048, 2048), (9000, 8192), (65536, 2048), (2, 1), (37, 5)])
+def test_device_swap_chain_reproduces_numpy_choice(cuda_device, n_valid, n_pts):
+    """The reference-exact resampling draw with its swap chain on the device: host-extracted swap partners of numpy's stream
+    (cg_host_numpy_shuffle_partners) + cg_apply_shuffle_rows == np.random.choice(np.arange(n_valid), n_pts, replace=False) call
+    after call, bit for bit, with numpy's generator left where the reference would leave it; row counts that do not fill the last
+    workgroup, and an index offset."""
+    from catgrasp_amd import ops
+    count = 70 if n_valid < 60000 else 3
+    np.random.seed(11); np.random.rand(3)
+    want = np.stack([np.random.choice(np.arange(n_valid), size=(n_pts), replace=False) for _ in range(count)])
+    after_want = np.random.randint(0, 2 ** 31, 4)
+    np.random.seed(11); np.random.rand(3)
+    st = transforms.NumpyChoiceStream(n_valid, n_pts)
+    parts = [st.draw_partners(c) for c in (count - 1, 1)]
+    st.close()
+    after_got = np.random.randint(0, 2 ** 31, 4)
+    got = torch.cat([ops.apply_shuffle_rows(torch.from_numpy(p).to(cuda_device), n_valid, n_pts, base=7) for p in parts]).cpu().numpy()
+    assert got.dtype == np.int32 and np.array_equal(got - 7, want) and np.array_equal(after_got, after_want)
+
+
+def test_predict_batch_numpy_mode_uses_the_reference_stream(cuda_device):
+    """predict_batch's default rng='numpy' (host partners + device swap chain, chunked one chunk ahead) == predict_batch on the
+    ids np.random.choice would have drawn, and numpy's generator ends where the reference's loop would leave it."""
+    from catgrasp_amd import synth
+    from catgrasp_amd.predicter import DEFAULT_GRASP_CFG, GraspPredicter
+    ob = synth.make_scene(1, 2300, seed=5)[0]
+    P = list(synth.make_candidates(ob, 90, np.random.default_rng(1)))
+    gp = GraspPredicter('nut', cfg=DEFAULT_GRASP_CFG, state_dict=synth.make_state_dict('cls', 6, 10, seed=3), device=cuda_device, chunk=32)
+    data = {'cloud_xyz': ob['xyz'], 'cloud_normal': ob['normal']}
+    np.random.seed(21)
+    ids = np.stack([np.random.choice(np.arange(2300), size=(2048), replace=False) for _ in P])
+    nxt_want = np.random.rand()
+    want = gp.predict_batch(data, P, ids=ids)
+    np.random.seed(21)
+    got = gp.predict_batch(data, P, rng='numpy')
+    nxt_got = np.random.rand()
+    assert nxt_got == nxt_want and len(got) == len(want)
+    assert all(a[0] == b[0] and np.array_equal(a[2], b[2]) for a, b in zip(got, want))
