@@ -113,12 +113,22 @@ class GraspPredicter:
             return id_chunks[s]
         C = len(self.cfg['classes']) - 1
         logits = torch.empty((G, C), dtype=torch.float32, device=self.device)
-        starts = list(range(0, G, self.chunk))
+        # chunk boundaries: uniform, or -- for an id source that is produced on the host while the device works (ids.ramp) -- a
+        # short first chunk doubling up to the full size, so that the device starts after a fraction of the first draw
+        sizes = [min(self.chunk, r) for r in getattr(ids, 'ramp', ())]
+        bounds, s = [], 0
+        while s < G:
+            e = min(G, s + (sizes.pop(0) if sizes else self.chunk))
+            bounds.append((s, e)); s = e
+        if hasattr(ids, 'plan'):
+            ids.plan(bounds)
+        starts = [b[0] for b in bounds]
+        ends = dict(bounds)
         guard = engine.PRECISION in engine.HALF_MODES
         status = engine.new_status(self.device, len(starts)) if guard else None      # one range word per chunk
 
         def run(s, st):
-            e = min(G, s + self.chunk)
+            e = ends[s]
             x = ops.build_grasp_input(cloud_xyz, cloud_normal, ids_of(s, e), pose_inv[s:e], self._mean, self._inv_std)
             logits[s:e] = engine.cls_forward(self._W, x, st)[0]
         for k, s in enumerate(starts):
@@ -141,20 +151,26 @@ class GraspPredicter:
         stream = transforms.NumpyChoiceStream(n_valid, n_pts)
         pool = ThreadPoolExecutor(max_workers=1)
         chunk, dev = self.chunk, self.device
-        pending = {}
+        pending, plan = {}, {}
         on_device = stream.on_device_chain
         draw = stream.draw_partners if on_device else stream.draw
 
         def submit(s):
-            if s < G and s not in pending:
-                pending[s] = pool.submit(draw, min(G, s + chunk) - s)
+            if s in plan and s not in pending:
+                pending[s] = pool.submit(draw, plan[s] - s)
 
         def ids(s, e):
+            if not plan:
+                plan.update({a: min(G, a + chunk) for a in range(0, G, chunk)})
+            assert plan.get(s) == e, 'chunks must be asked for in the planned order'
             submit(s)
             host = pending.pop(s).result()
             submit(e)                                   # the next chunk is drawn while this one is uploaded and scored
             up = torch.from_numpy(host).to(dev, non_blocking=True)
             return ops.apply_shuffle_rows(up, n_valid, n_pts) if on_device else up
+
+        ids.ramp = (2048, 4096, 8192)
+        ids.plan = lambda bounds: (plan.clear(), plan.update(dict(bounds)))
 
         def close():
             for f in pending.values():
