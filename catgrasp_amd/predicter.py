@@ -187,7 +187,8 @@ class GraspPredicter:
         draw of GraspDataset.transform (dataset_grasp.py:72-73) comes from
           rng='numpy'  (default; $CATGRASP_AMD_RNG): numpy's GLOBAL generator, consumed exactly like the reference's one
                        np.random.choice per pose -- seeding numpy reproduces the reference's draws.  The stream is replayed in C one
-                       chunk ahead of the device (the draw is inherently sequential: ~15-25 us per pose on one host core);
+                       chunk ahead of the device (the rejection sampling of the stream is inherently sequential: ~6 us per pose on one
+                       host core; the permutation swap chains run on the device);
           rng='device': the same distribution drawn by a counter-based generator on the device (cg_draw_resample_ids; seeded
                        from one draw of numpy's global generator, so it is still reproducible under np.random.seed) -- no
                        host loop and no 8 KB/pose upload."""
