@@ -19,6 +19,18 @@ from oracle import transforms_ref as tref
 pytestmark = pytest.mark.gpu
 
 
+_WORKLOADS = {}
+
+
+def _flat_workload(device, G, seed, n_objects, kind='nut'):
+    """build_flat_workload, built once per configuration: the arithmetic modes of a test share the (read-only) synthetic batch --
+    generating 10^5 candidate poses is a host-side python loop that would otherwise be repeated for every mode."""
+    key = (str(device), G, seed, n_objects, kind)
+    if key not in _WORKLOADS:
+        _WORKLOADS[key] = workload.build_flat_workload(device, G, seed=seed, n_objects=n_objects, pts_per_object=2500, kind=kind)
+    return _WORKLOADS[key]
+
+
 def _candidate_owner(wl):
     """global candidate index -> (object k, local index j), following workload.build_flat_workload's per-object blocks"""
     start = np.concatenate([[0], np.cumsum(wl['per'])])
@@ -27,7 +39,7 @@ def _candidate_owner(wl):
 
 @pytest.mark.parametrize('n_obj,G,kind', [(8, 10000, 'nut'), (16, 200000, 'screw')])
 def test_scoring_properties_at_baseline_sizes(cuda_device, n_obj, G, kind):
-    wl = workload.build_flat_workload(cuda_device, G, seed=0, n_objects=n_obj, pts_per_object=2500, kind=kind)
+    wl = _flat_workload(cuda_device, G, 0, n_obj, kind)
     assert wl['cloud_xyz'].shape[0] == n_obj * 2500 and wl['ids'].shape == (G, 2048)
     sd = synth.make_state_dict('cls', 6, 10, seed=0)
     gp = GraspPredicter(kind, cfg=DEFAULT_GRASP_CFG, state_dict=sd, device=cuda_device)
