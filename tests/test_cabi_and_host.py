@@ -2,6 +2,7 @@
 (BN folding, fragment packing, pose inversion, RNG semantics, sharding) is correct; the product refuses to
 run without its HIP path instead of falling back."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -19,6 +20,28 @@ def test_library_loads_and_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s)
     assert b'gfx950' in lib.cg_version()
+
+
+def test_header_is_plain_c_and_links_from_c(tmp_path):
+    """The drop-in boundary is a C ABI: include/catgrasp_amd.h must compile as strict C99 (no C++, no HIP, no torch types in the
+    signatures) and a C program must link every declared entry point from the shared library and call it -- here cg_version()
+    and one argument-error path, which need no GPU."""
+    import shutil
+    import subprocess
+    if shutil.which('gcc') is None:
+        pytest.skip('gcc not available')
+    syms = _lib.declared_symbols()
+    src = ('#include "catgrasp_amd.h"\n#include <stdio.h>\ntypedef void (*fn_t)(void);\nint main(void) {\n  fn_t table[] = {\n' +
+           ''.join(f'    (fn_t)&{s},\n' for s in syms) +
+           '  };\n  printf("%s %d\\n", cg_version(), (int)(sizeof table / sizeof table[0]));\n'
+           '  return cg_draw_resample_ids(0, 2048, 4, 1ULL, 0, 0, (int*)16, (void*)0) == CG_ERR_ARG ? 0 : 1;\n}\n')
+    (tmp_path / 'main.c').write_text(src)
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.check_call(['gcc', '-std=c99', '-Wall', '-Wextra', '-Werror', '-pedantic', '-I', os.path.dirname(_lib.HEADER_PATH), 'main.c',
+                           '-L', libdir, '-lcatgrasp_amd', f'-Wl,-rpath,{libdir}', '-Wl,--allow-shlib-undefined', '-o', 'main'], cwd=tmp_path)
+    out = subprocess.run([str(tmp_path / 'main')], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    assert 'gfx950' in out.stdout and out.stdout.split()[-1] == str(len(syms))
 
 
 def test_argument_errors_are_reported_not_crashed():
