@@ -96,3 +96,34 @@ def test_live_against_imported_reference():
         sa, sb = a.state_dict(), b.state_dict()
         assert list(sa.keys()) == list(sb.keys())
         assert all(sa[k].shape == sb[k].shape for k in sa)
+
+
+@pytest.mark.skipif(not os.path.exists('/root/reference/pointnet2.py'), reason='reference checkout only exists in the build container')
+def test_training_mode_equals_the_imported_reference_bit_for_bit():
+    """trainer_grasp.py / trainer_nunocs.py must keep working on the drop-in modules.  With the same state_dict, the
+    same input and the same torch seed (Dropout p=0.4 in PointNetCls), the drop-in's train-mode forward, the gradients of every
+    parameter and the BatchNorm running statistics after the step are IDENTICAL to the reference modules'."""
+    for m in ('cv2', 'torchvision'):
+        sys.modules.setdefault(m, types.ModuleType(m))
+    sys.path.insert(0, '/root/reference')
+    try:
+        sys.modules.pop('pointnet2', None)
+        import pointnet2 as ref
+    finally:
+        sys.path.remove('/root/reference')
+        sys.modules.pop('pointnet2', None)
+    from catgrasp_amd import pointnet2 as ours
+    x = torch.from_numpy(np.random.default_rng(8).normal(0, 0.5, (4, 120, 6)).astype(np.float32))
+    for kind, n_out, name in (('cls', 10, 'PointNetCls'), ('seg', 30, 'PointNetSeg')):
+        sd = synth.make_state_dict(kind, 6, n_out, seed=3)
+        a, b = getattr(ours, name)(6, n_out), getattr(ref, name)(6, n_out)
+        a.load_state_dict(sd); b.load_state_dict(sd)
+        a.train(); b.train()
+        torch.manual_seed(0); ya, ta = a(x.clone())
+        torch.manual_seed(0); yb, tb = b(x.clone())
+        assert torch.equal(ya, yb) and torch.equal(ta, tb)
+        ya.square().sum().backward(); yb.square().sum().backward()
+        gb = dict(b.named_parameters())
+        assert all(torch.equal(p.grad, gb[k].grad) for k, p in a.named_parameters())
+        sb = b.state_dict()
+        assert all(torch.equal(v, sb[k]) for k, v in a.state_dict().items())
