@@ -21,6 +21,9 @@ All inputs are resident in HBM before the timed region; weights are seeded rando
 `value` is measured under --precision (default f32: exact-f32 MFMA, the reference's arithmetic); the split-precision modes of
 the product (f16x3, f16fp8x2, bf16x3; opt-in via CATGRASP_AMD_PRECISION) are measured in the same run and reported under `secondary`.
 
+`roofline.traffic` is a labelled constant from the PMC profiles under profiles/ unless --pmc-traffic is given (N = 1): then two child
+passes of the same workload run under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` and the figure is measured for this run.
+
 Launch: python bench.py --gpus 1 --steps K --warmup W
         python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
         ... bench.py --gpus 8 --scaling strong --candidates-total 200000        (C4)
@@ -207,6 +210,57 @@ def cpu_baseline(batch, sd_cls, sd_seg, n_score=100, n_coll=4096):
             'thread_scan_ms_per_candidate': scan}
 
 
+def pmc_traffic(args, precision):
+    """roofline.traffic measured for THIS run's workload instead of quoted from profiles/ (opt-in: --pmc-traffic, N = 1): two child
+    runs of this script under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes, counters only -- no tracing
+    domain next to --pmc; MI355X_MICROARCH.md, HBM section), one warm-up + one step each; HBM bytes of the encoder-pass kernel =
+    (2 x FETCH_SIZE [gfx950 correction] + WRITE_SIZE) x 1024 summed over its dispatches / the candidates those dispatches scored.
+    -> (bytes per candidate, source text) or (None, reason)."""
+    import csv
+    import glob
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which('rocprofv3') or '/opt/rocm/bin/rocprofv3'
+    if not os.path.exists(exe):
+        return None, 'rocprofv3 not found'
+    pat = re.compile(r'pointmlp_max(_split)?_kernel<2[,>]')
+    tmp = tempfile.mkdtemp(prefix='cg_pmc_', dir='/tmp')
+    env = dict(os.environ, TMPDIR='/tmp')
+    kb, cand = {}, None
+    try:
+        for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+            d = os.path.join(tmp, counter)
+            cmd = [exe, '--pmc', counter, '--output-format', 'csv', '-d', d, '--', sys.executable, os.path.abspath(__file__), '--pmc-child',
+                   '--gpus', '1', '--precision', precision, '--workload', args.workload, '--candidates', str(args.candidates),
+                   '--candidates-total', str(args.candidates_total), '--steps', '1', '--warmup', '1']
+            r = subprocess.run(cmd, cwd='/tmp', env=env, capture_output=True, text=True, timeout=900)
+            if r.returncode != 0:
+                return None, f'rocprofv3 --pmc {counter} exited with {r.returncode}: {r.stderr[-300:]}'
+            child = [ln for ln in r.stdout.splitlines() if ln.startswith('{"pmc_child"')]
+            if not child:
+                return None, 'the counter pass printed no child record'
+            cand = json.loads(child[-1])['candidate_equivalents']
+            total, rows = 0.0, 0
+            for path in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
+                with open(path) as f:
+                    for row in csv.DictReader(f):
+                        name = row.get('Kernel_Name') or row.get('kernel_name') or ''
+                        if (row.get('Counter_Name') or row.get('counter_name')) == counter and pat.search(name):
+                            total += float(row.get('Counter_Value') or row.get('counter_value')); rows += 1
+            if rows == 0:
+                return None, f'no {counter} rows for the encoder-pass kernel in the rocprofv3 output'
+            kb[counter] = total
+    except Exception as e:          # the measurement is an extra: never let it take the bench line down
+        return None, f'{type(e).__name__}: {e}'
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    per = (2.0 * kb['FETCH_SIZE'] + kb['WRITE_SIZE']) * 1024.0 / cand
+    return per, (f'measured for this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate child passes of this command, 1 warm-up + 1 step '
+                 f'each): (2 x {kb["FETCH_SIZE"]:.0f} + {kb["WRITE_SIZE"]:.0f}) KB over {cand:.0f} candidates = {per:.0f} B/candidate, x candidates per launch')
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -225,6 +279,10 @@ def main():
     ap.add_argument('--secondary', default='f16x3,bf16x3,f16fp8x2', help='comma list of further precisions measured in the same run ("" = none)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-api', action='store_true', help='skip the reference-API wall-clock block')
+    ap.add_argument('--pmc-traffic', action='store_true',
+                    help='measure roofline.traffic for this run with two rocprofv3 --pmc child passes (N = 1 only; adds ~1-2 min) instead of '
+                         'quoting the constant from profiles/')
+    ap.add_argument('--pmc-child', action='store_true', help=argparse.SUPPRESS)      # the child run of --pmc-traffic: workload only
     args = ap.parse_args()
     if args.workload is None:
         args.workload = 'C4' if args.scaling == 'strong' else 'C3'
@@ -283,6 +341,18 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    if args.pmc_child:          # counter pass of --pmc-traffic: run the step, report how many candidates the encoder-pass kernel scored
+        engine.set_precision(args.precision)
+        ops.KERNEL_TIMER = {'mid_mode': 2, 'events': []}
+        with torch.no_grad():
+            for _ in range(args.warmup + args.steps):
+                cgd.score_sharded(batch.score_slice, n_total)
+        torch.cuda.synchronize()
+        ev = ops.KERNEL_TIMER['events']
+        print(json.dumps({'pmc_child': True, 'launches': len(ev), 'candidate_equivalents': float(sum(B * N / 2048.0 for _, _, (B, N) in ev))}),
+              flush=True)
+        return
+
     def measure(precision):
         engine.set_precision(precision)
         marks = []
@@ -326,14 +396,19 @@ def main():
                           'algorithmic_bytes_per_launch': int(b_bytes)}
         return res
 
+    measured_traffic = {}
+
     def roofline(precision, r):
         per = PMC_HBM_BYTES_PER_CANDIDATE[precision]
+        source = ('constant from profiles/r2_pmc_hbm_pointmlp_{f32,split,f16fp8x2}.csv (2*FETCH_SIZE + WRITE_SIZE per candidate at B=4096) x candidates per '
+                  'launch -- not a counter read in this run; algorithmic bytes are 69,632 B/candidate')
+        if precision in measured_traffic:
+            per, source = measured_traffic[precision]
         hbm_gbs = ALG_HBM_BYTES_PER_CANDIDATE * r['avg_cand'] / (r['avg_ms'] * 1e-3) / 1e9
         common = {'achieved': round(r['tflops'], 2), 'unit': 'TFLOP/s', 'avg_launch_ms': round(r['avg_ms'], 4), 'launches': r['launches'],
                   'candidates_per_launch': round(r['avg_cand'], 1), 'flop_per_candidate_launch': 2 * MAC_PER_POINT_ENC * 2048,
                   'traffic': int(per * r['avg_cand']),
-                  'traffic_source': 'constant from profiles/r2_pmc_hbm_pointmlp_{f32,split,f16fp8x2}.csv (2*FETCH_SIZE + WRITE_SIZE per candidate at B=4096) x candidates per '
-                                    'launch -- not a counter read in this run; algorithmic bytes are 69,632 B/candidate',
+                  'traffic_source': source,
                   'hbm_achieved_gbs': round(hbm_gbs, 1), 'hbm_frac': round(hbm_gbs / PEAK_HBM_GBS, 5)}
         if precision == 'f32':
             return dict({'bound': 'mfma', 'kernel': 'pointmlp_max_kernel<2> (encoder pass: conv1, x.T64, conv2, conv3, max; exact-f32 MFMA)',
@@ -367,6 +442,12 @@ def main():
                           'codes_identical_to_primary': bool(torch.equal(r['out'][:, 1], ref_out[:, 1]))})
     engine.set_precision(args.precision)
 
+    if rank == 0 and world == 1 and args.pmc_traffic:
+        per, why = pmc_traffic(args, args.precision)
+        if per is not None:
+            measured_traffic[args.precision] = (per, why + '; algorithmic bytes are 69,632 B/candidate')
+        else:
+            print(f'bench.py: --pmc-traffic failed ({why}); quoting the constant from profiles/', file=sys.stderr)
     if rank == 0:
         from catgrasp_amd.workload import SYMMETRY_COUNT
         sym_txt = ' / '.join(str(SYMMETRY_COUNT[c]) for c in cats)

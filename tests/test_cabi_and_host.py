@@ -451,3 +451,40 @@ def test_f16fp8x2_weight_image_layout_and_arithmetic():
     assert np.max(np.abs(y - ref) / scale) < 2.0 ** -15          # vs 2^-12 for the bare f16 product: the corrections are in place
     y_main = w_hi.astype(np.float64) @ x_hi.reshape(300, 128).T
     assert np.max(np.abs(y_main - ref) / scale) > 2 * np.max(np.abs(y - ref) / scale)
+
+
+def test_bench_pmc_traffic_parses_a_counter_pass(tmp_path, monkeypatch):
+    """bench.py --pmc-traffic: the arithmetic and CSV handling of the in-run HBM-traffic measurement, against a stand-in `rocprofv3`
+    that writes a counter_collection.csv in the tool's layout and echoes the child record (the real passes need the GPU)."""
+    import stat
+    import sys
+    import types
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..'))
+    import bench
+    stub = tmp_path / 'rocprofv3'
+    stub.write_text('''#!/usr/bin/env python3
+import os, sys
+a = sys.argv[1:]
+counter = a[a.index('--pmc') + 1]; d = a[a.index('-d') + 1]
+assert '--kernel-trace' not in a and '--' in a and '--pmc-child' in a
+os.makedirs(os.path.join(d, 'host', '123'), exist_ok=True)
+val = {'FETCH_SIZE': 1000.0, 'WRITE_SIZE': 300.0}[counter]
+with open(os.path.join(d, 'host', '123', '123_counter_collection.csv'), 'w') as f:
+    f.write('Correlation_Id,Dispatch_Id,Agent_Id,Kernel_Name,Counter_Name,Counter_Value\\n')
+    for disp in (1, 2):
+        for xcd in range(2):          # a dispatch may be reported in several rows: they add up
+            f.write(f'{disp},{disp},4,"void (anonymous namespace)::pointmlp_max_kernel<2>((anonymous namespace)::Args)",{counter},{val / 4}\\n')
+    f.write(f'3,3,4,"void (anonymous namespace)::pointmlp_max_kernel<0>((anonymous namespace)::Args)",{counter},777\\n')
+    f.write(f'4,4,4,"(anonymous namespace)::filter_grasp_pose_kernel((anonymous namespace)::FilterArgs)",{counter},555\\n')
+print('rocprofv3 chatter')
+print('{"pmc_child": true, "launches": 2, "candidate_equivalents": 100.0}')
+''')
+    stub.chmod(stub.stat().st_mode | stat.S_IEXEC)
+    monkeypatch.setenv('PATH', f'{tmp_path}:{os.environ["PATH"]}')
+    args = types.SimpleNamespace(workload='C3', candidates=50000, candidates_total=200000)
+    per, why = bench.pmc_traffic(args, 'f32')
+    assert per == (2 * 1000.0 + 300.0) * 1024 / 100.0 and 'measured for this run' in why
+    # a failing tool must not take the bench line down
+    stub.write_text('#!/bin/sh\nexit 3\n')
+    per, why = bench.pmc_traffic(args, 'f32')
+    assert per is None and 'exited with 3' in why
