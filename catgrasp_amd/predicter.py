@@ -273,6 +273,8 @@ class NunocsPredicter:
             if ids is None:
                 ids = transforms.draw_ids_reference(cloud.n, self.cfg['n_pts'], 1)[0]
             ids = np.ascontiguousarray(ids, dtype=np.int32).reshape(1, -1)
+            if ids.size and (ids.min() < 0 or ids.max() >= cloud.n):         # the device gather does no bounds checking
+                raise IndexError(f'resample index out of range for a cloud of {cloud.n} valid points')
             coords, conf, _ = self.nocs_on_device(cloud.xyz, cloud.normal, torch.from_numpy(ids).to(self.device))
             self.data_transformed = {'cloud_xyz_original': cloud.xyz64[ids[0]].copy(), 'keep_ids': cloud.keep_ids[ids[0]],
                                      'cloud_normal': cloud.normal64[ids[0]].copy()}

@@ -90,3 +90,24 @@ def test_chunk_ramp_plan(host_predicter):
     gp.chunk = 3000; asked.clear(); planned.clear()
     gp.score_on_device(None, None, ids, torch.zeros((7000, 12)))
     assert asked == [(0, 2048), (2048, 5048), (5048, 7000)]
+
+
+def test_explicit_resample_ids_are_range_checked_before_any_device_work():
+    """The device gathers do no bounds checking: explicit ids outside [0, n_valid) must raise like numpy indexing would in the
+    reference, for both predicters, before anything is launched (so this runs without a GPU)."""
+    from catgrasp_amd.predicter import DEFAULT_NUNOCS_CFG, NunocsPredicter
+    ob = synth.make_scene(1, 300, seed=1)[0]
+    data = {'cloud_xyz': ob['xyz'], 'cloud_normal': ob['normal']}
+    npred = NunocsPredicter('nut', cfg=DEFAULT_NUNOCS_CFG, state_dict=synth.make_state_dict('seg', 6, 300, seed=1), device='cpu')
+    n_pts = DEFAULT_NUNOCS_CFG['n_pts']
+    for bad in (-1, 300):
+        ids = np.zeros(n_pts, dtype=np.int64); ids[7] = bad
+        with pytest.raises(IndexError):
+            npred.predict_nocs(data, ids=ids)
+    gp = GraspPredicter('nut', cfg=DEFAULT_GRASP_CFG, state_dict=synth.make_state_dict('cls', 6, 10, seed=0), device='cpu')
+    P = list(synth.make_candidates(ob, 2, np.random.default_rng(2)))
+    ids = np.zeros((2, DEFAULT_GRASP_CFG['n_pts']), dtype=np.int64); ids[1, 3] = 300
+    with pytest.raises(IndexError):
+        gp.predict_batch(data, P, ids=ids)
+    with pytest.raises(ValueError):
+        gp.predict_batch(data, P, ids=ids[:1])
