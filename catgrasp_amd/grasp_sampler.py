@@ -61,12 +61,74 @@ def cone_grasp_poses(points_for_sample, normals_for_sample, sample_ids, sphere_p
 # device.  They return lists of `ParallelJawPtGrasp3D` (an object with `.grasp_pose`, 4x4) like the reference.
 
 class ParallelJawPtGrasp3D:
+    """The fields of dexnet/grasping/grasp.py:113-166 this path reads: `.grasp_pose` (4x4, grasp in object / camera frame) and
+    `.perturbation_score`.  Instances unpickled from the reference's grasp files keep every other attribute they were saved with."""
+
     def __init__(self, grasp_pose=None, perturbation_score=0.0):
         self.grasp_pose = None if grasp_pose is None else np.asarray(grasp_pose)
         self.perturbation_score = perturbation_score
 
     def get_grasp_pose_matrix(self):
-        return self.grasp_pose
+        if self.grasp_pose is None:      # grasp.py:163-166 falls back to T_grasp_obj (autolab_core); the files of this pipeline carry the pose
+            raise ValueError('grasp without grasp_pose (configuration-only grasps are not part of the scoring path)')
+        return np.array(self.grasp_pose, copy=True)
+
+
+class ReferenceObject:
+    """Attribute bag for a pickled reference object whose class lives in a package that is not installed here (dexnet contacts,
+    autolab_core transforms, meshpy / trimesh meshes): keeps the saved attributes, carries no behaviour."""
+
+    def __setstate__(self, state):
+        if isinstance(state, tuple) and len(state) == 2:          # (dict state, slots state)
+            state = {**(state[0] or {}), **(state[1] or {})}
+        if isinstance(state, dict):
+            self.__dict__.update(state)
+        else:
+            self.__dict__['state'] = state
+
+
+_REFERENCE_PACKAGES = ('dexnet', 'autolab_core', 'meshpy', 'trimesh', 'perception', 'visualization')
+_reference_classes = {}
+
+
+def _reference_unpickler(f):
+    import pickle
+
+    class Unpickler(pickle.Unpickler):
+        def find_class(self, module, name):
+            if module == 'dexnet.grasping.grasp' and name == 'ParallelJawPtGrasp3D':
+                return ParallelJawPtGrasp3D
+            if module.split('.')[0] in _REFERENCE_PACKAGES:
+                key = (module, name)
+                if key not in _reference_classes:
+                    _reference_classes[key] = type(name, (ReferenceObject,), {'__module__': module})
+                return _reference_classes[key]
+            return super().find_class(module, name)
+    return Unpickler(f)
+
+
+def load_reference_pickle(path):
+    """Read a gzip pickle written by the reference -- `data/object_models/{class}_canonical.pkl` (make_canonical.py:155-164: dict with
+    'canonical_cloud', 'canonical_normals', 'canonical_affordance', 'canonical_grasps', 'transforms_to_nocs', 'obj_files'; read at
+    run_grasp_simulation.py:706-707) or a `*_complete_grasp.pkl` grasp list (generate_grasp.py) -- without dexnet / autolab_core:
+    grasps come back as this module's ParallelJawPtGrasp3D with all saved attributes, other reference objects as attribute bags.
+    Like any pickle, only load files you trust."""
+    import gzip
+    with open(path, 'rb') as raw:
+        gz = raw.read(2) == b'\x1f\x8b'
+    with (gzip.open(path, 'rb') if gz else open(path, 'rb')) as f:
+        return _reference_unpickler(f).load()
+
+
+def load_canonical(path):
+    """The canonical model of a category as NocsTransferGraspSampler and the affordance stage take it: the dict of
+    `{class}_canonical.pkl` with 'canonical_grasps' as a python list."""
+    canonical = dict(load_reference_pickle(path))
+    for k in ('canonical_cloud', 'canonical_normals', 'canonical_affordance', 'canonical_grasps'):
+        if k not in canonical:
+            raise KeyError(f'{path}: not a canonical model file (no {k!r})')
+    canonical['canonical_grasps'] = list(canonical['canonical_grasps'])
+    return canonical
 
 
 def hinter_sampling(min_n_pts, radius=1):

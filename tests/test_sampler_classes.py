@@ -119,3 +119,37 @@ def test_point_cone_sampler_reproduces_the_reference_candidate_list(cuda_device)
     assert not extra and mine.shape == gold.shape               # same groups in the same order on this fixture
     same = np.abs(mine - gold).max((1, 2)) < 1e-9                # poses whose un-centred version is identical
     assert same.sum() >= n_per_point and np.abs(mine_c[same] - gold_c[same]).max() < 1e-9
+
+
+def test_reference_canonical_and_grasp_files_load_without_the_reference_packages():
+    """run_grasp_simulation.py:706-707 unpickles `{class}_canonical.pkl` -- which needs dexnet / autolab_core importable in the
+    reference.  tests/golden/canonical_golden.pkl and complete_grasp_golden.pkl were written with the REAL reference classes
+    (tests/golden/make_golden_canonical.py); the drop-in's loader must read them with none of those packages present, hand the
+    grasps to NocsTransferGraspSampler unchanged, and keep the attributes it does not interpret."""
+    import os
+    import sys
+    assert not any(m == 'dexnet' or m.startswith('dexnet.') for m in sys.modules), 'the reference package leaked into this process'
+    here = os.path.join(os.path.dirname(__file__), 'golden')
+    exp = np.load(os.path.join(here, 'canonical_golden_expect.npz'))
+    can = gs.load_canonical(os.path.join(here, 'canonical_golden.pkl'))
+    assert set(can) >= {'canonical_cloud', 'canonical_normals', 'canonical_affordance', 'canonical_grasps', 'transforms_to_nocs', 'obj_files'}
+    assert np.array_equal(can['canonical_cloud'], exp['cloud']) and np.array_equal(can['canonical_normals'], exp['normals'])
+    assert np.array_equal(can['canonical_affordance'], exp['affordance'])
+    grasps = can['canonical_grasps']
+    assert isinstance(grasps, list) and len(grasps) == 9 and all(type(g) is gs.ParallelJawPtGrasp3D for g in grasps)
+    assert np.array_equal(np.stack([g.get_grasp_pose_matrix() for g in grasps]), exp['poses'])
+    assert np.array_equal([g.perturbation_score for g in grasps], exp['scores'])
+    g0 = grasps[0]
+    assert isinstance(g0.c1, gs.ReferenceObject) and type(g0.c1).__name__ == 'Contact3D' and g0.c1.graspable_ is None
+    assert np.array_equal(np.stack([g.c1.point_ for g in grasps]), exp['c1']) and g0.grasp_id_ == 0 and g0.frame_ == 'object'
+    pose = g0.get_grasp_pose_matrix(); pose[0, 3] += 1.0
+    assert np.array_equal(g0.get_grasp_pose_matrix(), exp['poses'][0])              # a copy, like grasp.py:160-161
+    # straight into the sampler (grasp_sampler.py:302-327): score threshold + best-n on the loaded objects
+    s = gs.NocsTransferGraspSampler(_gripper(), None, can, 'nut', score_larger_than=0.6, max_n_grasp=3)
+    kept = [g.perturbation_score for g in s.canonical['canonical_grasps']]
+    want = sorted([x for x in exp['scores'] if x >= 0.6], reverse=True)[:3]
+    assert kept == want
+    lst = gs.load_reference_pickle(os.path.join(here, 'complete_grasp_golden.pkl'))
+    assert isinstance(lst, list) and len(lst) == 4 and np.array_equal(lst[3].get_grasp_pose_matrix(), exp['poses'][3])
+    with pytest.raises((KeyError, TypeError, ValueError)):                           # a grasp list is not a canonical model
+        gs.load_canonical(os.path.join(here, 'complete_grasp_golden.pkl'))
