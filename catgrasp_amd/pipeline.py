@@ -35,16 +35,30 @@ def _background_points(scene_pts, ob_pts, gripper_diameter, device):
     return bg[np.sort(first)]
 
 
+def canonical_fields(canonical):
+    """The canonical model of a category in the form evaluate_object uses -- dict(cloud, normals, affordance, grasps (m,4,4)).  Accepts
+    that form, or the reference's own `{class}_canonical.pkl` dict (grasp_sampler.load_canonical: 'canonical_cloud',
+    'canonical_normals', 'canonical_affordance', 'canonical_grasps' = grasp objects; run_grasp_simulation.py:706-707)."""
+    if canonical is None or 'canonical_cloud' not in canonical:
+        return canonical
+    grasps = list(canonical['canonical_grasps'])
+    return {'cloud': np.asarray(canonical['canonical_cloud'], dtype=np.float64), 'normals': np.asarray(canonical['canonical_normals'], dtype=np.float64),
+            'affordance': np.asarray(canonical['canonical_affordance'], dtype=np.float64).reshape(-1),
+            'grasps': np.stack([g.get_grasp_pose_matrix() for g in grasps]) if grasps else np.zeros((0, 4, 4))}
+
+
 def evaluate_object(ob_pts, ob_normals, scene_pts, K, gripper, grasp_predicter, nunocs_predicter, canonical=None, symmetry_tfs=None,
                     n_surface_samples=50, sphere_pts=None, approach_step=0.004, resolution=0.0005, cam_in_world=None, timings=None, ik=None):
     """Returns dict(poses (n,4,4) f32, p_G, p_T_given_G, p_T_G, order) for the surviving candidates, best first.
     `gripper`: dict with vertices/faces/enclosed_vertices/enclosed_faces/gripper_in_grasp/hand_depth/init_bite/diameter and
     finger_vertices (list of 2 arrays), grip_dirs.  `canonical`: optional dict(cloud, normals, affordance, grasps (m,4,4))
-    in the canonical (NUNOCS-scaled) frame; without it P(T|G) = 1 and only cone-sampled candidates are produced.
+    in the canonical (NUNOCS-scaled) frame, or the reference's `{class}_canonical.pkl` dict as grasp_sampler.load_canonical returns it
+    (canonical_fields); without it P(T|G) = 1 and only cone-sampled candidates are produced.
     `ik`: optional dict(ee_in_grasp 4x4, upper[7], lower[7]) -> filter_ik=True with the device iiwa14 solver (cam_in_world must
     then be the camera pose in the robot base frame, common.cpp:214-226)."""
     dev = grasp_predicter.device
     t = time.perf_counter
+    canonical = canonical_fields(canonical)
 
     def lap(name, t0):
         if timings is not None:
