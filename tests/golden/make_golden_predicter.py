@@ -94,3 +94,24 @@ out['nocs_top2_gap'] = (srt[..., -1] - srt[..., -2]).astype(np.float32)
 path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'predicter_golden.npz')
 np.savez_compressed(path, **out)
 print('wrote', path, os.path.getsize(path), 'bytes')
+
+# ---- BASELINE.json configs[0] (C1) at its stated size: one 'nut' instance, 2048-pt cloud, 256 grasp candidates through the REAL
+# ---- GraspPredicter.predict_batch on the CPU (n_valid == n_pts: every pose draws a full permutation of the cloud) ----
+torch.set_num_threads(min(8, os.cpu_count() or 1))
+rng1 = np.random.default_rng(31)
+ob1 = synth.make_scene(1, 2048, 17)[0]
+poses1 = synth.make_candidates(ob1, 256, rng1)
+cfg1 = {'n_pts': 2048, 'input_channel': 6, 'classes': [0, 0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8, 0.9, 1.01]}      # no normaliser (predicter.py:48-56 optional)
+gp1 = types.SimpleNamespace(cfg=cfg1)
+gp1.dataset = types.SimpleNamespace(cfg=cfg1, phase='test')
+gp1.dataset.transform = lambda data, pose: dataset_grasp.GraspDataset.transform(gp1.dataset, data, pose)
+model1 = ref_pn.PointNetCls(6, 10)
+model1.load_state_dict(synth.make_state_dict('cls', 6, 10, seed=79))
+gp1.model = model1.eval()
+np.random.seed(456)
+ret1 = ref_pred.GraspPredicter.predict_batch(gp1, {'cloud_xyz': ob1['xyz'].copy(), 'cloud_normal': ob1['normal'].copy()}, list(poses1))
+after = np.random.randint(0, 2 ** 31, 4)          # numpy's global generator as the reference's loop leaves it
+path1 = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'predicter_golden_c1.npz')
+np.savez_compressed(path1, xyz=ob1['xyz'], normal=ob1['normal'], poses=poses1, grasp_labels=np.array([r[0] for r in ret1]),
+                    grasp_conf=np.array([r[1] for r in ret1]), grasp_probs=np.array([r[2] for r in ret1]).astype(np.float32), rng_after=after)
+print('wrote', path1, os.path.getsize(path1), 'bytes')

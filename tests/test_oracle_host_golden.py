@@ -190,3 +190,32 @@ def test_pointgroup_host_ops_oracle_matches_the_reference_cpp():
         ci, co = ref.bfs_cluster(g['bfs_label'], g['bfs_idx'], g['bfs_start_len'], thr)
         assert np.array_equal(ci, g[f'bfs_thr{thr}_cluster_idxs']) and np.array_equal(co, g[f'bfs_thr{thr}_cluster_offsets'])
     assert len(g['bfs_thr1_cluster_offsets']) - 1 > 20 and len(g['bfs_thr50_cluster_offsets']) - 1 >= 4
+
+
+def test_c1_config_oracle_chain_against_real_predict_batch():
+    """BASELINE.json configs[0] (C1) at its stated size -- one 'nut' instance, 2048-pt cloud, 256 grasp candidates, the reference's
+    own CPU path: tests/golden/predicter_golden_c1.npz holds what the REAL GraspPredicter.predict_batch returned
+    (make_golden_predicter.py); the oracle chain must reproduce it, and its resampling draw (n_valid == n_pts: a full permutation
+    per pose) must leave numpy's global generator where the reference's loop left it."""
+    import torch
+    from catgrasp_amd import synth
+    from oracle import pointnet_ref as oref
+    p = np.load(os.path.join(os.path.dirname(GOLD), 'predicter_golden_c1.npz'))
+    assert p['xyz'].shape == (2048, 3) and p['poses'].shape == (256, 4, 4)
+    sd = synth.make_state_dict('cls', 6, 10, seed=79)
+    np.random.seed(456)
+    xs = []
+    for pose in p['poses']:
+        ids = tref.draw_ids(2048, 2048)
+        assert len(np.unique(ids)) == 2048
+        xs.append(tref.grasp_transform(p['xyz'].copy(), p['normal'].copy(), pose, ids)['input'])
+    assert np.array_equal(np.random.randint(0, 2 ** 31, 4), p['rng_after'])
+    with torch.no_grad():
+        logits = torch.cat([oref.pointnet_cls_forward(sd, torch.from_numpy(np.stack(xs[s:s + 64])).float())[0] for s in range(0, 256, 64)])
+    post = tref.predict_batch_post(logits.numpy())
+    probs = np.array([r[2] for r in post])
+    assert np.abs(probs - p['grasp_probs']).max() < 5e-6
+    srt = np.sort(p['grasp_probs'], axis=1)
+    sure = srt[:, -1] - srt[:, -2] > 1e-5
+    assert sure.mean() > 0.95 and np.array_equal(np.array([r[0] for r in post])[sure], p['grasp_labels'][sure])
+    assert np.abs(np.array([r[1] for r in post]) - p['grasp_conf']).max() < 5e-6
