@@ -10,9 +10,12 @@ One "step" = one pass of the hot path over one batch of synthetic candidates (ca
   -> one all_gather of the packed (p_G, code) records when --gpus > 1 (catgrasp_amd/distributed.py).
 
 Workloads (config.workload):
-  C3 (default; BASELINE.json configs[2]): nut clutter pile, 20k-pt scene (8 objects x 2500 pts), 12 nut symmetries,
-      50,000 candidates PER GPU; --gpus N is weak scaling (every rank scores its own 50k candidates of the same scene).
-  C4 (--scaling strong; configs[3]): screw category, 40k-pt scene (16 x 2500), 72 symmetries, --candidates-total (200,000)
+  C3 (default; BASELINE.json configs[2]): nut clutter pile, 20k-pt scene (8 objects x 2500 pts), 12 nut symmetries, ONE batch of
+      --candidates (50,000) candidates.  --gpus N is STRONG scaling of that same batch (contiguous slices over the ranks + the one
+      all_gather), so the N = 1 line is the single-GPU bench line and value(N) / value(1) is the speed-up on a fixed job; the weak
+      figure (every rank scores its own 50k candidates of the same scene: --scaling weak) is measured in the same run and reported
+      under `secondary` when N > 1.
+  C4 (--workload C4; configs[3]): screw category, 40k-pt scene (16 x 2500), 72 symmetries, --candidates-total (200,000)
       candidates in TOTAL cut into contiguous slices over the ranks.
   C5 (--workload C5; configs[4]): mixed-category bin, 60k-pt scene (24 x 2500: nut / hnm / screw in turn, 12 / 2 / 72 symmetries, one
       GraspPredicter + NunocsPredicter per category with its own weights), --candidates-total (500,000) candidates in TOTAL cut into
@@ -21,12 +24,15 @@ All inputs are resident in HBM before the timed region; weights are seeded rando
 `value` is measured under --precision (default f32: exact-f32 MFMA, the reference's arithmetic); the split-precision modes of
 the product (f16x3, f16fp8x2, bf16x3; opt-in via CATGRASP_AMD_PRECISION) are measured in the same run and reported under `secondary`.
 
-`roofline.traffic` is a labelled constant from the PMC profiles under profiles/ unless --pmc-traffic is given (N = 1): then two child
-passes of the same workload run under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` and the figure is measured for this run.
+`roofline.traffic` is MEASURED for the run at N = 1 whenever rocprofv3 is on the box (default; --no-pmc-traffic turns it off): after
+the timed region two bounded child passes of the same workload run under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate
+passes, counters only).  If a pass fails the line falls back to the labelled constant from profiles/ and says so.
+`rccl_selftest` (N = 1): after the timed region the step's records are gathered once more through a ONE-rank `nccl` process group with
+the collective forced -- the pad / all_gather_into_tensor / trim of the N-rank job on RCCL itself -- and compared with the ungathered ones.
 
 Launch: python bench.py --gpus 1 --steps K --warmup W
         python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
-        ... bench.py --gpus 8 --scaling strong --candidates-total 200000        (C4)
+        ... bench.py --gpus 8 --workload C4 --candidates-total 200000           (C4)
         ... bench.py --gpus 8 --workload C5                                     (C5)
 """
 import argparse
@@ -235,7 +241,7 @@ def pmc_traffic(args, precision):
             cmd = [exe, '--pmc', counter, '--output-format', 'csv', '-d', d, '--', sys.executable, os.path.abspath(__file__), '--pmc-child',
                    '--gpus', '1', '--precision', precision, '--workload', args.workload, '--candidates', str(args.candidates),
                    '--candidates-total', str(args.candidates_total), '--steps', '1', '--warmup', '1']
-            r = subprocess.run(cmd, cwd='/tmp', env=env, capture_output=True, text=True, timeout=900)
+            r = subprocess.run(cmd, cwd='/tmp', env=env, capture_output=True, text=True, timeout=300)
             if r.returncode != 0:
                 return None, f'rocprofv3 --pmc {counter} exited with {r.returncode}: {r.stderr[-300:]}'
             child = [ln for ln in r.stdout.splitlines() if ln.startswith('{"pmc_child"')]
@@ -261,15 +267,46 @@ def pmc_traffic(args, precision):
                  f'each): (2 x {kb["FETCH_SIZE"]:.0f} + {kb["WRITE_SIZE"]:.0f}) KB over {cand:.0f} candidates = {per:.0f} B/candidate, x candidates per launch')
 
 
+def rccl_selftest(batch, n_total, ref_out, device):
+    """The collective of the N-rank job on RCCL itself, on this one GPU (outside the timed region): a ONE-rank `nccl` process group, the
+    step's records gathered with the collective forced (catgrasp_amd/distributed.py: pad -> all_gather_into_tensor -> trim) and compared
+    with the records of the timed run.  Never takes the bench line down: a failure is reported in the block."""
+    import socket
+    from catgrasp_amd import distributed as cgd
+    info = {'what': 'one-rank nccl group, all_gather_into_tensor forced on the step records', 'ok': False}
+    try:
+        s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+        torch.distributed.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{port}', rank=0, world_size=1, device_id=device)
+        try:
+            with torch.no_grad():
+                rec = batch.score_slice(0, n_total)
+                per, _ = cgd.shard_bounds(n_total, 1)
+                cgd.gather_records(rec[:64], 64, 64, force_collective=True)        # communicator set-up outside the timing
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                out = cgd.gather_records(rec, per, n_total, force_collective=True)
+                e1.record(); torch.cuda.synchronize()
+            info.update(ok=bool(torch.equal(out, rec) and torch.equal(out, ref_out)), backend=torch.distributed.get_backend(),
+                        rccl_version='.'.join(str(v) for v in torch.cuda.nccl.version()), records=int(n_total), bytes=int(out.numel() * 4),
+                        all_gather_ms=round(e0.elapsed_time(e1), 4))
+        finally:
+            torch.distributed.destroy_process_group()
+    except Exception as e:
+        info['error'] = f'{type(e).__name__}: {e}'[:300]
+    return info
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--scaling', choices=['weak', 'strong'], default=None, help='default: weak (C3); C4 and C5 are strong-scaling workloads')
-    ap.add_argument('--workload', choices=['C3', 'C4', 'C5'], default=None,
-                    help='BASELINE.json configs[2] / [3] / [4]; default C3, or C4 under --scaling strong')
-    ap.add_argument('--candidates', type=int, default=50000, help='weak scaling: grasp candidates per GPU per step (C3: 50,000)')
+    ap.add_argument('--scaling', choices=['weak', 'strong'], default='strong',
+                    help='strong (default): one fixed batch cut over the ranks; weak (C3 only): --candidates per GPU')
+    ap.add_argument('--workload', choices=['C3', 'C4', 'C5'], default='C3', help='BASELINE.json configs[2] / [3] / [4]')
+    ap.add_argument('--candidates', type=int, default=50000,
+                    help='C3: grasp candidates per step -- in total (strong, the default) or per GPU (--scaling weak)')
     ap.add_argument('--candidates-total', type=int, default=None,
                     help='strong scaling: candidates per step over ALL GPUs (default C4: 200,000; C5: 500,000)')
     ap.add_argument('--precision', choices=['f32', 'f16x3', 'bf16x3', 'f16fp8x2'], default=None,
@@ -279,17 +316,18 @@ def main():
     ap.add_argument('--secondary', default='f16x3,bf16x3,f16fp8x2', help='comma list of further precisions measured in the same run ("" = none)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-api', action='store_true', help='skip the reference-API wall-clock block')
-    ap.add_argument('--pmc-traffic', action='store_true',
-                    help='measure roofline.traffic for this run with two rocprofv3 --pmc child passes (N = 1 only; adds ~1-2 min) instead of '
-                         'quoting the constant from profiles/')
+    ap.add_argument('--pmc-traffic', dest='pmc_traffic', action='store_true', default=None,
+                    help='measure roofline.traffic for this run with two rocprofv3 --pmc child passes (N = 1 only; adds ~1 min).  Default: on '
+                         'when rocprofv3 is present')
+    ap.add_argument('--no-pmc-traffic', dest='pmc_traffic', action='store_false', help='quote the constant from profiles/ instead')
+    ap.add_argument('--no-rccl-selftest', action='store_true', help='skip the one-rank RCCL all-gather check after the timed region (N = 1)')
     ap.add_argument('--pmc-child', action='store_true', help=argparse.SUPPRESS)      # the child run of --pmc-traffic: workload only
     args = ap.parse_args()
-    if args.workload is None:
-        args.workload = 'C4' if args.scaling == 'strong' else 'C3'
-    want = 'weak' if args.workload == 'C3' else 'strong'
-    if args.scaling not in (None, want):
-        ap.error(f'--workload {args.workload} is a {want}-scaling workload')
-    args.scaling = want
+    if args.scaling == 'weak' and args.workload != 'C3':
+        ap.error(f'--workload {args.workload} is a strong-scaling workload')
+    if args.pmc_traffic is None:
+        import shutil
+        args.pmc_traffic = bool(shutil.which('rocprofv3') or os.path.exists('/opt/rocm/bin/rocprofv3'))
     if args.precision is None:
         args.precision = 'bf16x3' if args.workload == 'C5' else 'f32'
     if args.candidates_total is None:
@@ -317,7 +355,6 @@ def main():
     from catgrasp_amd import engine, ops, synth
     from catgrasp_amd.predicter import DEFAULT_GRASP_CFG, DEFAULT_NUNOCS_CFG, GraspPredicter, NunocsPredicter
     from catgrasp_amd.workload import SceneBatch
-    strong = args.scaling == 'strong'
     cats = {'C3': ['nut'], 'C4': ['screw'], 'C5': ['nut', 'hnm', 'screw']}[args.workload]
     # one GraspPredicter / NunocsPredicter per category, each with its own seeded random-init weights (run_grasp_simulation.py:701-702)
     sds = {c: (synth.make_state_dict('cls', 6, 10, seed=2 * i), synth.make_state_dict('seg', 6, 300, seed=2 * i + 1)) for i, c in enumerate(cats)}
@@ -325,15 +362,21 @@ def main():
     gps = {c: GraspPredicter(c, cfg=DEFAULT_GRASP_CFG, state_dict=sds[c][0], device=device) for c in cats}
     npreds = {c: NunocsPredicter(c, cfg=DEFAULT_NUNOCS_CFG, state_dict=sds[c][1], device=device) for c in cats}
     gp = gps[cats[0]]
-    if strong:      # C4 / C5: one fixed batch cut into `world` contiguous slices
-        n_total = args.candidates_total
-        per, bounds = cgd.shard_bounds(n_total, world)
-        batch = SceneBatch(device, gps, npreds, kind='screw' if args.workload == 'C4' else 'bin', n_objects=16 if args.workload == 'C4' else 24,
-                           pts_per_object=2500, per_replica=n_total, replicas=1, materialize=bounds[rank])
-    else:           # C3: every rank scores its own replica of the candidate set (global order is replica-major: slice r == replica r)
-        n_total = args.candidates * world
-        batch = SceneBatch(device, gps, npreds, kind='nut', n_objects=8, pts_per_object=2500, per_replica=args.candidates, replicas=world,
-                           materialize=(rank * args.candidates, (rank + 1) * args.candidates))
+
+    def make_batch(scaling):
+        """-> (SceneBatch, n_total).  strong: one fixed batch cut into `world` contiguous slices (C3: --candidates in total; C4 / C5:
+        --candidates-total); weak (C3): every rank scores its own replica of the candidate set (global order is replica-major: slice r
+        == replica r).  A rank only generates the candidate poses of its own slice."""
+        if scaling == 'weak':
+            n = args.candidates * world
+            return SceneBatch(device, gps, npreds, kind='nut', n_objects=8, pts_per_object=2500, per_replica=args.candidates, replicas=world,
+                              materialize=(rank * args.candidates, (rank + 1) * args.candidates)), n
+        n = args.candidates if args.workload == 'C3' else args.candidates_total
+        _, bounds = cgd.shard_bounds(n, world)
+        kind, n_obj = {'C3': ('nut', 8), 'C4': ('screw', 16), 'C5': ('bin', 24)}[args.workload]
+        return SceneBatch(device, gps, npreds, kind=kind, n_objects=n_obj, pts_per_object=2500, per_replica=n, replicas=1, materialize=bounds[rank]), n
+
+    batch, n_total = make_batch(args.scaling)
     assert batch.n_total == n_total
 
     def barrier():
@@ -353,7 +396,7 @@ def main():
               flush=True)
         return
 
-    def measure(precision):
+    def measure(precision, batch=batch, n_total=n_total):
         engine.set_precision(precision)
         marks = []
         with torch.no_grad():
@@ -440,7 +483,20 @@ def main():
                           'ms_per_step': round(r['dt'] / args.steps * 1e3, 3), 'roofline': roofline(other, r),
                           'max_abs_p_G_difference_vs_primary': float((r['out'][:, 0] - ref_out[:, 0]).abs().max().item()),
                           'codes_identical_to_primary': bool(torch.equal(r['out'][:, 1], ref_out[:, 1]))})
+    if world > 1 and args.workload == 'C3' and args.scaling == 'strong':
+        # the weak-scaling figure of the same scene next to the strong one: every rank scores its own --candidates (different seeds)
+        wbatch, wn = make_batch('weak')
+        r = measure(args.precision, wbatch, wn)
+        secondary.append({'scaling': 'weak', 'precision': args.precision, 'dtype': DTYPE[args.precision], 'candidates_per_gpu': args.candidates,
+                          'candidates_total': wn, 'value': round(wn * args.steps / r['dt'], 1), 'ms_per_step': round(r['dt'] / args.steps * 1e3, 3),
+                          'per_rank_ms': [[round(v, 3) for v in pr] for pr in r['per_rank']],
+                          'note': 'per-GPU work fixed: N x the single-GPU batch, gathered by the same one all_gather'})
+        del wbatch, r
     engine.set_precision(args.precision)
+
+    selftest = None
+    if world == 1 and not args.no_rccl_selftest and backend == 'nccl':
+        selftest = rccl_selftest(batch, n_total, ref_out, device)
 
     if rank == 0 and world == 1 and args.pmc_traffic:
         per, why = pmc_traffic(args, args.precision)
@@ -461,8 +517,9 @@ def main():
             'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None,
             'dtype': DTYPE[args.precision],
             'data': 'synthetic (seeded clouds/candidates/gripper, random-init weights)',
-            'config': {'workload': {'C3': 'C3 (BASELINE.json configs[2]): nut clutter pile, 20k-pt scene (8 objects x 2500 pts), '
-                                          f'{args.candidates} candidates/GPU',
+            'config': {'workload': {'C3': 'C3 (BASELINE.json configs[2]): nut clutter pile, 20k-pt scene (8 objects x 2500 pts), ' +
+                                          (f'{args.candidates} candidates/GPU' if args.scaling == 'weak' else
+                                           f'{n_total} candidates in total over {world} GPU(s)'),
                                     'C4': 'C4 (BASELINE.json configs[3]): screw category, 40k-pt scene (16 objects x 2500 pts), '
                                           f'{n_total} candidates in total over {world} GPU(s)',
                                     'C5': 'C5 (BASELINE.json configs[4]): mixed-category bin, 60k-pt scene (24 objects x 2500 pts: nut / hnm / screw '
@@ -481,6 +538,8 @@ def main():
             'per_rank_ms': {'columns': ['local scoring (HIP events)', 'all_gather of the (p_G, code) records (HIP events)', 'step wall-clock'],
                             'ranks': [[round(v, 3) for v in pr] for pr in prim['per_rank']]},
         }
+        if selftest is not None:
+            line['rccl_selftest'] = selftest
         if 'bgi' in prim:
             line['roofline_hbm'] = prim['bgi']
         if secondary:

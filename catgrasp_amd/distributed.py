@@ -17,13 +17,15 @@ def shard_bounds(n_total, world):
     return per, [(min(n_total, r * per), min(n_total, (r + 1) * per)) for r in range(world)]
 
 
-def gather_records(local_rec, per, n_total, group=None):
+def gather_records(local_rec, per, n_total, group=None, force_collective=False):
     """local_rec: (n_local, C) tensor of this rank's slice (n_local <= per).  Pads to `per` rows (all_gather
     needs equal counts), gathers over all ranks in one collective and trims to (n_total, C), in candidate order.
     Device tensors go through ONE all_gather_into_tensor (RCCL over xGMI); under a gloo group (CPU tests, 1-GPU dev runs)
-    the same buffers are exchanged through host memory."""
+    the same buffers are exchanged through host memory.  A single rank skips the collective unless `force_collective` is set
+    and a process group exists: the one-rank RCCL self-test (tests/test_distributed_rccl_gpu.py, bench.py `rccl_selftest`) drives
+    the very same pad / all_gather_into_tensor / trim code the N-rank job runs."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world == 1:
+    if world == 1 and not (force_collective and dist.is_initialized()):
         return local_rec[:n_total]
     C = local_rec.shape[1]
     buf = torch.zeros((per, C), dtype=local_rec.dtype, device=local_rec.device)
@@ -39,7 +41,7 @@ def gather_records(local_rec, per, n_total, group=None):
     return out[:n_total]
 
 
-def score_sharded(score_fn, n_total, group=None, marks=None):
+def score_sharded(score_fn, n_total, group=None, marks=None, force_collective=False):
     """Run score_fn(lo, hi) -> (hi-lo, C) on this rank's slice and return the full (n_total, C) record array
     on every rank.  score_fn sees global candidate indices.  `marks` (optional list): receives three device events per call
     -- start, after the local scoring, after the gather -- for per-phase timing."""
@@ -56,7 +58,7 @@ def score_sharded(score_fn, n_total, group=None, marks=None):
     assert rec.shape[0] == hi - lo
     if ev:
         ev[1].record()
-    out = gather_records(rec, per, n_total, group)
+    out = gather_records(rec, per, n_total, group, force_collective)
     if ev:
         ev[2].record()
         marks.append(ev)

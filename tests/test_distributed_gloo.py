@@ -59,23 +59,23 @@ class HostBatch(workload.SceneBatch):
         return torch.sin(ids[:, 1].float() * 0.37) * 0.25 * w + pinv[:, 3] * 1e-6
 
 
-def _worker(rank, world, port, cfg, q):
+def _worker(rank, world, port, cfg, q, force=False):
     os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
         b = HostBatch(*cfg)
-        out = cgd.score_sharded(b.score_slice, b.n_total)
+        out = cgd.score_sharded(b.score_slice, b.n_total, force_collective=force)
         q.put((rank, out.numpy().copy(), b.nunocs_calls))      # by value: a shared-memory tensor could outlive its producer
         dist.barrier()
     finally:
         dist.destroy_process_group()
 
 
-def _run(cfg, world=2):
+def _run(cfg, world=2, force=False):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, cfg, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, cfg, q, force)) for r in range(world)]
     for p in procs:
         p.start()
     got = [q.get(timeout=120) for _ in range(world)]
@@ -103,6 +103,16 @@ def test_sharded_step_equals_unsharded_world2():
         if cfg[2] == 'bin':             # one scoring batch per run of same-category rows, all categories present
             assert {c for c, _ in whole.net_calls} == {'nut', 'hnm', 'screw'}
             assert sum(n for _, n in whole.net_calls) == whole.n_total and len(whole.net_calls) == cfg[0] * cfg[3]
+
+
+def test_one_rank_group_with_the_collective_forced():
+    """The shape of the 1-GPU RCCL self-test (tests/test_distributed_rccl_gpu.py, bench.py `rccl_selftest`): a 1-rank group whose
+    gather is forced through the collective returns the unsharded records; without a process group the flag is inert."""
+    cfg = (3, 101, 12, 1)
+    whole = HostBatch(*cfg)
+    ref = whole.score_slice(0, whole.n_total)
+    assert torch.equal(_run(cfg, world=1, force=True)[0][0], ref)
+    assert torch.equal(cgd.score_sharded(whole.score_slice, whole.n_total, force_collective=True), ref)
 
 
 def test_slicing_arithmetic():
