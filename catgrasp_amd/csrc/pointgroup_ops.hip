@@ -151,21 +151,24 @@ __global__ __launch_bounds__(256) void voxel_fill_maps_kernel(const long long* _
   }
 }
 
-__global__ __launch_bounds__(256) void cc_propagate_kernel(const int* __restrict__ label, const int* __restrict__ nbr,
+// Rows are clamped to the n_idx entries that exist and entries outside [0, n) are skipped: a truncated / corrupt CSR list can
+// make the result incomplete but never an out-of-bounds access (the host wrapper rejects such input before it gets here).
+__global__ __launch_bounds__(256) void cc_propagate_kernel(const int* __restrict__ label, const int* __restrict__ nbr, int n_idx,
                                                            const int* __restrict__ start_len, int n, int* __restrict__ comp,
                                                            int* __restrict__ changed) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int li = label[i];
-  const int s = start_len[2 * i], e = s + start_len[2 * i + 1];
+  const long s0 = start_len[2 * i], e0 = s0 + (long)start_len[2 * i + 1];
+  const int s = (int)(s0 < 0 ? 0 : (s0 > n_idx ? n_idx : s0)), e = (int)(e0 < s ? s : (e0 > n_idx ? n_idx : e0));
   int c = comp[i];
-  for (int q = s; q < e; ++q) { const int j = nbr[q]; if (label[j] == li) c = min(c, comp[j]); }
+  for (int q = s; q < e; ++q) { const int j = nbr[q]; if ((unsigned)j < (unsigned)n && label[j] == li) c = min(c, comp[j]); }
   c = min(c, comp[c]);                                   // pointer jumping
   bool ch = false;
   if (c < comp[i]) { atomicMin(comp + i, c); ch = true; }
   for (int q = s; q < e; ++q) {                          // push to the neighbours too: the relation is used symmetrically
     const int j = nbr[q];
-    if (label[j] == li && comp[j] > c) { atomicMin(comp + j, c); ch = true; }
+    if ((unsigned)j < (unsigned)n && label[j] == li && comp[j] > c) { atomicMin(comp + j, c); ch = true; }
   }
   if (ch) *changed = 1;
 }
@@ -240,12 +243,12 @@ extern "C" int cg_pg_voxel_fill_maps(const long long* perm, const int* seg, cons
   return cg_hip_status(hipGetLastError());
 }
 
-extern "C" int cg_pg_cc_propagate(const int* semantic_label, const int* ball_query_idxs, const int* start_len, int n, int* comp,
+extern "C" int cg_pg_cc_propagate(const int* semantic_label, const int* ball_query_idxs, int n_idx, const int* start_len, int n, int* comp,
                                   int* changed, void* stream) {
-  if (n < 0) return CG_ERR_ARG;
+  if (n < 0 || n_idx < 0) return CG_ERR_ARG;
   if (n == 0) return CG_OK;
-  if (!semantic_label || !start_len || !comp || !changed) return CG_ERR_ARG;
+  if (!semantic_label || !start_len || !comp || !changed || (n_idx > 0 && !ball_query_idxs)) return CG_ERR_ARG;
   hipLaunchKernelGGL(cc_propagate_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, semantic_label,
-                     ball_query_idxs, start_len, n, comp, changed);
+                     ball_query_idxs, n_idx, start_len, n, comp, changed);
   return cg_hip_status(hipGetLastError());
 }

@@ -11,11 +11,27 @@ from ._lib import _p, _stream, check, require_cuda
 _c_int = ctypes.c_int
 
 
+def _on_device(*tensors):
+    """The reference calls voxelization_idx / bfs_cluster with CPU tensors (predicter.py:285: `locs` is a CPU LongTensor;
+    pointgroup.py:240,245: semantic_preds_cpu, idx.cpu(), start_len.cpu()) and indexes CPU tensors with the results.  Host tensors are
+    therefore accepted: they are uploaded to the current HIP device, the kernels run there (there is no CPU implementation), and the
+    results go back to the inputs' device.  -> (device tensors ..., device of the first input)."""
+    home = tensors[0].device
+    if all(t.is_cuda for t in tensors):
+        return tensors + (home,)
+    if not torch.cuda.is_available():
+        raise L.CatgraspAmdError('catgrasp_amd.pointgroup_ops needs a HIP device (host tensors are uploaded to it; there is no CPU fallback)')
+    dev = next((t.device for t in tensors if t.is_cuda), torch.device('cuda', torch.cuda.current_device()))
+    return tuple(t.to(dev) for t in tensors) + (home,)
+
+
 def ballquery_batch_p(coords, batch_idxs, batch_offsets, radius, meanActive):
     """-> (idx (nActive,) int32, start_len (n,2) int32): neighbours of every point within `radius` inside its own batch
     (pointgroup_ops.py BallQueryBatchP; bfs_cluster.cu:15-91).  The reference hands out CSR start positions with an
     atomicAdd (order = thread arrival); here they are the prefix sum in point order, one of its valid outcomes, with the
-    same 1000-neighbour and n*meanActive caps."""
+    same 1000-neighbour cap per point.  `meanActive` is only the reference's first guess of the list capacity: its wrapper retries
+    with a larger one until nActive <= n*meanActive (pointgroup_ops.py:134-141), so the lists it returns are never cut -- the counts
+    of the first pass size `idx` exactly here, which is that loop's fixed point."""
     require_cuda(coords, batch_idxs, batch_offsets)
     coords = coords.contiguous().float(); batch_idxs = batch_idxs.contiguous().int(); batch_offsets = batch_offsets.contiguous().int()
     n = coords.shape[0]
@@ -23,13 +39,14 @@ def ballquery_batch_p(coords, batch_idxs, batch_offsets, radius, meanActive):
     lib = L.lib()
     check(lib.cg_pg_ballquery_batch_p(_p(coords), _p(batch_idxs), _p(batch_offsets), _c_int(n), ctypes.c_float(radius), _c_int(0), None, None,
                                       _p(counts), None, _stream()), 'cg_pg_ballquery_batch_p')
-    start = (torch.cumsum(counts, 0) - counts).int()
-    thre = n * meanActive
-    length = torch.clamp(torch.minimum(counts, thre - start), min=0).int()          # writes are cut at n*meanActive (bfs_cluster.cu:52-57)
-    total = int(min(int(counts.sum().item()), thre))
-    idx = torch.zeros((max(thre, 1),), dtype=torch.int32, device=coords.device)
-    check(lib.cg_pg_ballquery_batch_p(_p(coords), _p(batch_idxs), _p(batch_offsets), _c_int(n), ctypes.c_float(radius), _c_int(1), _p(start.contiguous()),
-                                      _p(length.contiguous()), None, _p(idx), _stream()), 'cg_pg_ballquery_batch_p')
+    csum = torch.cumsum(counts.long(), 0)
+    total = int(csum[-1].item()) if n else 0
+    if total >= 2 ** 31:
+        raise ValueError('ballquery_batch_p: more than 2^31 neighbour entries')
+    start = (csum - counts).int().contiguous()
+    idx = torch.zeros((max(total, 1),), dtype=torch.int32, device=coords.device)
+    check(lib.cg_pg_ballquery_batch_p(_p(coords), _p(batch_idxs), _p(batch_offsets), _c_int(n), ctypes.c_float(radius), _c_int(1), _p(start),
+                                      _p(counts), None, _p(idx), _stream()), 'cg_pg_ballquery_batch_p')
     start_len = torch.stack([start, counts], dim=1).contiguous()
     return idx[:total].contiguous(), start_len
 
@@ -88,9 +105,12 @@ def voxelization_idx(coords, batchsize, mode=4):
     """pointgroup_ops.voxelization_idx (Voxelization_Idx.forward; voxelize.cpp:11-151; called at predicter.py:285):
     coords (N,4) [batch,x,y,z] or (N,3) int64 -> (output_coords (M,ncol) int64, input_map (N) int32, output_map (M, 1+maxActive)
     int32).  Voxels are numbered in order of first appearance; output_map row = [count, member point ids ascending, 0 ...]
-    (mode 3/4), [1, first] (mode 1), [1, last] (mode 2).  The reference builds the maps on the host from CPU tensors; here the
-    coordinates stay on the device (the returned tensors live on coords.device)."""
-    require_cuda(coords)
+    (mode 3/4), [1, first] (mode 1), [1, last] (mode 2).  The reference builds the maps on the host from CPU tensors
+    (predicter.py:285 passes a CPU LongTensor and gets CPU tensors back); the maps are built by device kernels here, and the
+    returned tensors live on coords.device -- a host `coords` is uploaded and its results are downloaded (see _on_device)."""
+    coords, home = _on_device(coords)
+    if home != coords.device:
+        return tuple(t.to(home) for t in voxelization_idx(coords, batchsize, mode))
     coords = coords.contiguous().long()
     n, ncol = coords.shape
     dev = coords.device
@@ -133,18 +153,31 @@ def bfs_cluster(semantic_label, ball_query_idxs, start_len, threshold):
     components of the neighbour graph restricted to equal semantic labels with >= threshold points, numbered by their smallest
     point index (the order the reference's seed loop finds them).  Members are listed in ascending point index; the reference
     lists them in queue-visit order (same sets).  The neighbour relation is used symmetrically (it is symmetric unless the ball
-    query's 1000-neighbour / n*meanActive caps truncated a list)."""
-    require_cuda(semantic_label, ball_query_idxs, start_len)
+    query's 1000-neighbour cap truncated a list).  Host tensors are accepted like the reference's (pointgroup.py:240,245 pass
+    `.cpu()` tensors) and the results returned on the inputs' device (see _on_device).  A CSR row that reaches past the end of
+    `ball_query_idxs`, or an entry outside [0, N), raises (the reference's queue BFS would read out of bounds there)."""
+    semantic_label, ball_query_idxs, start_len, home = _on_device(semantic_label, ball_query_idxs, start_len)
+    if home != semantic_label.device:
+        return tuple(t.to(home) for t in bfs_cluster(semantic_label, ball_query_idxs, start_len, threshold))
     label = semantic_label.contiguous().int(); nbr = ball_query_idxs.contiguous().int(); sl = start_len.contiguous().int()
     n = sl.shape[0]
     dev = label.device
+    if label.shape[0] != n:
+        raise ValueError('bfs_cluster: semantic_label and start_len disagree on the number of points')
+    n_idx = nbr.shape[0]
+    if n:
+        ends = sl[:, 0].long() + sl[:, 1].long()
+        if int(sl.min().item()) < 0 or int(ends.max().item()) > n_idx:
+            raise ValueError(f'bfs_cluster: start_len addresses entries beyond the {n_idx} of ball_query_idxs (a truncated neighbour list?)')
+        if n_idx and (int(nbr.min().item()) < 0 or int(nbr.max().item()) >= n):
+            raise ValueError('bfs_cluster: ball_query_idxs holds a point index outside [0, N)')
     comp = torch.arange(n, dtype=torch.int32, device=dev)
     changed = torch.zeros((1,), dtype=torch.int32, device=dev)
     lib = L.lib()
     for _ in range(max(n, 1) + 1):
         changed.zero_()
         for _ in range(4):                                              # a few sweeps per host round trip
-            check(lib.cg_pg_cc_propagate(_p(label), _p(nbr), _p(sl), _c_int(n), _p(comp), _p(changed), _stream()), 'cg_pg_cc_propagate')
+            check(lib.cg_pg_cc_propagate(_p(label), _p(nbr), _c_int(n_idx), _p(sl), _c_int(n), _p(comp), _p(changed), _stream()), 'cg_pg_cc_propagate')
         if int(changed.item()) == 0:
             break
     sizes = torch.bincount(comp.long(), minlength=n)

@@ -401,9 +401,11 @@ int cg_pg_voxel_fill_maps(const long long* perm, const int* seg, const int* seg_
 /* bfs_cluster (src/bfs_cluster/bfs_cluster.cpp:34-121; called at PointGroup/model/pointgroup/pointgroup.py:240,245): one sweep
  * of min-label propagation with pointer jumping over the CSR neighbour lists (ball_query_idxs, start_len (n,2)) restricted to
  * equal semantic labels; comp (n) starts as 0..n-1; *changed is set when any entry dropped.  Iterate to the fixed point:
- * comp[i] = smallest point index of i's connected component. */
-int cg_pg_cc_propagate(const int* semantic_label, const int* ball_query_idxs, const int* start_len, int n, int* comp, int* changed,
-                       void* stream);
+ * comp[i] = smallest point index of i's connected component.  n_idx = number of entries of ball_query_idxs: CSR rows are
+ * clamped to it and entries outside [0, n) are skipped, so a truncated list cannot cause an out-of-bounds access (the reference's
+ * queue BFS, bfs_cluster.cpp:52-64, reads such lists unchecked). */
+int cg_pg_cc_propagate(const int* semantic_label, const int* ball_query_idxs, int n_idx, const int* start_len, int n, int* comp,
+                       int* changed, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused PointNet++ set abstraction (north_star: "grouped per-neighbourhood MLP reductions"): the consumer of

@@ -15,9 +15,13 @@ import numpy as np
 
 
 def ballquery_batch_p(xyz, batch_idxs, batch_offsets, radius, mean_active):
+    """BallQueryBatchP.forward (pointgroup_ops.py:114-143) around the kernel of bfs_cluster.cu:15-62: the kernel cuts its writes at
+    n*meanActive but always returns the full count nActive; the wrapper retries with meanActive = nActive // n + 1 until everything
+    fits, so the lists it hands back are never truncated (only the 1000-neighbour cap per point remains)."""
     xyz = np.asarray(xyz, dtype=np.float32)
     n = len(xyz); r2 = np.float32(radius) * np.float32(radius)
     lists = []
+    d2 = None
     for p in range(n):
         s, e = batch_offsets[batch_idxs[p]], batch_offsets[batch_idxs[p] + 1]
         d = xyz[p] - xyz[s:e]
@@ -26,9 +30,14 @@ def ballquery_batch_p(xyz, batch_idxs, batch_offsets, radius, mean_active):
         lists.append(nb)
     counts = np.array([len(l) for l in lists], dtype=np.int32)
     start = (np.cumsum(counts) - counts).astype(np.int32)
-    thre = n * mean_active
-    idx = np.concatenate(lists)[:thre].astype(np.int32) if n else np.zeros((0,), np.int32)
-    return idx, np.stack([start, counts], 1), d2
+    n_active = int(counts.sum())
+    while True:                                     # pointgroup_ops.py:134-141
+        thre = n * mean_active
+        idx = np.concatenate(lists)[:thre].astype(np.int32) if n else np.zeros((0,), np.int32)      # the kernel's cut (bfs_cluster.cu:52-57)
+        if n_active <= thre:
+            break
+        mean_active = int(n_active // n + 1)
+    return idx[:n_active], np.stack([start, counts], 1), d2
 
 
 def segment(inp, offsets, mode):

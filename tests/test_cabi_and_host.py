@@ -87,7 +87,8 @@ def test_argument_errors_are_reported_not_crashed():
     assert lib.cg_sa_group_mlp_max(one, null, one, one, 0, 100, 4, 32, 0, 2, cin, cout, ptrs, ptrs, one, null, null) == 0
     assert lib.cg_pg_voxel_pack_keys(one, 5, 2, one, null, null) == -1                                            # ncol must be 3 or 4
     assert lib.cg_pg_voxel_fill_maps(one, one, one, one, 5, 1, 4, one, one, null) == -1                           # width < 2
-    assert lib.cg_pg_cc_propagate(one, one, one, 5, null, one, null) == -1
+    assert lib.cg_pg_cc_propagate(one, one, 3, one, 5, null, one, null) == -1
+    assert lib.cg_pg_cc_propagate(one, one, -1, one, 5, one, one, null) == -1
     assert lib.cg_pointmlp_max_f16x3(null, 1, 64, null, null, null, 0, null, null, null, null, null, null, null, 0, 1, 256, null, null, null, null) == -1
     assert lib.cg_pointmlp_max_f16fp8x2(null, 1, 64, null, null, null, 0, null, null, null, null, null, null, null, 0, 1, 256, null, null, null, null) == -1
     assert lib.cg_pointmlp_max_f16fp8x2(one, 1, 64, null, one, one, 0, null, null, null, one, one, one, one, 0, 1, 64, one, null, null, null) == -2   # 256-point tiles only

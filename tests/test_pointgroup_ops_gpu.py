@@ -31,12 +31,13 @@ def test_ballquery_batch_p(cuda_device):
     xyz = np.concatenate([rng.normal(0, 0.05, (s, 3)) + i for i, s in enumerate(sizes)]).astype(np.float32)
     batch_idxs = np.concatenate([np.full(s, i) for i, s in enumerate(sizes)]).astype(np.int32)
     batch_offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
-    for mean_active in (50, 3):                           # 3 -> the n*meanActive cap truncates
+    for mean_active in (50, 3):                           # 3 -> the reference wrapper's first guess is too small and it retries: never truncated
         idx, start_len = pg.ballquery_batch_p(torch.from_numpy(xyz).to(cuda_device), torch.from_numpy(batch_idxs).to(cuda_device),
                                               torch.from_numpy(batch_offsets).to(cuda_device), 0.03, mean_active)
         r_idx, r_sl, _ = ref.ballquery_batch_p(xyz, batch_idxs, batch_offsets, 0.03, mean_active)
         assert np.array_equal(start_len.cpu().numpy(), r_sl)
         assert np.array_equal(idx.cpu().numpy(), r_idx)
+        assert idx.shape[0] == int(r_sl[:, 1].sum()) > len(xyz) * 3      # the full lists, beyond n * 3
     # neighbours never cross batches
     sl = start_len.cpu().numpy()
     assert (sl[:, 1] >= 1).all()                          # every point finds itself
@@ -111,6 +112,30 @@ def test_bfs_cluster_matches_the_host_bfs(cuda_device):
         for c in range(len(rco) - 1):
             assert np.array_equal(ci[rco[c]:rco[c + 1], 1], np.sort(rci[rco[c]:rco[c + 1], 1]))
     assert len(rco) - 1 >= 3
+    # the reference call sites hand CPU tensors over and index CPU tensors with the result (pointgroup.py:240,245; predicter.py:285):
+    # host tensors are accepted, the kernels still run on the device, the results come back on the host
+    ci_h, co_h = pg.bfs_cluster(torch.from_numpy(label), idx.cpu(), start_len.cpu(), 50)
+    assert not ci_h.is_cuda and not co_h.is_cuda and np.array_equal(ci_h.numpy(), ci) and np.array_equal(co_h.numpy(), co_)
+    coords = torch.from_numpy(np.concatenate([np.zeros((n, 1)), np.floor(xyz * 50) + 10], 1).astype(np.int64))
+    oc_h, im_h, om_h = pg.voxelization_idx(coords, 1, 4)
+    oc_d, im_d, om_d = pg.voxelization_idx(coords.to(cuda_device), 1, 4)
+    assert not oc_h.is_cuda and not im_h.is_cuda and not om_h.is_cuda
+    assert torch.equal(oc_h, oc_d.cpu()) and torch.equal(im_h, im_d.cpu()) and torch.equal(om_h, om_d.cpu())
+    # a CSR row that reaches past the end of the neighbour array (a truncated list) is rejected, not read
+    with pytest.raises(ValueError):
+        pg.bfs_cluster(t(label), idx[:idx.shape[0] // 2].contiguous(), start_len, 1)
+    bad = idx.clone(); bad[5] = n + 7
+    with pytest.raises(ValueError):
+        pg.bfs_cluster(t(label), bad, start_len, 1)
+    # ... and the kernel itself is memory-safe on such input (rows clamped to n_idx, foreign indices skipped): call the C ABI directly
+    import ctypes
+    from catgrasp_amd import _lib as L
+    comp = torch.arange(n, dtype=torch.int32, device=cuda_device); changed = torch.zeros(1, dtype=torch.int32, device=cuda_device)
+    half = bad[:idx.shape[0] // 2].contiguous()
+    st = L.lib().cg_pg_cc_propagate(L._p(t(label)), L._p(half), ctypes.c_int(half.shape[0]), L._p(start_len.contiguous()), ctypes.c_int(n), L._p(comp),
+                                    L._p(changed), L._stream())
+    torch.cuda.synchronize()
+    assert st == 0 and int(comp.min()) >= 0 and int(comp.max()) < n
 
 
 def test_host_side_ops_against_the_reference_cpp_golden(cuda_device):
