@@ -81,10 +81,19 @@ __global__ __launch_bounds__(256) void gemm_bias_act_split_kernel(GemmArgsB a) {
     }
   }
   if constexpr (F16) {      // amax covers this thread's share of the workgroup's X tile over the whole K
-    int flags = 0;
-    if (__builtin_amdgcn_ballot_w64(!(amax < HALF_MAX)) != 0) flags |= CG_HALF_OVERFLOW;
-    if (__builtin_amdgcn_ballot_w64(amax >= HALF_LOW) == 0) flags |= CG_HALF_UNDERFLOW;
-    if (flags && lane == 0 && a.status) atomicOr(a.status, flags);
+    // Overflow: any value anywhere.  Underflow: decided over the WHOLE 128-row tile the workgroup staged (all four waves), not over
+    // one wave's strided share of it -- a share that happens to hold only dead post-ReLU entries must not flag a healthy tile.
+    __shared__ int seen_large;
+    if (tid == 0) seen_large = 0;
+    __syncthreads();
+    const bool over = __builtin_amdgcn_ballot_w64(!(amax < HALF_MAX)) != 0;
+    const bool large = __builtin_amdgcn_ballot_w64(amax >= HALF_LOW) != 0;
+    if (lane == 0 && large) atomicOr(&seen_large, 1);
+    __syncthreads();
+    if (lane == 0 && a.status && blockIdx.y == 0) {      // the column blocks (blockIdx.y) stage the same X tile: report once
+      const int flags = (over ? CG_HALF_OVERFLOW : 0) | ((w == 0 && !seen_large) ? CG_HALF_UNDERFLOW : 0);
+      if (flags) atomicOr(a.status, flags);
+    }
   }
   if (!active) return;
   const int col = nb * 32 + l31;

@@ -9,6 +9,7 @@ Call graph per PointNetCls.forward (pointnet2.py:289-299), B samples of N points
           3x cg_gemm_bias_act             fc1,fc2,fc3                          (B,n_out)
 """
 import os
+import threading
 
 from . import ops
 
@@ -26,14 +27,31 @@ from . import ops
 # 'bf16x3': the same with bf16 pieces (8 + 8 bits; ~2e-5): float32's exponent range, per-point layers + segmentation head only.
 # For scale: the reference's own GPU path runs its Conv1d layers through cuDNN, where TF32 (10-bit mantissa) is PyTorch's default
 # on Ampere and later.
-PRECISION = os.environ.get('CATGRASP_AMD_PRECISION', 'f32')
+MODES = ('f32', 'bf16x3', 'f16x3', 'f16fp8x2')
+_default = os.environ.get('CATGRASP_AMD_PRECISION', 'f32')      # process-wide default (set_precision)
+_tls = threading.local()                                        # per-thread override stack of the `precision` context manager
 TILE_POINTS = 256   # bf16x3 kernel geometry: points per workgroup tile (8 waves, one workgroup per CU)
 
 
+def current_precision():
+    """The arithmetic in force on THIS thread: the innermost `with precision(...)` of the thread, else the process default.  The
+    override is thread-local, so two predicters used from two threads (or the range guard's bf16x3 re-run on one of them) cannot
+    switch each other's arithmetic; `engine.PRECISION` reads the same value."""
+    stack = getattr(_tls, 'stack', None)
+    return stack[-1] if stack else _default
+
+
+def __getattr__(name):          # engine.PRECISION stays readable as an attribute (bench.py, tests)
+    if name == 'PRECISION':
+        return current_precision()
+    raise AttributeError(name)
+
+
 def set_precision(p):
-    global PRECISION
-    assert p in ('f32', 'bf16x3', 'f16x3', 'f16fp8x2'), p
-    PRECISION = p
+    """Set the process-wide default arithmetic (threads inside a `with precision(...)` block keep their override)."""
+    global _default
+    assert p in MODES, p
+    _default = p
 
 
 HALF_OVERFLOW, HALF_UNDERFLOW = 1, 2        # CG_STATUS_HALF_* bits of include/catgrasp_amd.h
@@ -60,18 +78,19 @@ def warn_range(bits):
 
 
 class precision:
-    """Context manager: run a block under another arithmetic."""
+    """Context manager: run a block of THIS thread under another arithmetic (thread-local; see current_precision)."""
 
     def __init__(self, p):
+        assert p in MODES, p
         self.p = p
 
     def __enter__(self):
-        global PRECISION
-        self.old, PRECISION = PRECISION, self.p
+        if not hasattr(_tls, 'stack'):
+            _tls.stack = []
+        _tls.stack.append(self.p)
 
     def __exit__(self, *exc):
-        global PRECISION
-        PRECISION = self.old
+        _tls.stack.pop()
 
 
 def run_guarded(forward, W, x):
@@ -79,7 +98,7 @@ def run_guarded(forward, W, x):
     (or layer outputs that sank into the half subnormals) in a per-call status word; such a batch is evaluated again with bf16
     pieces -- float32's exponent range, ~2e-5 instead of ~2e-6 logits error, still inside the 1e-4 bar -- so a valid checkpoint
     never raises and never returns range-damaged numbers.  Costs one 4-byte read-back per call."""
-    if PRECISION not in HALF_MODES:
+    if current_precision() not in HALF_MODES:
         return forward(W, x, None)
     st = new_status(x.device)
     out = forward(W, x, st)
@@ -96,7 +115,7 @@ def run_guarded_features(forward, W, x):
     transform itself rather than logits behind FC layers and a softmax.  The 2-unit mode's e4m3 correction terms reach ~1e-4 of the
     feature scale there (measured 1.1e-4 on tests/test_predicter_gpu.py's encoder case) -- the mode is specified on the nets' logits --
     so under 'f16fp8x2' these blocks run 'f16x3'."""
-    if PRECISION == 'f16fp8x2':
+    if current_precision() == 'f16fp8x2':
         with precision('f16x3'):
             return run_guarded(forward, W, x)
     return run_guarded(forward, W, x)
@@ -115,16 +134,16 @@ def _dense(W, name, x, n_out, bias, status=None, **kw):
     image (FC tails and segmentation head; the 9- and 10-wide output layers stay exact f32).  'bf16x3': only the per-point
     segmentation head -- measured, splitting the per-candidate FC tails with bf16 pieces buys 3 % of the step and raises the
     logits error from ~2e-5 to ~6e-5 of the 1e-4 bar."""
-    if PRECISION in HALF_MODES and W.half_ok.get(name + '.h', False):       # a layer whose weights do not fit the half pieces stays f32
+    if current_precision() in HALF_MODES and W.half_ok.get(name + '.h', False):       # a layer whose weights do not fit the half pieces stays f32
         return ops.gemm_bias_act(x, W[name + '.h'], n_out, bias, split='f16', status=status, **kw)
-    if PRECISION == 'bf16x3' and (name + '.s') in W:
+    if current_precision() == 'bf16x3' and (name + '.s') in W:
         return ops.gemm_bias_act(x, W[name + '.s'], n_out, bias, split='bf16', **kw)
     return ops.gemm_bias_act(x, W[name], n_out, bias, **kw)
 
 
 def encoder_forward(W, x, want_pointfeat=False, status=None):
     """x:(B,N,6) cuda f32 -> global feature (B,1024), trans (B,9), trans_feat TRANSPOSED (B,4096) [, pointfeat]."""
-    if PRECISION != 'f32':
+    if current_precision() != 'f32':
         return _encoder_forward_split(W, x, want_pointfeat, status)
     B, N, _ = x.shape
     ns = _nsplit(B, N)
@@ -154,9 +173,9 @@ def _encoder_forward_split(W, x, want_pointfeat=False, status=None):
 
     def point_pass(w1, tag, relu3, mid=None, **kw):
         names = [tag + '.w2', tag + '.w3'] + ([mid] if mid else [])
-        half = PRECISION in HALF_MODES and all(W.half_ok.get(n + '.h', False) for n in names)
+        half = current_precision() in HALF_MODES and all(W.half_ok.get(n + '.h', False) for n in names)
         sfx = '.h' if half else '.s'
-        mx = half and PRECISION == 'f16fp8x2'
+        mx = half and current_precision() == 'f16fp8x2'
         extra = dict(wm=W[mid + sfx], bm=W[mid[:-3] + '.bm']) if mid else {}
         return ops.pointmlp_max(x, W[w1 + '.w1'], W[w1 + '.b1'], W[tag + '.w2' + sfx], W[tag + '.b2'], W[tag + '.w3' + ('.q' if mx else sfx)], W[tag + '.b3'],
                                 relu3, nsplit=ns, split=('f16fp8' if mx else 'f16') if half else 'bf16', tile_points=TILE_POINTS,
@@ -179,12 +198,12 @@ def _encoder_forward_split(W, x, want_pointfeat=False, status=None):
 def stn3d_forward(W, x, status=None):
     """A standalone STN3d (pointnet2.py:170-185).  x:(B,N,6) -> (B,9) row-major 3x3."""
     B, N, _ = x.shape
-    if PRECISION == 'f32':
+    if current_precision() == 'f32':
         g = ops.pointmlp_max(x, W['stn.w1'], W['stn.b1'], W['stn.w2'], W['stn.b2'], W['stn.w3'], W['stn.b3'], True, nsplit=_nsplit(B, N))
     else:
-        half = PRECISION in HALF_MODES and all(W.half_ok.get(n + '.h', False) for n in ('stn.w2', 'stn.w3'))
+        half = current_precision() in HALF_MODES and all(W.half_ok.get(n + '.h', False) for n in ('stn.w2', 'stn.w3'))
         sfx = '.h' if half else '.s'
-        mx = half and PRECISION == 'f16fp8x2'
+        mx = half and current_precision() == 'f16fp8x2'
         g = ops.pointmlp_max(x, W['stn.w1'], W['stn.b1'], W['stn.w2' + sfx], W['stn.b2'], W['stn.w3' + ('.q' if mx else sfx)], W['stn.b3'], True,
                              nsplit=_nsplit(B, N, TILE_POINTS), split=('f16fp8' if mx else 'f16') if half else 'bf16', tile_points=TILE_POINTS,
                              status=status if half else None)

@@ -89,6 +89,15 @@ class ReferenceObject:
 
 _REFERENCE_PACKAGES = ('dexnet', 'autolab_core', 'meshpy', 'trimesh', 'perception', 'visualization')
 _reference_classes = {}
+# The only non-reference globals a canonical-model / grasp-list pickle needs: numpy array reconstruction and plain containers.
+# Anything else (os.system, builtins.eval, ...) is refused instead of resolved -- a crafted .pkl cannot run code through this loader.
+_SAFE_GLOBALS = {('numpy.core.multiarray', '_reconstruct'), ('numpy._core.multiarray', '_reconstruct'), ('numpy.core.multiarray', 'scalar'),
+                 ('numpy._core.multiarray', 'scalar'), ('numpy', 'ndarray'), ('numpy', 'dtype'), ('numpy.core.numeric', '_frombuffer'),
+                 ('numpy._core.numeric', '_frombuffer'), ('collections', 'OrderedDict'), ('collections', 'defaultdict'),
+                 ('builtins', 'list'), ('builtins', 'dict'), ('builtins', 'tuple'), ('builtins', 'set'), ('builtins', 'frozenset'),
+                 ('builtins', 'int'), ('builtins', 'float'), ('builtins', 'bool'), ('builtins', 'str'), ('builtins', 'bytes'),
+                 ('builtins', 'complex'), ('builtins', 'slice'), ('builtins', 'range'), ('builtins', 'bytearray'), ('copyreg', '_reconstructor'),
+                 ('builtins', 'object')}
 
 
 def _reference_unpickler(f):
@@ -103,7 +112,9 @@ def _reference_unpickler(f):
                 if key not in _reference_classes:
                     _reference_classes[key] = type(name, (ReferenceObject,), {'__module__': module})
                 return _reference_classes[key]
-            return super().find_class(module, name)
+            if (module, name) in _SAFE_GLOBALS:
+                return super().find_class(module, name)
+            raise pickle.UnpicklingError(f'load_reference_pickle: global {module}.{name} is not on the allowlist of this loader')
     return Unpickler(f)
 
 
@@ -112,7 +123,8 @@ def load_reference_pickle(path):
     'canonical_cloud', 'canonical_normals', 'canonical_affordance', 'canonical_grasps', 'transforms_to_nocs', 'obj_files'; read at
     run_grasp_simulation.py:706-707) or a `*_complete_grasp.pkl` grasp list (generate_grasp.py) -- without dexnet / autolab_core:
     grasps come back as this module's ParallelJawPtGrasp3D with all saved attributes, other reference objects as attribute bags.
-    Like any pickle, only load files you trust."""
+    Stricter than the reference's plain pickle.load: only numpy reconstruction and plain containers are resolved besides the
+    reference's own classes (which become inert attribute bags); any other global raises pickle.UnpicklingError."""
     import gzip
     with open(path, 'rb') as raw:
         gz = raw.read(2) == b'\x1f\x8b'

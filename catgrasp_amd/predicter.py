@@ -103,14 +103,18 @@ class GraspPredicter:
         each chunk of candidates in order, exactly once; pose_inv (G,12) f32 cuda.
         -> probs (G,C), label (G) i32, confidence (G), p_G (G) cuda tensors."""
         G = pose_inv.shape[0]
-        id_chunks = {}
+        guard = engine.PRECISION in engine.HALF_MODES
+        id_chunks = {}      # chunks of a callable id source, kept ONLY under the half-range guard (a tripped chunk is scored again)
 
         def ids_of(s, e):
             if not callable(ids):
                 return ids[s:e]
-            if s not in id_chunks:
-                id_chunks[s] = ids(s, e)
-            return id_chunks[s]
+            if s in id_chunks:
+                return id_chunks[s]
+            c = ids(s, e)
+            if guard:
+                id_chunks[s] = c
+            return c
         C = len(self.cfg['classes']) - 1
         logits = torch.empty((G, C), dtype=torch.float32, device=self.device)
         # chunk boundaries: uniform, or -- for an id source that is produced on the host while the device works (ids.ramp) -- a
@@ -124,7 +128,6 @@ class GraspPredicter:
             ids.plan(bounds)
         starts = [b[0] for b in bounds]
         ends = dict(bounds)
-        guard = engine.PRECISION in engine.HALF_MODES
         status = engine.new_status(self.device, len(starts)) if guard else None      # one range word per chunk
 
         def run(s, st):
@@ -198,6 +201,7 @@ class GraspPredicter:
                 return []
             cloud = self.upload_cloud(data)
             n_pts = self.cfg['n_pts']
+            pinv = torch.from_numpy(transforms.pose_inverse_rows(grasp_poses, cloud.center)).to(self.device)   # validates the poses first
             if ids is None:
                 rng = rng or self.rng
                 if rng == 'device':
@@ -213,7 +217,6 @@ class GraspPredicter:
                 if ids.size and (ids.min() < 0 or ids.max() >= cloud.n):      # numpy indexing in the reference raises too
                     raise IndexError(f'resample index out of range for a cloud of {cloud.n} valid points')
                 ids_d = torch.from_numpy(ids).to(self.device)
-            pinv = torch.from_numpy(transforms.pose_inverse_rows(grasp_poses, cloud.center)).to(self.device)
             try:
                 probs, label, conf, _ = self.score_on_device(cloud.xyz, cloud.normal, ids_d, pinv)
             finally:

@@ -9,7 +9,7 @@ sd = synth.make_state_dict('cls', 6, 10, seed=11)
 W = folding.prepare_cls(sd, dev)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 if len(sys.argv) > 2:
-    engine.PRECISION = sys.argv[2]
+    engine.set_precision(sys.argv[2])
 x = (torch.randn(B, 2048, 6) * 0.5).to(dev)
 for _ in range(2):
     engine.cls_forward(W, x)

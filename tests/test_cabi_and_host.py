@@ -489,3 +489,35 @@ print('{"pmc_child": true, "launches": 2, "candidate_equivalents": 100.0}')
     stub.write_text('#!/bin/sh\nexit 3\n')
     per, why = bench.pmc_traffic(args, 'f32')
     assert per is None and 'exited with 3' in why
+
+
+def test_precision_override_is_thread_local():
+    """engine.precision(...) overrides the arithmetic of the calling thread only (the range guard's bf16x3 re-run, the per-mode blocks
+    of bench.py): a second predicter working on another thread keeps its own; set_precision moves the process default."""
+    import threading
+    from catgrasp_amd import engine
+    old = engine.PRECISION
+    seen, go, done = {}, threading.Event(), threading.Event()
+
+    def other():
+        seen['before'] = engine.PRECISION
+        go.wait(10)
+        seen['during'] = engine.PRECISION
+        with engine.precision('f16x3'):
+            seen['own'] = engine.PRECISION
+        done.set()
+    try:
+        engine.set_precision('f32')
+        t = threading.Thread(target=other); t.start()
+        with engine.precision('bf16x3'):
+            assert engine.PRECISION == 'bf16x3' == engine.current_precision()
+            with engine.precision('f16fp8x2'):
+                assert engine.PRECISION == 'f16fp8x2'
+            assert engine.PRECISION == 'bf16x3'
+            go.set(); done.wait(10)
+        t.join(10)
+        assert seen == {'before': 'f32', 'during': 'f32', 'own': 'f16x3'} and engine.PRECISION == 'f32'
+        with pytest.raises(AssertionError):
+            engine.precision('fp64')
+    finally:
+        engine.set_precision(old)

@@ -159,3 +159,26 @@ def test_reference_canonical_and_grasp_files_load_without_the_reference_packages
     assert isinstance(lst, list) and len(lst) == 4 and np.array_equal(lst[3].get_grasp_pose_matrix(), exp['poses'][3])
     with pytest.raises((KeyError, TypeError, ValueError)):                           # a grasp list is not a canonical model
         gs.load_canonical(os.path.join(here, 'complete_grasp_golden.pkl'))
+
+
+def test_reference_pickle_loader_refuses_foreign_globals(tmp_path):
+    """load_reference_pickle resolves the reference's own classes (as inert attribute bags), numpy reconstruction and plain containers
+    -- nothing else: a pickle that names os.system / builtins.eval raises instead of executing."""
+    import gzip
+    import os
+    import pickle
+    from catgrasp_amd import grasp_sampler as gs
+
+    class Evil:
+        def __reduce__(self):
+            return (os.system, ('echo pwned > /dev/null',))
+    for payload in (pickle.dumps(Evil()), pickle.dumps({'canonical_cloud': Evil()}), b"cbuiltins\neval\n(S'1+1'\ntR."):
+        p = tmp_path / 'evil.pkl'
+        p.write_bytes(gzip.compress(payload))
+        with pytest.raises(pickle.UnpicklingError):
+            gs.load_reference_pickle(str(p))
+    good = {'canonical_cloud': np.arange(6.0).reshape(2, 3), 'n': 3, 'names': ['a', 'b'], 'scalar': np.float32(2.5)}
+    p = tmp_path / 'good.pkl'
+    p.write_bytes(gzip.compress(pickle.dumps(good)))
+    back = gs.load_reference_pickle(str(p))
+    assert np.array_equal(back['canonical_cloud'], good['canonical_cloud']) and back['names'] == ['a', 'b'] and back['scalar'] == np.float32(2.5)
