@@ -250,6 +250,32 @@ __global__ __launch_bounds__(256) void nunocs_decode_kernel(const float* __restr
 
 }  // namespace
 
+namespace {
+// out[g][c] = max over the `rows` consecutive rows of group g of x[.][c] (the max-pool over points of pointnet2.py:176,214 for an
+// activation tensor that was materialised, i.e. the standalone STNkd).  One workgroup per (group, 64-channel slab): lanes map to
+// channels (coalesced 256-byte row reads), the four waves split the rows and combine through LDS.
+__global__ __launch_bounds__(256) void group_max_kernel(const float* __restrict__ x, long rows, int C, float* __restrict__ out) {
+  __shared__ float part[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = blockIdx.y * 64 + lane;
+  const float* xg = x + (size_t)blockIdx.x * rows * C;
+  float m = -INFINITY;
+  if (c < C)
+    for (long r = w; r < rows; r += 4) m = fmaxf(m, xg[(size_t)r * C + c]);
+  part[w][lane] = m;
+  __syncthreads();
+  if (w == 0 && c < C) out[(size_t)blockIdx.x * C + c] = fmaxf(fmaxf(part[0][lane], part[1][lane]), fmaxf(part[2][lane], part[3][lane]));
+}
+}  // namespace
+
+extern "C" int cg_group_max(const float* x, long groups, long rows_per_group, int C, float* out, void* stream) {
+  if (groups < 0 || rows_per_group <= 0 || C <= 0) return CG_ERR_ARG;
+  if (groups == 0) return CG_OK;
+  if (!x || !out || groups > 0x7fffffffL) return CG_ERR_ARG;
+  hipLaunchKernelGGL(group_max_kernel, dim3((unsigned)groups, (unsigned)((C + 63) / 64)), dim3(256), 0, (hipStream_t)stream, x, rows_per_group, C, out);
+  return cg_hip_status(hipGetLastError());
+}
+
 extern "C" int cg_build_grasp_input(const float* cloud_xyz, const float* cloud_normal, int n_cloud, const int* ids,
                                     const float* pose_inv, const float* mean, const float* inv_std, int G, int n_pts,
                                     float* out, void* stream) {

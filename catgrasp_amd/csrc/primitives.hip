@@ -50,6 +50,30 @@ __global__ __launch_bounds__(256) void square_distance_kernel(const float* __res
     out[((size_t)b * N + n0 + r) * M + m] = sqdist_expanded(srow[r][0], srow[r][1], srow[r][2], srow[r][3], dx, dy, dz, d2);
 }
 
+// The same expression for C-dimensional points (pointnet2.py:14-33 is generic in C): dot and squared norms accumulate over the
+// channels in index order, (((x0 y0 + x1 y1) + x2 y2) + ...), which is the C = 3 kernel's order.  Source rows are read through the
+// scalar/vector caches (every lane of a wave reads the same address), destination rows once per thread.
+__global__ __launch_bounds__(256) void square_distance_nd_kernel(const float* __restrict__ src, const float* __restrict__ dst,
+                                                                 int N, int M, int C, float* __restrict__ out) {
+  const int b = blockIdx.z;
+  const int n0 = blockIdx.y * SQ_ROWS;
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  if (m >= M) return;
+  const float* d = dst + ((size_t)b * M + m) * C;
+  float d2 = d[0] * d[0];
+  for (int c = 1; c < C; ++c) d2 = d2 + d[c] * d[c];
+  const int rows = min(SQ_ROWS, N - n0);
+  for (int r = 0; r < rows; ++r) {
+    const float* s = src + ((size_t)b * N + n0 + r) * C;
+    float dot = s[0] * d[0], s2 = s[0] * s[0];
+    for (int c = 1; c < C; ++c) { dot = dot + s[c] * d[c]; s2 = s2 + s[c] * s[c]; }
+    float v = -2.0f * dot;
+    v = v + s2;
+    v = v + d2;
+    out[((size_t)b * N + n0 + r) * M + m] = v;
+  }
+}
+
 // ---------------------------------------------------------------- index_points
 __global__ __launch_bounds__(256) void index_points_kernel(const float* __restrict__ points, const long long* __restrict__ idx,
                                                            int N, int C, long S, long total, float* __restrict__ out, int* __restrict__ err) {
@@ -262,6 +286,16 @@ extern "C" int cg_square_distance(const float* src, const float* dst, int B, int
   if (!src || !dst || !out) return CG_ERR_ARG;
   dim3 grid((unsigned)((M + 255) / 256), (unsigned)((N + SQ_ROWS - 1) / SQ_ROWS), (unsigned)B);
   hipLaunchKernelGGL(square_distance_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, dst, N, M, out);
+  return cg_hip_status(hipGetLastError());
+}
+
+extern "C" int cg_square_distance_nd(const float* src, const float* dst, int B, int N, int M, int C, float* out, void* stream) {
+  if (B < 0 || N < 0 || M < 0 || C <= 0) return CG_ERR_ARG;
+  if ((long)B * N * M == 0) return CG_OK;
+  if (!src || !dst || !out) return CG_ERR_ARG;
+  if (C == 3) return cg_square_distance(src, dst, B, N, M, out, stream);
+  dim3 grid((unsigned)((M + 255) / 256), (unsigned)((N + SQ_ROWS - 1) / SQ_ROWS), (unsigned)B);
+  hipLaunchKernelGGL(square_distance_nd_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, dst, N, M, C, out);
   return cg_hip_status(hipGetLastError());
 }
 

@@ -141,8 +141,27 @@ def _dense(W, name, x, n_out, bias, status=None, **kw):
     return ops.gemm_bias_act(x, W[name], n_out, bias, **kw)
 
 
+def pad_points(x, cin):
+    """x (B,N,cin), cin = 3..6 -> (B,N,6): the fused passes read 6 floats per point; missing feature channels are zeros that meet
+    zero weight columns (folding._pad_first_layer), i.e. they add exactly +0."""
+    import torch
+    if x.shape[2] != cin:
+        raise ValueError(f'the model takes {cin} input channels, the tensor has {x.shape[2]}')
+    if cin == 6:
+        return x
+    return torch.cat([x, x.new_zeros((x.shape[0], x.shape[1], 6 - cin))], dim=2).contiguous()
+
+
+def _identity_t64(B, device):
+    """The feature transform of an encoder built WITHOUT one (pointnet2.py:229,254-259: feature_transform=False, the reference
+    default): pass <2> multiplies by the identity -- exact in f32 (x*1 + 0 + ...), to split precision in the split modes."""
+    import torch
+    return torch.eye(64, dtype=torch.float32, device=device).reshape(1, 4096).repeat(B, 1).contiguous()
+
+
 def encoder_forward(W, x, want_pointfeat=False, status=None):
-    """x:(B,N,6) cuda f32 -> global feature (B,1024), trans (B,9), trans_feat TRANSPOSED (B,4096) [, pointfeat]."""
+    """x:(B,N,6) cuda f32 -> global feature (B,1024), trans (B,9), trans_feat TRANSPOSED (B,4096) [, pointfeat].
+    For an encoder without a feature transform (W.has_fstn False) trans_feat is None and pass B is skipped."""
     if current_precision() != 'f32':
         return _encoder_forward_split(W, x, want_pointfeat, status)
     B, N, _ = x.shape
@@ -152,6 +171,10 @@ def encoder_forward(W, x, want_pointfeat=False, status=None):
     h = _dense(W, 'stn.fc1', g, 512, W['stn.fc1b'], relu=True)
     h = _dense(W, 'stn.fc2', h, 256, W['stn.fc2b'], relu=True)
     t3 = _dense(W, 'stn.fc3', h, 9, W['stn.fc3b'], eye_k=3)
+    if not getattr(W, 'has_fstn', True):
+        r = ops.pointmlp_max(x, W['enc.w1'], W['enc.b1'], W['enc.w2'], W['enc.b2'], W['enc.w3'], W['enc.b3'], False,
+                             t3=t3, mid_mode=2, t64=_identity_t64(B, x.device), nsplit=ns, pointfeat=want_pointfeat)
+        return (r[0], t3, None, r[1]) if want_pointfeat else (r, t3, None)
     g = ops.pointmlp_max(x, W['enc.w1'], W['enc.b1'], W['fstn.w2'], W['fstn.b2'], W['fstn.w3'], W['fstn.b3'], True,
                          t3=t3, mid_mode=1, wm=W['fstn.wm'], bm=W['fstn.bm'], nsplit=ns)
     h = _dense(W, 'fstn.fc1', g, 512, W['fstn.fc1b'], relu=True)
@@ -185,6 +208,9 @@ def _encoder_forward_split(W, x, want_pointfeat=False, status=None):
     h = _dense(W, 'stn.fc1', g, 512, W['stn.fc1b'], relu=True, status=status)
     h = _dense(W, 'stn.fc2', h, 256, W['stn.fc2b'], relu=True, status=status)
     t3 = _dense(W, 'stn.fc3', h, 9, W['stn.fc3b'], eye_k=3)
+    if not getattr(W, 'has_fstn', True):
+        r = point_pass('enc', 'enc', False, t3=t3, mid_mode=2, t64=_identity_t64(B, x.device), pointfeat=want_pointfeat)
+        return (r[0], t3, None, r[1]) if want_pointfeat else (r, t3, None)
     g = point_pass('enc', 'fstn', True, mid='fstn.wm', t3=t3, mid_mode=1)
     h = _dense(W, 'fstn.fc1', g, 512, W['fstn.fc1b'], relu=True, status=status)
     h = _dense(W, 'fstn.fc2', h, 256, W['fstn.fc2b'], relu=True, status=status)
@@ -212,6 +238,31 @@ def stn3d_forward(W, x, status=None):
     return _dense(W, 'stn.fc3', h, 9, W['stn.fc3b'], eye_k=3)
 
 
+def stnkd_forward(W, x):
+    """A free-standing STNkd(k) (pointnet2.py:189-223) on x (B,N,k): conv1..3 as row-batched GEMMs over the B*N points (exact f32 in
+    every mode: this module is not on the scoring path), max over each cloud's points (cg_group_max), the FC tail + I_k.  The
+    (B*N,1024) activation is materialised -- cloud batches are processed in slices of <= 2^18 points to bound it at 1 GB.
+    -> (B, k*k) row-major."""
+    import torch
+    B, N, k = x.shape
+    if k != W.k:
+        raise ValueError(f'STNkd({W.k}) got a {k}-channel tensor')
+    if W.k_pad != k:
+        x = torch.cat([x, x.new_zeros((B, N, W.k_pad - k))], dim=2)
+    x = x.contiguous()
+    step = max(1, (1 << 18) // max(N, 1))
+    g = torch.empty((B, 1024), dtype=torch.float32, device=x.device)
+    for s in range(0, B, step):
+        e = min(B, s + step)
+        h = ops.gemm_bias_act(x[s:e].reshape(-1, W.k_pad), W['c1'], 64, W['c1b'], relu=True)
+        h = ops.gemm_bias_act(h, W['c2'], 128, W['c2b'], relu=True)
+        h = ops.gemm_bias_act(h, W['c3'], 1024, W['c3b'], relu=True)
+        g[s:e] = ops.group_max(h, e - s)
+    h = ops.gemm_bias_act(g, W['fc1'], 512, W['fc1b'], relu=True)
+    h = ops.gemm_bias_act(h, W['fc2'], 256, W['fc2b'], relu=True)
+    return ops.gemm_bias_act(h, W['fc3'], k * k, W['fc3b'], eye_k=k)
+
+
 def encoder_module_forward(W, x, global_feat, status=None):
     """A standalone PointNetEncoder(feature_transform=True).forward (pointnet2.py:240-271) with the module's return layout.
     x:(B,N,6) -> (global (B,1024) | cat([global repeated, pointfeat]) (B,1088,N), trans (B,3,3), trans_feat (B,64,64))."""
@@ -219,7 +270,7 @@ def encoder_module_forward(W, x, global_feat, status=None):
     B, N, _ = x.shape
     r = encoder_forward(W, x, want_pointfeat=not global_feat, status=status)
     g, t3, t64 = r[0], r[1], r[2]
-    trans, trans_feat = t3.view(B, 3, 3), t64.view(B, 64, 64).transpose(1, 2)
+    trans, trans_feat = t3.view(B, 3, 3), (t64.view(B, 64, 64).transpose(1, 2) if t64 is not None else None)
     if global_feat:
         return g, trans, trans_feat
     return torch.cat([g.view(B, 1024, 1).expand(-1, -1, N), r[3].transpose(1, 2)], 1), trans, trans_feat

@@ -179,11 +179,25 @@ class DeviceWeights:
         return self.t[k]
 
 
+IN_CH = 6      # input width of the fused per-point passes (xyz + normal); narrower inputs (the reference's default channel=3 ... 5)
+               # ride zero-padded: a zero weight column times a zero input adds exactly +0 to an fmaf chain
+
+
+def _pad_first_layer(w, what):
+    """First-layer weights (64, cin) of an STN3d / encoder conv1 -> (64, 6): cin = 3..6 input channels (pointnet2.py:153,227: the
+    reference default is channel=3), the missing ones as zero columns (the input is zero-padded to match, engine.pad_points)."""
+    cin = w.shape[1]
+    if not 3 <= cin <= IN_CH:
+        raise NotImplementedError(f'{what}: the fused HIP passes take 3..6 input channels (xyz [+ up to 3 features]), got {cin}')
+    return np.concatenate([w, np.zeros((w.shape[0], IN_CH - cin))], axis=1) if cin < IN_CH else w
+
+
 def _prepare_tnet(W, sd, q, tag, k):
     """Fold/pack one STN3d (k=3) / STNkd (k=64) (pointnet2.py:153-223): parameters under prefix q, stored under tag."""
     w, b = fold_bn(*_conv(sd, q + 'conv1'), _bn(sd, q + 'bn1'))
     if k == 3:
-        W.put(tag + '.w1', w); W.put(tag + '.b1', b)          # 6 -> 64 on VALU, unpacked
+        W.cin = w.shape[1]
+        W.put(tag + '.w1', _pad_first_layer(w, 'STN3d.conv1')); W.put(tag + '.b1', b)          # 6 -> 64 on VALU, unpacked
     else:
         W.put(tag + '.wm', pack_b(w)); W.put(tag + '.bm', b)   # 64 -> 64, packed
         W.put_split(tag + '.wm.s', w)
@@ -206,8 +220,26 @@ def _prepare_tnet(W, sd, q, tag, k):
         W.put_half(tag + '.fc3.h', w)       # 256 -> 4096; the 9-wide stn.fc3 stays exact f32
 
 
+def prepare_stnkd(sd, device):
+    """A free-standing STNkd(k) (pointnet2.py:189-223) on an arbitrary k-channel tensor: every layer as a packed GEMM (the fused
+    pass <1> that contains STNkd inside the encoder starts from the 6-channel points, so it cannot serve this module).  k is
+    zero-padded to a multiple of 8 (the GEMM kernel's K granularity); exact-f32 images only."""
+    sd = {k_.replace('module.', ''): v for k_, v in sd.items()}
+    W = DeviceWeights(device)
+    w, b = fold_bn(*_conv(sd, 'conv1'), _bn(sd, 'bn1'))
+    k = w.shape[1]
+    W.k, W.k_pad = k, (k + 7) // 8 * 8
+    W.put('c1', pack_b(np.concatenate([w, np.zeros((64, W.k_pad - k))], axis=1))); W.put('c1b', b)
+    w, b = fold_bn(*_conv(sd, 'conv2'), _bn(sd, 'bn2')); W.put('c2', pack_b(w)); W.put('c2b', b)
+    w, b = fold_bn(*_conv(sd, 'conv3'), _bn(sd, 'bn3')); W.put('c3', pack_b(w)); W.put('c3b', b)
+    w, b = fold_bn(_get(sd, 'fc1.weight'), _get(sd, 'fc1.bias'), _bn(sd, 'bn4')); W.put('fc1', pack_b(w)); W.put('fc1b', b)
+    w, b = fold_bn(_get(sd, 'fc2.weight'), _get(sd, 'fc2.bias'), _bn(sd, 'bn5')); W.put('fc2', pack_b(w)); W.put('fc2b', b)
+    W.put('fc3', pack_b(_get(sd, 'fc3.weight'))); W.put('fc3b', _get(sd, 'fc3.bias'))
+    return W
+
+
 def prepare_stn3d(sd, device):
-    """A standalone STN3d(channel=6) (pointnet2.py:153-185)."""
+    """A standalone STN3d(channel=3..6) (pointnet2.py:153-185)."""
     sd = {k.replace('module.', ''): v for k, v in sd.items()}
     W = DeviceWeights(device)
     _prepare_tnet(W, sd, '', 'stn', 3)
@@ -215,14 +247,19 @@ def prepare_stn3d(sd, device):
 
 
 def prepare_encoder(sd, prefix, device, out=None):
-    """Fold/pack PointNetEncoder(feature_transform=True) weights (pointnet2.py:226-238)."""
+    """Fold/pack PointNetEncoder weights (pointnet2.py:226-238): channel = 3..6, with or without the feature transform (the
+    reference default is feature_transform=False: no `fstn` parameters -- W.has_fstn tells the engine to skip that pass)."""
     sd = {k.replace('module.', ''): v for k, v in sd.items()}
     W = out or DeviceWeights(device)
     p = prefix
     _prepare_tnet(W, sd, p + 'stn.', 'stn', 3)
-    _prepare_tnet(W, sd, p + 'fstn.', 'fstn', 64)
+    W.has_fstn = (p + 'fstn.conv1.weight') in sd
+    if W.has_fstn:
+        _prepare_tnet(W, sd, p + 'fstn.', 'fstn', 64)
     w, b = fold_bn(*_conv(sd, p + 'conv1'), _bn(sd, p + 'bn1'))
-    W.put('enc.w1', w); W.put('enc.b1', b)
+    if w.shape[1] != W.cin:
+        raise ValueError(f'PointNetEncoder: conv1 takes {w.shape[1]} channels but its STN3d {W.cin}')
+    W.put('enc.w1', _pad_first_layer(w, 'PointNetEncoder.conv1')); W.put('enc.b1', b)
     w, b = fold_bn(*_conv(sd, p + 'conv2'), _bn(sd, p + 'bn2'))
     W.put('enc.w2', pack_b(w)); W.put('enc.b2', b); W.put_split('enc.w2.s', w)
     w, b = fold_bn(*_conv(sd, p + 'conv3'), _bn(sd, p + 'bn3'))

@@ -77,6 +77,17 @@ def gemm_bias_act(x, wp, n_out, bias=None, relu=False, eye_k=0, row_bias=None, r
     return y
 
 
+def group_max(x, groups):
+    """x (groups * rows, C) -> (groups, C): max over the rows of every group (cg_group_max)."""
+    require_cuda(x)
+    f32c(x)
+    rows = x.shape[0] // max(groups, 1)
+    assert groups * rows == x.shape[0]
+    out = torch.empty((groups, x.shape[1]), dtype=torch.float32, device=x.device)
+    check(L.lib().cg_group_max(_p(x), _c_long(groups), _c_long(rows), _c_int(x.shape[1]), _p(out), _stream()), 'cg_group_max')
+    return out
+
+
 def softmax_pg(logits):
     """logits:(B,C) -> probs (B,C), label (B) int32, confidence (B), p_G (B)."""
     require_cuda(logits)

@@ -11,8 +11,10 @@ Execution:
   * training mode (or grad enabled)    -> ordinary differentiable torch ops, so the reference trainers
     keep working (training is out of scope of the HIP path).
   * eval mode on a CPU tensor           -> RuntimeError: there is no CPU inference fallback.
-The same rule holds for the building blocks used on their own: STN3d and PointNetEncoder dispatch to the fused HIP passes, and a
-free-standing STNkd (which only exists fused into the encoder passes) raises instead of silently running stock torch ops.
+The same rule holds for the building blocks used on their own: STN3d and PointNetEncoder (channel = 3..6, with or without the
+feature transform -- the reference defaults are channel=3, feature_transform=False) dispatch to the fused HIP passes; a
+free-standing STNkd(k) runs its layers on the HIP GEMM kernel (inside the encoder it is fused into pass <1>).  More than 6 input
+channels raise NotImplementedError (INTEGRATION.md, "contract limits").
 """
 import torch
 import torch.nn as nn
@@ -94,10 +96,9 @@ class STN3d(_TNet):
 
     def _hip_forward(self, x):
         """Eval-mode inference of a standalone STN3d: the fused STN pass + FC tail (engine.stn3d_forward)."""
-        if self._channel != 6:
-            raise NotImplementedError('HIP path is built for the 6-channel (xyz+normal) input')
-        W = _cached_weights(self, x.device, folding.prepare_stn3d)
-        return engine.run_guarded_features(engine.stn3d_forward, W, x.float().transpose(1, 2).contiguous()).view(-1, 3, 3)
+        W = _cached_weights(self, x.device, folding.prepare_stn3d)       # channel = 3..6 (more: NotImplementedError from the fold)
+        xt = engine.pad_points(x.float().transpose(1, 2).contiguous(), W.cin)
+        return engine.run_guarded_features(engine.stn3d_forward, W, xt).view(-1, 3, 3)
 
 
 class STNkd(_TNet):
@@ -106,11 +107,11 @@ class STNkd(_TNet):
         self.k = k
 
     def _hip_forward(self, x):
-        # The HIP pass that contains STNkd (<1>) starts from the 6-channel points and applies the encoder's conv1 first; a
-        # free-standing STNkd on an arbitrary 64-channel tensor has no kernel.  No silent torch fallback on an inference path:
-        raise NotImplementedError('catgrasp_amd.pointnet2.STNkd has no standalone HIP inference path (it is fused into '
-                                  'PointNetEncoder / PointNetCls / PointNetSeg); call the enclosing module, or run it with grad '
-                                  'enabled / in train() mode for the differentiable torch ops')
+        """Eval-mode inference of a free-standing STNkd on an arbitrary (B,k,N) tensor (pointnet2.py:206-223): the fused pass that
+        contains STNkd inside the encoder starts from the 6-channel points, so here every layer runs on the HIP GEMM kernel, with the
+        max over points on cg_group_max (engine.stnkd_forward; exact f32 in every arithmetic mode)."""
+        W = _cached_weights(self, x.device, folding.prepare_stnkd)
+        return engine.stnkd_forward(W, x.float().transpose(1, 2).contiguous()).view(-1, self.k, self.k)
 
 
 class PointNetEncoder(nn.Module):
@@ -132,10 +133,8 @@ class PointNetEncoder(nn.Module):
         """x:(B,D,N).  Eval-mode inference on a HIP tensor runs the fused passes (the same kernels PointNetCls / PointNetSeg use);
         training / grad-enabled calls use the differentiable torch ops below."""
         if _use_hip(self, x):
-            if x.shape[1] != 6 or not self.feature_transform:
-                raise NotImplementedError('HIP path is built for PointNetEncoder(feature_transform=True, channel=6)')
             W = _cached_weights(self, x.device, lambda sd, dev: folding.prepare_encoder(sd, '', dev))
-            xt = x.float().transpose(1, 2).contiguous()
+            xt = engine.pad_points(x.float().transpose(1, 2).contiguous(), W.cin)
             gf = self.global_feat
             return engine.run_guarded_features(lambda w, xx, st: engine.encoder_module_forward(w, xx, gf, st), W, xt)
         return self._torch_forward(x)
@@ -187,9 +186,8 @@ class PointNetCls(_HipCached):
 
     def forward(self, x):
         if _use_hip(self, x):
-            if self._n_in != 6:
-                raise NotImplementedError('HIP path is built for the 6-channel (xyz+normal) input of config_grasp.yml')
-            return engine.run_guarded(engine.cls_forward, self._device_weights(x.device), x.float().contiguous())
+            W = self._device_weights(x.device)                               # n_in = 3..6 (config_grasp.yml: 6)
+            return engine.run_guarded(engine.cls_forward, W, engine.pad_points(x.float().contiguous(), W.cin))
         g, _, trans_feat = self.feat._torch_forward(x.permute(0, 2, 1))
         h = F.relu(self.bn1(self.fc1(g)))
         h = F.relu(self.bn2(self.fc2(self.dropout(h))))
@@ -214,9 +212,8 @@ class PointNetSeg(_HipCached):
 
     def forward(self, x):
         if _use_hip(self, x):
-            if self._n_in != 6:
-                raise NotImplementedError('HIP path is built for the 6-channel (xyz+normal) input of config_nunocs.yml')
-            return engine.run_guarded(engine.seg_forward, self._device_weights(x.device), x.float().contiguous())
+            W = self._device_weights(x.device)                               # n_in = 3..6 (config_nunocs.yml: 6)
+            return engine.run_guarded(engine.seg_forward, W, engine.pad_points(x.float().contiguous(), W.cin))
         f, _, trans_feat = self.feat._torch_forward(x.permute(0, 2, 1))
         h = F.relu(self.bn1(self.conv1(f)))
         h = F.relu(self.bn2(self.conv2(h)))

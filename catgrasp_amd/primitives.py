@@ -16,15 +16,16 @@ def _f32(t):
 
 
 def square_distance(src, dst):
-    """src (B,N,C=3), dst (B,M,3) -> (B,N,M) squared distances (-2ab + a^2 + b^2, pointnet2.py:30-32)."""
+    """src (B,N,C), dst (B,M,C) -> (B,N,M) squared distances (-2ab + a^2 + b^2, pointnet2.py:30-32).  Any C, like the reference
+    (its callers pass xyz: C = 3 takes the tiled kernel, other widths the generic one)."""
     require_cuda(src, dst)
     src = _f32(src); dst = _f32(dst)
     B, N, C = src.shape
     M = dst.shape[1]
-    if C != 3 or dst.shape[2] != 3:
-        raise NotImplementedError('square_distance HIP kernel is built for 3-D points')
+    if dst.shape[0] != B or dst.shape[2] != C or C < 1:
+        raise ValueError(f'square_distance: src {tuple(src.shape)} and dst {tuple(dst.shape)} do not match')
     out = torch.empty((B, N, M), dtype=torch.float32, device=src.device)
-    check(L.lib().cg_square_distance(_p(src), _p(dst), _c_int(B), _c_int(N), _c_int(M), _p(out), _stream()), 'cg_square_distance')
+    check(L.lib().cg_square_distance_nd(_p(src), _p(dst), _c_int(B), _c_int(N), _c_int(M), _c_int(C), _p(out), _stream()), 'cg_square_distance_nd')
     return out
 
 

@@ -61,6 +61,30 @@ def make_state_dict(kind, n_in, n_out, seed=0, prefix='', gain=1.6):
     return sd
 
 
+def seeded_like(state_dict, seed=0, gain=1.6):
+    """A seeded synthetic checkpoint for ANY module of the pointnet2 family, from the names / shapes of its own state_dict (key
+    order = the module's): BatchNorm statistics as in make_state_dict, weights ~ U(+-gain/sqrt(fan_in)).  Used for the standalone
+    building blocks (STN3d / STNkd / PointNetEncoder with the reference's other constructor arguments)."""
+    rng = np.random.default_rng(seed)
+    out = {}
+    fan = {}
+    for name, t in state_dict.items():
+        shp = tuple(t.shape)
+        leaf = name.rsplit('.', 1)[-1]
+        is_bn = (name.rsplit('.', 1)[0] + '.running_var') in state_dict
+        if leaf == 'num_batches_tracked':
+            out[name] = torch.tensor(100, dtype=torch.long)
+        elif is_bn:
+            v = rng.uniform(0.5, 1.5, shp) if leaf in ('weight', 'running_var') else rng.normal(0, 0.1, shp)
+            out[name] = torch.from_numpy(v.astype(np.float32))
+        else:
+            if leaf == 'weight':
+                fan[name.rsplit('.', 1)[0]] = int(np.prod(shp[1:]))
+            b = gain / np.sqrt(fan[name.rsplit('.', 1)[0]])
+            out[name] = torch.from_numpy(rng.uniform(-b, b, shp).astype(np.float32))
+    return out
+
+
 # ---------------------------------------------------------------------------------------------
 # objects, scenes
 # ---------------------------------------------------------------------------------------------

@@ -56,11 +56,11 @@ int cg_pointmlp_max_bf16x3(const float* x, int B, int N, const float* t3, const 
                            const float* b3, int relu3, int nsplit, int tile_points, float* out, float* pointfeat,
                            void* stream);
 /* Same with IEEE-half pieces ("f16x3", 11 + 11 significant bits instead of 8 + 8): logits within ~2e-6 of the float64 evaluation,
- * i.e. float32's own distance, at the same three MFMAs per product block.  Weights packed by folding.pack_b_split(w, 'f16').  The
- * default arithmetic of the engine.  The half pieces have a limited exponent range; `status` (optional device int, owned and
+ * i.e. float32's own distance, at the same three MFMAs per product block.  Weights packed by folding.pack_b_split(w, 'f16').  OPT-IN
+ * (CATGRASP_AMD_PRECISION=f16x3): the engine's default arithmetic is the exact-f32 cg_pointmlp_max.  The half pieces have a limited exponent range; `status` (optional device int, owned and
  * zeroed by the caller, one per call or per batch -- there is no process-global state) gets CG_STATUS_HALF_OVERFLOW OR-ed in if
  * a value handed to the split reached 65504 (the result is then meaningless) and CG_STATUS_HALF_UNDERFLOW if a whole layer
- * output of some 32-point tile stayed below 2^-6 (its low pieces then sit in the half subnormals: absolute instead of relative
+ * output of some 32-point tile (cg_gemm_bias_act_f16x3: the whole 128-row X tile of some workgroup) stayed below 2^-6 (its low pieces then sit in the half subnormals: absolute instead of relative
  * error).  On either bit re-run the batch with the bf16x3 (float32 exponent range) or f32 entry point. */
 #define CG_STATUS_HALF_OVERFLOW 1
 #define CG_STATUS_HALF_UNDERFLOW 2
@@ -75,7 +75,9 @@ int cg_pointmlp_max_f16x3(const float* x, int B, int N, const float* t3, const f
  * instruction, f32 accumulation into the same registers) -- 128 instead of 192 matrix passes per 32x32x128 product block.  The e4m3
  * rounding of the OTHER factor of each correction term (2^-4 relative, on a term that is 2^-11 of the product) puts the logits within
  * ~5e-5 of the float64 evaluation (parity bar 1e-4).  w3_mx: folding.pack_b_f16fp8x2 (16,640 B per 32 output channels); every
- * other argument, the front layers (f16x3) and `status` as cg_pointmlp_max_f16x3.  Opt-in: CATGRASP_AMD_PRECISION=f16fp8x2. */
+ * other argument, the front layers (f16x3) and `status` as cg_pointmlp_max_f16x3.  EXPERIMENTAL, opt-in
+ * (CATGRASP_AMD_PRECISION=f16fp8x2): the mode is specified on the networks' logits / probabilities; on raw encoder features it measures
+ * ~1.1e-4 of the feature scale, so the free-standing STN3d / PointNetEncoder modules run f16x3 under it (engine.run_guarded_features). */
 int cg_pointmlp_max_f16fp8x2(const float* x, int B, int N, const float* t3, const float* w1, const float* b1,
                              int mid_mode, const unsigned short* wm_split, const float* bm, const float* t64,
                              const unsigned short* w2_split, const float* b2, const void* w3_mx,
@@ -99,6 +101,11 @@ int cg_gemm_bias_act_bf16x3(const float* x, int M, int K, int ldx, const unsigne
 int cg_gemm_bias_act_f16x3(const float* x, int M, int K, int ldx, const unsigned short* w_split, int N,
                             const float* bias, const float* row_bias, int rows_per_group, int ld_rb,
                             int relu, int eye_k, float* y, int ldy, int* status, void* stream);
+
+/* Max-pool over points of a MATERIALISED activation tensor: x (groups * rows_per_group, C) -> out (groups, C), out[g][c] = max over
+ * the rows of group g (torch.max(x, 2)[0] of pointnet2.py:176,214).  The fused passes above never materialise it; this serves the
+ * free-standing STNkd module (pointnet2.py:189-223), whose input is an arbitrary k-channel tensor. */
+int cg_group_max(const float* x, long groups, long rows_per_group, int C, float* out, void* stream);
 
 /* softmax / argmax / confidence (predicter.py:86-91) and p_G = sum_k p_k * k / C
  * (run_grasp_simulation.py:313).  logits (B,C) -> probs (B,C), label (B) i32, conf (B), p_g (B). */
@@ -248,6 +255,9 @@ int cg_pose_inverse_rows(const float* poses, long n_poses, const double* h_cente
 
 /* square_distance (pointnet2.py:14-33): src (B,N,3), dst (B,M,3) -> out (B,N,M) = -2 s.d + |s|^2 + |d|^2. */
 int cg_square_distance(const float* src, const float* dst, int B, int N, int M, float* out, void* stream);
+/* The same for C-dimensional points, src (B,N,C), dst (B,M,C) (pointnet2.py:14-33 is generic in C; the live callers pass xyz):
+ * sums over the channels in index order.  C == 3 forwards to cg_square_distance. */
+int cg_square_distance_nd(const float* src, const float* dst, int B, int N, int M, int C, float* out, void* stream);
 
 /* index_points (pointnet2.py:35-51): points (B,N,C), idx (B,S) [S may be S*K flattened] -> out (B,S,C).
  * *err_flag (device int, pre-zeroed) is set to 1 on an out-of-range index (the reference raises IndexError). */

@@ -1,5 +1,6 @@
 """Summarise a rocprofv3 --pmc run (--output-format csv) into a small per-kernel CSV of counter means for profiles/.
-usage: python scripts/pmc_summary.py <dir with *_counter_collection.csv [+ *_kernel_trace.csv]> <out.csv> [kernel-name filter]"""
+usage: python scripts/pmc_summary.py <dir with *_counter_collection.csv [+ *_kernel_trace.csv]> <out.csv> [kernel-name filter]
+Launches of one kernel with different grid sizes (e.g. one cloud vs 16 clouds) are reported as separate rows: kernel@grid."""
 import csv
 import glob
 import os
@@ -30,16 +31,18 @@ for path in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursiv
                 continue
             key = (r.get('Dispatch_Id') or r.get('dispatch_id'), r.get('Counter_Name') or r.get('counter_name'))
             per_dispatch[key] += float(r.get('Counter_Value') or r.get('counter_value'))
-            names[key[0]] = k
+            names[key[0]] = k + '@' + str(r.get('Grid_Size') or r.get('grid_size') or '')
     for (disp, cname), v in per_dispatch.items():
-        vals[(short(names[disp]), cname)].append(v)
+        nm, grid = names[disp].rsplit('@', 1)
+        vals[(short(nm) + ('@grid=' + grid if grid else ''), cname)].append(v)
 for path in glob.glob(os.path.join(d, '**', '*kernel_trace.csv'), recursive=True):
     with open(path) as f:
         for r in csv.DictReader(f):
             k = r.get('Kernel_Name')
             if flt and flt not in k:
                 continue
-            vals[(short(k), 'duration_ns')].append(float(r['End_Timestamp']) - float(r['Start_Timestamp']))
+            grid = r.get('Grid_Size') or r.get('Grid_Size_X') or ''
+            vals[(short(k) + ('@grid=' + str(grid) if grid else ''), 'duration_ns')].append(float(r['End_Timestamp']) - float(r['Start_Timestamp']))
 with open(out, 'w') as f:
     f.write('kernel,counter,mean,launches\n')
     for (k, c), v in sorted(vals.items()):

@@ -22,7 +22,8 @@ def cuda_device():
 
 # Every GPU test module that runs the PointNet kernels is executed under ALL arithmetic modes of the engine (exact-f32 MFMA, the
 # split-half "f16x3" MFMA path, its bf16 sibling, and the 2-unit "f16fp8x2" mode), against the same oracle and bar.
-_NET_MODULES = ('test_pointnet_gpu', 'test_predicter_gpu', 'test_pipeline_gpu', 'test_fullsize_properties_gpu', 'test_workload_gpu', 'test_zz_c1_config_gpu')
+_NET_MODULES = ('test_pointnet_gpu', 'test_predicter_gpu', 'test_pipeline_gpu', 'test_fullsize_properties_gpu', 'test_workload_gpu', 'test_zz_c1_config_gpu',
+                'test_pointnet_blocks_gpu')
 
 
 def pytest_generate_tests(metafunc):

@@ -127,3 +127,39 @@ def test_training_mode_equals_the_imported_reference_bit_for_bit():
         assert all(torch.equal(p.grad, gb[k].grad) for k, p in a.named_parameters())
         sb = b.state_dict()
         assert all(torch.equal(v, sb[k]) for k, v in a.state_dict().items())
+
+
+def test_dropin_building_blocks_with_every_constructor_setting_match_the_reference():
+    """The drop-in modules in their torch formulation (grad enabled: the path the trainers use; CPU) vs the REAL reference classes for
+    the constructor arguments the live pipeline does not use -- STN3d(3|5), STNkd(64|20), PointNetEncoder(global_feat x
+    feature_transform x channel 3|4|6) incl. the reference defaults, PointNetCls(3,10), PointNetSeg(4,30)
+    (tests/golden/pointnet2_blocks_golden.npz).  Same state_dict keys, same numbers.  The HIP path of the same modules is checked
+    against the same file on the GPU (tests/test_pointnet_blocks_gpu.py)."""
+    from catgrasp_amd import pointnet2 as p2
+    g = np.load(os.path.join(os.path.dirname(GOLD), 'pointnet2_blocks_golden.npz'))
+
+    def sample(t):
+        if t.dim() == 3 and t.shape[1] == 1088:
+            return t[:, ::9, ::4]
+        if t.dim() == 3 and tuple(t.shape[1:]) == (64, 64):
+            return t[:, ::3, ::3]
+        return t
+    cases = [(f'stn3d_c{c}', lambda c=c: p2.STN3d(c)) for c in (3, 5)] + [(f'stnkd_k{k}', lambda k=k: p2.STNkd(k=k)) for k in (64, 20)]
+    cases += [(f'enc_g{int(gf)}_f{int(ft)}_c{c}', lambda gf=gf, ft=ft, c=c: p2.PointNetEncoder(global_feat=gf, feature_transform=ft, channel=c))
+              for gf in (True, False) for ft in (False, True) for c in (3, 4, 6)]
+    cases += [('cls_c3', lambda: p2.PointNetCls(3, 10)), ('seg_c4', lambda: p2.PointNetSeg(4, 30))]
+    for tag, make in cases:
+        m = make()
+        m.load_state_dict(synth.seeded_like(m.state_dict(), int(g[tag + '_seed'][0])))
+        m.eval()
+        with torch.enable_grad():
+            y = m(torch.from_numpy(g[tag + '_x']))
+        ys = y if isinstance(y, tuple) else (y,)
+        for i, t in enumerate(ys):
+            ref = g[f'{tag}_y{i}']
+            if t is None:
+                assert ref.size == 0, tag
+                continue
+            got = sample(t.detach()).numpy()
+            assert got.shape == ref.shape, (tag, i)
+            assert np.abs(got - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max()), (tag, i)

@@ -219,3 +219,22 @@ def test_c1_config_oracle_chain_against_real_predict_batch():
     sure = srt[:, -1] - srt[:, -2] > 1e-5
     assert sure.mean() > 0.95 and np.array_equal(np.array([r[0] for r in post])[sure], p['grasp_labels'][sure])
     assert np.abs(np.array([r[1] for r in post]) - p['grasp_conf']).max() < 5e-6
+
+
+def test_oracle_kdtree_evaluation_matches_the_real_worker():
+    """aligning.estimate9DTransform_worker(use_kdtree_for_eval=True) (aligning.py:63-76) run for real (cv2 / open3d substituted as
+    tests/golden/make_golden_aligning_kd.py states) vs oracle/aligning_ref.worker: same accept / reject, ratios, transforms, inliers."""
+    from oracle import aligning_ref as aref
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'aligning_kd_golden.npz'))
+    n_acc = 0
+    for si, (thr, res) in enumerate(g['settings']):
+        for k in range(len(g['ids'])):
+            o = aref.worker(g['src'][g['ids'][k]], g['dst'][g['ids'][k]], g['src'], g['dst'], thr, np.array([0.05] * 3), np.array([0.005, 0.005, 0.001]),
+                            np.array([1.2] * 3), True, res)
+            if g[f'ratio{si}'][k] < 0:
+                assert o is None
+                continue
+            n_acc += 1
+            m = np.zeros(len(g['src']), dtype=np.uint8); m[o[2]] = 1
+            assert abs(o[0] - g[f'ratio{si}'][k]) < 1e-12 and np.abs(o[1] - g[f'tf{si}'][k]).max() < 1e-12 and np.array_equal(m, g[f'inliers{si}'][k])
+    assert n_acc >= 40

@@ -92,8 +92,13 @@ def test_nunocs_predict_nocs(cuda_device):
     assert np.array_equal(nocs[clear], rcoords[clear])
     zclear = clear[:, 2]
     assert np.abs(conf[zclear] - rconf[zclear]).max() <= 1e-4
-    out = npred.predict(data)       # device RANSAC; random weights -> either outcome of the reference contract
-    assert out == (None, None) or (out[0].shape == (8192, 3) and out[1].shape == (4, 4))
+    # predict(): the device RANSAC replayed through the oracle on the same numpy stream (tests/test_aligning_gpu.py holds the helpers)
+    from test_aligning_gpu import _oracle_predict_tail, _same_outcome
+    np.random.seed(9)
+    out = npred.predict(data)
+    np.random.seed(9)
+    nocs2, _, dt2 = npred.predict_nocs(data)
+    _same_outcome(out, _oracle_predict_tail(nocs2, dt2['cloud_xyz_original'], npred.min_scale, npred.max_scale, 10000), npred)
 
 
 def test_pointnet2_modules_dropin(cuda_device):
@@ -138,7 +143,7 @@ def test_pointnet2_modules_dropin(cuda_device):
 
 def test_standalone_building_blocks_run_on_the_hip_passes(cuda_device, mlp_precision):
     """`from pointnet2 import *` users who call STN3d / PointNetEncoder directly in eval mode get the fused HIP passes
-    (not a silent stock-torch second backend); a free-standing STNkd, which has no kernel of its own, raises."""
+    (not a silent stock-torch second backend); a free-standing STNkd runs its layers on the HIP GEMM kernel."""
     from catgrasp_amd import ops
     from catgrasp_amd import pointnet2 as p2
     sd = synth.make_state_dict('seg', 6, 300, seed=12)
@@ -174,12 +179,13 @@ def test_standalone_building_blocks_run_on_the_hip_passes(cuda_device, mlp_preci
         assert calls == [0] and (t2.detach().cpu() - rt).abs().max().item() <= 1e-4
     finally:
         ops.pointmlp_max = real
-    kd = p2.STNkd(64).cuda().eval()
-    with pytest.raises(NotImplementedError):
-        with torch.no_grad():
-            kd(torch.zeros(2, 64, 100, device=cuda_device))
+    kd = p2.STNkd(64).cuda().eval()              # free-standing STNkd: GEMM kernels + group max (parity: tests/test_pointnet_blocks_gpu.py)
+    xk = torch.randn(2, 64, 100, device=cuda_device)
+    with torch.no_grad():
+        t_hip = kd(xk)
     with torch.enable_grad():
-        assert kd(torch.zeros(2, 64, 100, device=cuda_device)).shape == (2, 64, 64)
+        t_torch = kd(xk)
+    assert t_hip.shape == (2, 64, 64) and (t_hip - t_torch.detach()).abs().max().item() <= 1e-4
 
 
 def test_dropin_predicters_against_the_real_reference_outputs(cuda_device, mlp_precision):
