@@ -11,6 +11,7 @@
 // torch CPU evaluation only where |d^2 - r^2| is within float rounding of the -2ab+a^2+b^2 expansion.
 #include "cg_common.hpp"
 #include "../../include/catgrasp_amd.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -88,90 +89,137 @@ __global__ __launch_bounds__(256) void index_points_kernel(const float* __restri
 }
 
 // ---------------------------------------------------------------- farthest point sampling
-// One workgroup (1024 threads) per cloud.  Thread t owns points t, t+1024, ... (PPT of them) in registers.
-// Each of the npoint rounds: update the running min distance to the chosen set, then one arg-max over the cloud (first index on
-// ties).  The round is a dependent chain, so its latency is what counts:
-//  * (distance, index) travel as ONE 64-bit key  bits(dist) << 32 | (INT_MAX - index)  (distances are >= 0, so their bit patterns
-//    order like the values; the low word makes the smaller index win ties) reduced with DPP row operations -- quad_perm, row
-//    mirrors, row broadcasts: ~8 cycles each instead of a ds_bpermute per value and step;
-//  * the winner's COORDINATES travel with it through LDS (the owning lane publishes them), so the next round does not start with
-//    a dependent global load of xyz[farthest];
-//  * one workgroup barrier per round (double-buffered exchange).
-// Round-1 form (ds_bpermute shuffles + centroid re-read from global memory): 4.1 us per round at N = 20,000.
-__device__ __forceinline__ unsigned long long dpp_max_u64(unsigned long long k, unsigned long long o) { return o > k ? o : k; }
-
+// One workgroup per cloud.  Thread t owns points t, t+NT, ... (PPT of them) in registers.  Each of the npoint rounds: update the
+// running min distance to the chosen set, then one arg-max over the cloud (first index on ties).  The round is a dependent chain on
+// ONE CU (splitting a cloud over CUs would put a >= 4 us device-scope barrier into a ~1.5 us round: MI355X_MICROARCH.md, barrier
+// table), so what counts is the VALU work per point and the latency of the exchange:
+//  * round-3 inner loop, 8 VALU per point: two points per packed-f32 instruction for the bit-exact (dx*dx + dy*dy) + dz*dz
+//    (3 v_pk_add, 3 v_pk_mul, 2 v_pk_add per PAIR), v_min for the running distance, and a branch-free (value, slot) arg-max
+//    (v_cmp + 2 v_cndmask) -- round 2 spent ~15 VALU + 5 SALU per point on an exec-mask branch per slot that also carried the
+//    winner's coordinates and index along;
+//  * the reduction travels as a 32-bit VALUE (v_max with DPP row operations: 6 steps per wave); the winner lane is the single lane
+//    that holds it -- ties (duplicate points, lattices) take a wave-uniform slow path that reduces the indices too, so the result is
+//    still "first index among equal maxima";
+//  * only the wave's winner needs its coordinates: its slot number is made wave-uniform (v_readlane) and a uniform binary search
+//    picks the slot's registers, no per-slot select;
+//  * the winners of the waves meet in LDS as (value, x, y, z) + index, ONE workgroup barrier per round (double-buffered), and the next
+//    centre is taken out of the exchanged records with v_readlane -- no dependent LDS or global read at the top of the round.
+// History (N = 20,000 -> 1,024, one cloud): 4.19 ms (round 1) -> 2.71 ms (round 2: 64-bit DPP keys) -> see profiles/ (round 3).
 template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ unsigned long long dpp_step(unsigned long long k) {
-  const unsigned lo = (unsigned)k, hi = (unsigned)(k >> 32);
-  const unsigned olo = (unsigned)__builtin_amdgcn_update_dpp((int)lo, (int)lo, CTRL, ROW_MASK, 0xf, false);
-  const unsigned ohi = (unsigned)__builtin_amdgcn_update_dpp((int)hi, (int)hi, CTRL, ROW_MASK, 0xf, false);
-  return dpp_max_u64(k, ((unsigned long long)ohi << 32) | olo);
+__device__ __forceinline__ float dpp_max_f32(float v) {
+  const float o = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+  return o > v ? o : v;
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_min_i32(int v) {
+  const int o = __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xf, false);
+  return o < v ? o : v;
+}
+// max / min over the 16 lanes of every DPP row (all lanes of the row get it)
+__device__ __forceinline__ float row_max_f32(float v) {
+  v = dpp_max_f32<0xB1, 0xf>(v);      // quad_perm [1,0,3,2]
+  v = dpp_max_f32<0x4E, 0xf>(v);      // quad_perm [2,3,0,1]
+  v = dpp_max_f32<0x141, 0xf>(v);     // row_half_mirror
+  return dpp_max_f32<0x140, 0xf>(v);  // row_mirror
+}
+__device__ __forceinline__ int row_min_i32(int v) {
+  v = dpp_min_i32<0xB1, 0xf>(v); v = dpp_min_i32<0x4E, 0xf>(v); v = dpp_min_i32<0x141, 0xf>(v);
+  return dpp_min_i32<0x140, 0xf>(v);
+}
+// over the wavefront, returned wave-uniform
+__device__ __forceinline__ float wave_max_f32(float v) {
+  v = row_max_f32(v);
+  v = dpp_max_f32<0x142, 0xa>(v);     // row_bcast15 into rows 1 and 3
+  v = dpp_max_f32<0x143, 0xc>(v);     // row_bcast31 into rows 2 and 3: lane 63 holds the wave maximum
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ int wave_min_i32(int v) {
+  v = row_min_i32(v);
+  v = dpp_min_i32<0x142, 0xa>(v);
+  v = dpp_min_i32<0x143, 0xc>(v);
+  return __builtin_amdgcn_readlane(v, 63);
 }
 
-// max over the 16 lanes of every DPP row (all lanes of the row get it)
-__device__ __forceinline__ unsigned long long row_max_u64(unsigned long long k) {
-  k = dpp_step<0xB1, 0xf>(k);      // quad_perm [1,0,3,2]
-  k = dpp_step<0x4E, 0xf>(k);      // quad_perm [2,3,0,1]
-  k = dpp_step<0x141, 0xf>(k);     // row_half_mirror
-  k = dpp_step<0x140, 0xf>(k);     // row_mirror
-  return k;
+// registers of slot k (wave-uniform k) by a uniform binary search: log2(PPT) scalar branches instead of a select per slot
+template <int LO, int HI, int H>
+__device__ __forceinline__ void fps_pick(int k, const f32x2 (&px)[H], const f32x2 (&py)[H], const f32x2 (&pz)[H], float& x, float& y, float& z) {
+  if constexpr (HI - LO == 1) { x = px[LO >> 1][LO & 1]; y = py[LO >> 1][LO & 1]; z = pz[LO >> 1][LO & 1]; }
+  else {
+    constexpr int MID = (LO + HI) / 2;
+    if (k < MID) fps_pick<LO, MID, H>(k, px, py, pz, x, y, z);
+    else fps_pick<MID, HI, H>(k, px, py, pz, x, y, z);
+  }
 }
 
-// max over the wavefront, returned in every lane
-__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long k) {
-  k = row_max_u64(k);
-  k = dpp_step<0x142, 0xa>(k);     // row_bcast15 into rows 1 and 3
-  k = dpp_step<0x143, 0xc>(k);     // row_bcast31 into rows 2 and 3: lane 63 holds the wave maximum
-  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)k, 63);
-  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(k >> 32), 63);
-  return ((unsigned long long)hi << 32) | lo;
-}
-
-// NT threads, thread t owns points t, t+NT, ...: 1024 threads (<= 128 registers each) for clouds up to 8,192 points, 512 threads
-// (<= 256 registers: 40-48 points per thread without spilling) for clouds up to 24,576.
+// NT threads, thread t owns points t, t+NT, ...; PPT even.
 template <int NT, int PPT>
 __global__ __launch_bounds__(NT) void fps_kernel(const float* __restrict__ xyz, const long long* __restrict__ start, int N, int npoint,
                                                  long long* __restrict__ out) {
-  __shared__ unsigned long long red_k[2][16];
-  __shared__ float red_c[2][16][4];
+  static_assert(PPT % 2 == 0 && NT % 64 == 0 && NT <= 1024, "geometry");
+  constexpr int H = PPT / 2;
+  __shared__ f32x4 red_v[2][16];       // per wave: (best distance, x, y, z) of its winner
+  __shared__ int red_i[2][16];         //           its point index
   const int b = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  if (tid < 32) red_k[tid >> 4][tid & 15] = 0ull;          // slots of absent waves: key 0 loses against every real candidate
+  if (tid < 32) { red_v[tid >> 4][tid & 15] = f32x4{-1.f, 0.f, 0.f, 0.f}; red_i[tid >> 4][tid & 15] = 0x7fffffff; }   // absent waves never win
   __syncthreads();
   const float* xb = xyz + (size_t)b * N * 3;
-  float px[PPT], py[PPT], pz[PPT], dist[PPT];
+  f32x2 px[H], py[H], pz[H];
+  float dist[PPT];
 #pragma unroll
   for (int k = 0; k < PPT; ++k) {
     const int p = tid + k * NT;
-    if (p < N) { px[k] = xb[p * 3 + 0]; py[k] = xb[p * 3 + 1]; pz[k] = xb[p * 3 + 2]; dist[k] = 1e10f; }
-    else { px[k] = 0.f; py[k] = 0.f; pz[k] = 0.f; dist[k] = 0.0f; }    // padding: distance 0 and the largest indices -> loses every tie
+    float x = 0.f, y = 0.f, z = 0.f, d0 = 0.0f;     // padding: running distance 0 never shrinks (d >= 0) and never beats a real point first
+    if (p < N) { x = xb[p * 3 + 0]; y = xb[p * 3 + 1]; z = xb[p * 3 + 2]; d0 = 1e10f; }
+    px[k >> 1][k & 1] = x; py[k >> 1][k & 1] = y; pz[k >> 1][k & 1] = z; dist[k] = d0;
   }
   int farthest = (int)start[b];
   float cx = xb[farthest * 3 + 0], cy = xb[farthest * 3 + 1], cz = xb[farthest * 3 + 2];
   for (int it = 0; it < npoint; ++it) {
     if (tid == 0) out[(size_t)b * npoint + it] = farthest;
-    float bv = -1.0f, bx = 0.f, by = 0.f, bz = 0.f; int bi = 0x7fffffff;
+    const f32x2 c2x = {cx, cx}, c2y = {cy, cy}, c2z = {cz, cz};
+    float bv = -1.0f; int bk = 0;
 #pragma unroll
-    for (int k = 0; k < PPT; ++k) {
-      const float dx = px[k] - cx, dy = py[k] - cy, dz = pz[k] - cz;
-      const float d = (dx * dx + dy * dy) + dz * dz;        // torch.sum((xyz - centroid) ** 2, -1)
-      const int p = tid + k * NT;
-      if (p < N && d < dist[k]) dist[k] = d;                 // mask = dist < distance
-      if (dist[k] > bv) { bv = dist[k]; bi = p; bx = px[k]; by = py[k]; bz = pz[k]; }      // ascending p within a thread: first maximum kept
+    for (int h = 0; h < H; ++h) {
+      const f32x2 dx = px[h] - c2x, dy = py[h] - c2y, dz = pz[h] - c2z;
+      const f32x2 d = (dx * dx + dy * dy) + dz * dz;        // torch.sum((xyz - centroid) ** 2, -1), two points per instruction
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const float nd = d[e] < dist[2 * h + e] ? d[e] : dist[2 * h + e];     // mask = dist < distance; distance[mask] = dist[mask]
+        dist[2 * h + e] = nd;
+        const bool g = nd > bv;                              // ascending point index within a thread: the first maximum is kept
+        bv = g ? nd : bv; bk = g ? 2 * h + e : bk;
+      }
     }
-    const unsigned long long key = ((unsigned long long)__float_as_uint(bv) << 32) | (unsigned)(0x7fffffff - bi);
-    const unsigned long long wmax = wave_max_u64(key);
+    // ---- wave: who holds the largest running distance (smallest index among equals) ----
+    const float wmax = wave_max_f32(bv);
+    const int bi = tid + bk * NT;
+    unsigned long long cand = __ballot(bv == wmax);
+    if (__builtin_popcountll(cand) != 1) {                   // ties inside the wave: the smallest point index wins
+      const int mi = wave_min_i32(bv == wmax ? bi : 0x7fffffff);
+      cand = __ballot(bv == wmax && bi == mi);
+    }
+    const int wl = __builtin_ctzll(cand);
+    const int kw = __builtin_amdgcn_readlane(bk, wl), iw = __builtin_amdgcn_readlane(bi, wl);
+    float bx, by, bz;
+    fps_pick<0, PPT, H>(kw, px, py, pz, bx, by, bz);       // every lane picks ITS slot kw; only the winner lane's values are used
     const int buf = it & 1;
-    if (key == wmax) {           // exactly one lane per wave (indices are unique)
-      red_k[buf][wv] = key;
-      red_c[buf][wv][0] = bx; red_c[buf][wv][1] = by; red_c[buf][wv][2] = bz;
-    }
+    if (lane == wl) { red_v[buf][wv] = f32x4{wmax, bx, by, bz}; red_i[buf][wv] = iw; }
     __syncthreads();
-    unsigned long long k16 = red_k[buf][lane & 15];
-    const unsigned long long best = row_max_u64(k16);
-    const int win = __builtin_ctzll(__ballot(k16 == best));      // the wave that holds the winner (lanes 0..15 answer first)
-    farthest = 0x7fffffff - (int)(unsigned)best;
-    cx = red_c[buf][win][0]; cy = red_c[buf][win][1]; cz = red_c[buf][win][2];
+    // ---- workgroup: the same over the (<= 16) wave winners; every wave redoes it on its own copy ----
+    const f32x4 e = red_v[buf][lane & 15];
+    const int ei = red_i[buf][lane & 15];
+    const float best = row_max_f32(e[0]);
+    unsigned c16 = (unsigned)__ballot(e[0] == best) & 0xffffu;
+    if (__builtin_popcount(c16) != 1) {
+      const int mi = row_min_i32(e[0] == best ? ei : 0x7fffffff);
+      c16 = (unsigned)__ballot(e[0] == best && ei == mi) & 0xffffu;
+    }
+    const int win = __builtin_ctz(c16);
+    farthest = __builtin_amdgcn_readlane(ei, win);
+    cx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e[1]), win));
+    cy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e[2]), win));
+    cz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e[3]), win));
   }
 }
 
@@ -317,8 +365,10 @@ extern "C" int cg_farthest_point_sample(const float* xyz, const long long* start
   if (!xyz || !start || !out) return CG_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((unsigned)B), block(1024);
+  static const int variant = getenv("CATGRASP_FPS_VARIANT") ? atoi(getenv("CATGRASP_FPS_VARIANT")) : 0;      // dev A/B switch, 0 = shipped choice
   if (N <= 1024 * 2) hipLaunchKernelGGL((fps_kernel<1024, 2>), grid, block, 0, s, xyz, start, N, npoint, out);
   else if (N <= 1024 * 8) hipLaunchKernelGGL((fps_kernel<1024, 8>), grid, block, 0, s, xyz, start, N, npoint, out);
+  else if (N <= 1024 * 20 && variant != 1) hipLaunchKernelGGL((fps_kernel<1024, 20>), grid, block, 0, s, xyz, start, N, npoint, out);
   else if (N <= 512 * 40) hipLaunchKernelGGL((fps_kernel<512, 40>), grid, dim3(512), 0, s, xyz, start, N, npoint, out);
   else if (N <= 512 * 48) hipLaunchKernelGGL((fps_kernel<512, 48>), grid, dim3(512), 0, s, xyz, start, N, npoint, out);
   else {

@@ -7,14 +7,18 @@
 //   -> permute to (B,3+D,K,S) -> [Conv2d(1x1) -> BatchNorm2d -> ReLU] x L -> max over K -> (B,C_L,S)
 // without ever materialising the grouped tensor (K x the input in HBM) or any activation.
 //
-// One wavefront owns one neighbourhood (b, s).  Its K neighbours are the 32 rows of an MFMA tile (K > 32: several row tiles,
-// K < 32: rows padded by repeating neighbour 0 -- the max is idempotent): the gathered, centred coordinates + features are
-// staged in a wave-private LDS strip, every layer is  act(W' x + b')  with BatchNorm folded on the host, evaluated as
-// v_mfma_f32_32x32x2_f32 (exact f32) with the neighbours as the M dimension and the channels as N; a layer computes ALL its output
-// channel blocks before storing anything, so it overwrites its own input strip (no ping-pong pair), and the last layer's max over
-// neighbours is a per-lane reduction over the accumulator registers + one lane^32 exchange -- no workgroup barrier anywhere in the
-// kernel.  The strip is as wide as the widest STORED activation, so e.g. the 64-64-128 layer needs 8.7 KB per wave: 8 waves per
-// workgroup, two workgroups per CU.
+// Round-3 form: PERSISTENT workgroups with the layer weights resident in LDS.
+//   * A workgroup stages the folded, fragment-packed weights + biases of every layer into LDS ONCE (53 KB for 9-64-64-128) and then
+//     loops over neighbourhoods; the B operand of every MFMA is a conflict-free ds_read_b128 instead of an L2 round trip per
+//     k-step per wave (round 2: ~700 cycles exposed per 8..16 MFMAs).  Layers that do not fit next to the strips stay in L2.
+//   * One wavefront owns one 32-row MFMA tile = PACK neighbourhoods of 32/PACK rows (K <= 8: 4, K <= 16: 2, else 1 and K > 32 takes
+//     several row tiles with a running max; short neighbourhoods are padded by repeating neighbour 0 -- the max is idempotent).
+//     The accumulator registers of a lane split by neighbourhood (rows 8*(r>>2) + (r&3) + 4*(lane>>5)), so the segmented max
+//     is still a per-lane reduction + one lane^32 exchange.
+//   * The gather of the NEXT tile (index -> point -> centre, two dependent L2 accesses) is issued while the current tile is in the
+//     matrix pipe: indices two tiles ahead, coordinates/features one tile ahead, both held in registers.
+//   * Every layer computes ALL its output channel blocks before storing anything, so it overwrites its own input strip; fragments
+//     of the next k-step are requested before the current k-step's MFMAs.  No workgroup barrier after the staging.
 #include "cg_common.hpp"
 #include "../../include/catgrasp_amd.h"
 
@@ -28,6 +32,9 @@ struct SAArgs {
   int B, N, S, K, D;
   int nlayers; int cin[SA_MAX_LAYERS]; int cout[SA_MAX_LAYERS];
   const float* w[SA_MAX_LAYERS]; const float* b[SA_MAX_LAYERS];
+  int w_off[SA_MAX_LAYERS];       // float offset of the layer's packed weights inside the LDS weight region, or -1: read from L2
+  int b_off[SA_MAX_LAYERS];       // float offset of the layer's bias (always staged)
+  int wb_floats;                  // size of the LDS weight + bias region
   float* out; int* err_flag;
 };
 
@@ -36,13 +43,11 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 
-// One layer for the wave's 32-row tile: ALL NNB output channel blocks at once, so an activation fragment is read from LDS once per
-// k-step and feeds 4 x NNB MFMAs on NNB independent accumulators, and the NNB weight fragments of a k-step are requested
-// together.  Because every accumulator is complete before anything is stored, the layer writes its output over its own input: one
-// strip per wave instead of a ping-pong pair.  Last layer: the ReLU'd accumulators go straight into the running max.
-template <int NNB>
-__device__ __forceinline__ void sa_layer(float* strip, int CS, const float* __restrict__ w, const float* __restrict__ bias, int nks, bool last,
-                                         int lane, float* run) {
+// One layer for the wave's 32-row tile.  w: fragment-packed weights Wp[nb][ks][lane][4] (LDS or global), bias: LDS.
+// Last layer: the ReLU'd accumulators go straight into the running maxima run[nb][p] of the tile's PACK neighbourhoods.
+template <int NNB, int PACK>
+__device__ __forceinline__ void sa_layer(float* strip, int CS, const float* w, const float* bias, int nks, bool last, int lane,
+                                         float (*run)[PACK]) {
   const int l31 = lane & 31, lhi = lane >> 5;
   f32x16 c[NNB];
 #pragma unroll
@@ -53,15 +58,46 @@ __device__ __forceinline__ void sa_layer(float* strip, int CS, const float* __re
   }
   const float* arow = strip + l31 * CS + lhi * 4;
   const f32x4* wp = (const f32x4*)w + lane;
-  for (int ks = 0; ks < nks; ++ks) {
-    const f32x4 av = *(const f32x4*)(arow + ks * 8);
+  if constexpr (NNB <= 4) {
+    // software pipeline, one k-step deep: the fragments of k-step ks+1 are requested before the MFMAs of k-step ks
+    f32x4 av = *(const f32x4*)arow;
     f32x4 bv[NNB];
 #pragma unroll
-    for (int nb = 0; nb < NNB; ++nb) bv[nb] = wp[(size_t)(nb * nks + ks) * 64];
+    for (int nb = 0; nb < NNB; ++nb) bv[nb] = wp[(size_t)(nb * nks) * 64];
+    for (int ks = 0; ks < nks; ++ks) {
+      const int kn = ks + 1 < nks ? ks + 1 : ks;
+      f32x4 an = *(const f32x4*)(arow + kn * 8);
+      f32x4 bn[NNB];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+      for (int nb = 0; nb < NNB; ++nb) bn[nb] = wp[(size_t)(nb * nks + kn) * 64];
+      __builtin_amdgcn_sched_barrier(0);                  // the requests go out BEFORE the MFMA block, whatever the scheduler prefers
 #pragma unroll
-      for (int nb = 0; nb < NNB; ++nb) c[nb] = mfma32(av[j], bv[nb][j], c[nb]);
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int nb = 0; nb < NNB; ++nb) c[nb] = mfma32(av[j], bv[nb][j], c[nb]);
+      // Pin the prefetch to THIS iteration: without a use here LLVM sinks the loads to the top of the next iteration (right in front
+      // of the MFMAs that need them), i.e. it undoes the software pipeline.  The empty asm is the use; by now the data has landed.
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("" : "+v"(an));
+#pragma unroll
+      for (int nb = 0; nb < NNB; ++nb) asm volatile("" : "+v"(bn[nb]));
+      av = an;
+#pragma unroll
+      for (int nb = 0; nb < NNB; ++nb) bv[nb] = bn[nb];
+    }
+  } else {
+    // 5..8 channel blocks: 80..128 accumulator registers leave no room for a second fragment set (it would spill); 20..32 MFMAs per
+    // k-step and the SIMD's other wave cover the fragment latency instead
+    for (int ks = 0; ks < nks; ++ks) {
+      const f32x4 av = *(const f32x4*)(arow + ks * 8);
+      f32x4 bv[NNB];
+#pragma unroll
+      for (int nb = 0; nb < NNB; ++nb) bv[nb] = wp[(size_t)(nb * nks + ks) * 64];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int nb = 0; nb < NNB; ++nb) c[nb] = mfma32(av[j], bv[nb][j], c[nb]);
+    }
   }
   wave_sync();                       // every lane's fragment reads of the strip are done before it is overwritten
 #pragma unroll
@@ -72,85 +108,174 @@ __device__ __forceinline__ void sa_layer(float* strip, int CS, const float* __re
 #pragma unroll
       for (int r = 0; r < 16; ++r) strip[acc_row(r, lane) * CS + nb * 32 + l31] = c[nb][r];
     } else {
-      float m = max16(c[nb]);
-      m = fmaxf(m, __shfl_xor(m, 32));
-      run[nb] = fmaxf(run[nb], m);
+      constexpr int RP = 16 / PACK;     // accumulator registers per neighbourhood: r in [p*RP, (p+1)*RP) <-> rows [p*32/PACK, ...)
+#pragma unroll
+      for (int p = 0; p < PACK; ++p) {
+        float m = c[nb][p * RP];
+#pragma unroll
+        for (int r = 1; r < RP; ++r) m = fmaxf(m, c[nb][p * RP + r]);
+        m = fmaxf(m, __shfl_xor(m, 32));
+        run[nb][p] = fmaxf(run[nb][p], m);
+      }
     }
   }
   wave_sync();
 }
 
+template <int PACK, bool WIDE>
+__device__ __forceinline__ void sa_layer_any(int nnb, float* strip, int CS, const float* w, const float* bias, int nks, bool last, int lane,
+                                             float (*run)[PACK]) {
+  if (nnb == 1) sa_layer<1, PACK>(strip, CS, w, bias, nks, last, lane, run);
+  else if (nnb == 2) sa_layer<2, PACK>(strip, CS, w, bias, nks, last, lane, run);
+  else if (nnb == 3) sa_layer<3, PACK>(strip, CS, w, bias, nks, last, lane, run);
+  else if (nnb == 4) sa_layer<4, PACK>(strip, CS, w, bias, nks, last, lane, run);
+  else if constexpr (WIDE) {
+    if (nnb == 5) sa_layer<5, PACK>(strip, CS, w, bias, nks, last, lane, run);
+    else if (nnb == 6) sa_layer<6, PACK>(strip, CS, w, bias, nks, last, lane, run);
+    else if (nnb == 7) sa_layer<7, PACK>(strip, CS, w, bias, nks, last, lane, run);
+    else sa_layer<8, PACK>(strip, CS, w, bias, nks, last, lane, run);
+  }
+}
+
 // CS: row stride (floats) of the wave-private activation strip = widest STORED activation (layer inputs; the last layer's output
-// goes straight from the accumulators into the max) + 4 -> conflict-free 16-byte fragment reads.  A run-time value, so narrow
-// networks get small strips and therefore more resident waves (the chain inside a wave is latency bound: more waves = more overlap).
-template <int MAXNB>          // widest layer / 32: 4 (all widths <= 128; fits 128 registers, 4 waves per SIMD) or 8
+// goes straight from the accumulators into the max) + 4 -> conflict-free 16-byte fragment reads.
+// MAXNB: widest layer / 32 -- 4 (all widths <= 128) or 8.  PACK: neighbourhoods per 32-row tile.
+template <int MAXNB, int PACK>
 __global__ __launch_bounds__(512) void sa_group_mlp_max_kernel(SAArgs a, int CS, int WAVES) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int l31 = lane & 31, lhi = lane >> 5;
-  float* strip = smem + (size_t)wv * 32 * CS;
-  const long g = (long)blockIdx.x * WAVES + wv;     // neighbourhood index b*S + s
-  if (g >= (long)a.B * a.S) return;
-  const int b = (int)(g / a.S), s = (int)(g - (long)b * a.S);
-  const float cx = a.new_xyz[g * 3 + 0], cy = a.new_xyz[g * 3 + 1], cz = a.new_xyz[g * 3 + 2];
-  const long long* idg = a.idx + g * a.K;
-  const int c_last = a.cout[a.nlayers - 1];
-  float run[MAXNB];
-#pragma unroll
-  for (int q = 0; q < MAXNB; ++q) run[q] = -INFINITY;
-
-  for (int k0 = 0; k0 < a.K; k0 += 32) {
-    // ---- gather + centre: lane (row r, half h) writes channels [8h, 8h+8) of neighbour k0 + r ----
-    {
-      const int kk = k0 + l31;
-      long long id = idg[kk < a.K ? kk : 0];
-      if (id < 0 || id >= a.N) { if (a.err_flag) *a.err_flag = 1; id = 0; }      // index_points raises on such an index
-      const float* px = a.xyz + ((size_t)b * a.N + id) * 3;
-      const float* pf = a.points ? a.points + ((size_t)b * a.N + id) * a.D : nullptr;
-      float v[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int ch = 8 * lhi + j;
-        float x = 0.f;
-        if (ch == 0) x = px[0] - cx; else if (ch == 1) x = px[1] - cy; else if (ch == 2) x = px[2] - cz;
-        else if (ch - 3 < a.D) x = pf[ch - 3];
-        v[j] = x;
-      }
-      *(f32x4*)(strip + l31 * CS + 8 * lhi) = f32x4{v[0], v[1], v[2], v[3]};
-      *(f32x4*)(strip + l31 * CS + 8 * lhi + 4) = f32x4{v[4], v[5], v[6], v[7]};
+  // ---- stage the weights (16-byte copies, all threads) and biases once per workgroup ----
+  for (int l = 0; l < a.nlayers; ++l) {
+    if (a.w_off[l] >= 0) {
+      const int n4 = a.cin[l] * a.cout[l] / 4;
+      const f32x4* src = (const f32x4*)a.w[l];
+      f32x4* dst = (f32x4*)(smem + a.w_off[l]);
+      for (int i = threadIdx.x; i < n4; i += blockDim.x) dst[i] = src[i];
     }
-    wave_sync();
-    for (int l = 0; l < a.nlayers; ++l) {
-      const int nks = a.cin[l] / 8;
-      const bool last = (l == a.nlayers - 1);
-      const int nnb = a.cout[l] / 32;        // wave-uniform
-      if (nnb == 1) sa_layer<1>(strip, CS, a.w[l], a.b[l], nks, last, lane, run);
-      else if (nnb == 2) sa_layer<2>(strip, CS, a.w[l], a.b[l], nks, last, lane, run);
-      else if (nnb == 3) sa_layer<3>(strip, CS, a.w[l], a.b[l], nks, last, lane, run);
-      else if (nnb == 4) sa_layer<4>(strip, CS, a.w[l], a.b[l], nks, last, lane, run);
-      else if constexpr (MAXNB == 8) {
-        if (nnb == 5) sa_layer<5>(strip, CS, a.w[l], a.b[l], nks, last, lane, run);
-        else if (nnb == 6) sa_layer<6>(strip, CS, a.w[l], a.b[l], nks, last, lane, run);
-        else if (nnb == 7) sa_layer<7>(strip, CS, a.w[l], a.b[l], nks, last, lane, run);
-        else sa_layer<8>(strip, CS, a.w[l], a.b[l], nks, last, lane, run);
-      }
-    }
+    for (int i = threadIdx.x; i < a.cout[l]; i += blockDim.x) smem[a.b_off[l] + i] = a.b[l][i];
   }
-  if (lane < 32) {
+  __syncthreads();
+  float* strip = smem + a.wb_floats + (size_t)wv * 32 * CS;
+
+  constexpr int RPN = 32 / PACK;                         // rows per neighbourhood
+  const int G = a.B * a.S;                               // < 2^31 (checked by the launcher)
+  const int nslots = (G + PACK - 1) / PACK;              // a slot = the PACK neighbourhoods of one tile
+  const int RT = PACK == 1 ? (a.K + 31) / 32 : 1;        // row tiles per slot
+  const int stride = gridDim.x * WAVES;
+  const int c_last = a.cout[a.nlayers - 1];
+  struct Tile { int slot; int kt; };                     // the wave's tiles in order: (slot0, 0..RT-1), (slot0 + stride, 0..RT-1), ...
+  auto next = [&](Tile t) { return t.kt + 1 < RT ? Tile{t.slot, t.kt + 1} : Tile{t.slot + stride, 0}; };
+  Tile cur{(int)blockIdx.x * WAVES + wv, 0};
+  if (cur.slot >= nslots) return;
+
+  // lane's row r = l31 belongs to neighbourhood p = r / RPN of the tile's slot
+  auto nbhd_of = [&](Tile t) -> int {
+    const int g = t.slot * PACK + l31 / RPN;
+    return g < G ? g : G - 1;                            // tail slot: duplicate the last neighbourhood (its result is not stored)
+  };
+  auto load_id = [&](Tile t) -> long long {
+    const int kk = PACK == 1 ? t.kt * 32 + l31 : l31 % RPN;
+    return a.idx[(size_t)nbhd_of(t) * a.K + (kk < a.K ? kk : 0)];
+  };
+  // lane (row r, half h) gathers channels [8h, 8h+8) of its row: centred xyz ++ features, zero padded to 16
+  auto gather = [&](Tile t, long long id, float* v) {
+    const int g = nbhd_of(t);
+    if (id < 0 || id >= a.N) { if (a.err_flag) *a.err_flag = 1; id = 0; }        // index_points raises on such an index
+    const int b = g / a.S;
+    const float* px = a.xyz + ((size_t)b * a.N + id) * 3;
+    const float* pf = a.points ? a.points + ((size_t)b * a.N + id) * a.D : nullptr;
 #pragma unroll
-    for (int q = 0; q < MAXNB; ++q)
-      if (q * 32 < c_last) a.out[((size_t)b * c_last + q * 32 + lane) * a.S + s] = run[q];
+    for (int j = 0; j < 8; ++j) {
+      const int ch = 8 * lhi + j;
+      float x = 0.f;
+      if (ch < 3) x = px[ch] - a.new_xyz[(size_t)g * 3 + ch];
+      else if (ch - 3 < a.D) x = pf[ch - 3];
+      v[j] = x;
+    }
+  };
+
+  float run[MAXNB][PACK];
+  float v[8];
+  gather(cur, load_id(cur), v);
+  Tile nxt = next(cur);
+  long long id_next = nxt.slot < nslots ? load_id(nxt) : 0;
+  for (;;) {
+    if (cur.kt == 0) {
+#pragma unroll
+      for (int q = 0; q < MAXNB; ++q)
+#pragma unroll
+        for (int p = 0; p < PACK; ++p) run[q][p] = -INFINITY;
+    }
+    *(f32x4*)(strip + l31 * CS + 8 * lhi) = f32x4{v[0], v[1], v[2], v[3]};
+    *(f32x4*)(strip + l31 * CS + 8 * lhi + 4) = f32x4{v[4], v[5], v[6], v[7]};
+    wave_sync();
+    // next tile's rows (their indices arrived during the previous tile) and the indices of the tile after: in flight during the layers
+    const bool more = nxt.slot < nslots;
+    if (more) {
+      gather(nxt, id_next, v);
+      const Tile after = next(nxt);
+      if (after.slot < nslots) id_next = load_id(after);
+    }
+    for (int l = 0; l < a.nlayers; ++l) {
+      const bool last = l == a.nlayers - 1;
+      // two call sites so that each sees ONE address space: ds_read_b128 for LDS-resident weights, global_load for the others
+      if (a.w_off[l] >= 0) sa_layer_any<PACK, MAXNB == 8>(a.cout[l] / 32, strip, CS, smem + a.w_off[l], smem + a.b_off[l], a.cin[l] / 8, last, lane, run);
+      else sa_layer_any<PACK, MAXNB == 8>(a.cout[l] / 32, strip, CS, a.w[l], smem + a.b_off[l], a.cin[l] / 8, last, lane, run);
+    }
+    if (cur.kt == RT - 1 && lane < 32) {
+#pragma unroll
+      for (int p = 0; p < PACK; ++p) {
+        const int g = cur.slot * PACK + p;
+        if (g < G) {
+          const int b = g / a.S, s = g - b * a.S;
+#pragma unroll
+          for (int q = 0; q < MAXNB; ++q)
+            if (q * 32 < c_last) a.out[((size_t)b * c_last + q * 32 + lane) * a.S + s] = run[q][p];
+        }
+      }
+    }
+    if (!more) break;
+    cur = nxt; nxt = next(cur);
   }
 }
 
-template <int MAXNB>
-int launch_sa(const SAArgs& a, int cs, hipStream_t s, int dev) {
+constexpr size_t SA_LDS_BUDGET = 158 * 1024;      // of the CU's 160 KB
+
+template <int MAXNB, int PACK>
+int launch_sa(SAArgs& a, int cs, hipStream_t s, int dev) {
   const size_t per_wave = (size_t)32 * cs * 4;
-  int waves = (int)((size_t)(78 * 1024) / per_wave);        // <= half a CU's LDS per workgroup: two workgroups co-reside
+  // Weight residency plan: biases always; a layer's weights go to LDS if, with them, at least 4 waves' strips still fit.  Layers are
+  // taken in order of matrix work (cin*cout = bytes, so simply largest first until the budget is spent).
+  int off = 0;
+  for (int l = 0; l < a.nlayers; ++l) { a.b_off[l] = off; off += a.cout[l]; a.w_off[l] = -1; }
+  off = (off + 3) & ~3;
+  bool taken[SA_MAX_LAYERS] = {};
+  for (int round = 0; round < a.nlayers; ++round) {
+    int best = -1;
+    for (int l = 0; l < a.nlayers; ++l)
+      if (!taken[l] && (best < 0 || a.cin[l] * a.cout[l] > a.cin[best] * a.cout[best])) best = l;
+    taken[best] = true;
+    const size_t need = (size_t)(off + a.cin[best] * a.cout[best]) * 4 + 4 * per_wave;
+    if (need <= SA_LDS_BUDGET) { a.w_off[best] = off; off += a.cin[best] * a.cout[best]; }
+  }
+  a.wb_floats = off;
+  const size_t wb = (size_t)off * 4;
+  if (wb + per_wave > SA_LDS_BUDGET) return CG_ERR_UNSUPPORTED;
+  int waves = (int)((SA_LDS_BUDGET - wb) / per_wave);
   if (waves > 8) waves = 8;
-  if (waves < 1) return CG_ERR_UNSUPPORTED;
-  const size_t lds = per_wave * waves;
-  auto kern = sa_group_mlp_max_kernel<MAXNB>;
+  const int n_cu = cg_device_cu_count(dev);
+  if (n_cu <= 0) return CG_ERR_UNSUPPORTED;
+  const long nslots = ((long)a.B * a.S + PACK - 1) / PACK;
+  // small launches: fewer waves per workgroup so that every CU gets one (a neighbourhood is one dependent chain: spread first)
+  if (nslots < (long)n_cu * waves) { waves = (int)((nslots + n_cu - 1) / n_cu); if (waves < 1) waves = 1; }
+  const size_t lds = wb + per_wave * waves;
+  int wg_per_cu = (int)(SA_LDS_BUDGET / lds);
+  if (wg_per_cu * waves > 8) wg_per_cu = 8 / waves > 0 ? 8 / waves : 1;        // registers: two waves per SIMD
+  if (wg_per_cu < 1) wg_per_cu = 1;
+  long grid = (nslots + waves - 1) / waves;
+  if (grid > (long)n_cu * wg_per_cu) grid = (long)n_cu * wg_per_cu;              // persistent: the waves loop over the slots
+  auto kern = sa_group_mlp_max_kernel<MAXNB, PACK>;
   static bool attr_set[CG_MAX_DEVICES] = {};
   if (dev < 0 || dev >= CG_MAX_DEVICES) return CG_ERR_UNSUPPORTED;
   if (!attr_set[dev]) {
@@ -158,9 +283,15 @@ int launch_sa(const SAArgs& a, int cs, hipStream_t s, int dev) {
     if (e != hipSuccess) return (int)e;
     attr_set[dev] = true;
   }
-  const long groups = (long)a.B * a.S;
-  hipLaunchKernelGGL(kern, dim3((unsigned)((groups + waves - 1) / waves)), dim3(64 * waves), lds, s, a, cs, waves);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * waves), lds, s, a, cs, waves);
   return cg_hip_status(hipGetLastError());
+}
+
+template <int MAXNB>
+int launch_sa_pack(SAArgs& a, int cs, hipStream_t s, int dev) {
+  if (a.K <= 8) return launch_sa<MAXNB, 4>(a, cs, s, dev);
+  if (a.K <= 16) return launch_sa<MAXNB, 2>(a, cs, s, dev);
+  return launch_sa<MAXNB, 1>(a, cs, s, dev);
 }
 
 }  // namespace
@@ -172,7 +303,7 @@ extern "C" int cg_sa_group_mlp_max(const float* xyz, const float* points, const 
   if (!h_cin || !h_cout || !h_w_packed || !h_bias) return CG_ERR_ARG;
   if ((long)B * S == 0) return CG_OK;
   if (!xyz || !new_xyz || !idx || !out || (D > 0 && !points)) return CG_ERR_ARG;
-  if (3 + D > C0) return CG_ERR_UNSUPPORTED;
+  if (3 + D > C0 || (long)B * S >= 0x7fffffffL / 4) return CG_ERR_UNSUPPORTED;
   SAArgs a{};
   a.xyz = xyz; a.points = D > 0 ? points : nullptr; a.new_xyz = new_xyz; a.idx = idx;
   a.B = B; a.N = N; a.S = S; a.K = K; a.D = D; a.nlayers = n_layers; a.out = out; a.err_flag = err_flag;
@@ -181,6 +312,7 @@ extern "C" int cg_sa_group_mlp_max(const float* xyz, const float* points, const 
     if (!h_w_packed[l] || !h_bias[l]) return CG_ERR_ARG;
     if (h_cin[l] != (l == 0 ? C0 : h_cout[l - 1])) return CG_ERR_ARG;          // layer 0: K padded to 16 by the host
     if (h_cout[l] <= 0 || (h_cout[l] % 32) != 0) return CG_ERR_UNSUPPORTED;
+    if (((uintptr_t)h_w_packed[l] & 15) != 0) return CG_ERR_ARG;
     a.cin[l] = h_cin[l]; a.cout[l] = h_cout[l]; a.w[l] = h_w_packed[l]; a.b[l] = h_bias[l];
     if (h_cout[l] > cmax) cmax = h_cout[l];
     if (l + 1 < n_layers && h_cout[l] > cstore) cstore = h_cout[l];
@@ -188,6 +320,6 @@ extern "C" int cg_sa_group_mlp_max(const float* xyz, const float* points, const 
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return CG_ERR_UNSUPPORTED;
   if (cmax > 256) return CG_ERR_UNSUPPORTED;
-  if (cmax <= 128) return launch_sa<4>(a, cstore + 4, (hipStream_t)stream, dev);
-  return launch_sa<8>(a, cstore + 4, (hipStream_t)stream, dev);
+  if (cmax <= 128) return launch_sa_pack<4>(a, cstore + 4, (hipStream_t)stream, dev);
+  return launch_sa_pack<8>(a, cstore + 4, (hipStream_t)stream, dev);
 }
