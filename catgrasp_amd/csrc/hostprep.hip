@@ -154,11 +154,18 @@ __global__ __launch_bounds__(256) void draw_ids_iid_kernel(int n_valid, int n_pt
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pose_inverse_rows_kernel(const float* __restrict__ poses, long E, double cx, double cy,
-                                                                double cz, float* __restrict__ out) {
+template <typename TIn>      // float: poses produced on the device (the filter's output); double: the caller's float64 pose list, uploaded as is
+__global__ __launch_bounds__(256) void pose_inverse_rows_kernel(const TIn* __restrict__ poses, long E, double cx, double cy,
+                                                                double cz, float* __restrict__ out, int* __restrict__ bad) {
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= E) return;
-  const float* P = poses + e * 16;
+  const TIn* P = poses + e * 16;
+  if (bad) {                    // the reference's np.linalg.inv propagates NaN / Inf into the network input; here the call is refused
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) ok = ok && isfinite((double)P[k]);
+    if (!ok) *bad = 1;
+  }
   const double a00 = P[0], a01 = P[1], a02 = P[2], t0 = P[3];
   const double a10 = P[4], a11 = P[5], a12 = P[6], t1 = P[7];
   const double a20 = P[8], a21 = P[9], a22 = P[10], t2 = P[11];
@@ -295,8 +302,17 @@ extern "C" int cg_pose_inverse_rows(const float* poses, long n_poses, const doub
   if (n_poses < 0) return CG_ERR_ARG;
   if (n_poses == 0) return CG_OK;
   if (!poses || !out || !h_center) return CG_ERR_ARG;
-  hipLaunchKernelGGL(pose_inverse_rows_kernel, dim3((unsigned)((n_poses + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     poses, n_poses, h_center[0], h_center[1], h_center[2], out);
+  hipLaunchKernelGGL(pose_inverse_rows_kernel<float>, dim3((unsigned)((n_poses + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     poses, n_poses, h_center[0], h_center[1], h_center[2], out, (int*)nullptr);
+  return cg_hip_status(hipGetLastError());
+}
+
+extern "C" int cg_pose_inverse_rows_f64(const double* poses, long n_poses, const double* h_center, float* out, int* bad_flag, void* stream) {
+  if (n_poses < 0) return CG_ERR_ARG;
+  if (n_poses == 0) return CG_OK;
+  if (!poses || !out || !h_center) return CG_ERR_ARG;
+  hipLaunchKernelGGL(pose_inverse_rows_kernel<double>, dim3((unsigned)((n_poses + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     poses, n_poses, h_center[0], h_center[1], h_center[2], out, bad_flag);
   return cg_hip_status(hipGetLastError());
 }
 

@@ -104,10 +104,15 @@ __global__ __launch_bounds__(256) void index_points_kernel(const float* __restri
 //    picks the slot's registers, no per-slot select;
 //  * the winners of the waves meet in LDS as (value, x, y, z) + index, ONE workgroup barrier per round (double-buffered), and the next
 //    centre is taken out of the exchanged records with v_readlane -- no dependent LDS or global read at the top of the round.
-// History (N = 20,000 -> 1,024, one cloud): 4.19 ms (round 1) -> 2.71 ms (round 2: 64-bit DPP keys) -> see profiles/ (round 3).
+// History (N = 20,000 -> 1,024, one cloud): 4.19 ms (round 1) -> 2.71 ms (round 2: 64-bit DPP keys) -> 2.04 ms (round 3: packed math,
+// branch-free arg-max, 32-bit reduction) -> 1.73 ms (unsigned-bit min / max): 1.69 us per round; the VALU floor of this formulation on
+// one CU is 20,000 points x 8 VALU / 4 SIMDs x 4 clocks = 1.39 us at the 2.3 GHz the kernel runs at.
+// Running distances are >= +0 (sums of squares; 1e10 initially), so their BIT PATTERNS order like the values: min / max / compare run
+// on them as unsigned integers -- one v_min_u32 / v_max_u32 (with the DPP row operation folded in) where the float forms cost a
+// compare + select or drag a canonicalising v_max along.
 template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_max_f32(float v) {
-  const float o = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+__device__ __forceinline__ unsigned dpp_max_u32(unsigned v) {
+  const unsigned o = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xf, false);
   return o > v ? o : v;
 }
 template <int CTRL, int ROW_MASK>
@@ -116,22 +121,22 @@ __device__ __forceinline__ int dpp_min_i32(int v) {
   return o < v ? o : v;
 }
 // max / min over the 16 lanes of every DPP row (all lanes of the row get it)
-__device__ __forceinline__ float row_max_f32(float v) {
-  v = dpp_max_f32<0xB1, 0xf>(v);      // quad_perm [1,0,3,2]
-  v = dpp_max_f32<0x4E, 0xf>(v);      // quad_perm [2,3,0,1]
-  v = dpp_max_f32<0x141, 0xf>(v);     // row_half_mirror
-  return dpp_max_f32<0x140, 0xf>(v);  // row_mirror
+__device__ __forceinline__ unsigned row_max_u32(unsigned v) {
+  v = dpp_max_u32<0xB1, 0xf>(v);      // quad_perm [1,0,3,2]
+  v = dpp_max_u32<0x4E, 0xf>(v);      // quad_perm [2,3,0,1]
+  v = dpp_max_u32<0x141, 0xf>(v);     // row_half_mirror
+  return dpp_max_u32<0x140, 0xf>(v);  // row_mirror
 }
 __device__ __forceinline__ int row_min_i32(int v) {
   v = dpp_min_i32<0xB1, 0xf>(v); v = dpp_min_i32<0x4E, 0xf>(v); v = dpp_min_i32<0x141, 0xf>(v);
   return dpp_min_i32<0x140, 0xf>(v);
 }
 // over the wavefront, returned wave-uniform
-__device__ __forceinline__ float wave_max_f32(float v) {
-  v = row_max_f32(v);
-  v = dpp_max_f32<0x142, 0xa>(v);     // row_bcast15 into rows 1 and 3
-  v = dpp_max_f32<0x143, 0xc>(v);     // row_bcast31 into rows 2 and 3: lane 63 holds the wave maximum
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+  v = row_max_u32(v);
+  v = dpp_max_u32<0x142, 0xa>(v);     // row_bcast15 into rows 1 and 3
+  v = dpp_max_u32<0x143, 0xc>(v);     // row_bcast31 into rows 2 and 3: lane 63 holds the wave maximum
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 __device__ __forceinline__ int wave_min_i32(int v) {
   v = row_min_i32(v);
@@ -157,42 +162,43 @@ __global__ __launch_bounds__(NT) void fps_kernel(const float* __restrict__ xyz, 
                                                  long long* __restrict__ out) {
   static_assert(PPT % 2 == 0 && NT % 64 == 0 && NT <= 1024, "geometry");
   constexpr int H = PPT / 2;
-  __shared__ f32x4 red_v[2][16];       // per wave: (best distance, x, y, z) of its winner
+  __shared__ f32x4 red_v[2][16];       // per wave: (bits of the best distance, x, y, z) of its winner
   __shared__ int red_i[2][16];         //           its point index
   const int b = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  if (tid < 32) { red_v[tid >> 4][tid & 15] = f32x4{-1.f, 0.f, 0.f, 0.f}; red_i[tid >> 4][tid & 15] = 0x7fffffff; }   // absent waves never win
+  if (tid < 32) { red_v[tid >> 4][tid & 15] = f32x4{0.f, 0.f, 0.f, 0.f}; red_i[tid >> 4][tid & 15] = 0x7fffffff; }   // absent waves: distance 0, index "none"
   __syncthreads();
   const float* xb = xyz + (size_t)b * N * 3;
   f32x2 px[H], py[H], pz[H];
-  float dist[PPT];
+  unsigned dist[PPT];                  // bit patterns of the running distances (all >= +0)
 #pragma unroll
   for (int k = 0; k < PPT; ++k) {
     const int p = tid + k * NT;
     float x = 0.f, y = 0.f, z = 0.f, d0 = 0.0f;     // padding: running distance 0 never shrinks (d >= 0) and never beats a real point first
     if (p < N) { x = xb[p * 3 + 0]; y = xb[p * 3 + 1]; z = xb[p * 3 + 2]; d0 = 1e10f; }
-    px[k >> 1][k & 1] = x; py[k >> 1][k & 1] = y; pz[k >> 1][k & 1] = z; dist[k] = d0;
+    px[k >> 1][k & 1] = x; py[k >> 1][k & 1] = y; pz[k >> 1][k & 1] = z; dist[k] = __float_as_uint(d0);
   }
   int farthest = (int)start[b];
   float cx = xb[farthest * 3 + 0], cy = xb[farthest * 3 + 1], cz = xb[farthest * 3 + 2];
   for (int it = 0; it < npoint; ++it) {
     if (tid == 0) out[(size_t)b * npoint + it] = farthest;
     const f32x2 c2x = {cx, cx}, c2y = {cy, cy}, c2z = {cz, cz};
-    float bv = -1.0f; int bk = 0;
+    unsigned bv = 0u; int bk = 0;       // every thread's slot 0 is >= 0, and a strict '>' keeps the first maximum: bk = 0 is the right start
 #pragma unroll
     for (int h = 0; h < H; ++h) {
       const f32x2 dx = px[h] - c2x, dy = py[h] - c2y, dz = pz[h] - c2z;
       const f32x2 d = (dx * dx + dy * dy) + dz * dz;        // torch.sum((xyz - centroid) ** 2, -1), two points per instruction
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
-        const float nd = d[e] < dist[2 * h + e] ? d[e] : dist[2 * h + e];     // mask = dist < distance; distance[mask] = dist[mask]
+        const unsigned db = __float_as_uint(d[e]);
+        const unsigned nd = db < dist[2 * h + e] ? db : dist[2 * h + e];      // mask = dist < distance; distance[mask] = dist[mask]
         dist[2 * h + e] = nd;
         const bool g = nd > bv;                              // ascending point index within a thread: the first maximum is kept
         bv = g ? nd : bv; bk = g ? 2 * h + e : bk;
       }
     }
     // ---- wave: who holds the largest running distance (smallest index among equals) ----
-    const float wmax = wave_max_f32(bv);
+    const unsigned wmax = wave_max_u32(bv);
     const int bi = tid + bk * NT;
     unsigned long long cand = __ballot(bv == wmax);
     if (__builtin_popcountll(cand) != 1) {                   // ties inside the wave: the smallest point index wins
@@ -204,16 +210,17 @@ __global__ __launch_bounds__(NT) void fps_kernel(const float* __restrict__ xyz, 
     float bx, by, bz;
     fps_pick<0, PPT, H>(kw, px, py, pz, bx, by, bz);       // every lane picks ITS slot kw; only the winner lane's values are used
     const int buf = it & 1;
-    if (lane == wl) { red_v[buf][wv] = f32x4{wmax, bx, by, bz}; red_i[buf][wv] = iw; }
+    if (lane == wl) { red_v[buf][wv] = f32x4{__uint_as_float(wmax), bx, by, bz}; red_i[buf][wv] = iw; }
     __syncthreads();
     // ---- workgroup: the same over the (<= 16) wave winners; every wave redoes it on its own copy ----
     const f32x4 e = red_v[buf][lane & 15];
     const int ei = red_i[buf][lane & 15];
-    const float best = row_max_f32(e[0]);
-    unsigned c16 = (unsigned)__ballot(e[0] == best) & 0xffffu;
+    const unsigned ev = __float_as_uint(e[0]);
+    const unsigned best = row_max_u32(ev);
+    unsigned c16 = (unsigned)__ballot(ev == best) & 0xffffu;
     if (__builtin_popcount(c16) != 1) {
-      const int mi = row_min_i32(e[0] == best ? ei : 0x7fffffff);
-      c16 = (unsigned)__ballot(e[0] == best && ei == mi) & 0xffffu;
+      const int mi = row_min_i32(ev == best ? ei : 0x7fffffff);
+      c16 = (unsigned)__ballot(ev == best && ei == mi) & 0xffffu;
     }
     const int win = __builtin_ctz(c16);
     farthest = __builtin_amdgcn_readlane(ei, win);
@@ -365,10 +372,10 @@ extern "C" int cg_farthest_point_sample(const float* xyz, const long long* start
   if (!xyz || !start || !out) return CG_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((unsigned)B), block(1024);
-  static const int variant = getenv("CATGRASP_FPS_VARIANT") ? atoi(getenv("CATGRASP_FPS_VARIANT")) : 0;      // dev A/B switch, 0 = shipped choice
   if (N <= 1024 * 2) hipLaunchKernelGGL((fps_kernel<1024, 2>), grid, block, 0, s, xyz, start, N, npoint, out);
   else if (N <= 1024 * 8) hipLaunchKernelGGL((fps_kernel<1024, 8>), grid, block, 0, s, xyz, start, N, npoint, out);
-  else if (N <= 1024 * 20 && variant != 1) hipLaunchKernelGGL((fps_kernel<1024, 20>), grid, block, 0, s, xyz, start, N, npoint, out);
+  // 8,193 .. 24,576 points: 512 threads x 40 / 48 points (two waves per SIMD).  Measured at N = 20,000: 1.73 ms per 1,024 samples
+  // against 1.81 ms for 1024 threads x 20 points -- the round is VALU bound (8 VALU per point), more waves only add exchange work.
   else if (N <= 512 * 40) hipLaunchKernelGGL((fps_kernel<512, 40>), grid, dim3(512), 0, s, xyz, start, N, npoint, out);
   else if (N <= 512 * 48) hipLaunchKernelGGL((fps_kernel<512, 48>), grid, dim3(512), 0, s, xyz, start, N, npoint, out);
   else {

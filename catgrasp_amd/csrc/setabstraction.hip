@@ -7,7 +7,18 @@
 //   -> permute to (B,3+D,K,S) -> [Conv2d(1x1) -> BatchNorm2d -> ReLU] x L -> max over K -> (B,C_L,S)
 // without ever materialising the grouped tensor (K x the input in HBM) or any activation.
 //
-// Round-3 form: PERSISTENT workgroups with the layer weights resident in LDS.
+// Two kernels.  sa_reg_kernel (all layer widths <= 128): the ACTIVATIONS NEVER LEAVE REGISTERS.  Hidden layers run "transposed" --
+// weights are the MFMA A operand (rows = output channels), the neighbours' activations the B operand (columns = neighbours) -- so a
+// layer's accumulator registers ARE the next layer's operand fragments: lane (neighbour n, half h) holds, in register 4q+j of channel
+// block nb, channel 32nb + 8q + 4h + j, which is exactly the element the next layer's MFMA j of k-step 4nb+q wants from that lane
+// (v_mfma_f32_32x32x2_f32 takes A[i = lane&31][k = lane>>5] and B[k = lane>>5][j = lane&31] from the same lane positions).  Bias
+// = the accumulators' initial value (read from LDS straight into them), ReLU = one v_max per register, no LDS round trip, no
+// wave barrier between layers.  The LAST layer flips back (activations = A, weights = B), so its rows are the neighbours and the
+// max over a neighbourhood is a per-lane reduction over accumulator registers + one lane^32 exchange; its bias + ReLU commute with
+// the max (same bias for every row, monotone) and are applied once per output.  LDS holds only the weights (53 KB for 9-64-64-128).
+// sa_group_mlp_max_kernel (a layer wider than 128): the round-2/3 strip kernel below, activations staged in a wave-private LDS strip.
+//
+// Common to both: PERSISTENT workgroups with the layer weights resident in LDS.
 //   * A workgroup stages the folded, fragment-packed weights + biases of every layer into LDS ONCE (53 KB for 9-64-64-128) and then
 //     loops over neighbourhoods; the B operand of every MFMA is a conflict-free ds_read_b128 instead of an L2 round trip per
 //     k-step per wave (round 2: ~700 cycles exposed per 8..16 MFMAs).  Layers that do not fit next to the strips stay in L2.
@@ -21,6 +32,7 @@
 //     of the next k-step are requested before the current k-step's MFMAs.  No workgroup barrier after the staging.
 #include "cg_common.hpp"
 #include "../../include/catgrasp_amd.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -35,6 +47,7 @@ struct SAArgs {
   int w_off[SA_MAX_LAYERS];       // float offset of the layer's packed weights inside the LDS weight region, or -1: read from L2
   int b_off[SA_MAX_LAYERS];       // float offset of the layer's bias (always staged)
   int wb_floats;                  // size of the LDS weight + bias region
+  int dephase;                    // register kernel: start-up offset between the waves that share a SIMD, in steps of 4096 clocks
   float* out; int* err_flag;
 };
 
@@ -240,6 +253,351 @@ __global__ __launch_bounds__(512) void sa_group_mlp_max_kernel(SAArgs a, int CS,
   }
 }
 
+
+// ================================================================ register-resident kernel (all widths <= 128)
+// wp: fragment-packed weights Wp[nb][ks][lane][4] (+lane applied by the caller), element j of lane l = W[32nb + (l&31)][8ks + 4(l>>5) + j]
+template <int NOUT>
+__device__ __forceinline__ void sa_frags(const f32x4* wp, int nks, int ks, f32x4 (&f)[NOUT]) {
+#pragma unroll
+  for (int nb = 0; nb < NOUT; ++nb) f[nb] = wp[(size_t)(nb * nks + ks) * 64];
+}
+
+// accumulators of a hidden layer start as its bias: rows of D^T are channels 32nb + 8q + 4h + (r&3)
+template <int NOUT>
+__device__ __forceinline__ void sa_bias_init(const float* bias, int lhi, f32x16 (&out)[NOUT]) {
+#pragma unroll
+  for (int nb = 0; nb < NOUT; ++nb)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 b4 = *(const f32x4*)(bias + nb * 32 + q * 8 + lhi * 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) out[nb][4 * q + j] = b4[j];
+    }
+}
+
+template <int NOUT>
+__device__ __forceinline__ void sa_relu(f32x16 (&a)[NOUT]) {
+#pragma unroll
+  for (int nb = 0; nb < NOUT; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a[nb][r] = fmaxf(a[nb][r], 0.f);
+}
+
+// One layer over its input blocks, fully unrolled, as an explicit one-k-step-ahead software pipeline: the weight fragments of k-step
+// ks+1 are requested, THEN the 4 x NOUT MFMAs of k-step ks issue (scheduling barriers keep that order and bound the live fragment
+// sets to two -- left alone, the scheduler hoists every fragment load of the layer to its top and spills).
+// HIDDEN: weights = A operand, activations = B (D^T orientation);  !HIDDEN (last layer): activations = A, weights = B.
+template <int NIN, int NOUT, bool HIDDEN>
+__device__ __forceinline__ void sa_layer_regs(const f32x16 (&in)[NIN], const f32x4* wp, f32x16 (&out)[NOUT]) {
+  constexpr int NKS = NIN * 4;
+  f32x4 wf[2][NOUT];
+  sa_frags<NOUT>(wp, NKS, 0, wf[0]);
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) {
+    if (ks + 1 < NKS) sa_frags<NOUT>(wp, NKS, ks + 1, wf[(ks + 1) & 1]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int nb = 0; nb < NOUT; ++nb) {
+        const float act = in[ks >> 2][4 * (ks & 3) + j], wgt = wf[ks & 1][nb][j];
+        out[nb] = HIDDEN ? mfma32(wgt, act, out[nb]) : mfma32(act, wgt, out[nb]);
+      }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+template <int NIN, int NOUT>
+__device__ __forceinline__ void sa_hidden(const f32x16 (&in)[NIN], const float* w, const float* bias, int lane, f32x16 (&out)[NOUT]) {
+  sa_bias_init<NOUT>(bias, lane >> 5, out);
+  sa_layer_regs<NIN, NOUT, true>(in, (const f32x4*)w + lane, out);
+  sa_relu<NOUT>(out);
+}
+// first layer as a hidden layer: the gathered rows x0 (2 k-steps: channels 4h + j and 8 + 4h + j) are the B operand
+template <int NOUT>
+__device__ __forceinline__ void sa_hidden0(const float (&x0)[8], const float* w, const float* bias, int lane, f32x16 (&out)[NOUT]) {
+  const f32x4* wp = (const f32x4*)w + lane;
+  sa_bias_init<NOUT>(bias, lane >> 5, out);
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    f32x4 wf[NOUT];
+    sa_frags<NOUT>(wp, 2, ks, wf);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int nb = 0; nb < NOUT; ++nb) out[nb] = mfma32(wf[nb][j], x0[4 * ks + j], out[nb]);
+  }
+  sa_relu<NOUT>(out);
+}
+
+// last layer: activations = A operand (rows = neighbours), weights = B; accumulate from 0, fold the rows of each neighbourhood into run
+template <int NOUT, int PACK>
+__device__ __forceinline__ void sa_last_fold(f32x16 (&c)[NOUT], float (*run)[PACK]) {
+  constexpr int RP = 16 / PACK;       // accumulator registers per neighbourhood: r in [p*RP, (p+1)*RP) <-> rows [p*32/PACK, ...)
+#pragma unroll
+  for (int nb = 0; nb < NOUT; ++nb)
+#pragma unroll
+    for (int p = 0; p < PACK; ++p) {
+      float m = c[nb][p * RP];
+#pragma unroll
+      for (int r = 1; r < RP; ++r) m = fmaxf(m, c[nb][p * RP + r]);
+      m = fmaxf(m, __shfl_xor(m, 32));
+      run[nb][p] = fmaxf(run[nb][p], m);
+    }
+}
+template <int NIN, int NOUT, int PACK>
+__device__ __forceinline__ void sa_last(const f32x16 (&in)[NIN], const float* w, int lane, float (*run)[PACK]) {
+  f32x16 c[NOUT];
+#pragma unroll
+  for (int nb = 0; nb < NOUT; ++nb) c[nb] = f32x16{0};
+  sa_layer_regs<NIN, NOUT, false>(in, (const f32x4*)w + lane, c);
+  sa_last_fold<NOUT, PACK>(c, run);
+}
+template <int NOUT, int PACK>
+__device__ __forceinline__ void sa_last0(const float (&x0)[8], const float* w, int lane, float (*run)[PACK]) {
+  const f32x4* wp = (const f32x4*)w + lane;
+  f32x16 c[NOUT];
+#pragma unroll
+  for (int nb = 0; nb < NOUT; ++nb) c[nb] = f32x16{0};
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    f32x4 wf[NOUT];
+    sa_frags<NOUT>(wp, 2, ks, wf);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int nb = 0; nb < NOUT; ++nb) c[nb] = mfma32(x0[4 * ks + j], wf[nb][j], c[nb]);
+  }
+  sa_last_fold<NOUT, PACK>(c, run);
+}
+
+// The layer widths are template parameters (N_l = cout_l / 32, 0 = layer absent; up to 3 layers of width 32 / 64 / 128): the register
+// arrays then have exactly the extents a network needs (9-64-64-128: 32 + 32 + 64 accumulator registers), which decides how many waves
+// a SIMD holds.  NT = threads per workgroup, from the same estimate (sa_reg_threads).
+constexpr int sa_reg_threads(int n0, int n1, int n2) {
+  const int a = n0 + (n1 ? n1 : 0), b = n2 ? n1 + n2 : 0;
+#ifndef SA_REG_PAD
+#define SA_REG_PAD 72
+#endif
+  const int est = 16 * (a > b ? a : b) + SA_REG_PAD;    // live accumulator blocks of the widest layer pair + fragments, gather, addresses
+  return est <= 124 ? 1024 : est <= 164 ? 768 : 512;
+}
+
+template <int N0, int N1, int N2, int PACK, int NT>
+__global__ __launch_bounds__(NT) void sa_reg_kernel(SAArgs a) {
+  constexpr int L = N2 ? 3 : N1 ? 2 : 1;
+  constexpr int NL = N2 ? N2 : N1 ? N1 : N0;             // channel blocks of the last layer
+  const int WAVES = blockDim.x >> 6;                     // <= NT / 64: small launches use smaller workgroups to reach every CU
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  // ---- stage every layer's weights (16-byte copies, all threads) and biases once per workgroup ----
+#pragma unroll
+  for (int l = 0; l < L; ++l) {
+    const int n4 = a.cin[l] * a.cout[l] / 4;
+    const f32x4* src = (const f32x4*)a.w[l];
+    f32x4* dst = (f32x4*)(smem + a.w_off[l]);
+    for (int i = threadIdx.x; i < n4; i += blockDim.x) dst[i] = src[i];
+    for (int i = threadIdx.x; i < a.cout[l]; i += blockDim.x) smem[a.b_off[l] + i] = a.b[l][i];
+  }
+  __syncthreads();
+  // The waves that share a SIMD (w, w+4, w+8, ...) run the same program on equally sized work: left alone they stay in lockstep, all
+  // in the matrix pipe together and all out of it together (epilogues, gather, stores), and the pipe idles in between.  A one-off
+  // start-up offset puts their non-MFMA phases opposite each other's MFMA phases; the offset persists (the late wave keeps the
+  // pipe while the early one is in its epilogue and vice versa).
+  if (a.dephase > 0) {
+    for (int i = (wv >> 2) * a.dephase; i > 0; --i) __builtin_amdgcn_s_sleep(64);       // 64 x 64 clocks per step
+  }
+
+  constexpr int RPN = 32 / PACK;                         // rows per neighbourhood
+  const int G = a.B * a.S;                               // < 2^31 (checked by the launcher)
+  const int nslots = (G + PACK - 1) / PACK;              // a slot = the PACK neighbourhoods of one tile
+  const int RT = PACK == 1 ? (a.K + 31) / 32 : 1;        // row tiles per slot
+  const int stride = gridDim.x * WAVES;
+  constexpr int c_last = NL * 32;
+  struct Tile { int slot; int kt; };
+  auto next = [&](Tile t) { return t.kt + 1 < RT ? Tile{t.slot, t.kt + 1} : Tile{t.slot + stride, 0}; };
+  Tile cur{(int)blockIdx.x * WAVES + wv, 0};
+  if (cur.slot >= nslots) return;
+  auto nbhd_of = [&](Tile t) -> int {
+    const int g = t.slot * PACK + l31 / RPN;
+    return g < G ? g : G - 1;                            // tail slot: duplicate the last neighbourhood (its result is not stored)
+  };
+  auto load_id = [&](Tile t) -> long long {
+    const int kk = PACK == 1 ? t.kt * 32 + l31 : l31 % RPN;
+    return a.idx[(size_t)nbhd_of(t) * a.K + (kk < a.K ? kk : 0)];
+  };
+  // lane (neighbour row r = l31, half h) gathers the operand elements of the two first-layer k-steps: channels 4h + j and 8 + 4h + j
+  // of centred xyz ++ features (zero padded to 16).  In two halves so that the loads stay in flight across the layers of the
+  // current tile: `issue` only computes (clamped, always valid) addresses and loads; `finish` -- run AFTER the layers -- applies
+  // the channel layout with selects.  (A select right behind its load makes the wave wait for L2 at the top of every tile.)
+  struct Raw { float f[8]; float p[3]; float c[3]; };
+  auto issue = [&](Tile t, long long id, Raw& r) {
+    const int g = nbhd_of(t);
+    const bool bad = id < 0 || id >= a.N;                                        // index_points raises on such an index
+    if (bad && a.err_flag) *a.err_flag = 1;
+    id = bad ? 0 : id;
+    const int b = g / a.S;
+    const float* px = a.xyz + ((size_t)b * a.N + id) * 3;
+    const float* pc = a.new_xyz + (size_t)g * 3;
+#pragma unroll
+    for (int e = 0; e < 3; ++e) { r.p[e] = px[e]; r.c[e] = pc[e]; }
+    if (a.D > 0) {                                                               // wave-uniform
+      const float* pf = a.points + ((size_t)b * a.N + id) * a.D;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int f = (e >> 2) * 8 + 4 * lhi + (e & 3) - 3;                      // feature index of this element (negative: a coordinate)
+        r.f[e] = pf[f < 0 ? 0 : (f < a.D ? f : a.D - 1)];
+      }
+    }
+  };
+  auto finish = [&](const Raw& r, float (&v)[8]) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int f = (e >> 2) * 8 + 4 * lhi + (e & 3) - 3;
+      v[e] = (a.D > 0 && f >= 0 && f < a.D) ? r.f[e] : 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < 3; ++e) v[e] = lhi ? v[e] : r.p[e] - r.c[e];
+  };
+  const float* W0 = smem + a.w_off[0]; const float* W1 = smem + a.w_off[1]; const float* W2 = smem + a.w_off[2];
+  const float* B0 = smem + a.b_off[0]; const float* B1 = smem + a.b_off[1];
+
+  float run[NL][PACK];
+  float x0[8];
+  Raw raw;
+  issue(cur, load_id(cur), raw);
+  Tile nxt = next(cur);
+  long long id_next = nxt.slot < nslots ? load_id(nxt) : 0;
+  finish(raw, x0);
+  for (;;) {
+    if (cur.kt == 0) {
+#pragma unroll
+      for (int q = 0; q < NL; ++q)
+#pragma unroll
+        for (int p = 0; p < PACK; ++p) run[q][p] = -INFINITY;
+    }
+    // next tile's rows (their indices arrived during the previous tile) and the indices of the tile after: in flight during the layers
+    // (Unconditional: past the end the loads are repeated on valid addresses and never used -- a conditional load would meet the old
+    // value in a phi, and the register copies behind that phi make the wave wait for the loads right here.)
+    const bool more = nxt.slot < nslots;
+    issue(more ? nxt : cur, more ? id_next : 0, raw);
+    Tile after = next(nxt);
+    if (after.slot >= nslots) after = cur;
+    id_next = load_id(after);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (L == 1) {
+      sa_last0<N0, PACK>(x0, W0, lane, run);
+    } else {
+      f32x16 A[N0];
+      sa_hidden0<N0>(x0, W0, B0, lane, A);
+      if constexpr (L == 2) {
+        sa_last<N0, N1, PACK>(A, W1, lane, run);
+      } else {
+        f32x16 Bf[N1];
+        sa_hidden<N0, N1>(A, W1, B1, lane, Bf);
+        sa_last<N1, N2, PACK>(Bf, W2, lane, run);
+      }
+    }
+    if (cur.kt == RT - 1 && lane < 32) {
+      const float* bl = smem + a.b_off[L - 1];
+#pragma unroll
+      for (int p = 0; p < PACK; ++p) {
+        const int g = cur.slot * PACK + p;
+        if (g < G) {
+          const int b = g / a.S, s = g - b * a.S;
+#pragma unroll
+          for (int q = 0; q < NL; ++q)                     // bias + ReLU after the max: both commute with it (see the header)
+            a.out[((size_t)b * c_last + q * 32 + lane) * a.S + s] = fmaxf(run[q][p] + bl[q * 32 + lane], 0.f);
+        }
+      }
+    }
+    if (!more) break;
+    __builtin_amdgcn_sched_barrier(0);
+    finish(raw, x0);                                       // the loads were issued a whole tile ago
+    cur = nxt; nxt = next(cur);
+  }
+}
+
+template <int N0, int N1, int N2, int PACK>
+int launch_sa_reg(SAArgs& a, hipStream_t s, int dev) {
+  constexpr int NT = sa_reg_threads(N0, N1, N2);
+  constexpr int WAVES = NT / 64;                         // most waves per workgroup the register budget allows
+  int off = 0;
+  for (int l = 0; l < SA_MAX_LAYERS; ++l) { a.b_off[l] = 0; a.w_off[l] = 0; }
+  for (int l = 0; l < a.nlayers; ++l) { a.b_off[l] = off; off += a.cout[l]; }
+  off = (off + 3) & ~3;
+  for (int l = 0; l < a.nlayers; ++l) { a.w_off[l] = off; off += a.cin[l] * a.cout[l]; }
+  a.wb_floats = off;
+  const size_t lds = (size_t)off * 4;                    // <= (16 + 128 + 128) * 128 floats + biases = 140 KB: always fits
+  const int n_cu = cg_device_cu_count(dev);
+  if (n_cu <= 0 || dev < 0 || dev >= CG_MAX_DEVICES || lds > 158 * 1024) return CG_ERR_UNSUPPORTED;
+  const long nslots = ((long)a.B * a.S + PACK - 1) / PACK;
+  // Persistent grid, one workgroup per CU (registers: NT threads fill a CU exactly once).  Waves per workgroup: the most the register
+  // budget allows, unless fewer waves balance the slots better over the chip (a wave's slots are one dependent chain each: with
+  // 16,384 slots 8 waves x 256 CUs take 8 slots each, 12 waves would take 5 or 6) or the launch is too small to give every CU one.
+  static const int force_waves = getenv("CATGRASP_SA_WAVES") ? atoi(getenv("CATGRASP_SA_WAVES")) : 0;      // dev A/B switches
+  static const int dephase = getenv("CATGRASP_SA_DEPHASE") ? atoi(getenv("CATGRASP_SA_DEPHASE")) : 1;
+  int waves = WAVES;
+  double best = -1.0;
+  for (int w = WAVES; w >= 1; --w) {
+    const long rounds = (nslots + (long)n_cu * w - 1) / ((long)n_cu * w);
+    const double eff = (double)nslots / ((double)rounds * n_cu * w);
+    if (eff > best + 0.03) { best = eff; waves = w; }
+  }
+  if (force_waves > 0 && force_waves <= WAVES) waves = force_waves;
+  a.dephase = dephase;
+  long grid = (nslots + waves - 1) / waves;
+  if (grid > n_cu) grid = n_cu;
+  auto kern = sa_reg_kernel<N0, N1, N2, PACK, NT>;
+  static bool attr_set[CG_MAX_DEVICES] = {};
+  if (!attr_set[dev]) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_set[dev] = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * waves), lds, s, a);
+  return cg_hip_status(hipGetLastError());
+}
+
+// dispatch over the supported signatures: up to three layers, every width 32 / 64 / 128
+template <int N0, int N1, int N2>
+int launch_sa_reg_pack(SAArgs& a, hipStream_t s, int dev) {
+  if (a.K <= 8) return launch_sa_reg<N0, N1, N2, 4>(a, s, dev);
+  if (a.K <= 16) return launch_sa_reg<N0, N1, N2, 2>(a, s, dev);
+  return launch_sa_reg<N0, N1, N2, 1>(a, s, dev);
+}
+template <int N0, int N1>
+int launch_sa_reg_2(SAArgs& a, int n2, hipStream_t s, int dev) {
+  switch (n2) {
+    case 0: return launch_sa_reg_pack<N0, N1, 0>(a, s, dev);
+    case 1: return launch_sa_reg_pack<N0, N1, 1>(a, s, dev);
+    case 2: return launch_sa_reg_pack<N0, N1, 2>(a, s, dev);
+    case 4: return launch_sa_reg_pack<N0, N1, 4>(a, s, dev);
+  }
+  return CG_ERR_UNSUPPORTED;
+}
+template <int N0>
+int launch_sa_reg_1(SAArgs& a, int n1, int n2, hipStream_t s, int dev) {
+  switch (n1) {
+    case 0: return n2 == 0 ? launch_sa_reg_pack<N0, 0, 0>(a, s, dev) : CG_ERR_UNSUPPORTED;
+    case 1: return launch_sa_reg_2<N0, 1>(a, n2, s, dev);
+    case 2: return launch_sa_reg_2<N0, 2>(a, n2, s, dev);
+    case 4: return launch_sa_reg_2<N0, 4>(a, n2, s, dev);
+  }
+  return CG_ERR_UNSUPPORTED;
+}
+// -> CG_ERR_UNSUPPORTED when the network is outside the register kernel's signatures (4 layers, a width of 96, ...): strip kernel
+int launch_sa_reg_any(SAArgs& a, hipStream_t s, int dev) {
+  if (a.nlayers > 3) return CG_ERR_UNSUPPORTED;
+  const int n0 = a.cout[0] / 32, n1 = a.nlayers > 1 ? a.cout[1] / 32 : 0, n2 = a.nlayers > 2 ? a.cout[2] / 32 : 0;
+  switch (n0) {
+    case 1: return launch_sa_reg_1<1>(a, n1, n2, s, dev);
+    case 2: return launch_sa_reg_1<2>(a, n1, n2, s, dev);
+    case 4: return launch_sa_reg_1<4>(a, n1, n2, s, dev);
+  }
+  return CG_ERR_UNSUPPORTED;
+}
+
 constexpr size_t SA_LDS_BUDGET = 158 * 1024;      // of the CU's 160 KB
 
 template <int MAXNB, int PACK>
@@ -320,6 +678,11 @@ extern "C" int cg_sa_group_mlp_max(const float* xyz, const float* points, const 
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return CG_ERR_UNSUPPORTED;
   if (cmax > 256) return CG_ERR_UNSUPPORTED;
+  static const bool force_strip = getenv("CATGRASP_SA_STRIP") != nullptr;      // dev A/B switch
+  if (cmax <= 128 && !force_strip) {
+    const int st = launch_sa_reg_any(a, (hipStream_t)stream, dev);
+    if (st != CG_ERR_UNSUPPORTED) return st;             // outside the register kernel's signatures (4 layers, a width of 96): strip kernel
+  }
   if (cmax <= 128) return launch_sa_pack<4>(a, cstore + 4, (hipStream_t)stream, dev);
   return launch_sa_pack<8>(a, cstore + 4, (hipStream_t)stream, dev);
 }

@@ -88,6 +88,18 @@ def group_max(x, groups):
     return out
 
 
+def pose_inverse_rows_f64(poses, center, bad=None):
+    """poses (E,16) float64 cuda (row-major 4x4, the caller's own numbers) -> (E,12) float32 rows of inv(pose) re-expressed for a cloud
+    shifted by -center (cg_pose_inverse_rows_f64: float64 arithmetic, rounded once).  bad: optional (1,) int32 cuda flag, set when a
+    pose holds NaN / Inf."""
+    require_cuda(poses)
+    assert poses.dtype == torch.float64 and poses.is_contiguous() and poses.shape[1] == 16
+    out = torch.empty((poses.shape[0], 12), dtype=torch.float32, device=poses.device)
+    c = (ctypes.c_double * 3)(*[float(v) for v in center])
+    check(L.lib().cg_pose_inverse_rows_f64(_p(poses), _c_long(poses.shape[0]), c, _p(out), _p(bad), _stream()), 'cg_pose_inverse_rows_f64')
+    return out
+
+
 def softmax_pg(logits):
     """logits:(B,C) -> probs (B,C), label (B) int32, confidence (B), p_G (B)."""
     require_cuda(logits)

@@ -88,6 +88,23 @@ def split_eval_range(n_sym, a, b):
     return out
 
 
+def segment_poses_host(objs, gripper, nocs_poses, seg):
+    """Candidate poses (n_pose,4,4) float64 of a segment: a deterministic function of (replica, object, kind), so any rank -- and the
+    CPU-side studies under oracle/ -- can build any segment without a device.  'nocs' poses live in the object's NUNOCS frame
+    (grasp_sampler.py:337-339)."""
+    from . import synth
+    rng = np.random.default_rng([1000 + seg.replica, seg.obj, 0 if seg.kind == 'nocs' else 1])
+    P = synth.make_candidates(objs[seg.obj], seg.n_pose, rng, gripper['hand_depth'], gripper['init_bite'])
+    if seg.kind == 'nocs':
+        P = np.linalg.inv(nocs_poses[seg.obj]) @ P
+    return P
+
+
+def scene_nocs_pose(ob, nocs_scale=0.02):
+    """The synthetic 9-D NUNOCS pose of a scene object (object pose x isotropic scale)."""
+    return ob['pose'] @ np.diag([nocs_scale, nocs_scale, nocs_scale, 1.0])
+
+
 def pack_records(p_g, codes):
     """The per-candidate record that crosses xGMI: (p_G, reject code) as two float32 lanes, 8 B/candidate."""
     import torch
@@ -133,7 +150,7 @@ class SceneBatch:
             g = self.gripper
             self.scenes.append(my_cpp.GripperScene(g['vertices'], g['faces'], g['enclosed_vertices'], g['enclosed_faces'], ob['xyz'], bg,
                                                    0.0005, device))
-            self.nocs_pose.append(ob['pose'] @ np.diag([nocs_scale, nocs_scale, nocs_scale, 1.0]))
+            self.nocs_pose.append(scene_nocs_pose(ob, nocs_scale))
         self.cloud_xyz = torch.cat([c.xyz for c in self.clouds]).contiguous()
         self.cloud_normal = torch.cat([c.normal for c in self.clouds]).contiguous()
         gen = torch.Generator(device=device); gen.manual_seed(1234)
@@ -150,13 +167,9 @@ class SceneBatch:
     # ---- candidate poses of a segment: a deterministic function of (replica, object, kind), so any rank can build any segment
     def segment_poses(self, seg):
         import torch
-        from . import synth
         key = (seg.replica, seg.obj, seg.kind)
         if key not in self._poses:
-            rng = np.random.default_rng([1000 + seg.replica, seg.obj, 0 if seg.kind == 'nocs' else 1])
-            P = synth.make_candidates(self.objs[seg.obj], seg.n_pose, rng, self.gripper['hand_depth'], self.gripper['init_bite'])
-            if seg.kind == 'nocs':          # canonical grasps live in the object's NUNOCS frame (grasp_sampler.py:337-339)
-                P = np.linalg.inv(self.nocs_pose[seg.obj]) @ P
+            P = segment_poses_host(self.objs, self.gripper, self.nocs_pose, seg)
             self._poses[key] = torch.from_numpy(P.astype(np.float32).reshape(-1, 16)).to(self.device)
         return self._poses[key]
 

@@ -248,6 +248,10 @@ int cg_apply_shuffle_rows(const unsigned short* partners, long row_stride, int n
  * row 0 0 0 1 -> out (n,12) rows [R | t] with x_grasp = R x_centred + t, where x_centred = x_cam - h_center (HOST,
  * 3 doubles).  float64 arithmetic, rounded once (same contract as the host helper transforms.pose_inverse_rows). */
 int cg_pose_inverse_rows(const float* poses, long n_poses, const double* h_center, float* out, void* stream);
+/* The same for the caller's float64 poses (predict_batch's grasp_poses list, predicter.py:67: uploaded unconverted, so the inverse
+ * is taken of the very numbers np.linalg.inv sees at dataset_grasp.py:69-70).  *bad_flag (optional device int, pre-zeroed) is set
+ * when a pose holds NaN / Inf. */
+int cg_pose_inverse_rows_f64(const double* poses, long n_poses, const double* h_center, float* out, int* bad_flag, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * PointNet++ grouping primitives (pointnet2.py:14-149).  Index tensors are int64 like the reference's.

@@ -120,6 +120,90 @@ int cr_tri_box_overlap(const float c[3], float h, const float a[3], const float 
   return plane_box_overlap(n, v0, h);
 }
 
+/* ---------------- alternative formulations of the same predicate (sensitivity study, profiles/r3_collision_sensitivity.json) --------
+ * FCL and octomap are absent, so what CAN be measured is how much the answer depends on the details this restatement had to choose:
+ *   leaf_mode 1  the leaf box FCL actually hands to its narrow phase: not ((float)k + 0.5f) * res, but the box reached by 16
+ *                float halvings of the root BV [-d, d]^3, d = (float)((1 << 16) * resolution / 2) (fcl::OcTree<float>::getRootBV,
+ *                computeChildBV: child.min/max = (bv.min + bv.max) * 0.5 per set / unset bit of the child index), then
+ *                constructBox(): side = max - min, centre = (min + max) * 0.5 -- a different rounding path, ~1 ulp of 0.6 m;
+ *   dh           the cube's half edge grown / shrunk by dh metres (+-1e-6 m: the scale of libccd's GJK tolerances at contact);
+ *   narrow 1     closed-set intersection by Sutherland-Hodgman clipping of the triangle against the six half-spaces in float64 -- no
+ *                separating axes at all (the C twin of oracle/tribox_exact.py, fast enough for whole batches).
+ * cr_set_variant(0, 0, 0) (the default) leaves every code path of the parity oracle exactly as it was. */
+static struct { int leaf_mode; float dh; int narrow; } g_variant = {0, 0.0f, 0};
+void cr_set_variant(int leaf_mode, float dh, int narrow) { g_variant.leaf_mode = leaf_mode; g_variant.dh = dh; g_variant.narrow = narrow; }
+
+/* FCL's leaf box of key k (0 .. 65535 per axis) by recursive float halving; out: centre c[3], half extents h[3] */
+static void fcl_leaf_box(const int key_minus[3], float resolution, float c[3], float h[3]) {
+  const float d = (float)((double)(1 << 16) * (double)resolution / 2.0);
+  for (int a = 0; a < 3; ++a) {
+    float lo = -d, hi = d;
+    const int k = key_minus[a] + TREE_MAX_VAL;
+    for (int lvl = 15; lvl >= 0; --lvl) {
+      const float mid = (lo + hi) * 0.5f;
+      if ((k >> lvl) & 1) lo = mid; else hi = mid;
+    }
+    const float side = hi - lo;                 /* constructBox: Box(bv.max_ - bv.min_), tf.translation() = bv.center() */
+    c[a] = (lo + hi) * 0.5f;
+    h[a] = side * 0.5f;                         /* the narrow phase sees the box through its half sides */
+  }
+}
+
+/* 13-axis SAT with per-axis half extents (identical to cr_tri_box_overlap when h[0] == h[1] == h[2]) */
+int cr_tri_box_overlap_h3(const float c[3], const float h[3], const float a[3], const float b[3], const float d[3]) {
+  float v0[3], v1[3], v2[3], e[3][3];
+  for (int i = 0; i < 3; ++i) { v0[i] = a[i] - c[i]; v1[i] = b[i] - c[i]; v2[i] = d[i] - c[i]; }
+  for (int i = 0; i < 3; ++i) { e[0][i] = v1[i] - v0[i]; e[1][i] = v2[i] - v1[i]; e[2][i] = v0[i] - v2[i]; }
+  const float* vs[3] = {v0, v1, v2};
+  for (int k = 0; k < 3; ++k) {
+    const float fex = fabsf(e[k][0]), fey = fabsf(e[k][1]), fez = fabsf(e[k][2]);
+    const float* p = vs[k == 1 ? 0 : (k == 2 ? 0 : 0)]; (void)p;
+    /* the two distinct projections per axis are those of a vertex ON the edge and of the vertex OPPOSITE to it */
+    const float* on = vs[k]; const float* opp = vs[(k + 2) % 3];
+    { float pa = e[k][2] * on[1] - e[k][1] * on[2], pb = e[k][2] * opp[1] - e[k][1] * opp[2]; AXIS(pa, pb, fez * h[1] + fey * h[2]); }
+    { float pa = -e[k][2] * on[0] + e[k][0] * on[2], pb = -e[k][2] * opp[0] + e[k][0] * opp[2]; AXIS(pa, pb, fez * h[0] + fex * h[2]); }
+    { float pa = e[k][1] * on[0] - e[k][0] * on[1], pb = e[k][1] * opp[0] - e[k][0] * opp[1]; AXIS(pa, pb, fey * h[0] + fex * h[1]); }
+  }
+  for (int i = 0; i < 3; ++i)
+    if (min3f(v0[i], v1[i], v2[i]) > h[i] || max3f(v0[i], v1[i], v2[i]) < -h[i]) return 0;
+  float n[3];
+  n[0] = e[0][1] * e[1][2] - e[0][2] * e[1][1];
+  n[1] = e[0][2] * e[1][0] - e[0][0] * e[1][2];
+  n[2] = e[0][0] * e[1][1] - e[0][1] * e[1][0];
+  float vmin[3], vmax[3];
+  for (int q = 0; q < 3; ++q) {
+    if (n[q] > 0.0f) { vmin[q] = -h[q] - v0[q]; vmax[q] = h[q] - v0[q]; }
+    else { vmin[q] = h[q] - v0[q]; vmax[q] = -h[q] - v0[q]; }
+  }
+  if ((n[0] * vmin[0] + n[1] * vmin[1]) + n[2] * vmin[2] > 0.0f) return 0;
+  return (n[0] * vmax[0] + n[1] * vmax[1]) + n[2] * vmax[2] >= 0.0f;
+}
+
+/* closed triangle vs closed box by polygon clipping in float64 (no separating axes): 1 iff the clipped polygon is non-empty */
+int cr_tri_box_clip64(const float c[3], const float h[3], const float a[3], const float b[3], const float d[3]) {
+  double poly[16][3], tmp[16][3];
+  int n = 3;
+  for (int k = 0; k < 3; ++k) { poly[0][k] = (double)a[k] - (double)c[k]; poly[1][k] = (double)b[k] - (double)c[k]; poly[2][k] = (double)d[k] - (double)c[k]; }
+  for (int axis = 0; axis < 3; ++axis)
+    for (int sgn = 1; sgn >= -1; sgn -= 2) {
+      int m = 0;
+      for (int i = 0; i < n; ++i) {
+        const double* p = poly[i]; const double* q = poly[(i + 1) % n];
+        const double sp = (double)h[axis] - sgn * p[axis], sq = (double)h[axis] - sgn * q[axis];      /* >= 0 inside */
+        if (sp >= 0) { memcpy(tmp[m++], p, sizeof(double) * 3); }
+        if ((sp >= 0) != (sq >= 0)) {
+          const double t = sp / (sp - sq);
+          for (int k = 0; k < 3; ++k) tmp[m][k] = p[k] + t * (q[k] - p[k]);
+          ++m;
+        }
+      }
+      n = m;
+      if (n == 0) return 0;
+      memcpy(poly, tmp, sizeof(double) * 3 * (size_t)n);
+    }
+  return 1;
+}
+
 /* ---------------- CollisionManager (collision_manager.cpp:15-111) ---------------- */
 
 /* posed vertex: R v + t with the pose's upper 3x4 (setTransform(pose.block(0,0,3,3), pose.block(0,3,3,1))) */
@@ -142,6 +226,24 @@ int cr_mesh_voxels_collide(const float* V, int nv, const int* F, int nf, const f
       for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], tri[f * 9 + k * 3 + a]); hi[a] = fmaxf(hi[a], tri[f * 9 + k * 3 + a]); }
     }
   int hit = 0;
+  if (g_variant.leaf_mode || g_variant.dh != 0.0f || g_variant.narrow) {       /* sensitivity study only; see cr_set_variant */
+    for (int i = 0; i < nk && !hit; ++i) {
+      float c[3], h3[3];
+      if (g_variant.leaf_mode == 1) fcl_leaf_box(keys + i * 3, resolution, c, h3);
+      else for (int a = 0; a < 3; ++a) { c[a] = ((float)keys[i * 3 + a] + 0.5f) * resolution; h3[a] = h; }
+      int out = 0;
+      for (int a = 0; a < 3; ++a) {
+        h3[a] += g_variant.dh;
+        if (c[a] - h3[a] > hi[a] + 1e-5f || c[a] + h3[a] < lo[a] - 1e-5f) out = 1;
+      }
+      if (out) continue;
+      for (int f = 0; f < nf; ++f)
+        if (g_variant.narrow ? cr_tri_box_clip64(c, h3, tri + f * 9, tri + f * 9 + 3, tri + f * 9 + 6)
+                             : cr_tri_box_overlap_h3(c, h3, tri + f * 9, tri + f * 9 + 3, tri + f * 9 + 6)) { hit = 1; break; }
+    }
+    free(tri);
+    return hit;
+  }
   for (int i = 0; i < nk && !hit; ++i) {
     float c[3];
     int out = 0;

@@ -221,3 +221,54 @@ def test_mesh_vs_voxels_properties_implied_by_fcl_semantics():
         inner = (inner @ T[:3, :3].T.astype(np.float64) + T[:3, 3]).astype(np.float32)
         assert not co.mesh_voxels_collide(V, F, T, co.voxelize(inner, res), res)
     assert 60 < n_hit < 280
+
+
+def test_sensitivity_of_the_predicate_to_its_unpinnable_details():
+    """FCL / octomap cannot be run here, so the exposure is MEASURED instead (oracle/collision_sensitivity.py; the full C3 batch is in
+    profiles/r3_collision_sensitivity.json: 6 of 50,000 evaluations change under any variant).  On a 6,000-evaluation cut of the same
+    batch: FCL's own leaf boxes (16 float halvings of the root BV) and an independent narrow phase (float64 polygon clipping, no
+    separating axes) must reproduce the parity oracle's codes / nudges / poses exactly, and a +-1 um change of the cube's half edge
+    (the GJK-tolerance scale) may move at most 0.1 % of the codes.  The variant switch must leave the default path untouched."""
+    from oracle import collision_sensitivity as cs
+    batch, objs, gripper, nocs, cats, n_total = cs.c3_batch(per_replica=6000)
+    cs.set_variant()
+    base = cs.run_batch(batch, objs, gripper, nocs, cats)
+    assert n_total == 6000 and len(base[0]) == n_total and set(np.unique(base[0])) <= {0, 1, 3, 4}
+    try:
+        for name in ('fcl_halving', 'clip64', 'fcl_halving+clip64'):
+            cs.set_variant(*cs.VARIANTS[name])
+            c, n, p = cs.run_batch(batch, objs, gripper, nocs, cats)
+            assert np.array_equal(c, base[0]) and np.array_equal(n, base[1]) and np.array_equal(p, base[2]), name
+        for name in ('grow_1um', 'shrink_1um'):
+            cs.set_variant(*cs.VARIANTS[name])
+            c, n, _ = cs.run_batch(batch, objs, gripper, nocs, cats)
+            assert (c != base[0]).sum() <= 6 and ((n != base[1]) & (c == base[0])).sum() <= 6, name
+    finally:
+        cs.set_variant()
+    again = cs.run_batch(batch, objs, gripper, nocs, cats)
+    assert all(np.array_equal(a, b) for a, b in zip(again, base))
+    # grazing pairs (closest approach within +-2 um of contact): the float32 SAT and the float64 clipping agree on every one of them;
+    # the FCL-halved leaf boxes move ~1 % of THESE (they differ from (k + 0.5) res by an ulp of 0.6 m = 6e-8 m)
+    keys, a, b, e = cs.grazing_pairs(4000, seed=1)
+    g0 = cs.grazing_decisions(keys, a, b, e, 0, 0.0, 0)
+    assert 0.3 < g0.mean() < 0.7
+    assert (cs.grazing_decisions(keys, a, b, e, 0, 0.0, 1) != g0).sum() == 0
+    assert (cs.grazing_decisions(keys, a, b, e, 1, 0.0, 0) != g0).mean() < 0.03
+
+
+def test_general_half_extent_sat_equals_the_cube_sat():
+    """cr_tri_box_overlap_h3 (per-axis half extents, used by the sensitivity variants) == cr_tri_box_overlap when the box is a cube."""
+    import ctypes
+    rng = np.random.default_rng(4)
+    l = co.lib()
+    n = 20000
+    c = rng.normal(0, 0.01, (n, 3)).astype(np.float32); h = np.float32(0.00025)
+    tri = (c[:, None, :] + rng.normal(0, 0.0004, (n, 3, 3))).astype(np.float32)
+    h3 = np.array([h, h, h], dtype=np.float32)
+    P = lambda x: x.ctypes.data_as(ctypes.c_void_p)
+    agree = 0
+    for i in range(n):
+        a = l.cr_tri_box_overlap(P(c[i]), ctypes.c_float(h), P(tri[i, 0]), P(tri[i, 1]), P(tri[i, 2]))
+        b = l.cr_tri_box_overlap_h3(P(c[i]), P(h3), P(tri[i, 0]), P(tri[i, 1]), P(tri[i, 2]))
+        agree += int(a == b)
+    assert agree == n

@@ -37,6 +37,17 @@ def host_predicter(monkeypatch):
         p = torch.softmax(logits, 1)
         conf, label = p.max(1)
         return p, label.int(), conf, (p * torch.arange(10)).sum(1) / 10
+    def pose_inverse_rows_f64(poses, center, bad=None):
+        from catgrasp_amd import transforms
+        return torch.from_numpy(transforms.pose_inverse_rows(poses.numpy().reshape(-1, 4, 4), center))
+
+    class _Ev:
+        def synchronize(self):
+            pass
+    from catgrasp_amd import predicter as pred_mod
+    monkeypatch.setattr(pred_mod, '_pin', lambda t: t)
+    monkeypatch.setattr(pred_mod, '_event', lambda: _Ev())
+    monkeypatch.setattr(ops, 'pose_inverse_rows_f64', pose_inverse_rows_f64)
     monkeypatch.setattr(ops, 'apply_shuffle_rows', _apply_shuffle_rows_host)
     monkeypatch.setattr(ops, 'build_grasp_input', build_grasp_input)
     monkeypatch.setattr(engine, 'cls_forward', cls_forward)
@@ -66,7 +77,7 @@ def test_numpy_mode_pipeline_equals_the_reference_loop(host_predicter, n_cloud, 
     assert np.array_equal(torch.cat(seen['ids']).numpy(), want_ids)
     assert len(got) == G and all(a[0] == b[0] and a[1] == b[1] and np.array_equal(a[2], b[2]) for a, b in zip(got, want))
     assert isinstance(got[0][0], (int, np.integer)) and got[0][2].shape == (10,) and got[0][2].dtype == np.float32
-    # chunk plans: explicit ids in uniform chunks; the host-produced stream in a ramp capped by the chunk size
+    # chunk plans: the ramp (2048, 4096, 8192, then full chunks) capped by the predicter's chunk size -- 64 here, i.e. uniform
     assert explicit_chunks == [min(64, G - s) for s in range(0, G, 64)]
     assert sum(seen['chunks']) == G and all(c <= 64 for c in seen['chunks'])
 

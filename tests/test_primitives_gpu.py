@@ -118,7 +118,11 @@ def test_sample_and_group(cuda_device):
     assert torch.equal(nx.cpu(), rx) and torch.equal(npnts.cpu(), rp)
 
 
-@pytest.mark.parametrize('D,K,mlp', [(6, 32, [64, 64, 128]), (0, 16, [32, 64]), (13, 64, [128, 128, 256]), (3, 40, [64])])
+# register-resident kernel: 1..3 layers of width 32 / 64 / 128, one / two / four neighbourhoods per 32-row tile (K <= 32 / 16 / 8) and
+# several row tiles (K = 40, 64); strip kernel: a 256-wide layer, a 96-wide layer, four layers
+@pytest.mark.parametrize('D,K,mlp', [(6, 32, [64, 64, 128]), (0, 16, [32, 64]), (13, 64, [128, 128, 256]), (3, 40, [64]), (6, 8, [32, 32, 64]),
+                                     (2, 12, [128, 128, 128]), (6, 5, [128]), (0, 32, [32]), (9, 16, [64, 128]), (6, 33, [128, 64, 32]),
+                                     (6, 32, [64, 96, 128]), (3, 16, [32, 32, 64, 64]), (6, 24, [128, 128, 128])])
 def test_fused_set_abstraction_matches_sample_and_group_plus_torch_ops(cuda_device, D, K, mlp):
     """Row X1: group -> shared MLP -> max in one kernel vs the reference pipeline it replaces: sample_and_group
     (pointnet2.py:101-129, restated in oracle/pointnet_ref.py and pinned to the real one) followed by the torch
