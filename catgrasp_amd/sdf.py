@@ -116,7 +116,9 @@ class SdfFile:
     def filepath(self):
         return self.filepath_
 
-    def read(self, device=None):
+    def read_arrays(self):
+        """-> (data (nx,ny,nz) float64 with data[i][j][k], origin (3,), resolution): the three constructor arguments
+        sdf_file.py:87 hands to Sdf3D; None if the file does not exist."""
         import os
         if not os.path.exists(self.filepath_):
             return None
@@ -126,7 +128,13 @@ class SdfFile:
             resolution = float(f.readline())
             vals = np.array(f.read().split(), dtype=np.float64)
         data = vals[:nx * ny * nz].reshape(nz, ny, nx).transpose(2, 1, 0)   # file order: k slowest, i fastest
-        return Sdf3D(np.ascontiguousarray(data), origin, resolution, device=device)
+        return np.ascontiguousarray(data), origin, resolution
+
+    def read(self, device=None):
+        parts = self.read_arrays()
+        if parts is None:
+            return None
+        return Sdf3D(parts[0], parts[1], parts[2], device=device)
 
     @staticmethod
     def write(path, data, origin, resolution):

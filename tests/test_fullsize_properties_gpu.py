@@ -20,6 +20,26 @@ pytestmark = pytest.mark.gpu
 
 
 _WORKLOADS = {}
+_ORACLE_PROBS = {}
+N_ORACLE = 1024        # oracle-scored candidates per configuration; computed once, shared by the arithmetic modes
+
+
+def _oracle_probs(key, sd, make_inputs):
+    """softmax of the oracle network (the torch-nn-ops formulation, pinned to the reference's golden outputs in
+    tests/test_oracle_golden.py) on N_ORACLE candidates, in chunks of 200 like predicter.py:69; cached per configuration."""
+    if key not in _ORACLE_PROBS:
+        import os
+        x = torch.from_numpy(make_inputs()).float()
+        psd = oref.prepared_state_dict(sd)
+        old = torch.get_num_threads()
+        torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
+        try:
+            with torch.no_grad():
+                lg = torch.cat([oref.pointnet_cls_forward_nnops(psd, x[s:s + 200])[0] for s in range(0, len(x), 200)])
+        finally:
+            torch.set_num_threads(old)
+        _ORACLE_PROBS[key] = torch.softmax(lg, 1).numpy()
+    return _ORACLE_PROBS[key]
 
 
 def _flat_workload(device, G, seed, n_objects, kind='nut'):
@@ -64,20 +84,26 @@ def test_scoring_properties_at_baseline_sizes(cuda_device, n_obj, G, kind):
         per, bounds = distributed.shard_bounds(G, 8)
         parts = [gp.score_on_device(xyz, nrm, ids[lo:hi], pinv[lo:hi])[0] for lo, hi in bounds if hi > lo]
         assert torch.equal(torch.cat(parts), probs)
-    # oracle spot check on a random sample of the same batch
+    # the oracle on 1,024 candidates of the same batch, spread over every object: transform restatement + oracle network
     rng = np.random.default_rng(3)
-    pick = np.sort(rng.choice(G, 32, replace=False))
+    pick = np.sort(rng.choice(G, N_ORACLE, replace=False))
     start = _candidate_owner(wl)
-    ids_h = ids[torch.from_numpy(pick).to(cuda_device)].cpu().numpy()
-    xs = []
-    for g, row in zip(pick, ids_h):
-        kob = int(np.searchsorted(start, g, side='right') - 1)
-        ob = wl['objs'][kob]
-        P = wl['poses_dev'][kob][g - start[kob]].cpu().numpy().reshape(4, 4).astype(np.float64)
-        xs.append(tref.grasp_transform(ob['xyz'].copy(), ob['normal'].copy(), P, row - kob * 2500)['input'])
-    ref_logits, _ = oref.pointnet_cls_forward(sd, torch.from_numpy(np.stack(xs)).float())
-    ref_probs = torch.softmax(ref_logits, 1).numpy()
-    assert np.abs(probs[torch.from_numpy(pick).to(cuda_device)].cpu().numpy() - ref_probs).max() <= 1e-4
+    owners = np.searchsorted(start, pick, side='right') - 1
+    assert set(owners.tolist()) == set(range(n_obj))
+
+    def make_inputs():
+        ids_h = ids[torch.from_numpy(pick).to(cuda_device)].cpu().numpy()
+        poses_h = [p.cpu().numpy().reshape(-1, 4, 4).astype(np.float64) for p in wl['poses_dev']]
+        xs = []
+        for g, row, kob in zip(pick, ids_h, owners):
+            ob = wl['objs'][kob]
+            xs.append(tref.grasp_transform(ob['xyz'].copy(), ob['normal'].copy(), poses_h[kob][g - start[kob]], row - kob * 2500)['input'])
+        return np.stack(xs)
+    ref_probs = _oracle_probs((n_obj, G, kind), sd, make_inputs)
+    got = probs[torch.from_numpy(pick).to(cuda_device)].cpu().numpy()
+    assert np.abs(got - ref_probs).max() <= 1e-4
+    ref_pg = (ref_probs * np.arange(10)).sum(1) / 10
+    assert np.abs(pg[torch.from_numpy(pick).to(cuda_device)].cpu().numpy() - ref_pg).max() <= 1e-4
 
 
 def test_mixed_category_bin_at_c5_size(cuda_device, mlp_precision):
@@ -124,8 +150,8 @@ def test_collision_and_nunocs_properties_at_c3_size(cuda_device):
     I4 = np.eye(4)
     sym_h = np.stack([nut_symmetry(i) for i in range(12)])      # nut: 12 symmetry transforms (Utils.py:79-94)
     sym = torch.from_numpy(sym_h.astype(np.float32)).to(cuda_device)
-    total = 0
-    for kob in (0, 5):
+    total = n_oracle = 0
+    for kob in range(8):                                          # every object of the scene
         ob, sc = wl['objs'][kob], wl['scenes'][kob]
         # grasp_sampler.py:345 call shape: canonical-frame grasps, 9-D nocs_pose (anisotropic scale), symmetry expansion, nudging
         nocs_pose = ob['pose'] @ np.diag([0.016, 0.016, 0.006, 1.0])
@@ -141,26 +167,38 @@ def test_collision_and_nunocs_properties_at_c3_size(cuda_device):
         assert codes.shape == (E,) and hist[0] > 0 and hist[3] + hist[4] > 0 and hist[1] == hist[2] == 0, hist
         # batch-composition independence, bit-exact: a random subset filtered alone gives the same codes / poses / nudges
         rng = np.random.default_rng(10 + kob)
-        sub = np.sort(rng.choice(n, 384, replace=False))
+        sub = np.sort(rng.choice(n, 100, replace=False))
         sub_t = torch.from_numpy(sub).to(cuda_device)
         c2, p2, n2 = my_cpp.filter_on_device(sc, P[sub_t].contiguous(), sym, *args)
         e_idx = (sub_t[:, None] * 12 + torch.arange(12, device=cuda_device)[None]).reshape(-1)
         assert torch.equal(c2, codes[e_idx]) and torch.equal(n2, nudge[e_idx])
         keep = c2 == 0
         assert torch.equal(p2[keep], poses[e_idx][keep])
-        # broad phase == exhaustive kernel at full size
         bg = synth.background_points(wl['objs'], kob, g['diameter'])
-        sc_ex = my_cpp.GripperScene(g['vertices'], g['faces'], g['enclosed_vertices'], g['enclosed_faces'], ob['xyz'], bg, 0.0005,
-                                    cuda_device, accel=False)
-        c3, p3, n3 = my_cpp.filter_on_device(sc_ex, P, sym, *args)
-        assert torch.equal(c3, codes) and torch.equal(n3, nudge) and torch.equal(p3[codes == 0], poses[codes == 0])
-        # the C oracle on the subset (bit-exact codes and nudge indices, poses of the survivors)
+        if kob in (0, 5):     # broad phase == exhaustive kernel at full size
+            sc_ex = my_cpp.GripperScene(g['vertices'], g['faces'], g['enclosed_vertices'], g['enclosed_faces'], ob['xyz'], bg, 0.0005,
+                                        cuda_device, accel=False)
+            c3, p3, n3 = my_cpp.filter_on_device(sc_ex, P, sym, *args)
+            assert torch.equal(c3, codes) and torch.equal(n3, nudge) and torch.equal(p3[codes == 0], poses[codes == 0])
+        # the C oracle on the subset (bit-exact codes and nudge indices, poses of the survivors): 1,200 evaluations per object
         oc, op, on = co.filter_grasp_pose(P[sub_t].cpu().numpy().reshape(-1, 4, 4), list(sym_h), nocs_pose, I4, I4, I4,
                                           g['gripper_in_grasp'], 0, 0, 1, g['vertices'], g['faces'], g['enclosed_vertices'],
                                           g['enclosed_faces'], ob['xyz'], bg, 0.0005)
         assert np.array_equal(oc, c2.cpu().numpy()) and np.array_equal(on, n2.cpu().numpy())
         assert np.array_equal(op[oc == 0], p2.cpu().numpy()[oc == 0])
-    assert total == 2 * 6250 * 12
+        n_oracle += len(oc)
+        # grasp_sampler.py:216 call shape on the same object: camera-frame poses, symmetry [I], approach-direction filter, no nudging
+        Pc = torch.from_numpy(P_cam.astype(np.float32).reshape(-1, 16)).to(cuda_device)
+        eye = torch.eye(4, device=cuda_device).reshape(1, 16)
+        cc, pc, _ = my_cpp.filter_on_device(sc, Pc, eye, I4, I4, I4, I4, g['gripper_in_grasp'], True, False, False)
+        sub2 = np.sort(rng.choice(n, 150, replace=False))
+        oc2, op2, _ = co.filter_grasp_pose(P_cam[sub2].astype(np.float32), [I4], I4, I4, I4, I4, g['gripper_in_grasp'], 1, 0, 0, g['vertices'],
+                                           g['faces'], g['enclosed_vertices'], g['enclosed_faces'], ob['xyz'], bg, 0.0005)
+        sub2_t = torch.from_numpy(sub2).to(cuda_device)
+        assert np.array_equal(oc2, cc[sub2_t].cpu().numpy()) and np.array_equal(op2[oc2 == 0], pc[sub2_t].cpu().numpy()[oc2 == 0])
+        n_oracle += len(oc2)
+    assert n_oracle >= 10000
+    assert total == 8 * 6250 * 12
     # NUNOCS over the 8 object clouds of the scene: every decoded coordinate is a bin centre in [-0.5, 0.5), and the batch of 8
     # equals 8 single-cloud calls bit for bit
     npred = NunocsPredicter('nut', cfg=DEFAULT_NUNOCS_CFG, state_dict=synth.make_state_dict('seg', 6, 300, seed=1), device=cuda_device)
@@ -172,6 +210,29 @@ def test_collision_and_nunocs_properties_at_c3_size(cuda_device):
         for k in (0, 7):
             ck, fk, _ = npred.nocs_on_device(wl['cloud_xyz'], wl['cloud_normal'], wl['nunocs_ids'][k:k + 1].contiguous())
             assert torch.equal(ck[0], coords[k]) and torch.equal(fk[0], conf[k])
+        # ... and against the oracle at full size: the logits of ALL 8 x 8192 points from the oracle network on the restated
+        # NunocsIsolatedDataset.transform of the same resampled points; decoded coordinates equal wherever the top-2 bin logits are
+        # separated by more than the tolerance
+        _, _, logits = npred.nocs_on_device(wl['cloud_xyz'], wl['cloud_normal'], wl['nunocs_ids'])
+    import os
+    ids_h = wl['nunocs_ids'].cpu().numpy()
+    xin = np.stack([tref.nunocs_transform(wl['objs'][k]['xyz'].copy(), wl['objs'][k]['normal'].copy(), ids_h[k] - k * 2500)['input'] for k in range(8)])
+    sd_seg = synth.make_state_dict('seg', 6, 300, seed=1)
+    old = torch.get_num_threads()
+    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
+    try:
+        with torch.no_grad():
+            ref_lg = torch.cat([oref.pointnet_seg_forward_nnops(oref.prepared_state_dict(sd_seg), torch.from_numpy(xin[k:k + 1]).float())[0] for k in range(8)])
+    finally:
+        torch.set_num_threads(old)
+    ref_lg = ref_lg.numpy()
+    got_lg = logits.cpu().numpy()
+    assert got_lg.shape == ref_lg.shape == (8, 8192, 300)
+    assert (np.abs(got_lg - ref_lg) / np.maximum(1.0, np.abs(ref_lg))).max() <= 1e-4
+    srt = np.sort(ref_lg.reshape(8, 8192, 3, 100), axis=-1)
+    clear = (srt[..., -1] - srt[..., -2]) > 2e-4
+    ref_coords = ref_lg.reshape(8, 8192, 3, 100).argmax(-1) / 100.0 - 0.5
+    assert clear.mean() > 0.99 and np.array_equal(coords.cpu().numpy()[clear], ref_coords.astype(np.float32)[clear])
 
 
 def nut_symmetry(i):

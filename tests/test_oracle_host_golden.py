@@ -238,3 +238,38 @@ def test_oracle_kdtree_evaluation_matches_the_real_worker():
             m = np.zeros(len(g['src']), dtype=np.uint8); m[o[2]] = 1
             assert abs(o[0] - g[f'ratio{si}'][k]) < 1e-12 and np.abs(o[1] - g[f'tf{si}'][k]).max() < 1e-12 and np.array_equal(m, g[f'inliers{si}'][k])
     assert n_acc >= 40
+
+
+def test_robot_gripper_loader_matches_the_real_class(tmp_path):
+    """catgrasp_amd.gripper.RobotGripper.load vs the REAL dexnet RobotGripper.load on the committed fixture directory
+    (tests/golden/gripper_fixture, tests/golden/gripper_golden.npz; only trimesh's OBJ parser and autolab_core's .tf parser were
+    stand-ins when the golden was made): both frame orders of T_grasp_gripper.tf, the finger extents in the grasp frame incl. the
+    reference's ymin / ymax convention, get_points_between_finger, every params.json key, and the SDF grids through SdfFile."""
+    import shutil
+    from catgrasp_amd import gripper as G
+    from catgrasp_amd import sdf as sdf_mod
+    here = os.path.dirname(os.path.abspath(__file__))
+    gold = np.load(os.path.join(here, 'golden', 'gripper_golden.npz'))
+    fix = os.path.join(here, 'golden', 'gripper_fixture')
+    for tag, tf_name in (('fwd', 'T_grasp_gripper.tf'), ('inv', 'T_grasp_gripper_inverted.tf')):
+        d = tmp_path / tag
+        shutil.copytree(fix, d)
+        shutil.copy(os.path.join(fix, tf_name), d / 'T_grasp_gripper.tf')
+        g = G.RobotGripper.load(str(d), load_sdf=False)
+        assert np.abs(g.T_grasp_gripper - gold[tag + '_T_grasp_gripper']).max() < 1e-12
+        assert np.abs(g.T_grasp_gripper - gold['T_true']).max() < 1e-6          # either stored frame order yields gripper -> grasp
+        assert np.abs(g.get_grasp_pose_in_gripper_base() - gold[tag + '_grasp_pose_in_gripper_base']).max() < 1e-12
+        ext = np.array([g.finger_xmin, g.finger_xmax, g.finger_ymin, g.finger_ymax, g.finger_zmin, g.finger_zmax])
+        assert np.abs(ext - gold[tag + '_finger_extents']).max() < 1e-12
+        assert np.abs(g.finger_mesh1_in_grasp.vertices - gold[tag + '_finger_in_grasp']).max() < 1e-12
+        V, F, Ve, Fe = g.filter_args()
+        assert np.array_equal(V, gold[tag + '_V']) and np.array_equal(F, gold[tag + '_F'])
+        assert np.array_equal(Ve, gold[tag + '_Ve']) and np.array_equal(Fe, gold[tag + '_Fe'])
+        between = g.get_points_between_finger(gold['pts'])
+        assert len(gold[tag + '_between']) > 10 and np.array_equal(between, gold[tag + '_between'])
+        assert np.array_equal(np.array([g.hand_depth, g.init_bite, g.finger_width, g.hand_height, g.max_width, g.min_width]), gold[tag + '_params'])
+        # the SDF text files as the real SdfFile.read hands them to Sdf3D (x fastest in the file, data[i][j][k])
+        data, origin, res = sdf_mod.SdfFile(str(d / 'gripper_air_tight.sdf')).read_arrays()
+        assert np.array_equal(data, gold[tag + '_sdf_data']) and np.array_equal(origin, gold[tag + '_sdf_origin']) and res == gold[tag + '_sdf_res'][0]
+        data_e, origin_e, _ = sdf_mod.SdfFile(str(d / 'gripper_enclosed_air_tight.sdf')).read_arrays()
+        assert np.array_equal(data_e, gold[tag + '_sdfe_data']) and np.array_equal(origin_e, gold[tag + '_sdfe_origin'])
