@@ -3,7 +3,7 @@ meaningful only for the scan/gather kernels").  For each kernel: ALGORITHMIC byt
 time measured with HIP events on the launch stream, against the 8 TB/s HBM3E peak (MI355X_MICROARCH.md).  Latency-bound
 kernels (FPS: sequential dependency over npoint; the collision filter: L2/LDS gathers) are reported with their own unit.
 
-    python scripts/hbm_kernels.py > profiles/r2_hbm_kernels.json          (on the GPU box)
+    python scripts/hbm_kernels.py > profiles/r3_hbm_kernels.json          (on the GPU box)
 """
 import json
 import sys
@@ -73,8 +73,13 @@ row('square_distance_kernel', timed(lambda: primitives.square_distance(new, pts)
 idx = torch.randint(0, N, (1, S, K), device=dev, generator=g)
 row('index_points (group) kernel', timed(lambda: primitives.index_points(feat, idx)), S * K * (8 + 24), '8 B index + 24 B row written per neighbour (gathers are L2 hits)')
 t_fps = timed(lambda: primitives.farthest_point_sample(pts, S, start=torch.zeros(1, dtype=torch.long, device=dev)), iters=5, warm=1)
-row('farthest_point_sample_kernel', t_fps, N * 12 + S * 8, 'N x 12 B read once + S x 8 B out', bound='latency (sequential over npoint)',
-    extra={'rounds_per_s': round(S / t_fps), 'note': 'one 1024-thread workgroup, points in VGPRs; reference CPU: 0.24 s'})
+row('farthest_point_sample_kernel', t_fps, N * 12 + S * 8, 'N x 12 B read once + S x 8 B out', bound='VALU of one CU (sequential over npoint)',
+    extra={'rounds_per_s': round(S / t_fps), 'us_per_round': round(t_fps / S * 1e6, 3),
+           'note': 'one 512-thread workgroup, 40 points per thread in VGPRs, 8 VALU per point per round; reference CPU: 0.24 s'})
+pts8 = (torch.rand(8, N, 3, device=dev, generator=g) * 0.1).contiguous()
+t_fps8 = timed(lambda: primitives.farthest_point_sample(pts8, S, start=torch.zeros(8, dtype=torch.long, device=dev)), iters=5, warm=1)
+row('farthest_point_sample_kernel (the 8 clouds of C3 in one launch)', t_fps8, 8 * (N * 12 + S * 8), 'as above x 8 clouds, one workgroup each', bound='VALU of one CU per cloud',
+    extra={'us_per_round_all_clouds': round(t_fps8 / S * 1e6, 3)})
 t_bq = timed(lambda: primitives.query_ball_point(0.02, K, pts, new), iters=10)
 row('query_ball_point_kernel', t_bq, (N + S) * 12 + S * K * 8, '(N+S) x 12 B read + S x nsample x 8 B written (HBM level)', bound='L2 scan',
     extra={'cache_level_GBps': round(S * N * 12 / t_bq / 1e9, 1), 'cache_level_bytes': 'S x N x 12 B distance tests'})
@@ -115,17 +120,17 @@ sa = primitives.SetAbstractionWeights([(np.random.default_rng(0).normal(0, 0.2, 
                                        (np.random.default_rng(2).normal(0, 0.1, (128, 64)), np.zeros(128), None)], 9, dev)
 idx_sa = primitives.query_ball_point(0.02, K, pts, new)
 idx_sa = torch.where(idx_sa >= N, torch.zeros_like(idx_sa), idx_sa)
-t_sa = timed(lambda: primitives.group_mlp_max(pts, feat, new, idx_sa, sa))
+t_sa = timed(lambda: primitives.group_mlp_max(pts, feat, new, idx_sa, sa, check=False))        # kernel alone: no per-call read-back of the error flag
 mac = S * K * (16 * 64 + 64 * 64 + 64 * 128)
 row('sa_group_mlp_max_kernel (N=20000, S=1024, K=32, mlp 9->64->64->128)', t_sa, S * K * (8 + 36) + S * (12 + 512),
     '8 B index + 36 B gathered row per neighbour + 12 B centroid in + 512 B out per neighbourhood (the unfused pipeline writes and re-reads S x K x (9 + 64 + 64 + 128) x 4 B = 35 MB)',
     bound='mfma (exact f32)', extra={'TFLOPs': round(2 * mac / t_sa / 1e12, 2), 'frac_of_157.3_TFLOPs': round(2 * mac / t_sa / 1e12 / 157.3, 4),
-                                     'note': 'one wave per neighbourhood; 1024 neighbourhoods = 256 workgroups: launch/latency bound at this size'})
+                                     'note': 'register-resident activations, weights in LDS; 1024 neighbourhoods = one 4-wave workgroup per CU: a neighbourhood is one dependent chain of 208 MFMAs'})
 Bb = 16
 ptsB = (torch.rand(Bb, N, 3, device=dev, generator=g) * 0.1).contiguous(); featB = torch.randn(Bb, N, 6, device=dev, generator=g)
 newB = ptsB[:, :S].contiguous()
 idxB = primitives.query_ball_point(0.02, K, ptsB, newB); idxB = torch.where(idxB >= N, torch.zeros_like(idxB), idxB)
-t_sb = timed(lambda: primitives.group_mlp_max(ptsB, featB, newB, idxB, sa))
+t_sb = timed(lambda: primitives.group_mlp_max(ptsB, featB, newB, idxB, sa, check=False))
 row('sa_group_mlp_max_kernel (16 clouds)', t_sb, Bb * (S * K * (8 + 36) + S * (12 + 512)), 'as above x 16 clouds', bound='mfma (exact f32)',
     extra={'TFLOPs': round(2 * mac * Bb / t_sb / 1e12, 2), 'frac_of_157.3_TFLOPs': round(2 * mac * Bb / t_sb / 1e12 / 157.3, 4)})
 coords = torch.cat([torch.zeros(100000, 1, dtype=torch.long, device=dev), torch.randint(0, 64, (100000, 3), device=dev, generator=g)], 1)
