@@ -301,6 +301,28 @@ def rccl_selftest(batch, n_total, ref_out, device):
     return info
 
 
+_REAL_STDOUT = None
+
+
+def claim_stdout():
+    """stdout is the driver's channel for ONE JSON line.  Libraries under this process write there too (RCCL prints a version banner
+    through C stdio when a communicator is created): point file descriptor 1 at stderr for the life of the process and keep the
+    original for emit()."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(obj):
+    data = (json.dumps(obj) + '\n').encode()
+    if _REAL_STDOUT is None:
+        sys.stdout.write(data.decode()); sys.stdout.flush()
+    else:
+        os.write(_REAL_STDOUT, data)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -332,6 +354,7 @@ def main():
     if args.pmc_traffic is None:
         import shutil
         args.pmc_traffic = bool(shutil.which('rocprofv3') or os.path.exists('/opt/rocm/bin/rocprofv3'))
+    claim_stdout()
     if args.precision is None:
         args.precision = 'bf16x3' if args.workload == 'C5' else 'f32'
     if args.candidates_total is None:
@@ -396,8 +419,7 @@ def main():
                 cgd.score_sharded(batch.score_slice, n_total)
         torch.cuda.synchronize()
         ev = ops.KERNEL_TIMER['events']
-        print(json.dumps({'pmc_child': True, 'launches': len(ev), 'candidate_equivalents': float(sum(B * N / 2048.0 for _, _, (B, N) in ev))}),
-              flush=True)
+        emit({'pmc_child': True, 'launches': len(ev), 'candidate_equivalents': float(sum(B * N / 2048.0 for _, _, (B, N) in ev))})
         return
 
     def measure(precision, batch=batch, n_total=n_total):
@@ -552,7 +574,7 @@ def main():
             line['api'] = api_block(batch, gp, device)
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(batch, sd_cls, sd_seg)
-        print(json.dumps(line), flush=True)
+        emit(line)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

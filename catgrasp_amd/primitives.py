@@ -150,11 +150,11 @@ class SetAbstractionWeights:
         self.in_channel = in_channel
 
 
-def group_mlp_max(xyz, points, new_xyz, idx, W, check=True):
+def group_mlp_max(xyz, points, new_xyz, idx, W, check_indices=True):
     """The consumer of sample_and_group fused into one kernel (cg_sa_group_mlp_max): neighbourhoods idx (B,S,K) of xyz/points
     around new_xyz -> centred coordinates ++ features -> shared MLP W (SetAbstractionWeights) -> max over the K neighbours.
     -> (B, C_out, S) float32, the layout torch.max(new_points, 2)[0] has in a PointNet++ set-abstraction layer.
-    check=False skips the read-back of the index-error flag (one host synchronisation per call) and returns (out, err_flag tensor):
+    check_indices=False skips the read-back of the index-error flag (one host synchronisation per call) and returns (out, err_flag tensor):
     for callers that batch the check, and for timing the kernel alone."""
     require_cuda(xyz, new_xyz, idx)
     xyz = _f32(xyz); new_xyz = _f32(new_xyz)
@@ -173,7 +173,7 @@ def group_mlp_max(xyz, points, new_xyz, idx, W, check=True):
     wp = (ctypes.c_void_p * L_)(*[t.data_ptr() for t in W.w]); bp = (ctypes.c_void_p * L_)(*[t.data_ptr() for t in W.b])
     check(L.lib().cg_sa_group_mlp_max(_p(xyz), _p(points), _p(new_xyz), _p(idx), _c_int(B), _c_int(N), _c_int(S), _c_int(K), _c_int(D),
                                       _c_int(L_), cin, cout, wp, bp, _p(out), _p(err), _stream()), 'cg_sa_group_mlp_max')
-    if not check:
+    if not check_indices:
         return out, err
     _raise_if(err, 'group_mlp_max (a query ball was empty or an index is out of range)')
     return out

@@ -120,7 +120,7 @@ sa = primitives.SetAbstractionWeights([(np.random.default_rng(0).normal(0, 0.2, 
                                        (np.random.default_rng(2).normal(0, 0.1, (128, 64)), np.zeros(128), None)], 9, dev)
 idx_sa = primitives.query_ball_point(0.02, K, pts, new)
 idx_sa = torch.where(idx_sa >= N, torch.zeros_like(idx_sa), idx_sa)
-t_sa = timed(lambda: primitives.group_mlp_max(pts, feat, new, idx_sa, sa, check=False))        # kernel alone: no per-call read-back of the error flag
+t_sa = timed(lambda: primitives.group_mlp_max(pts, feat, new, idx_sa, sa, check_indices=False))        # kernel alone: no per-call read-back of the error flag
 mac = S * K * (16 * 64 + 64 * 64 + 64 * 128)
 row('sa_group_mlp_max_kernel (N=20000, S=1024, K=32, mlp 9->64->64->128)', t_sa, S * K * (8 + 36) + S * (12 + 512),
     '8 B index + 36 B gathered row per neighbour + 12 B centroid in + 512 B out per neighbourhood (the unfused pipeline writes and re-reads S x K x (9 + 64 + 64 + 128) x 4 B = 35 MB)',
@@ -130,7 +130,7 @@ Bb = 16
 ptsB = (torch.rand(Bb, N, 3, device=dev, generator=g) * 0.1).contiguous(); featB = torch.randn(Bb, N, 6, device=dev, generator=g)
 newB = ptsB[:, :S].contiguous()
 idxB = primitives.query_ball_point(0.02, K, ptsB, newB); idxB = torch.where(idxB >= N, torch.zeros_like(idxB), idxB)
-t_sb = timed(lambda: primitives.group_mlp_max(ptsB, featB, newB, idxB, sa, check=False))
+t_sb = timed(lambda: primitives.group_mlp_max(ptsB, featB, newB, idxB, sa, check_indices=False))
 row('sa_group_mlp_max_kernel (16 clouds)', t_sb, Bb * (S * K * (8 + 36) + S * (12 + 512)), 'as above x 16 clouds', bound='mfma (exact f32)',
     extra={'TFLOPs': round(2 * mac * Bb / t_sb / 1e12, 2), 'frac_of_157.3_TFLOPs': round(2 * mac * Bb / t_sb / 1e12 / 157.3, 4)})
 coords = torch.cat([torch.zeros(100000, 1, dtype=torch.long, device=dev), torch.randint(0, 64, (100000, 3), device=dev, generator=g)], 1)
