@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void index_points_kernel(const float* __restri
 //    centre is taken out of the exchanged records with v_readlane -- no dependent LDS or global read at the top of the round.
 // History (N = 20,000 -> 1,024, one cloud): 4.19 ms (round 1) -> 2.71 ms (round 2: 64-bit DPP keys) -> 2.04 ms (round 3: packed math,
 // branch-free arg-max, 32-bit reduction) -> 1.73 ms (unsigned-bit min / max): 1.69 us per round; the VALU floor of this formulation on
-// one CU is 20,000 points x 8 VALU / 4 SIMDs x 4 clocks = 1.39 us at the 2.3 GHz the kernel runs at.
+// one CU is 20,000 points x 8 VALU / 64 lanes / 4 SIMDs x 4 clocks = 1.09 us at the 2.3 GHz the kernel runs at.
 // Running distances are >= +0 (sums of squares; 1e10 initially), so their BIT PATTERNS order like the values: min / max / compare run
 // on them as unsigned integers -- one v_min_u32 / v_max_u32 (with the DPP row operation folded in) where the float forms cost a
 // compare + select or drag a canonicalising v_max along.
