@@ -35,15 +35,22 @@ sample_and_group = _prim.sample_and_group
 sample_and_group_all = _prim.sample_and_group_all
 
 
+# The fused kernels max-pool with NaN-ignoring arithmetic (-fno-honor-nans): where the reference would hand back NaN outputs, a NaN / Inf
+# input point would be pooled away silently -- so every eval-mode forward first rejects non-finite input (one reduction over the input +
+# a 1-byte read-back, i.e. one host synchronisation per call).  A caller that guarantees finite inputs and wants its forwards to stay
+# asynchronous on the stream can switch the check off: catgrasp_amd.pointnet2.VALIDATE_INPUTS = False  (or CATGRASP_AMD_VALIDATE_INPUTS=0).
+# (The predicters do not pay for it: they validate the cloud once on the host, transforms.DeviceCloud.)
+import os as _os
+VALIDATE_INPUTS = _os.environ.get('CATGRASP_AMD_VALIDATE_INPUTS', '1') != '0'
+
+
 def _use_hip(module, x):
     if module.training or torch.is_grad_enabled():
         return False
     if not x.is_cuda:
         raise RuntimeError('catgrasp_amd.pointnet2: eval-mode inference needs a CUDA/HIP tensor '
                            '(the HIP kernels are the only inference path; there is no CPU fallback)')
-    # The fused kernels max-pool with NaN-ignoring arithmetic (-fno-honor-nans): where the reference would hand back NaN outputs, a
-    # NaN / Inf input point would be pooled away silently -- reject it instead (one reduction over the input + a 1-byte read-back).
-    if not bool(torch.isfinite(x).all()):
+    if VALIDATE_INPUTS and not bool(torch.isfinite(x).all()):
         raise ValueError('catgrasp_amd.pointnet2: the input contains NaN or Inf')
     return True
 

@@ -339,7 +339,7 @@ def test_symmetry_sets_form_groups():
         transforms.get_symmetry_tfs('bolt')
 
 
-@pytest.mark.parametrize('name', ['r1_bench_line.json', 'r2_bench_line.json'])
+@pytest.mark.parametrize('name', ['r1_bench_line.json', 'r2_bench_line.json', 'r3_bench_line.json'])
 def test_committed_bench_line_honours_the_contract(name):
     """profiles/r<N>_bench_line.json is the JSON line bench.py printed on the MI355X in that round: every field of the driver's
     contract (and the roofline / cpu_baseline objects) must be present and self-consistent; from round 2 on the line is measured
@@ -348,7 +348,7 @@ def test_committed_bench_line_honours_the_contract(name):
     import os
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles', name)
     d = json.loads(open(path).read())
-    if name.startswith('r2'):
+    if not name.startswith('r1'):
         assert d['config']['candidates_per_gpu'] == 50000 and d['config']['workload'].startswith('C3') and d['dtype'].startswith('f32 ')
         assert d['config']['evaluations_nocs_shape_adjust_true'] + d['config']['evaluations_cone_shape_adjust_false'] == 50000
         assert {x['precision'] for x in d['secondary']} >= {'f16x3', 'bf16x3'} and all(x['codes_identical_to_primary'] for x in d['secondary'])
@@ -357,7 +357,12 @@ def test_committed_bench_line_honours_the_contract(name):
     for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype',
               'data', 'config', 'roofline', 'cpu_baseline'):
         assert k in d, k
-    assert d['unit'] == 'candidates/s' and d['higher_is_better'] is True and d['scaling'] == 'weak' and d['vs_baseline'] is None
+    if name.startswith('r3'):        # round 3: traffic measured inside the run, RCCL exercised on the step's records, API within 5 % of `value`
+        assert d['roofline']['traffic_source'].startswith('measured for this run') and 1.0 <= d['roofline']['traffic'] / (69632 * d['roofline']['candidates_per_launch']) < 1.1
+        assert d['rccl_selftest']['ok'] is True and d['rccl_selftest']['backend'] == 'nccl' and d['rccl_selftest']['records'] == 50000
+        numpy_f32 = [x for x in d['api']['predict_batch'] if x['rng'].startswith('numpy') and x['precision'] == 'f32'][0]
+        assert numpy_f32['candidates_per_s'] >= 0.95 * d['value']
+    assert d['unit'] == 'candidates/s' and d['higher_is_better'] is True and d['scaling'] == ('strong' if name.startswith('r3') else 'weak') and d['vs_baseline'] is None
     assert 'workload' in d['config'] and 'model' not in d['config']
     per_gpu = d['config']['candidates_per_gpu']
     assert abs(d['value'] - d['n_gpus'] * per_gpu / (d['ms_per_step'] * 1e-3)) / d['value'] < 1e-3
