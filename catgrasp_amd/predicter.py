@@ -273,23 +273,23 @@ class GraspPredicter:
         probs_h, label_h, conf_h, flags_h = (stage[k].numpy() for k in ('probs', 'label', 'conf', 'flags'))
         rows, pending = [], []
 
-        def launch(k, s, e, precision_override=None):
-            pinv = ops.pose_inverse_rows_f64(torch.from_numpy(self._poses_f64(grasp_poses, s, e)).to(self.device, non_blocking=True), cloud.center, bad)
-            idc = ids_d(s, e) if callable(ids_d) else ids_d[s:e]
+        def score(s, e, idc, status, bad_flag):
+            """queue one chunk: pose upload + inverse, input transform, network, softmax, asynchronous copies into the staging buffers"""
+            pinv = ops.pose_inverse_rows_f64(torch.from_numpy(self._poses_f64(grasp_poses, s, e)).to(self.device, non_blocking=True), cloud.center,
+                                             bad_flag)
             x = ops.build_grasp_input(cloud.xyz, cloud.normal, idc, pinv, self._mean, self._inv_std)
-            st = engine.new_status(self.device) if (guard and precision_override is None) else None
-            if precision_override:
-                with engine.precision(precision_override):
-                    logits = engine.cls_forward(self._W, x, None)[0]
-            else:
-                logits = engine.cls_forward(self._W, x, st)[0]
-            probs, label, conf, _ = ops.softmax_pg(logits)
+            probs, label, conf, _ = ops.softmax_pg(engine.cls_forward(self._W, x, status)[0])
             stage['probs'][s:e].copy_(probs, non_blocking=True); stage['label'][s:e].copy_(label, non_blocking=True)
             stage['conf'][s:e].copy_(conf, non_blocking=True)
+
+        def launch(k, s, e):
+            idc = ids_d(s, e) if callable(ids_d) else ids_d[s:e]
+            st = engine.new_status(self.device) if guard else None
+            score(s, e, idc, st, bad)
             stage['flags'][k, 0:1].copy_(bad, non_blocking=True)
             if st is not None:
                 stage['flags'][k, 1:2].copy_(st, non_blocking=True)
-            return _event(), (idc if guard else None)
+            return _event(), (idc if guard else None)        # the id chunk is kept only while a range re-run is still possible
 
         def drain(k, s, e, ev, idc):
             ev.synchronize()
@@ -297,23 +297,14 @@ class GraspPredicter:
                 raise ValueError('grasp_poses contain NaN or Inf')
             if guard and flags_h[k, 1]:                 # this chunk left the half range: score it again with bf16 pieces (rare)
                 engine.warn_range(int(flags_h[k, 1]))
-                ev2, _ = launch_again(k, s, e, idc)
-                ev2.synchronize()
+                with engine.precision('bf16x3'):
+                    score(s, e, idc, None, None)
+                _event().synchronize()
             pr = np.array(probs_h[s:e])                  # own copy: the rows below are views of it, the staging buffer is reused
             if not np.isfinite(pr).all():
                 raise FloatingPointError('grasp-Q probabilities are not finite (non-finite weights or activations beyond float32)')
             # [label, confidence, probs row] per pose like predicter.py:87-91
             rows.extend(map(list, zip(label_h[s:e].copy(), conf_h[s:e].copy(), pr)))
-
-        def launch_again(k, s, e, idc):
-            pinv = ops.pose_inverse_rows_f64(torch.from_numpy(self._poses_f64(grasp_poses, s, e)).to(self.device), cloud.center, None)
-            x = ops.build_grasp_input(cloud.xyz, cloud.normal, idc, pinv, self._mean, self._inv_std)
-            with engine.precision('bf16x3'):
-                logits = engine.cls_forward(self._W, x, None)[0]
-            probs, label, conf, _ = ops.softmax_pg(logits)
-            stage['probs'][s:e].copy_(probs, non_blocking=True); stage['label'][s:e].copy_(label, non_blocking=True)
-            stage['conf'][s:e].copy_(conf, non_blocking=True)
-            return _event(), None
 
         for k, (s, e) in enumerate(bounds):
             ev, idc = launch(k, s, e)
