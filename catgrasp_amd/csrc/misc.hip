@@ -248,6 +248,62 @@ __global__ __launch_bounds__(256) void nunocs_decode_kernel(const float* __restr
   }
 }
 
+// nbins % 4 == 0 (config_nunocs.yml: 100): HALF a wavefront per row, one 16-byte load per lane (25 of 32 lanes for 100 bins), two
+// adjacent rows = 800 contiguous bytes per wave instruction, DEC4_PAIRS row pairs (3.2 KB) in flight per wave; the (value, index)
+// arg-max and the sum of exponentials reduce through DPP row operations + one lane^16 exchange instead of six ds_bpermute
+// round trips per value.  Same first-maximum semantics; 40 -> see profiles/ for the 8 x 8192-point decode.
+constexpr int DEC4_PAIRS = 4;
+template <int CTRL>
+__device__ __forceinline__ void dpp_argmax_step(float& m, int& am) {
+  const float om = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(m), __float_as_int(m), CTRL, 0xf, 0xf, false));
+  const int oa = __builtin_amdgcn_update_dpp(am, am, CTRL, 0xf, 0xf, false);
+  const bool take = om > m || (om == m && oa < am);
+  m = take ? om : m; am = take ? oa : am;
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_add_step(float s) {
+  return s + __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(s), __float_as_int(s), CTRL, 0xf, 0xf, false));
+}
+__global__ __launch_bounds__(256) void nunocs_decode_x4_kernel(const float* __restrict__ logits, long P, int nbins,
+                                                               float* __restrict__ coords, float* __restrict__ conf_z) {
+  const int lane = threadIdx.x & 63, half = lane >> 5, t = lane & 31;
+  const long nrows = P * 3;
+  const long row0 = ((long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * (2 * DEC4_PAIRS);
+  if (row0 >= nrows) return;
+  const int nq = nbins >> 2;                      // 16-byte pieces per row, <= 32
+  f32x4 v[DEC4_PAIRS];
+#pragma unroll
+  for (int q = 0; q < DEC4_PAIRS; ++q) {
+    const long row = row0 + 2 * q + half;
+    v[q] = (row < nrows && t < nq) ? *(const f32x4*)(logits + row * nbins + 4 * t) : f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+  }
+#pragma unroll
+  for (int q = 0; q < DEC4_PAIRS; ++q) {
+    const long row = row0 + 2 * q + half;
+    float m = v[q][0]; int am = 4 * t;
+#pragma unroll
+    for (int j = 1; j < 4; ++j) { if (v[q][j] > m) { m = v[q][j]; am = 4 * t + j; } }
+    dpp_argmax_step<0xB1>(m, am);                 // quad_perm [1,0,3,2]
+    dpp_argmax_step<0x4E>(m, am);                 // quad_perm [2,3,0,1]
+    dpp_argmax_step<0x141>(m, am);                // row_half_mirror
+    dpp_argmax_step<0x140>(m, am);                // row_mirror: every lane of a 16-lane row holds its row's result
+    {                                             // the two 16-lane rows of the half
+      const float om = __shfl_xor(m, 16); const int oa = __shfl_xor(am, 16);
+      const bool take = om > m || (om == m && oa < am);
+      m = take ? om : m; am = take ? oa : am;
+    }
+    if (t == 0 && row < nrows) coords[row] = (float)am * (1.0f / (float)nbins) - 0.5f;
+    if ((row0 + 2 * q) % 3 != 0) {                // one of the pair's two rows is a z row (wave-uniform test): softmax confidence of its arg-max
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s += (t < nq) ? expf(v[q][j] - m) : 0.f;
+      s = dpp_add_step<0xB1>(s); s = dpp_add_step<0x4E>(s); s = dpp_add_step<0x141>(s); s = dpp_add_step<0x140>(s);
+      s += __shfl_xor(s, 16);
+      if (t == 0 && row < nrows && (row % 3) == 2) conf_z[row / 3] = 1.f / s;
+    }
+  }
+}
+
 }  // namespace
 
 namespace {
@@ -317,6 +373,12 @@ extern "C" int cg_nunocs_decode(const float* logits, long P, int nbins, float* c
   if (!logits || !coords || !conf_z || P < 0 || nbins <= 0) return CG_ERR_ARG;
   if (nbins > 64 * DEC_MAX_PER_LANE) return CG_ERR_UNSUPPORTED;      // config_nunocs.yml: ce_loss_bins = 100
   if (P == 0) return CG_OK;
+  if ((nbins & 3) == 0 && (((uintptr_t)logits) & 15) == 0) {
+    const long waves4 = (P * 3 + 2 * DEC4_PAIRS - 1) / (2 * DEC4_PAIRS);
+    hipLaunchKernelGGL(nunocs_decode_x4_kernel, dim3((unsigned)((waves4 + 3) / 4)), dim3(256), 0, (hipStream_t)stream, logits, P, nbins, coords,
+                       conf_z);
+    return cg_hip_status(hipGetLastError());
+  }
   const long waves = (P * 3 + DEC_ROWS - 1) / DEC_ROWS;
   hipLaunchKernelGGL(nunocs_decode_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                      logits, P, nbins, coords, conf_z);

@@ -120,3 +120,26 @@ def test_predict_batch_numpy_mode_uses_the_reference_stream(cuda_device):
     nxt_got = np.random.rand()
     assert nxt_got == nxt_want and len(got) == len(want)
     assert all(a[0] == b[0] and np.array_equal(a[2], b[2]) for a, b in zip(got, want))
+
+
+@pytest.mark.parametrize('P,nbins', [(1, 100), (7, 100), (1000, 100), (333, 64), (50, 128), (41, 4), (97, 50), (10, 99)])
+def test_nunocs_decode_kernels_against_the_oracle(cuda_device, P, nbins):
+    """cg_nunocs_decode (predicter.py:144-150): the half-wave / 16-byte-load kernel (nbins % 4 == 0) and the generic one, on ragged row
+    counts, with planted ties (first maximum wins, torch.argmax semantics) and with the maximum in the last bin."""
+    import torch
+    from catgrasp_amd import ops
+    from oracle import transforms_ref as tref
+    rng = np.random.default_rng(P * 131 + nbins)
+    lg = rng.normal(0, 3, (P, 3 * nbins)).astype(np.float32)
+    v = lg.reshape(P, 3, nbins)
+    for p in range(0, P, 3):                      # ties: the same maximal value twice in a row, far apart and adjacent
+        a, b = sorted(rng.choice(nbins, 2, replace=False))
+        v[p, p % 3, a] = v[p, p % 3, b] = 50.0
+    if P > 2:
+        v[2, :, nbins - 1] = 60.0                 # arg-max in the last bin (the last, partly filled 16-byte piece)
+        v[1, 2, :] = -7.5                         # a constant row: arg-max 0, confidence 1 / nbins
+    t = torch.from_numpy(lg).to(cuda_device)
+    coords, conf = ops.nunocs_decode(t, nbins)
+    rc, rf = tref.nunocs_decode(lg, nbins)
+    assert np.array_equal(coords.cpu().numpy(), rc)
+    assert np.abs(conf.cpu().numpy() - rf).max() <= 1e-6
