@@ -32,7 +32,6 @@
 //     of the next k-step are requested before the current k-step's MFMAs.  No workgroup barrier after the staging.
 #include "cg_common.hpp"
 #include "../../include/catgrasp_amd.h"
-#include <stdlib.h>
 
 namespace {
 
@@ -47,7 +46,6 @@ struct SAArgs {
   int w_off[SA_MAX_LAYERS];       // float offset of the layer's packed weights inside the LDS weight region, or -1: read from L2
   int b_off[SA_MAX_LAYERS];       // float offset of the layer's bias (always staged)
   int wb_floats;                  // size of the LDS weight + bias region
-  int dephase;                    // register kernel: start-up offset between the waves that share a SIMD, in steps of 4096 clocks
   float* out; int* err_flag;
 };
 
@@ -400,14 +398,6 @@ __global__ __launch_bounds__(NT) void sa_reg_kernel(SAArgs a) {
     for (int i = threadIdx.x; i < a.cout[l]; i += blockDim.x) smem[a.b_off[l] + i] = a.b[l][i];
   }
   __syncthreads();
-  // The waves that share a SIMD (w, w+4, w+8, ...) run the same program on equally sized work: left alone they stay in lockstep, all
-  // in the matrix pipe together and all out of it together (epilogues, gather, stores), and the pipe idles in between.  A one-off
-  // start-up offset puts their non-MFMA phases opposite each other's MFMA phases; the offset persists (the late wave keeps the
-  // pipe while the early one is in its epilogue and vice versa).
-  if (a.dephase > 0) {
-    for (int i = (wv >> 2) * a.dephase; i > 0; --i) __builtin_amdgcn_s_sleep(64);       // 64 x 64 clocks per step
-  }
-
   constexpr int RPN = 32 / PACK;                         // rows per neighbourhood
   const int G = a.B * a.S;                               // < 2^31 (checked by the launcher)
   const int nslots = (G + PACK - 1) / PACK;              // a slot = the PACK neighbourhoods of one tile
@@ -535,8 +525,6 @@ int launch_sa_reg(SAArgs& a, hipStream_t s, int dev) {
   // Persistent grid, one workgroup per CU (registers: NT threads fill a CU exactly once).  Waves per workgroup: the most the register
   // budget allows, unless fewer waves balance the slots better over the chip (a wave's slots are one dependent chain each: with
   // 16,384 slots 8 waves x 256 CUs take 8 slots each, 12 waves would take 5 or 6) or the launch is too small to give every CU one.
-  static const int force_waves = getenv("CATGRASP_SA_WAVES") ? atoi(getenv("CATGRASP_SA_WAVES")) : 0;      // dev A/B switches
-  static const int dephase = getenv("CATGRASP_SA_DEPHASE") ? atoi(getenv("CATGRASP_SA_DEPHASE")) : 1;
   int waves = WAVES;
   double best = -1.0;
   for (int w = WAVES; w >= 1; --w) {
@@ -544,8 +532,6 @@ int launch_sa_reg(SAArgs& a, hipStream_t s, int dev) {
     const double eff = (double)nslots / ((double)rounds * n_cu * w);
     if (eff > best + 0.03) { best = eff; waves = w; }
   }
-  if (force_waves > 0 && force_waves <= WAVES) waves = force_waves;
-  a.dephase = dephase;
   long grid = (nslots + waves - 1) / waves;
   if (grid > n_cu) grid = n_cu;
   auto kern = sa_reg_kernel<N0, N1, N2, PACK, NT>;
@@ -678,8 +664,7 @@ extern "C" int cg_sa_group_mlp_max(const float* xyz, const float* points, const 
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return CG_ERR_UNSUPPORTED;
   if (cmax > 256) return CG_ERR_UNSUPPORTED;
-  static const bool force_strip = getenv("CATGRASP_SA_STRIP") != nullptr;      // dev A/B switch
-  if (cmax <= 128 && !force_strip) {
+  if (cmax <= 128) {
     const int st = launch_sa_reg_any(a, (hipStream_t)stream, dev);
     if (st != CG_ERR_UNSUPPORTED) return st;             // outside the register kernel's signatures (4 layers, a width of 96): strip kernel
   }
