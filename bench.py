@@ -340,6 +340,8 @@ def main():
                          'products (3 MFMAs on hi+lo 16-bit pieces, f32 accumulation; logits within ~2e-6 / ~2e-5 of the float64 evaluation).  '
                          'Default f32; bf16x3 for C5 (configs[4] names the bf16 MFMA path)')
     ap.add_argument('--secondary', default='f16x3,bf16x3,f16fp8x2', help='comma list of further precisions measured in the same run ("" = none)')
+    ap.add_argument('--chunk', type=int, default=None,
+                    help='candidates per network launch (default: GraspPredicter\'s 16,384 = 805 MB of materialised input per chunk)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-api', action='store_true', help='skip the reference-API wall-clock block')
     ap.add_argument('--pmc-traffic', dest='pmc_traffic', action='store_true', default=None,
@@ -386,7 +388,8 @@ def main():
     # one GraspPredicter / NunocsPredicter per category, each with its own seeded random-init weights (run_grasp_simulation.py:701-702)
     sds = {c: (synth.make_state_dict('cls', 6, 10, seed=2 * i), synth.make_state_dict('seg', 6, 300, seed=2 * i + 1)) for i, c in enumerate(cats)}
     sd_cls, sd_seg = sds[cats[0]]
-    gps = {c: GraspPredicter(c, cfg=DEFAULT_GRASP_CFG, state_dict=sds[c][0], device=device) for c in cats}
+    gp_kw = {'chunk': args.chunk} if args.chunk else {}
+    gps = {c: GraspPredicter(c, cfg=DEFAULT_GRASP_CFG, state_dict=sds[c][0], device=device, **gp_kw) for c in cats}
     npreds = {c: NunocsPredicter(c, cfg=DEFAULT_NUNOCS_CFG, state_dict=sds[c][1], device=device) for c in cats}
     gp = gps[cats[0]]
 
