@@ -55,9 +55,16 @@ def _load_artifacts(artifact_dir, cfg_name, cfg, state_dict, normalizer):
     return cfg, state_dict
 
 
-def _pin(t):
-    """Page-locked staging buffer for the asynchronous device -> host copies of predict_batch."""
-    return t.pin_memory()
+def _pin(shape, dtype):
+    """Page-locked staging buffer of predict_batch (both directions).  A copy from PAGEABLE host memory is not asynchronous on
+    ROCm whatever `non_blocking` says: the runtime stages it in order on the stream and blocks the calling thread until it has run,
+    i.e. until the device has finished the chunk before -- everything the host does after it (the rest of the chunk's launches,
+    the rows of the previous chunk) is then done with the device idle (measured: 20-30 ms of a 50,000-pose call, rocprofv3 kernel
+    trace).  torch's host allocator caches these blocks, so repeated calls of the same shape pay the page-locking once."""
+    return torch.empty(shape, dtype=dtype, pin_memory=True)
+
+
+_PIN_LIMIT = 512 << 20       # per staging buffer; a larger chunk of swap partners (a > 30k-point cloud at 16,384 poses) goes pageable
 
 
 def _event():
@@ -164,26 +171,45 @@ class GraspPredicter:
         stream = transforms.NumpyChoiceStream(n_valid, n_pts)
         pool = ThreadPoolExecutor(max_workers=1)
         chunk, dev = self.chunk, self.device
-        pending, plan = {}, {}
+        pending, plan, order = {}, {}, {}
         on_device = stream.on_device_chain
         draw = stream.draw_partners if on_device else stream.draw
+        width, dtype = (stream.partner_stride, torch.uint16) if on_device else (n_pts, torch.int32)
+        ring, uploaded = [None, None], [None, None]     # two page-locked staging buffers, chunk k goes through ring[k & 1]
+
+        def set_plan(bounds):
+            plan.clear(); plan.update(dict(bounds))
+            order.clear(); order.update({s: k for k, (s, _) in enumerate(bounds)})
+            rows = max(e - s for s, e in bounds)
+            if rows * width * (2 if on_device else 4) <= _PIN_LIMIT:
+                ring[:] = [_pin((rows, width), dtype) for _ in range(min(2, len(bounds)))] + [None] * (2 - min(2, len(bounds)))
+
+        def task(k, count):
+            buf = ring[k & 1]
+            if buf is None:
+                return torch.from_numpy(draw(count))
+            if uploaded[k & 1] is not None:
+                uploaded[k & 1].synchronize()           # chunk k-2 has left this buffer
+            draw(count, out=buf[:count].numpy())
+            return buf[:count]
 
         def submit(s):
             if s in plan and s not in pending:
-                pending[s] = pool.submit(draw, plan[s] - s)
+                pending[s] = pool.submit(task, order[s], plan[s] - s)
 
         def ids(s, e):
             if not plan:
-                plan.update({a: min(G, a + chunk) for a in range(0, G, chunk)})
+                set_plan([(a, min(G, a + chunk)) for a in range(0, G, chunk)])
             assert plan.get(s) == e, 'chunks must be asked for in the planned order'
             submit(s)
             host = pending.pop(s).result()
             submit(e)                                   # the next chunk is drawn while this one is uploaded and scored
-            up = torch.from_numpy(host).to(dev, non_blocking=True)
+            up = host.to(dev, non_blocking=True)
+            uploaded[order[s] & 1] = _event()
             return ops.apply_shuffle_rows(up, n_valid, n_pts) if on_device else up
 
         ids.ramp = (2048, 4096, 8192)
-        ids.plan = lambda bounds: (plan.clear(), plan.update(dict(bounds)))
+        ids.plan = set_plan
 
         def close():
             for f in pending.values():
@@ -195,10 +221,12 @@ class GraspPredicter:
 
     # ---- reference API ----
     def _chunk_plan(self, G, id_source):
-        """Chunk boundaries of a predict_batch call: full chunks of self.chunk candidates behind a short ramp (2048, 4096, 8192), so that
-        the device starts after a fraction of the host-side work of the first chunk (pose conversion, numpy-stream draw) and the LAST
-        chunk -- whose results are turned into python rows with nothing left to overlap -- is preceded by bigger ones."""
-        sizes = [min(self.chunk, r) for r in (2048, 4096, 8192)]
+        """Chunk boundaries of a predict_batch call: full chunks of self.chunk candidates behind a ramp that starts at 1,024 and grows by
+        1.5x, so that the device starts after a fraction of the host-side work of the first chunk (pose conversion, numpy-stream draw)
+        and the host stays AHEAD during the ramp: the exact-f32 network takes ~12 us per candidate, the replay of numpy's stream ~6 us,
+        so a doubling ramp is a dead heat (chunk k+1 is drawn in exactly the time chunk k is scored) and any slower host core stalls
+        the device at every step of it; 1.5x leaves 25 % slack."""
+        sizes = [min(self.chunk, r) for r in (1024, 1536, 2304, 3456, 5184, 7776, 11664)]
         bounds, s = [], 0
         while s < G:
             e = min(G, s + (sizes.pop(0) if sizes else self.chunk))
@@ -208,8 +236,9 @@ class GraspPredicter:
         return bounds
 
     @staticmethod
-    def _poses_f64(grasp_poses, s, e):
-        """grasp_poses[s:e] (list of 4x4 arrays / nested lists, or an (G,4,4) array) -> contiguous float64 (e-s, 16)."""
+    def _poses_f64(grasp_poses, s, e, out=None):
+        """grasp_poses[s:e] (list of 4x4 arrays / nested lists, or an (G,4,4) array) -> contiguous float64 (e-s, 16), written into
+        `out` (a staging buffer of that shape) when given."""
         part = grasp_poses[s:e]
         if isinstance(part, np.ndarray):
             P = np.ascontiguousarray(part, dtype=np.float64)
@@ -219,7 +248,11 @@ class GraspPredicter:
             P = np.asarray(part, dtype=np.float64)
         if P.size != (e - s) * 16:
             raise ValueError(f'grasp_poses[{s}:{e}] are not 4x4 matrices')
-        return P.reshape(-1, 16)
+        P = P.reshape(-1, 16)
+        if out is None:
+            return P
+        out[...] = P
+        return out
 
     def predict_batch(self, data, grasp_poses, ids=None, rng=None):
         """predicter.py:67-94.  Returns [[pred_label, confidence, probs(10,) float32], ...] per grasp pose.
@@ -258,7 +291,8 @@ class GraspPredicter:
                     raise IndexError(f'resample index out of range for a cloud of {cloud.n} valid points')
                 ids_d = torch.from_numpy(ids).to(self.device)
             try:
-                return self._predict_chunks(cloud, grasp_poses, ids_d, G)
+                with _gc_paused():
+                    return self._predict_chunks(cloud, grasp_poses, ids_d, G)
             finally:
                 if hasattr(ids_d, 'close'):
                     ids_d.close()
@@ -268,15 +302,15 @@ class GraspPredicter:
         C = len(self.cfg['classes']) - 1
         guard = engine.PRECISION in engine.HALF_MODES
         bad = torch.zeros((1,), dtype=torch.int32, device=self.device)
-        stage = {'probs': _pin(torch.empty((G, C), dtype=torch.float32)), 'label': _pin(torch.empty((G,), dtype=torch.int32)),
-                 'conf': _pin(torch.empty((G,), dtype=torch.float32)), 'flags': _pin(torch.zeros((len(bounds), 2), dtype=torch.int32))}
-        probs_h, label_h, conf_h, flags_h = (stage[k].numpy() for k in ('probs', 'label', 'conf', 'flags'))
+        stage = {'probs': _pin((G, C), torch.float32), 'label': _pin((G,), torch.int32), 'conf': _pin((G,), torch.float32),
+                 'flags': _pin((len(bounds), 2), torch.int32).zero_(), 'poses': _pin((G, 16), torch.float64)}
+        probs_h, label_h, conf_h, flags_h, poses_h = (stage[k].numpy() for k in ('probs', 'label', 'conf', 'flags', 'poses'))
         rows, pending = [], []
 
         def score(s, e, idc, status, bad_flag):
             """queue one chunk: pose upload + inverse, input transform, network, softmax, asynchronous copies into the staging buffers"""
-            pinv = ops.pose_inverse_rows_f64(torch.from_numpy(self._poses_f64(grasp_poses, s, e)).to(self.device, non_blocking=True), cloud.center,
-                                             bad_flag)
+            self._poses_f64(grasp_poses, s, e, out=poses_h[s:e])
+            pinv = ops.pose_inverse_rows_f64(stage['poses'][s:e].to(self.device, non_blocking=True), cloud.center, bad_flag)
             x = ops.build_grasp_input(cloud.xyz, cloud.normal, idc, pinv, self._mean, self._inv_std)
             probs, label, conf, _ = ops.softmax_pg(engine.cls_forward(self._W, x, status)[0])
             stage['probs'][s:e].copy_(probs, non_blocking=True); stage['label'][s:e].copy_(label, non_blocking=True)
@@ -314,6 +348,23 @@ class GraspPredicter:
         while pending:
             drain(*pending.pop(0))
         return rows
+
+
+class _gc_paused:
+    """The rows of a predict_batch call are ~4 container objects per pose; every few hundred of them CPython's generational collector
+    walks the young generations and, now and then, every tracked object of the process -- measured on the GPU box as 30-80 ms stalls
+    of the chunk pipeline in one call out of three (profiles/r3_predict_batch_api.json).  None of these objects can be part of a
+    cycle, so collection is held off for the duration of the call and the caller's setting restored."""
+
+    def __enter__(self):
+        import gc
+        self._was = gc.isenabled()
+        gc.disable()
+
+    def __exit__(self, *exc):
+        if self._was:
+            import gc
+            gc.enable()
 
 
 class NunocsPredicter:

@@ -50,14 +50,20 @@ class NumpyChoiceStream:
         permutation): the host then only extracts the swap partners from the stream (draw_partners)."""
         return self.n_pts <= self.n_valid <= 65536 and self.n_valid >= 2
 
-    def draw_partners(self, count):
+    @property
+    def partner_stride(self):
+        return (self.n_valid - 1 + 7) & ~7
+
+    def draw_partners(self, count, out=None):
         """The sequential part of `count` permutation(n_valid) draws alone (cg_host_numpy_shuffle_partners): the Fisher-Yates swap
         partners as a (count, stride) uint16 array, stride = n_valid-1 rounded up to 8; ops.apply_shuffle_rows turns them into the
         rows draw() would have returned.  Advances the generator exactly like draw()."""
         ct = self._ct
         from . import _lib as L
-        stride = (self.n_valid - 1 + 7) & ~7
-        out = np.empty((count, stride), dtype=np.uint16)
+        stride = self.partner_stride
+        if out is None:
+            out = np.empty((count, stride), dtype=np.uint16)
+        assert out.shape == (count, stride) and out.dtype == np.uint16 and out.flags.c_contiguous
         rc = L.lib().cg_host_numpy_shuffle_partners(self._key.ctypes.data_as(ct.c_void_p), ct.byref(self._pos), ct.c_int(self.n_valid),
                                                     ct.c_long(count), ct.c_long(stride), out.ctypes.data_as(ct.c_void_p))
         if rc != 0:

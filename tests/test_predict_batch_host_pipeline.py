@@ -45,7 +45,7 @@ def host_predicter(monkeypatch):
         def synchronize(self):
             pass
     from catgrasp_amd import predicter as pred_mod
-    monkeypatch.setattr(pred_mod, '_pin', lambda t: t)
+    monkeypatch.setattr(pred_mod, '_pin', lambda shape, dtype: torch.empty(shape, dtype=dtype))
     monkeypatch.setattr(pred_mod, '_event', lambda: _Ev())
     monkeypatch.setattr(ops, 'pose_inverse_rows_f64', pose_inverse_rows_f64)
     monkeypatch.setattr(ops, 'apply_shuffle_rows', _apply_shuffle_rows_host)
