@@ -93,39 +93,43 @@ __global__ __launch_bounds__(256) void index_points_kernel(const float* __restri
 // running min distance to the chosen set, then one arg-max over the cloud (first index on ties).  The round is a dependent chain on
 // ONE CU (splitting a cloud over CUs would put a >= 4 us device-scope barrier into a ~1.5 us round: MI355X_MICROARCH.md, barrier
 // table), so what counts is the VALU work per point and the latency of the exchange:
-//  * round-3 inner loop, 8 VALU per point: two points per packed-f32 instruction for the bit-exact (dx*dx + dy*dy) + dz*dz
-//    (3 v_pk_add, 3 v_pk_mul, 2 v_pk_add per PAIR), v_min for the running distance, and a branch-free (value, slot) arg-max
-//    (v_cmp + 2 v_cndmask) -- round 2 spent ~15 VALU + 5 SALU per point on an exec-mask branch per slot that also carried the
-//    winner's coordinates and index along;
-//  * the reduction travels as a 32-bit VALUE (v_max with DPP row operations: 6 steps per wave); the winner lane is the single lane
-//    that holds it -- ties (duplicate points, lattices) take a wave-uniform slow path that reduces the indices too, so the result is
-//    still "first index among equal maxima";
+//  * inner loop, 5.5 VALU per point: two points per packed-f32 instruction for the bit-exact (dx*dx + dy*dy) + dz*dz (3 v_pk_add,
+//    3 v_pk_mul, 2 v_pk_add per PAIR), one v_min_u32 per point for the running distance and ONE v_max3_u32 per pair for the running
+//    maximum -- which slot holds the maximum is not tracked (that was a v_cmp + 2 v_cndmask per point, 3 of 8 VALU): the slots are
+//    kept in groups of 8 with a maximum per group, and after the wave reduction the winner lane's group is made wave-uniform
+//    (v_readlane) and searched (7 compare + select), in that group's branch only;
+//  * the reduction travels as a 32-bit VALUE (v_max_u32 with the DPP row operation folded in by hand: 6 steps per wave -- the
+//    builtin compiles to v_mov + v_mov_dpp + v_max per step); the winner lane is the single lane that holds it -- ties (duplicate
+//    points, lattices) take a wave-uniform slow path that finds every lane's first slot and reduces the indices too, so the result
+//    is still "first index among equal maxima";
 //  * only the wave's winner needs its coordinates: its slot number is made wave-uniform (v_readlane) and a uniform binary search
-//    picks the slot's registers, no per-slot select;
+//    inside the group picks the slot's registers, no per-slot select;
 //  * the winners of the waves meet in LDS as (value, x, y, z) + index, ONE workgroup barrier per round (double-buffered), and the next
 //    centre is taken out of the exchanged records with v_readlane -- no dependent LDS or global read at the top of the round.
-// History (N = 20,000 -> 1,024, one cloud): 4.19 ms (round 1) -> 2.71 ms (round 2: 64-bit DPP keys) -> 2.04 ms (round 3: packed math,
-// branch-free arg-max, 32-bit reduction) -> 1.73 ms (unsigned-bit min / max): 1.69 us per round; the VALU floor of this formulation on
-// one CU is 20,000 points x 8 VALU / 64 lanes / 4 SIMDs x 4 clocks = 1.09 us at the 2.3 GHz the kernel runs at.
+// History (N = 20,000 -> 1,024, one cloud): 4.19 ms (round 1) -> 2.71 ms (round 2: 64-bit DPP keys) -> 1.73 ms (round 3: packed math,
+// branch-free arg-max, 32-bit reduction on unsigned bit patterns) -> 1.58 ms (maximum only, slot looked up afterwards) -> 1.51 ms
+// (hand-folded DPP): 1.47 us per round.  Ablations on the device (profiles/r3_fps_ablation.txt): distance update + wave reduction
+// alone 0.73 us; + the workgroup exchange (LDS, barrier, second reduction -- and the lockstep it forces, which exposes every latency of
+// the chain) + 0.54 us; + slot search and register pick + 0.27 us.  Measured and rejected: 1,024 threads x 20 points (1.65 us),
+// select-chain instead of branch pick (1.60), vector-typed storage for an indexed register read (LLVM emits the same select chain:
+// 1.48), batching the index stores (no change: the store is off the critical path).
 // Running distances are >= +0 (sums of squares; 1e10 initially), so their BIT PATTERNS order like the values: min / max / compare run
-// on them as unsigned integers -- one v_min_u32 / v_max_u32 (with the DPP row operation folded in) where the float forms cost a
-// compare + select or drag a canonicalising v_max along.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ unsigned dpp_max_u32(unsigned v) {
-  const unsigned o = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xf, false);
-  return o > v ? o : v;
-}
+// on them as unsigned integers -- one v_min_u32 / v_max_u32 where the float forms cost a compare + select or drag a canonicalising
+// v_max along.
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ int dpp_min_i32(int v) {
   const int o = __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xf, false);
   return o < v ? o : v;
 }
 // max / min over the 16 lanes of every DPP row (all lanes of the row get it)
+// the DPP operand folded into v_max_u32 by hand (the compiler emits v_mov_b32 + v_mov_b32_dpp + v_max_u32 for the builtin); the two
+// wait states a DPP read needs after a VALU write of the same register are ours to insert here
 __device__ __forceinline__ unsigned row_max_u32(unsigned v) {
-  v = dpp_max_u32<0xB1, 0xf>(v);      // quad_perm [1,0,3,2]
-  v = dpp_max_u32<0x4E, 0xf>(v);      // quad_perm [2,3,0,1]
-  v = dpp_max_u32<0x141, 0xf>(v);     // row_half_mirror
-  return dpp_max_u32<0x140, 0xf>(v);  // row_mirror
+  asm volatile("s_nop 1\n\tv_max_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+               "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+               "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+               "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf" : "+v"(v));
+  return v;
 }
 __device__ __forceinline__ int row_min_i32(int v) {
   v = dpp_min_i32<0xB1, 0xf>(v); v = dpp_min_i32<0x4E, 0xf>(v); v = dpp_min_i32<0x141, 0xf>(v);
@@ -134,8 +138,8 @@ __device__ __forceinline__ int row_min_i32(int v) {
 // over the wavefront, returned wave-uniform
 __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
   v = row_max_u32(v);
-  v = dpp_max_u32<0x142, 0xa>(v);     // row_bcast15 into rows 1 and 3
-  v = dpp_max_u32<0x143, 0xc>(v);     // row_bcast31 into rows 2 and 3: lane 63 holds the wave maximum
+  asm volatile("s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+               "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 0" : "+v"(v));
   return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 __device__ __forceinline__ int wave_min_i32(int v) {
@@ -148,11 +152,31 @@ __device__ __forceinline__ int wave_min_i32(int v) {
 // registers of slot k (wave-uniform k) by a uniform binary search: log2(PPT) scalar branches instead of a select per slot
 template <int LO, int HI, int H>
 __device__ __forceinline__ void fps_pick(int k, const f32x2 (&px)[H], const f32x2 (&py)[H], const f32x2 (&pz)[H], float& x, float& y, float& z) {
-  if constexpr (HI - LO == 1) { x = px[LO >> 1][LO & 1]; y = py[LO >> 1][LO & 1]; z = pz[LO >> 1][LO & 1]; }
+  if constexpr (HI - LO == 1) {
+    x = px[LO >> 1][LO & 1]; y = py[LO >> 1][LO & 1]; z = pz[LO >> 1][LO & 1];
+    asm volatile("" : "+v"(x), "+v"(y), "+v"(z));     // keeps the leaves apart: merged, they become a dynamically indexed array in scratch
+  }
   else {
     constexpr int MID = (LO + HI) / 2;
     if (k < MID) fps_pick<LO, MID, H>(k, px, py, pz, x, y, z);
     else fps_pick<MID, HI, H>(k, px, py, pz, x, y, z);
+  }
+}
+
+// the winner lane's first slot at the lane maximum `bv`, searched in group gw only (wave-uniform gw: a chain of scalar branches over
+// the groups, then GS-1 compare + select in every lane), and that slot's registers
+template <int G, int NG, int GS, int PPT, int H>
+__device__ __forceinline__ void fps_find(int gw, int wl, unsigned bv, const unsigned (&dist)[PPT], const f32x2 (&px)[H], const f32x2 (&py)[H],
+                                         const f32x2 (&pz)[H], int& kw, float& x, float& y, float& z) {
+  if (G == NG - 1 || gw == G) {
+    asm volatile("" : "+v"(bv));                            // the search stays inside its branch (hoisted, all NG of them run every round)
+    int k = G * GS + GS - 1;
+#pragma unroll
+    for (int j = GS - 2; j >= 0; --j) k = dist[G * GS + j] == bv ? G * GS + j : k;
+    kw = __builtin_amdgcn_readlane(k, wl);
+    fps_pick<G * GS, G * GS + GS, H>(kw, px, py, pz, x, y, z);
+  } else if constexpr (G < NG - 1) {
+    fps_find<G + 1, NG, GS, PPT, H>(gw, wl, bv, dist, px, py, pz, kw, x, y, z);
   }
 }
 
@@ -162,6 +186,8 @@ __global__ __launch_bounds__(NT) void fps_kernel(const float* __restrict__ xyz, 
                                                  long long* __restrict__ out) {
   static_assert(PPT % 2 == 0 && NT % 64 == 0 && NT <= 1024, "geometry");
   constexpr int H = PPT / 2;
+  constexpr int GS = PPT < 8 ? PPT : 8, NG = PPT / GS;
+  static_assert(PPT % GS == 0, "slots come in whole groups");
   __shared__ f32x4 red_v[2][16];       // per wave: (bits of the best distance, x, y, z) of its winner
   __shared__ int red_i[2][16];         //           its point index
   const int b = blockIdx.x;
@@ -176,39 +202,57 @@ __global__ __launch_bounds__(NT) void fps_kernel(const float* __restrict__ xyz, 
     const int p = tid + k * NT;
     float x = 0.f, y = 0.f, z = 0.f, d0 = 0.0f;     // padding: running distance 0 never shrinks (d >= 0) and never beats a real point first
     if (p < N) { x = xb[p * 3 + 0]; y = xb[p * 3 + 1]; z = xb[p * 3 + 2]; d0 = 1e10f; }
-    px[k >> 1][k & 1] = x; py[k >> 1][k & 1] = y; pz[k >> 1][k & 1] = z; dist[k] = __float_as_uint(d0);
+    px[k >> 1][k & 1] = x; py[k >> 1][k & 1] = y; pz[k >> 1][k & 1] = z;
+    dist[k] = __float_as_uint(d0);
   }
   int farthest = (int)start[b];
   float cx = xb[farthest * 3 + 0], cy = xb[farthest * 3 + 1], cz = xb[farthest * 3 + 2];
   for (int it = 0; it < npoint; ++it) {
     if (tid == 0) out[(size_t)b * npoint + it] = farthest;
     const f32x2 c2x = {cx, cx}, c2y = {cy, cy}, c2z = {cz, cz};
-    unsigned bv = 0u; int bk = 0;       // every thread's slot 0 is >= 0, and a strict '>' keeps the first maximum: bk = 0 is the right start
+    // the thread's slots in groups of GS: only the running MAXIMUM is tracked while the distances are updated (one v_max3_u32 per
+    // pair), per group and over all; which slot holds it is looked up afterwards, in the winner's group only
+    unsigned gmax[NG];
 #pragma unroll
-    for (int h = 0; h < H; ++h) {
-      const f32x2 dx = px[h] - c2x, dy = py[h] - c2y, dz = pz[h] - c2z;
-      const f32x2 d = (dx * dx + dy * dy) + dz * dz;        // torch.sum((xyz - centroid) ** 2, -1), two points per instruction
+    for (int g = 0; g < NG; ++g) {
+      unsigned m = 0u;
 #pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const unsigned db = __float_as_uint(d[e]);
-        const unsigned nd = db < dist[2 * h + e] ? db : dist[2 * h + e];      // mask = dist < distance; distance[mask] = dist[mask]
-        dist[2 * h + e] = nd;
-        const bool g = nd > bv;                              // ascending point index within a thread: the first maximum is kept
-        bv = g ? nd : bv; bk = g ? 2 * h + e : bk;
+      for (int h = g * (GS / 2); h < (g + 1) * (GS / 2); ++h) {
+        const f32x2 dx = px[h] - c2x, dy = py[h] - c2y, dz = pz[h] - c2z;
+        const f32x2 d = (dx * dx + dy * dy) + dz * dz;      // torch.sum((xyz - centroid) ** 2, -1), two points per instruction
+        const unsigned d0 = __float_as_uint(d[0]), d1 = __float_as_uint(d[1]);
+        const unsigned n0 = d0 < dist[2 * h] ? d0 : dist[2 * h];              // mask = dist < distance; distance[mask] = dist[mask]
+        const unsigned n1 = d1 < dist[2 * h + 1] ? d1 : dist[2 * h + 1];
+        dist[2 * h] = n0; dist[2 * h + 1] = n1;
+        const unsigned a = m > n0 ? m : n0;
+        m = a > n1 ? a : n1;
       }
+      gmax[g] = m;
     }
+    unsigned bv = gmax[0];
+#pragma unroll
+    for (int g = 1; g < NG; ++g) bv = bv > gmax[g] ? bv : gmax[g];
     // ---- wave: who holds the largest running distance (smallest index among equals) ----
     const unsigned wmax = wave_max_u32(bv);
-    const int bi = tid + bk * NT;
     unsigned long long cand = __ballot(bv == wmax);
     if (__builtin_popcountll(cand) != 1) {                   // ties inside the wave: the smallest point index wins
+      unsigned bt = bv;
+      asm volatile("" : "+v"(bt));                           // keeps the slot search of the rare path from being hoisted into every round
+      int bk = PPT - 1;                                      // the lane's first slot at its maximum (ascending slot = ascending index)
+#pragma unroll
+      for (int k = PPT - 2; k >= 0; --k) bk = dist[k] == bt ? k : bk;
+      const int bi = tid + bk * NT;
       const int mi = wave_min_i32(bv == wmax ? bi : 0x7fffffff);
       cand = __ballot(bv == wmax && bi == mi);
     }
     const int wl = __builtin_ctzll(cand);
-    const int kw = __builtin_amdgcn_readlane(bk, wl), iw = __builtin_amdgcn_readlane(bi, wl);
-    float bx, by, bz;
-    fps_pick<0, PPT, H>(kw, px, py, pz, bx, by, bz);       // every lane picks ITS slot kw; only the winner lane's values are used
+    int gi = NG - 1;                                         // per lane: the first group that holds the lane's maximum
+#pragma unroll
+    for (int g = NG - 2; g >= 0; --g) gi = gmax[g] == bv ? g : gi;
+    const int gw = __builtin_amdgcn_readlane(gi, wl);
+    int kw; float bx, by, bz;
+    fps_find<0, NG, GS, PPT, H>(gw, wl, bv, dist, px, py, pz, kw, bx, by, bz);   // the winner's slot (wave-uniform) and coordinates
+    const int iw = (wv * 64 + wl) + kw * NT;
     const int buf = it & 1;
     if (lane == wl) { red_v[buf][wv] = f32x4{__uint_as_float(wmax), bx, by, bz}; red_i[buf][wv] = iw; }
     __syncthreads();
@@ -374,8 +418,8 @@ extern "C" int cg_farthest_point_sample(const float* xyz, const long long* start
   dim3 grid((unsigned)B), block(1024);
   if (N <= 1024 * 2) hipLaunchKernelGGL((fps_kernel<1024, 2>), grid, block, 0, s, xyz, start, N, npoint, out);
   else if (N <= 1024 * 8) hipLaunchKernelGGL((fps_kernel<1024, 8>), grid, block, 0, s, xyz, start, N, npoint, out);
-  // 8,193 .. 24,576 points: 512 threads x 40 / 48 points (two waves per SIMD).  Measured at N = 20,000: 1.73 ms per 1,024 samples
-  // against 1.81 ms for 1024 threads x 20 points -- the round is VALU bound (8 VALU per point), more waves only add exchange work.
+  // 8,193 .. 24,576 points: 512 threads x 40 / 48 points (two waves per SIMD).  Measured at N = 20,000: 1.47 us per round against
+  // 1.65 us for 1024 threads x 20 points -- more waves only add exchange work.
   else if (N <= 512 * 40) hipLaunchKernelGGL((fps_kernel<512, 40>), grid, dim3(512), 0, s, xyz, start, N, npoint, out);
   else if (N <= 512 * 48) hipLaunchKernelGGL((fps_kernel<512, 48>), grid, dim3(512), 0, s, xyz, start, N, npoint, out);
   else {
