@@ -311,18 +311,23 @@ __device__ __forceinline__ void sa_hidden(const f32x16 (&in)[NIN], const float* 
   sa_relu<NOUT>(out);
 }
 // first layer as a hidden layer: the gathered rows x0 (2 k-steps: channels 4h + j and 8 + 4h + j) are the B operand
+// `c0` = 3 + D real input channels (wave-uniform): MFMA j of k-step ks carries channels 8ks + j and 8ks + 4 + j, so with c0 = 9 the
+// MFMAs (1, 1..3) multiply the zero padding only and are skipped (5 instead of 8 per output block: 6 of a 9-64-64-128 tile's 208)
 template <int NOUT>
-__device__ __forceinline__ void sa_hidden0(const float (&x0)[8], const float* w, const float* bias, int lane, f32x16 (&out)[NOUT]) {
+__device__ __forceinline__ void sa_hidden0(const float (&x0)[8], const float* w, const float* bias, int lane, int c0, f32x16 (&out)[NOUT]) {
   const f32x4* wp = (const f32x4*)w + lane;
   sa_bias_init<NOUT>(bias, lane >> 5, out);
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) {
+    if (8 * ks >= c0) break;
     f32x4 wf[NOUT];
     sa_frags<NOUT>(wp, 2, ks, wf);
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < 4; ++j) {
+      if (8 * ks + j >= c0) break;
 #pragma unroll
       for (int nb = 0; nb < NOUT; ++nb) out[nb] = mfma32(wf[nb][j], x0[4 * ks + j], out[nb]);
+    }
   }
   sa_relu<NOUT>(out);
 }
@@ -351,19 +356,22 @@ __device__ __forceinline__ void sa_last(const f32x16 (&in)[NIN], const float* w,
   sa_last_fold<NOUT, PACK>(c, run);
 }
 template <int NOUT, int PACK>
-__device__ __forceinline__ void sa_last0(const float (&x0)[8], const float* w, int lane, float (*run)[PACK]) {
+__device__ __forceinline__ void sa_last0(const float (&x0)[8], const float* w, int lane, int c0, float (*run)[PACK]) {
   const f32x4* wp = (const f32x4*)w + lane;
   f32x16 c[NOUT];
 #pragma unroll
   for (int nb = 0; nb < NOUT; ++nb) c[nb] = f32x16{0};
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) {
+    if (8 * ks >= c0) break;
     f32x4 wf[NOUT];
     sa_frags<NOUT>(wp, 2, ks, wf);
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < 4; ++j) {
+      if (8 * ks + j >= c0) break;
 #pragma unroll
       for (int nb = 0; nb < NOUT; ++nb) c[nb] = mfma32(x0[4 * ks + j], wf[nb][j], c[nb]);
+    }
   }
   sa_last_fold<NOUT, PACK>(c, run);
 }
@@ -377,7 +385,57 @@ constexpr int sa_reg_threads(int n0, int n1, int n2) {
 #define SA_REG_PAD 72
 #endif
   const int est = 16 * (a > b ? a : b) + SA_REG_PAD;    // live accumulator blocks of the widest layer pair + fragments, gather, addresses
-  return est <= 124 ? 1024 : est <= 164 ? 768 : 512;
+  return est <= 124 ? 1024 : est <= 140 ? 768 : 512;
+}
+
+// Weights + biases of every layer -> LDS, once per workgroup.  ALL loads are issued before the first LDS store: written as a loop
+// per layer the compiler waits for every load before its store (global_load; s_waitcnt vmcnt(0); ds_write in a rolled loop), ten
+// dependent L2 round trips for 9-64-64-128 at 512 threads -- several microseconds at the head of every launch.  The layer sizes are
+// template parameters, so a workgroup of >= 256 threads holds its whole share in registers (<= 13 x 16 B per thread).
+template <int N0, int N1, int N2>
+__device__ __forceinline__ void sa_stage(const SAArgs& a, float* smem) {
+  constexpr int L = N2 ? 3 : N1 ? 2 : 1;
+  constexpr int n4[3] = {C0 * N0 * 32 / 4, N0 * 32 * N1 * 32 / 4, N1 * 32 * N2 * 32 / 4};
+  const int tid = threadIdx.x, bd = blockDim.x;
+  if (bd >= 256) {
+    constexpr int U0 = (n4[0] + 255) / 256, U1 = L > 1 ? (n4[1] + 255) / 256 : 1, U2 = L > 2 ? (n4[2] + 255) / 256 : 1;
+    f32x4 r0[U0], r1[U1], r2[U2];
+    float bq[3] = {0.f, 0.f, 0.f};
+    const f32x4* s0 = (const f32x4*)a.w[0]; const f32x4* s1 = (const f32x4*)a.w[L > 1 ? 1 : 0]; const f32x4* s2 = (const f32x4*)a.w[L > 2 ? 2 : 0];
+#pragma unroll
+    for (int l = 0; l < L; ++l) if (tid < a.cout[l]) bq[l] = a.b[l][tid];       // widths <= 128 < 256 <= bd
+#pragma unroll
+    for (int u = 0; u < U0; ++u) if (tid + u * bd < n4[0]) r0[u] = s0[tid + u * bd];
+    if constexpr (L > 1) {
+#pragma unroll
+      for (int u = 0; u < U1; ++u) if (tid + u * bd < n4[1]) r1[u] = s1[tid + u * bd];
+    }
+    if constexpr (L > 2) {
+#pragma unroll
+      for (int u = 0; u < U2; ++u) if (tid + u * bd < n4[2]) r2[u] = s2[tid + u * bd];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int l = 0; l < L; ++l) if (tid < a.cout[l]) smem[a.b_off[l] + tid] = bq[l];
+#pragma unroll
+    for (int u = 0; u < U0; ++u) if (tid + u * bd < n4[0]) ((f32x4*)(smem + a.w_off[0]))[tid + u * bd] = r0[u];
+    if constexpr (L > 1) {
+#pragma unroll
+      for (int u = 0; u < U1; ++u) if (tid + u * bd < n4[1]) ((f32x4*)(smem + a.w_off[1]))[tid + u * bd] = r1[u];
+    }
+    if constexpr (L > 2) {
+#pragma unroll
+      for (int u = 0; u < U2; ++u) if (tid + u * bd < n4[2]) ((f32x4*)(smem + a.w_off[2]))[tid + u * bd] = r2[u];
+    }
+  } else {
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+      const f32x4* src = (const f32x4*)a.w[l];
+      f32x4* dst = (f32x4*)(smem + a.w_off[l]);
+      for (int i = tid; i < n4[l]; i += bd) dst[i] = src[i];
+      for (int i = tid; i < a.cout[l]; i += bd) smem[a.b_off[l] + i] = a.b[l][i];
+    }
+  }
 }
 
 template <int N0, int N1, int N2, int PACK, int NT>
@@ -388,16 +446,7 @@ __global__ __launch_bounds__(NT) void sa_reg_kernel(SAArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int l31 = lane & 31, lhi = lane >> 5;
-  // ---- stage every layer's weights (16-byte copies, all threads) and biases once per workgroup ----
-#pragma unroll
-  for (int l = 0; l < L; ++l) {
-    const int n4 = a.cin[l] * a.cout[l] / 4;
-    const f32x4* src = (const f32x4*)a.w[l];
-    f32x4* dst = (f32x4*)(smem + a.w_off[l]);
-    for (int i = threadIdx.x; i < n4; i += blockDim.x) dst[i] = src[i];
-    for (int i = threadIdx.x; i < a.cout[l]; i += blockDim.x) smem[a.b_off[l] + i] = a.b[l][i];
-  }
-  __syncthreads();
+  const int c0 = 3 + a.D;
   constexpr int RPN = 32 / PACK;                         // rows per neighbourhood
   const int G = a.B * a.S;                               // < 2^31 (checked by the launcher)
   const int nslots = (G + PACK - 1) / PACK;              // a slot = the PACK neighbourhoods of one tile
@@ -407,7 +456,8 @@ __global__ __launch_bounds__(NT) void sa_reg_kernel(SAArgs a) {
   struct Tile { int slot; int kt; };
   auto next = [&](Tile t) { return t.kt + 1 < RT ? Tile{t.slot, t.kt + 1} : Tile{t.slot + stride, 0}; };
   Tile cur{(int)blockIdx.x * WAVES + wv, 0};
-  if (cur.slot >= nslots) return;
+  const bool idle = cur.slot >= nslots;                  // still helps staging the weights
+  if (idle) cur.slot = nslots - 1;
   auto nbhd_of = [&](Tile t) -> int {
     const int g = t.slot * PACK + l31 / RPN;
     return g < G ? g : G - 1;                            // tail slot: duplicate the last neighbourhood (its result is not stored)
@@ -455,9 +505,16 @@ __global__ __launch_bounds__(NT) void sa_reg_kernel(SAArgs a) {
   float run[NL][PACK];
   float x0[8];
   Raw raw;
-  issue(cur, load_id(cur), raw);
+  // the first tile's gather (index -> point: two dependent L2 / HBM round trips) goes out BEFORE the weights are staged, and the
+  // indices of the second tile with it: both are in flight while the workgroup copies its weights
+  long long id0 = load_id(cur);
   Tile nxt = next(cur);
   long long id_next = nxt.slot < nslots ? load_id(nxt) : 0;
+  issue(cur, id0, raw);
+  __builtin_amdgcn_sched_barrier(0);
+  sa_stage<N0, N1, N2>(a, smem);
+  __syncthreads();
+  if (idle) return;
   finish(raw, x0);
   for (;;) {
     if (cur.kt == 0) {
@@ -476,10 +533,10 @@ __global__ __launch_bounds__(NT) void sa_reg_kernel(SAArgs a) {
     id_next = load_id(after);
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (L == 1) {
-      sa_last0<N0, PACK>(x0, W0, lane, run);
+      sa_last0<N0, PACK>(x0, W0, lane, c0, run);
     } else {
       f32x16 A[N0];
-      sa_hidden0<N0>(x0, W0, B0, lane, A);
+      sa_hidden0<N0>(x0, W0, B0, lane, c0, A);
       if constexpr (L == 2) {
         sa_last<N0, N1, PACK>(A, W1, lane, run);
       } else {
