@@ -20,4 +20,11 @@ rm -rf $O/pmc_sq $O/pmc_fetch $O/pmc_write $O/ktrace
 timeout 300 python scripts/time_predict_batch.py > $O/predict_batch_api.json 2> /dev/null
 ( time timeout 400 python bench.py --gpus 1 --workload C4 --steps 3 --warmup 1 --secondary "" --no-api --no-cpu-baseline ) > $O/bench_c4_n1.json 2> $O/bench_c4_n1.err
 ( time timeout 400 python bench.py --gpus 1 --workload C5 --steps 3 --warmup 1 --secondary "f32" --no-api --no-cpu-baseline ) > $O/bench_c5_n1.json 2> $O/bench_c5_n1.err
+timeout 200 rocprofv3 --kernel-trace --output-format csv -d $O/tr_sa -- python scripts/sa_scaling.py > $O/sa_scaling.log 2>&1
+find $O/tr_sa -name '*kernel_trace.csv' -exec cp {} $O/ktrace_sa_scaling.csv \; ; rm -rf $O/tr_sa
+timeout 100 python scripts/fps_time.py > $O/fps_time.txt 2> /dev/null
+timeout 100 python scripts/sa_time.py > $O/sa_time.txt 2> /dev/null
+for n in 50000 25000 12500 6250; do
+timeout 300 python bench.py --candidates $n --steps 10 --warmup 3 --secondary "" --no-cpu-baseline --no-api --no-pmc-traffic --no-rccl-selftest > $O/shard_$n.json 2> /dev/null
+done
 ls -la $O; head -c 600 $O/bench.json

@@ -75,7 +75,7 @@ row('index_points (group) kernel', timed(lambda: primitives.index_points(feat, i
 t_fps = timed(lambda: primitives.farthest_point_sample(pts, S, start=torch.zeros(1, dtype=torch.long, device=dev)), iters=5, warm=1)
 row('farthest_point_sample_kernel', t_fps, N * 12 + S * 8, 'N x 12 B read once + S x 8 B out', bound='VALU of one CU (sequential over npoint)',
     extra={'rounds_per_s': round(S / t_fps), 'us_per_round': round(t_fps / S * 1e6, 3),
-           'note': 'one 512-thread workgroup, 40 points per thread in VGPRs, 8 VALU per point per round; reference CPU: 0.24 s'})
+           'note': 'one 512-thread workgroup, 40 points per thread in VGPRs, 5.5 VALU per point per round; reference CPU: 0.24 s'})
 pts8 = (torch.rand(8, N, 3, device=dev, generator=g) * 0.1).contiguous()
 t_fps8 = timed(lambda: primitives.farthest_point_sample(pts8, S, start=torch.zeros(8, dtype=torch.long, device=dev)), iters=5, warm=1)
 row('farthest_point_sample_kernel (the 8 clouds of C3 in one launch)', t_fps8, 8 * (N * 12 + S * 8), 'as above x 8 clouds, one workgroup each', bound='VALU of one CU per cloud',
@@ -121,11 +121,11 @@ sa = primitives.SetAbstractionWeights([(np.random.default_rng(0).normal(0, 0.2, 
 idx_sa = primitives.query_ball_point(0.02, K, pts, new)
 idx_sa = torch.where(idx_sa >= N, torch.zeros_like(idx_sa), idx_sa)
 t_sa = timed(lambda: primitives.group_mlp_max(pts, feat, new, idx_sa, sa, check_indices=False))        # kernel alone: no per-call read-back of the error flag
-mac = S * K * (16 * 64 + 64 * 64 + 64 * 128)
+mac = S * K * (9 * 64 + 64 * 64 + 64 * 128)      # algorithmic: the 9 real input channels (the kernel skips the MFMAs of the zero padding to 16)
 row('sa_group_mlp_max_kernel (N=20000, S=1024, K=32, mlp 9->64->64->128)', t_sa, S * K * (8 + 36) + S * (12 + 512),
     '8 B index + 36 B gathered row per neighbour + 12 B centroid in + 512 B out per neighbourhood (the unfused pipeline writes and re-reads S x K x (9 + 64 + 64 + 128) x 4 B = 35 MB)',
     bound='mfma (exact f32)', extra={'TFLOPs': round(2 * mac / t_sa / 1e12, 2), 'frac_of_157.3_TFLOPs': round(2 * mac / t_sa / 1e12 / 157.3, 4),
-                                     'note': 'register-resident activations, weights in LDS; 1024 neighbourhoods = one 4-wave workgroup per CU: a neighbourhood is one dependent chain of 208 MFMAs'})
+                                     'note': 'register-resident activations, weights in LDS; 1024 neighbourhoods = one 4-wave workgroup per CU: a neighbourhood is one dependent chain of 202 MFMAs'})
 Bb = 16
 ptsB = (torch.rand(Bb, N, 3, device=dev, generator=g) * 0.1).contiguous(); featB = torch.randn(Bb, N, 6, device=dev, generator=g)
 newB = ptsB[:, :S].contiguous()
