@@ -102,17 +102,22 @@ def test_device_swap_chain_reproduces_numpy_choice(cuda_device, n_valid, n_pts):
     assert got.dtype == np.int32 and np.array_equal(got - 7, want) and np.array_equal(after_got, after_want)
 
 
-def test_predict_batch_numpy_mode_uses_the_reference_stream(cuda_device):
+@pytest.mark.parametrize('n_cloud,pinned', [(2300, True), (2300, False), (1500, True), (1500, False)])
+def test_predict_batch_numpy_mode_uses_the_reference_stream(cuda_device, monkeypatch, n_cloud, pinned):
     """predict_batch's default rng='numpy' (host partners + device swap chain, chunked one chunk ahead) == predict_batch on the
-    ids np.random.choice would have drawn, and numpy's generator ends where the reference's loop would leave it."""
-    from catgrasp_amd import synth
+    ids np.random.choice would have drawn, and numpy's generator ends where the reference's loop would leave it.  Both staging paths
+    of the id upload (the two-deep page-locked ring, reused across the 3+ chunks here, and the pageable fallback of oversized chunks)
+    and both draws (swap partners for replace=False, whole rows for a cloud smaller than n_pts)."""
+    from catgrasp_amd import predicter as pred_mod, synth
     from catgrasp_amd.predicter import DEFAULT_GRASP_CFG, GraspPredicter
-    ob = synth.make_scene(1, 2300, seed=5)[0]
+    if not pinned:
+        monkeypatch.setattr(pred_mod, '_PIN_LIMIT', 0)
+    ob = synth.make_scene(1, n_cloud, seed=5)[0]
     P = list(synth.make_candidates(ob, 90, np.random.default_rng(1)))
     gp = GraspPredicter('nut', cfg=DEFAULT_GRASP_CFG, state_dict=synth.make_state_dict('cls', 6, 10, seed=3), device=cuda_device, chunk=32)
     data = {'cloud_xyz': ob['xyz'], 'cloud_normal': ob['normal']}
     np.random.seed(21)
-    ids = np.stack([np.random.choice(np.arange(2300), size=(2048), replace=False) for _ in P])
+    ids = np.stack([np.random.choice(np.arange(n_cloud), size=(2048), replace=n_cloud < 2048) for _ in P])
     nxt_want = np.random.rand()
     want = gp.predict_batch(data, P, ids=ids)
     np.random.seed(21)
