@@ -5,6 +5,7 @@
 //   roipool_fp          src/roipool/roipool.cu:12-40           segmented arg-max pool
 //   get_iou             src/get_iou/get_iou.cu:12-37           proposal x instance IoU
 //   voxelize_fp         src/voxelize/voxelize.cu:10-34         mean/sum pool of point features through a rule book
+//   point_recover       src/voxelize/voxelize.cpp:182-192      voxel features back onto their member points (scatter-add)
 // One wavefront handles one (segment, 64-channel slab): lanes map to consecutive channels, so every row read is a
 // coalesced 256-byte access; per-channel accumulation order is the reference's (i = start..end), so sums are bitwise
 // those of a sequential float32 loop.
@@ -214,6 +215,38 @@ extern "C" int cg_pg_voxelize_fp(const float* feats, const int* rules, int n_row
   const long waves = (long)n_rows * ((C + 63) / 64);
   hipLaunchKernelGGL(voxelize_fp_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, feats, rules, n_rows, max_active,
                      C, average, out);
+  return cg_hip_status(hipGetLastError());
+}
+
+// point_recover forward (src/voxelize/voxelize.cpp:182-192 = voxelize_bp_cuda_ with average = false, voxelize.cu:35-49): every voxel row
+// adds its feature row to each of its member points.  One lane per (member, channel) pair of a row; atomicAdd like the reference (a
+// point listed by several rows receives their sum; in a map made by voxelization_idx every point has exactly one row, so the
+// result is a copy and independent of the order of the additions).  A member index outside [0, n_points) sets *err_flag instead of
+// writing (the reference writes wherever it points).
+__global__ __launch_bounds__(256) void point_recover_kernel(const float* __restrict__ feats, const int* __restrict__ rules, int nRows, int maxActive,
+                                                            int C, int nPoints, float* __restrict__ out, int* __restrict__ err) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= nRows) return;
+  const int* r = rules + (size_t)row * (maxActive + 1);
+  int nActive = r[0];
+  if (nActive < 0 || nActive > maxActive) { if (lane == 0) *err = 1; nActive = nActive < 0 ? 0 : maxActive; }
+  const float* f = feats + (size_t)row * C;
+  for (long t = lane; t < (long)nActive * C; t += 64) {
+    const int i = (int)(t / C), c = (int)(t - (long)i * C);
+    const int p = r[1 + i];
+    if (p < 0 || p >= nPoints) { *err = 1; continue; }
+    atomicAdd(out + (size_t)p * C + c, f[c]);
+  }
+}
+
+extern "C" int cg_pg_point_recover(const float* feats, const int* rules, int n_rows, int max_active, int C, int n_points, float* out,
+                                   int* err_flag, void* stream) {
+  if (n_rows < 0 || max_active < 0 || C <= 0 || n_points < 0) return CG_ERR_ARG;
+  if (n_rows == 0) return CG_OK;
+  if (!feats || !rules || !out || !err_flag) return CG_ERR_ARG;
+  hipLaunchKernelGGL(point_recover_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, feats, rules, n_rows,
+                     max_active, C, n_points, out, err_flag);
   return cg_hip_status(hipGetLastError());
 }
 

@@ -101,6 +101,25 @@ def voxelization(feats, map_rule, mode=4):
     return out
 
 
+def point_recover(feats, map_rule, nPoint):
+    """PointRecover forward (pointgroup_ops.py:77-99): feats (M,C) voxel features, map_rule (M, 1+maxActive) int32 [count, point ids...]
+    -> (nPoint, C): every voxel's row added onto each of its member points (zeros for points no voxel lists).  A count above
+    maxActive or a member id outside [0, nPoint) raises ValueError (the reference writes out of bounds)."""
+    require_cuda(feats, map_rule)
+    feats = feats.contiguous().float(); rules = map_rule.contiguous().int()
+    M, width = rules.shape
+    if feats.dim() != 2 or feats.shape[0] != M:
+        raise ValueError(f'feats {tuple(feats.shape)} does not have one row per rule ({M})')
+    C = feats.shape[1]
+    out = torch.zeros((int(nPoint), C), dtype=torch.float32, device=feats.device)
+    err = torch.zeros((1,), dtype=torch.int32, device=feats.device)
+    check(L.lib().cg_pg_point_recover(_p(feats), _p(rules), _c_int(M), _c_int(width - 1), _c_int(C), _c_int(int(nPoint)), _p(out), _p(err),
+                                      _stream()), 'cg_pg_point_recover')
+    if int(err.item()):
+        raise ValueError('point_recover: a rule lists more members than maxActive or a point outside [0, nPoint)')
+    return out
+
+
 def voxelization_idx(coords, batchsize, mode=4):
     """pointgroup_ops.voxelization_idx (Voxelization_Idx.forward; voxelize.cpp:11-151; called at predicter.py:285):
     coords (N,4) [batch,x,y,z] or (N,3) int64 -> (output_coords (M,ncol) int64, input_map (N) int32, output_map (M, 1+maxActive)

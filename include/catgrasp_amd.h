@@ -398,6 +398,11 @@ int cg_pg_get_iou(const int* proposals_idx, const int* proposals_offset, const l
  * rules (n_rows, 1+max_active) = [count, idx...]. */
 int cg_pg_voxelize_fp(const float* feats, const int* rules, int n_rows, int max_active, int C, int average, float* out,
                       void* stream);
+/* point_recover forward (src/voxelize/voxelize.cpp:182-192 -> voxelize.cu:35-49 with average = false; pointgroup_ops.py:77-99):
+ * out (n_points,C, pre-zeroed)[rules[m][1+i]] += feats (n_rows,C)[m] for i < rules[m][0].  *err_flag (device int, pre-zeroed) = 1 if a
+ * count exceeds max_active or a member index lies outside [0, n_points): such entries are skipped, never written. */
+int cg_pg_point_recover(const float* feats, const int* rules, int n_rows, int max_active, int C, int n_points, float* out,
+                        int* err_flag, void* stream);
 
 /* voxelization_idx (PointGroup/lib/pointgroup_ops/src/voxelize/voxelize.cpp:11-151; called at predicter.py:285), device pieces
  * around a stable device sort of the packed keys (the host side, catgrasp_amd/pointgroup_ops.py, owns sort/scan/allocation):

@@ -86,6 +86,17 @@ def voxelize_fp(feats, rules, average):
     return out
 
 
+def point_recover(feats, rules, n_point):
+    """voxelize.cpp:182-192 (point_recover_fp = voxelize_bp_cuda_ with average = false, voxelize.cu:35-49): row m of `feats` is added to
+    every member point rules[m][1..count]."""
+    feats = np.asarray(feats, dtype=np.float32)
+    out = np.zeros((n_point, feats.shape[1]), dtype=np.float32)
+    for r in range(len(rules)):
+        for i in range(1, rules[r, 0] + 1):
+            out[rules[r, i]] = (out[rules[r, i]] + feats[r]).astype(np.float32)
+    return out
+
+
 def voxelization_idx(coords, mode=4):
     """voxelize.cpp:58-151 (voxelize_inputmap + voxelize_outputmap): an insertion-ordered map from coordinate to voxel id."""
     coords = np.asarray(coords, dtype=np.int64)

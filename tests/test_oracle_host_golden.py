@@ -192,6 +192,21 @@ def test_pointgroup_host_ops_oracle_matches_the_reference_cpp():
     assert len(g['bfs_thr1_cluster_offsets']) - 1 > 20 and len(g['bfs_thr50_cluster_offsets']) - 1 >= 4
 
 
+def test_point_recover_oracle_inverts_the_golden_rule_books():
+    """oracle point_recover (voxelize.cpp:182-192 -> voxelize.cu:35-49, CUDA only in the reference, so not compilable here: restated,
+    parity unpinned beyond this property): on the REFERENCE's own rule books (pointgroup_golden.npz) every point receives exactly
+    the row of the voxel its input map names."""
+    from oracle import pointgroup_ops_ref as ref
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'pointgroup_golden.npz'))
+    om, im = g['vox_mode4_output_map'], g['vox_mode4_input_map']
+    n = len(im)
+    feats = np.random.default_rng(0).normal(size=(len(om), 6)).astype(np.float32)
+    back = ref.point_recover(feats, om, n)
+    assert back.shape == (n, 6) and np.array_equal(back, feats[im])
+    pooled = ref.voxelize_fp(back, om, True)                 # pooling the recovered rows gives the voxel rows back (mean of equal rows)
+    assert np.allclose(pooled, feats, rtol=0, atol=1e-6)
+
+
 def test_c1_config_oracle_chain_against_real_predict_batch():
     """BASELINE.json configs[0] (C1) at its stated size -- one 'nut' instance, 2048-pt cloud, 256 grasp candidates, the reference's
     own CPU path: tests/golden/predicter_golden_c1.npz holds what the REAL GraspPredicter.predict_batch returned

@@ -90,6 +90,36 @@ def test_voxelization_idx_matches_the_host_rulebook(cuda_device):
         pg.voxelization_idx(torch.tensor([[0, 1, 2, 70000]], device=cuda_device), 1, 4)
 
 
+def test_point_recover_puts_voxel_features_back_on_their_points(cuda_device):
+    """point_recover (pointgroup_ops.py:77-99; voxelize.cpp:182-192): against the oracle on a rule book made by voxelization_idx
+    (every point gets exactly its voxel's row: bit-exact), on rule books with empty rows, rows listing fewer members than maxActive and a
+    point listed by two rows (a sum), for C below and above one wavefront; bad rule books raise instead of writing out of bounds."""
+    from catgrasp_amd import pointgroup_ops as pg
+    rng = np.random.default_rng(11)
+    n = 4000
+    coords = np.concatenate([rng.integers(0, 2, (n, 1)), rng.integers(0, 9, (n, 3))], axis=1).astype(np.int64)
+    coords = coords[np.argsort(coords[:, 0], kind='stable')]
+    _, im, om = pg.voxelization_idx(torch.from_numpy(coords).to(cuda_device), 2, 4)
+    for C in (1, 16, 33, 150):
+        pt = rng.normal(size=(n, C)).astype(np.float32)
+        vox = pg.voxelization(torch.from_numpy(pt).to(cuda_device), om, 4)
+        back = pg.point_recover(vox, om, n)
+        assert back.shape == (n, C) and np.array_equal(back.cpu().numpy(), ref.point_recover(vox.cpu().numpy(), om.cpu().numpy(), n))
+        assert torch.equal(back, vox[im.long()])                         # == the gather through the input map
+    rules = np.zeros((6, 5), dtype=np.int32)
+    rules[0] = [3, 0, 1, 2, 99]; rules[1] = [0, 7, 7, 7, 7]; rules[2] = [1, 4, 0, 0, 0]; rules[3] = [4, 5, 6, 7, 8]; rules[4] = [2, 2, 9, 0, 0]      # point 2 twice
+    feats = rng.normal(size=(6, 5)).astype(np.float32)
+    got = pg.point_recover(torch.from_numpy(feats).to(cuda_device), torch.from_numpy(rules).to(cuda_device), 12).cpu().numpy()
+    want = ref.point_recover(feats, rules, 12)
+    assert np.array_equal(got[[0, 1, 4, 5, 6, 7, 8, 9, 10, 11]], want[[0, 1, 4, 5, 6, 7, 8, 9, 10, 11]]) and np.allclose(got[2], want[2], atol=1e-6)
+    assert not got[3].any() and not got[10:].any()
+    for bad in ([2, 0, 12, 0, 0], [5, 0, 1, 2, 3], [1, -1, 0, 0, 0]):
+        r2 = rules.copy(); r2[5] = bad
+        with pytest.raises(ValueError):
+            pg.point_recover(torch.from_numpy(feats).to(cuda_device), torch.from_numpy(r2).to(cuda_device), 12)
+    assert pg.point_recover(torch.zeros((0, 4), device=cuda_device), torch.zeros((0, 3), dtype=torch.int32, device=cuda_device), 5).shape == (5, 4)
+
+
 def test_bfs_cluster_matches_the_host_bfs(cuda_device):
     """bfs_cluster.cpp's sequential queue BFS vs min-label propagation on the device: same clusters (as point sets), same
     numbering (by smallest point index), same offsets; chains (worst case for propagation), isolated points, label boundaries."""
