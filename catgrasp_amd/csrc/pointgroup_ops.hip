@@ -218,7 +218,7 @@ extern "C" int cg_pg_voxelize_fp(const float* feats, const int* rules, int n_row
   return cg_hip_status(hipGetLastError());
 }
 
-// point_recover forward (src/voxelize/voxelize.cpp:182-192 = voxelize_bp_cuda_ with average = false, voxelize.cu:35-49): every voxel row
+// point_recover forward (src/voxelize/voxelize.cpp:182-192 = voxelize_bp_cuda_ with average = false, voxelize.cu:34-48): every voxel row
 // adds its feature row to each of its member points.  One lane per (member, channel) pair of a row; atomicAdd like the reference (a
 // point listed by several rows receives their sum; in a map made by voxelization_idx every point has exactly one row, so the
 // result is a copy and independent of the order of the additions).  A member index outside [0, n_points) sets *err_flag instead of

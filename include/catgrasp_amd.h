@@ -398,7 +398,7 @@ int cg_pg_get_iou(const int* proposals_idx, const int* proposals_offset, const l
  * rules (n_rows, 1+max_active) = [count, idx...]. */
 int cg_pg_voxelize_fp(const float* feats, const int* rules, int n_rows, int max_active, int C, int average, float* out,
                       void* stream);
-/* point_recover forward (src/voxelize/voxelize.cpp:182-192 -> voxelize.cu:35-49 with average = false; pointgroup_ops.py:77-99):
+/* point_recover forward (src/voxelize/voxelize.cpp:182-192 -> voxelize.cu:34-48 with average = false; pointgroup_ops.py:77-99):
  * out (n_points,C, pre-zeroed)[rules[m][1+i]] += feats (n_rows,C)[m] for i < rules[m][0].  *err_flag (device int, pre-zeroed) = 1 if a
  * count exceeds max_active or a member index lies outside [0, n_points): such entries are skipped, never written. */
 int cg_pg_point_recover(const float* feats, const int* rules, int n_rows, int max_active, int C, int n_points, float* out,

@@ -92,7 +92,7 @@ PGK_OUT = os.path.join(_DIR, '_ref', 'libpointgroup_kernels_ref.so')
 PGK_RANGES = {'pgk_ballquery.inc': ('bfs_cluster/bfs_cluster.cu', 15, 62), 'pgk_sec_mean.inc': ('sec_mean/sec_mean.cu', 12, 27),
               'pgk_sec_min.inc': ('sec_mean/sec_mean.cu', 38, 53), 'pgk_sec_max.inc': ('sec_mean/sec_mean.cu', 64, 79),
               'pgk_roipool_fp.inc': ('roipool/roipool.cu', 12, 31), 'pgk_get_iou.inc': ('get_iou/get_iou.cu', 12, 29),
-              'pgk_voxelize_fp.inc': ('voxelize/voxelize.cu', 9, 23)}
+              'pgk_voxelize_fp.inc': ('voxelize/voxelize.cu', 9, 23), 'pgk_voxelize_bp.inc': ('voxelize/voxelize.cu', 34, 48)}
 
 
 def build_pointgroup_kernels(force=False):

@@ -20,6 +20,7 @@ using Int = int32_t;      // src/datatype/datatype.h:9
 #include "_ref/pgk_roipool_fp.inc"
 #include "_ref/pgk_get_iou.inc"
 #include "_ref/pgk_voxelize_fp.inc"
+#include "_ref/pgk_voxelize_bp.inc"
 
 static int status() { return (int)hipGetLastError(); }
 
@@ -61,5 +62,14 @@ extern "C" int ref_voxelize_fp(int nOutputRows, int maxActive, int nPlanes, floa
   if (nOutputRows <= 0 || nPlanes <= 0) return 0;
   hipLaunchKernelGGL(voxelize_fp_cuda_<float>, dim3((unsigned)std::min(nOutputRows, 32768)), dim3((unsigned)std::min(nPlanes, 32)), 0, (hipStream_t)stream,
                      (Int)nOutputRows, (Int)maxActive, (Int)nPlanes, feats, output_feats, rules, (bool)average);
+  return status();
+}
+
+// point_recover_fp (voxelize.cpp:182-192): the reference runs its voxelize BACKWARD kernel with (d_output_feats, d_feats) = (voxel features,
+// pre-zeroed point features) and average = false
+extern "C" int ref_point_recover_fp(int nActive, int maxActive, int nPlanes, float* feats, float* output_feats, int* rules, void* stream) {
+  if (nActive <= 0 || nPlanes <= 0) return 0;
+  hipLaunchKernelGGL(voxelize_bp_cuda_<float>, dim3((unsigned)std::min(nActive, 32768)), dim3((unsigned)std::min(nPlanes, 32)), 0, (hipStream_t)stream,
+                     (Int)nActive, (Int)maxActive, (Int)nPlanes, feats, output_feats, rules, false);
   return status();
 }

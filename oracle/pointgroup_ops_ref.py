@@ -87,7 +87,7 @@ def voxelize_fp(feats, rules, average):
 
 
 def point_recover(feats, rules, n_point):
-    """voxelize.cpp:182-192 (point_recover_fp = voxelize_bp_cuda_ with average = false, voxelize.cu:35-49): row m of `feats` is added to
+    """voxelize.cpp:182-192 (point_recover_fp = voxelize_bp_cuda_ with average = false, voxelize.cu:34-48): row m of `feats` is added to
     every member point rules[m][1..count]."""
     feats = np.asarray(feats, dtype=np.float32)
     out = np.zeros((n_point, feats.shape[1]), dtype=np.float32)

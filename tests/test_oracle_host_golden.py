@@ -193,9 +193,9 @@ def test_pointgroup_host_ops_oracle_matches_the_reference_cpp():
 
 
 def test_point_recover_oracle_inverts_the_golden_rule_books():
-    """oracle point_recover (voxelize.cpp:182-192 -> voxelize.cu:35-49, CUDA only in the reference, so not compilable here: restated,
-    parity unpinned beyond this property): on the REFERENCE's own rule books (pointgroup_golden.npz) every point receives exactly
-    the row of the voxel its input map names."""
+    """oracle point_recover (voxelize.cpp:182-192 -> voxelize.cu:34-48; the reference's kernel itself is the GPU-side oracle,
+    tests/test_pointgroup_ops_gpu.py): on the REFERENCE's own rule books (pointgroup_golden.npz) every point receives exactly the row
+    of the voxel its input map names."""
     from oracle import pointgroup_ops_ref as ref
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'pointgroup_golden.npz'))
     om, im = g['vox_mode4_output_map'], g['vox_mode4_input_map']

@@ -191,7 +191,7 @@ def test_host_side_ops_against_the_reference_cpp_golden(cuda_device):
 
 def test_product_equals_the_reference_cuda_kernels_running_on_this_gpu(cuda_device):
     """Row N4 pinned to the reference implementation itself: oracle/_ref/libpointgroup_kernels_ref.so holds the reference's OWN
-    PointGroup CUDA kernels (bfs_cluster.cu:15-62, sec_mean.cu, roipool.cu:12-31, get_iou.cu:12-29, voxelize.cu:9-23), compiled for
+    PointGroup CUDA kernels (bfs_cluster.cu:15-62, sec_mean.cu, roipool.cu:12-31, get_iou.cu:12-29, voxelize.cu:9-23,34-48), compiled for
     gfx950 by oracle/build_ref.py:build_pointgroup_kernels from the text where it lies and launched with the reference's geometry.
     The product kernels must return the same tensors on the same device inputs: bitwise for the segmented reductions, the arg-max
     pool, the IoU table and the rule-book pooling; per-point neighbour lists and counts for the ball query (the reference hands out
@@ -238,6 +238,12 @@ def test_product_equals_the_reference_cuda_kernels_running_on_this_gpu(cuda_devi
         ref_v = torch.zeros(om.shape[0], 19, device=dev)
         assert lib.ref_voxelize_fp(om.shape[0], om.shape[1] - 1, 19, P(feats), P(ref_v), P(om), int(mode == 4), st) == 0
         assert torch.equal(pg.voxelization(feats, om, mode), ref_v)
+    # ---- point_recover: the reference's voxelize backward kernel on (voxel features, zeroed point features) (voxelize.cpp:182-192)
+    if hasattr(lib, 'ref_point_recover_fp'):
+        vox = pg.voxelization(feats, om, 4).contiguous()
+        ref_p = torch.zeros(N, 19, device=dev)
+        assert lib.ref_point_recover_fp(om.shape[0], om.shape[1] - 1, 19, P(vox), P(ref_p), P(om), st) == 0
+        assert torch.equal(pg.point_recover(vox, om, N), ref_p)
     # ---- ball query inside batches
     sizes = [700, 1200, 300]
     xyz = torch.cat([torch.rand(s, 3, device=dev, generator=g) * 0.3 for s in sizes]).contiguous()
