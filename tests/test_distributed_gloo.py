@@ -105,6 +105,20 @@ def test_sharded_step_equals_unsharded_world2():
             assert sum(n for _, n in whole.net_calls) == whole.n_total and len(whole.net_calls) == cfg[0] * cfg[3]
 
 
+def test_sharded_step_equals_unsharded_at_the_world_sizes_the_driver_launches():
+    """The 4- and 8-rank layouts of `bench.py --gpus N` (strong C3 / C4 / C5 shapes in small, the weak layout, a batch with fewer
+    candidates than ranks): uneven tails, empty shards, pad -> all_gather -> trim over more than two ranks, every rank holding
+    the whole result."""
+    for world, cfgs in ((4, ((8, 1003, 12, 1), (3, 50, 12, 4))), (8, ((16, 2001, 72, 1), (24, 1507, 'bin', 1), (2, 5, 12, 1)))):
+        for cfg in cfgs:
+            whole = HostBatch(*cfg)
+            ref = whole.score_slice(0, whole.n_total)
+            res = _run(cfg, world=world)
+            assert sorted(res) == list(range(world))
+            for r in range(world):
+                assert torch.equal(res[r][0], ref), (world, cfg, r)
+
+
 def test_one_rank_group_with_the_collective_forced():
     """The shape of the 1-GPU RCCL self-test (tests/test_distributed_rccl_gpu.py, bench.py `rccl_selftest`): a 1-rank group whose
     gather is forced through the collective returns the unsharded records; without a process group the flag is inert."""
