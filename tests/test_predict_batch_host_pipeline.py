@@ -103,6 +103,35 @@ def test_chunk_ramp_plan(host_predicter):
     assert asked == [(0, 2048), (2048, 5048), (5048, 7000)]
 
 
+def test_predict_batch_chunk_plan_collector_pause_and_shared_worker(host_predicter):
+    """The reference-API call: its chunk plan (1,024 growing by 1.5x up to the predicter's chunk size, every pose exactly once), the
+    garbage collector paused for the call and restored to the caller's setting on return AND on an exception, one process-wide
+    numpy-stream worker thread."""
+    import gc
+    from catgrasp_amd import predicter as pred_mod
+    gp, _ = host_predicter
+    gp.chunk = 16384
+    b = gp._chunk_plan(50000, None)
+    assert [e - s for s, e in b] == [1024, 1536, 2304, 3456, 5184, 7776, 11664, 16384, 672] and b[0][0] == 0 and b[-1][1] == 50000
+    assert all(a[1] == c[0] for a, c in zip(b[:-1], b[1:]))
+    assert gp._chunk_plan(700, None) == [(0, 700)] and gp._chunk_plan(1024, None) == [(0, 1024)] and gp._chunk_plan(1025, None) == [(0, 1024), (1024, 1025)]
+    gp.chunk = 3000
+    assert [e - s for s, e in gp._chunk_plan(9000, None)] == [1024, 1536, 2304, 3000, 1136]
+    for was in (True, False):
+        (gc.enable if was else gc.disable)()
+        try:
+            with pred_mod._gc_paused():
+                assert not gc.isenabled()
+            assert gc.isenabled() == was
+            with pytest.raises(KeyError):
+                with pred_mod._gc_paused():
+                    raise KeyError('x')
+            assert gc.isenabled() == was
+        finally:
+            gc.enable()
+    assert pred_mod._draw_worker() is pred_mod._draw_worker()
+
+
 def test_explicit_resample_ids_are_range_checked_before_any_device_work():
     """The device gathers do no bounds checking: explicit ids outside [0, n_valid) must raise like numpy indexing would in the
     reference, for both predicters, before anything is launched (so this runs without a GPU)."""
