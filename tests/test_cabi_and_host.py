@@ -526,3 +526,36 @@ def test_precision_override_is_thread_local():
             engine.precision('fp64')
     finally:
         engine.set_precision(old)
+
+
+def test_hot_kernels_stay_out_of_scratch():
+    """Code-object metadata of the built gfx950 images (scripts/kernel_resources.py; no GPU needed): the kernels whose design rests on
+    register-resident state -- the fused per-point MLP passes, every instantiation of the register-resident set abstraction, the FPS
+    kernels, the dense layers, the collision filter -- must compile without a private segment and without spilled vector registers
+    (a dynamically indexed register array or one VGPR too many puts them into scratch silently; the arithmetic stays right, the
+    kernel gets several times slower)."""
+    import glob
+    import importlib.util
+    import os
+    import shutil
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('kernel_resources', os.path.join(root, 'scripts', 'kernel_resources.py'))
+    kr = importlib.util.module_from_spec(spec); spec.loader.exec_module(kr)
+    if not all(os.path.exists(os.path.join(kr.LLVM, t)) for t in ('llvm-objcopy', 'clang-offload-bundler', 'llvm-readelf')) or shutil.which('c++filt') is None:
+        pytest.skip('ROCm llvm binutils / c++filt not found')
+    hot = {'pointmlp.o': ('pointmlp_max_kernel<',), 'setabstraction.o': ('sa_reg_kernel<',), 'primitives.o': ('fps_kernel<', 'square_distance', 'ball_query', 'group_points'),
+           'gemm.o': ('gemm_bias_act_kernel',), 'collision.o': ('filter_grasp_pose_kernel',), 'misc.o': ('build_grasp_input', 'softmax_pg', 'nunocs_decode'),
+           'pointmlp_split.o': ('pointmlp_max_split_kernel<0, 8, true, false>', 'pointmlp_max_split_kernel<2, 8, false, false>')}
+    seen = 0
+    for obj, prefixes in hot.items():
+        path = os.path.join(root, 'catgrasp_amd', 'csrc', obj)
+        if not os.path.exists(path):
+            pytest.skip(f'{obj} not built')
+        rows = kr.resources(path)
+        for r in rows:
+            name = r['kernel'].replace('void ', '')
+            if any(name.startswith(p) for p in prefixes):
+                seen += 1
+                assert r['private_segment_fixed_size'] == 0 and r['vgpr_spill_count'] == 0, r
+    assert seen >= 100          # 3 + 117 set-abstraction signatures + 4 FPS geometries + ...
+
