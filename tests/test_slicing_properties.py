@@ -1,0 +1,58 @@
+"""Property tests (hypothesis, CPU) of the arithmetic every multi-GPU run rests on: equal contiguous shards, the plan of a scene's
+evaluation segments, the cut of a shard through segments and through (pose x symmetry) rectangles.  Whatever the sizes, every
+evaluation must be computed exactly once, by exactly one rank, in the global order."""
+import numpy as np
+from hypothesis import given, settings, strategies as st
+
+from catgrasp_amd import distributed as cgd
+from catgrasp_amd import workload
+
+
+@settings(max_examples=300, deadline=None)
+@given(n=st.integers(0, 10 ** 7), world=st.integers(1, 64))
+def test_shard_bounds_tile_the_batch(n, world):
+    per, b = cgd.shard_bounds(n, world)
+    assert len(b) == world and b[0][0] == 0 and b[-1][1] == n
+    assert all(a[1] == c[0] for a, c in zip(b[:-1], b[1:])) and all(0 <= e - s <= per for s, e in b)
+    assert n <= per * world < n + world                                      # the padded all-gather holds every record with less than one record of slack per rank
+    assert all(e - s == per for s, e in b if e < n)                          # only the tail shards are short
+
+
+@settings(max_examples=150, deadline=None)
+@given(n_obj=st.integers(1, 24), per_replica=st.integers(1, 20000), sym=st.sampled_from([1, 2, 12, 72]), replicas=st.integers(1, 3),
+       mixed=st.booleans())
+def test_plan_segments_orders_every_evaluation_once(n_obj, per_replica, sym, replicas, mixed):
+    n_sym = [(12, 2, 72)[k % 3] for k in range(n_obj)] if mixed else sym
+    segs, n = workload.plan_segments(n_obj, per_replica, n_sym, replicas)
+    assert n == per_replica * replicas and sum(s.count for s in segs) == n
+    assert segs[0].start == 0 and all(a.start + a.count == b.start for a, b in zip(segs[:-1], segs[1:]))
+    assert all(s.count > 0 and 0 <= s.obj < n_obj and 0 <= s.replica < replicas for s in segs)
+    for s in segs:                                               # a 'nocs' segment is whole (pose x symmetry) groups except possibly its tail
+        want = (n_sym[s.obj] if mixed else sym) if s.kind == 'nocs' else 1
+        assert s.n_sym == want
+
+
+@settings(max_examples=200, deadline=None)
+@given(n_obj=st.integers(1, 16), per_replica=st.integers(1, 5000), sym=st.sampled_from([1, 2, 12, 72]), world=st.integers(1, 9))
+def test_shards_cut_segments_into_a_partition(n_obj, per_replica, sym, world):
+    segs, n = workload.plan_segments(n_obj, per_replica, sym, 1)
+    _, bounds = cgd.shard_bounds(n, world)
+    covered = np.zeros(n, dtype=np.int32)
+    for lo, hi in bounds:
+        pos = lo
+        for s, a, b in workload.intersect(segs, lo, hi):
+            assert 0 <= a < b <= s.count and s.start + a == pos           # in global order, without gaps inside a shard
+            covered[s.start + a:s.start + b] += 1
+            pos = s.start + b
+        assert pos == hi or lo == hi
+    assert (covered == 1).all()
+
+
+@settings(max_examples=300, deadline=None)
+@given(n_sym=st.integers(1, 80), a=st.integers(0, 3000), length=st.integers(0, 3000))
+def test_split_eval_range_is_at_most_three_rectangles(n_sym, a, length):
+    b = a + length
+    rects = workload.split_eval_range(n_sym, a, b)
+    ev = [i * n_sym + j for i0, i1, j0, j1 in rects for i in range(i0, i1) for j in range(j0, j1)]
+    assert ev == list(range(a, b)) and len(rects) <= 3
+    assert all(0 <= j0 < j1 <= n_sym and i0 < i1 for i0, i1, j0, j1 in rects)
