@@ -1,6 +1,6 @@
-"""Property tests (hypothesis, CPU) of the arithmetic every multi-GPU run rests on: equal contiguous shards, the plan of a scene's
+"""Property tests (hypothesis, CPU) of host-side arithmetic: what every multi-GPU run rests on -- equal contiguous shards, the plan of a scene's
 evaluation segments, the cut of a shard through segments and through (pose x symmetry) rectangles.  Whatever the sizes, every
-evaluation must be computed exactly once, by exactly one rank, in the global order."""
+evaluation must be computed exactly once, by exactly one rank, in the global order -- and the replay of numpy's random stream."""
 import numpy as np
 from hypothesis import given, settings, strategies as st
 
@@ -56,3 +56,30 @@ def test_split_eval_range_is_at_most_three_rectangles(n_sym, a, length):
     ev = [i * n_sym + j for i0, i1, j0, j1 in rects for i in range(i0, i1) for j in range(j0, j1)]
     assert ev == list(range(a, b)) and len(rects) <= 3
     assert all(0 <= j0 < j1 <= n_sym and i0 < i1 for i0, i1, j0, j1 in rects)
+
+
+@settings(max_examples=120, deadline=None)
+@given(n_valid=st.one_of(st.integers(1, 3000), st.sampled_from([255, 256, 257, 4095, 4096, 4097, 65535, 65536, 65537])),
+       n_pts=st.integers(1, 200), seed=st.integers(0, 2 ** 32 - 1), burn=st.integers(0, 1300), count=st.integers(1, 4))
+def test_numpy_stream_replay_at_arbitrary_sizes_and_positions(n_valid, n_pts, seed, burn, count):
+    """cg_host_numpy_choice_rows / cg_host_numpy_shuffle_partners (host code of the C-ABI library) against numpy itself for sizes around
+    the rejection-mask boundaries, from arbitrary positions of the Mersenne-Twister block: same rows, same generator state afterwards."""
+    from catgrasp_amd import transforms
+    np.random.seed(seed); np.random.randint(0, 7, burn)
+    want = np.stack([np.random.choice(np.arange(n_valid), size=(n_pts), replace=n_valid < n_pts) for _ in range(count)])
+    after_want = np.random.randint(0, 2 ** 31, 3)
+    np.random.seed(seed); np.random.randint(0, 7, burn)
+    stream = transforms.NumpyChoiceStream(n_valid, n_pts)
+    if stream.on_device_chain:                     # partner form: apply the swap chain the device would run
+        rows = []
+        for js in stream.draw_partners(count):
+            a = np.arange(n_valid)
+            for k, j in enumerate(js[:n_valid - 1]):
+                i = n_valid - 1 - k
+                a[i], a[j] = a[j], a[i]
+            rows.append(a[:n_pts])
+        got = np.stack(rows)
+    else:
+        got = stream.draw(count)
+    stream.close()
+    assert np.array_equal(got, want) and np.array_equal(np.random.randint(0, 2 ** 31, 3), after_want)
