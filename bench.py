@@ -145,6 +145,52 @@ def api_block(batch, gp, device, n=50000):
     return out
 
 
+def pick_cycle_block(batch, gp, npred, device, n_canonical=2000):
+    """One pick cycle's per-object work with the package's DEFAULT settings (exact f32, the reference's numpy stream for the resampling
+    draw AND for the 2 x 10,000 RANSAC hypothesis draws), as run_grasp_simulation.py:112-183,296-329 issues it: pipeline.evaluate_object
+    over the 8 C3 objects, per-stage wall-clock (host clock, device drained after every stage).  Next to it the same cycle with the
+    non-reference fast draws (ransac_sampling='fast', rng='device').  Random-init weights cannot recover a pose, so the canonical-grasp
+    branch takes the scene's true NUNOCS pose (the RANSAC still runs and is timed)."""
+    from catgrasp_amd import engine, pipeline, synth, transforms
+    from catgrasp_amd.predicter import DEFAULT_NUNOCS_CFG, NunocsPredicter
+    g = dict(batch.gripper)
+    g['finger_vertices'] = [g['vertices'][8:16], g['vertices'][16:24]]
+    g['grip_dirs'] = [[0, -1, 0], [0, 1, 0]]
+    objs = batch.objs
+    scene_pts = np.concatenate([o['xyz'] for o in objs])
+    K = np.array([[600, 0, 320], [0, 600, 240], [0, 0, 1.0]])
+    sym = transforms.get_symmetry_tfs('nut')
+    rng = np.random.default_rng(11)
+    canon_pts, canon_nrm = synth.nut_surface(3000, rng)
+    fast = NunocsPredicter('nut', cfg=DEFAULT_NUNOCS_CFG, state_dict=npred.model.state_dict(), device=device, ransac_sampling='fast')
+
+    def cycle(nun, rng_mode):
+        timings, total, surv = {}, 0, 0
+        np.random.seed(0)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for k, ob in enumerate(objs):
+            grasps = np.linalg.inv(batch.nocs_pose[k]) @ synth.make_candidates(ob, n_canonical, np.random.default_rng(100 + k), g['hand_depth'], g['init_bite'])
+            canonical = {'cloud': canon_pts, 'normals': canon_nrm, 'affordance': np.linspace(0, 1, 3000), 'grasps': grasps}
+            out = pipeline.evaluate_object(ob['xyz'], ob['normal'], scene_pts, K, g, gp, nun, canonical=canonical, symmetry_tfs=sym,
+                                           timings=timings, rng=rng_mode, nocs_pose_override=batch.nocs_pose[k])
+            total += out['n_evaluated']; surv += len(out['poses'])
+        torch.cuda.synchronize(); wall = time.perf_counter() - t0
+        return wall, total, surv, timings
+    res = {'objects': len(objs), 'precision': engine.current_precision()}
+    for name, nun, rng_mode in (('default', npred, 'numpy'), ('fast_draws', fast, 'device')):
+        cycle(nun, rng_mode)                                # warm-up: caches, allocator, worker thread
+        wall, total, surv, tm = cycle(nun, rng_mode)
+        res[name] = {'settings': {'default': "ransac_sampling='reference', rng='numpy' (bit-identical to a seeded reference run)",
+                                  'fast_draws': "ransac_sampling='fast', rng='device' (same distributions, not numpy's stream)"}[name],
+                     'wall_s_per_cycle': round(wall, 4), 'wall_ms_per_object': round(wall / len(objs) * 1e3, 2),
+                     'evaluations': total, 'survivors_scored': surv,
+                     'ms_per_object_by_stage': {k: round(v / len(objs) * 1e3, 3) for k, v in tm.items()}}
+    res['note'] = ("stages: occupancy (background ray cast), nunocs+ransac (= 'nunocs net + decode' + 'ransac id draw (exposed)' + 'ransac kernels + "
+                   "selection'; 'ransac id draw' is the duration of the stream replay itself on the worker thread, which starts before the network is queued), "
+                   'candidate generation (cone sampler), filterGraspPose (cone poses + canonical grasps x 12 symmetries, nudging on), affordance, grasp-Q scoring')
+    return res
+
+
 def cpu_baseline(batch, sd_cls, sd_seg, n_score=100, n_coll=4096):
     """BASELINE.md §3 on this box's host cores, bounded to ~30 s: the reference's op sequence (F.conv1d / F.batch_norm / F.linear
     port, oracle/pointnet_ref.py -- the reference package cannot travel to the GPU box) in chunks of 200 (predicter.py:69) fed by
@@ -508,6 +554,11 @@ def main():
     # the reference-API wall-clock right behind the primary measurement (same clock / thermal state as `value`), before the minutes of
     # split-precision runs below
     api = api_block(batch, gp, device) if (rank == 0 and world == 1 and not args.no_api) else None
+    if api is not None:
+        try:
+            api['pick_cycle'] = pick_cycle_block(batch, gp, npreds[cats[0]], device)
+        except Exception as e:          # an extra: never let it take the bench line down
+            api['pick_cycle'] = {'error': f'{type(e).__name__}: {e}'[:300]}
     secondary = []
     for other in [p for p in args.secondary.split(',') if p and p != args.precision]:
         r = measure(other)

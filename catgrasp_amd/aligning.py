@@ -15,9 +15,12 @@ def draw_hypothesis_ids(n_points, max_iter):
     """The reference's sampling (aligning.py:89-93): one `np.random.choice(n, size=4, replace=False)` per iteration from
     numpy's global generator, so a seeded run reproduces the reference's hypotheses.  -> (max_iter,4) int32."""
     from . import transforms
-    # np.random.choice(n, 4, replace=False) = permutation(n)[:4]: a full n-element shuffle per hypothesis.  Replayed in C from numpy's
-    # own generator state (transforms.NumpyChoiceStream: identical rows, identical state afterwards), ~2.5x faster than the python loop.
-    return transforms.draw_ids_reference(n_points, 4, max_iter)
+    if n_points < 4:
+        raise ValueError('Cannot take a larger sample than population when replace is False')     # numpy's own error
+    # np.random.choice(n, 4, replace=False) = permutation(n)[:4]: numpy runs a full n-element Fisher-Yates pass (~11,000 generator
+    # words at n = 8192) for four numbers.  transforms.draw_choice_heads replays the stream and keeps only what the four heads need
+    # (csrc/nprng_heads.hip): identical rows, identical generator state afterwards.
+    return transforms.draw_choice_heads(n_points, 4, max_iter)
 
 
 def draw_hypothesis_ids_fast(n_points, max_iter):
@@ -81,7 +84,7 @@ def estimate9DTransform(source, target, PassThreshold, max_iter=1000, use_kdtree
                         sampling='reference'):
     """-> (4x4 float64 transform, inlier index array) or (None, None), like aligning.py:83-119.
     `ids` (max_iter,4): explicit hypothesis samples; otherwise sampling='reference' reproduces the reference's
-    numpy-global-RNG draw call by call (each draw is a full-cloud shuffle in numpy's stream: ~50 us per hypothesis even replayed in C),
+    numpy-global-RNG draw call by call (each draw is a full-cloud shuffle in numpy's stream; replayed in C, a few us per hypothesis),
     sampling='fast' draws the same distribution vectorised.
     use_kdtree_for_eval=True (aligning.py:63-76; the live pipeline passes False) scores every accepted hypothesis by two-sided
     nearest-neighbour distances against voxel-down-sampled clouds of `kdtree_eval_resolution` (see _kdtree_eval)."""

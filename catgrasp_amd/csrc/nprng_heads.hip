@@ -1,0 +1,254 @@
+// HOST code (no kernel): the hypothesis draw of the 9-D RANSAC, `np.random.choice(n, size=k, replace=False)` once per
+// hypothesis from numpy's GLOBAL generator (aligning.py:89-93: k = 4, n = 8192, 2 x 10,000 draws per object,
+// predicter.py:167-170), replayed from numpy's own Mersenne-Twister state so a seeded run of the drop-in consumes the stream
+// exactly like a seeded run of the reference.
+//
+// What numpy does per draw: permutation(n)[:k] = a full Fisher-Yates pass  for i = n-1 .. 1: j = bounded(i); swap(a[i], a[j])
+// with bounded(i) = "next 32-bit word & mask(i) until <= i" -- 8,191 dependent steps and ~11,350 generator words for FOUR
+// numbers.  Replaying it literally (cg_host_numpy_choice_rows) costs 30-60 us per hypothesis = 0.6-1.2 s per object on one
+// core, two orders of magnitude more than the device work of the whole NUNOCS stage.  This file keeps the stream semantics
+// and drops everything that is not needed for the k heads:
+//   1. generator: blocks of 624 words produced OUT OF PLACE (new[kk] reads old[kk], old[kk+1] and either old[kk+397] or
+//      new[kk-227]: three spans without a loop-carried dependence inside a vector) and tempered a block at a time, 16 words per
+//      instruction; optionally on a second thread that runs ahead through a ring of blocks (the recurrence does not depend on
+//      how the words are consumed);
+//   2. rejection walk: 16 words per step.  accept(t) = (v_t <= i - #accepts before t) is resolved as the fixed point of
+//      a <- (v + prefix_count(a) <= i) started from the upper bound (v <= i): lane 0 is exact at once, lane t after t rounds,
+//      and in all but ~1 % of the vectors the first round already repeats its input.  The mask only changes when i crosses a
+//      power of two; a vector that crosses is cut at the accept that reaches the boundary (pdep/tzcnt on the accept mask).
+//      Accepted partners are compressed (vpcompressd) into a 16-bit row buffer that stays in L1;
+//   3. no permutation is ever built.  a[p] after the pass is found by undoing the swaps from the last to the first for the k
+//      tracked positions only: for i >= k the tracked position is < i, so the only swap that moves it is one whose partner
+//      j_i equals it -- a vector equality search over the partner row (32 partners per compare), ~ln(n) hits per head.
+// Result: identical heads and identical generator state afterwards (tests/test_cabi_and_host.py pins both to numpy itself).
+// Machines without AVX-512 (F, BW, VL, VPOPCNTDQ) + BMI2 take the scalar twin of the same three steps.
+#include <immintrin.h>
+#include <stdint.h>
+#include <string.h>
+#include <atomic>
+#include <thread>
+#include "../../include/catgrasp_amd.h"
+
+namespace {
+
+constexpr int MT_N = 624, MT_M = 397;
+constexpr int RING = 32;                                   // blocks the producer may run ahead (2 x 80 KB, L2 resident)
+
+#define CG_T512 __attribute__((target("avx512f,avx512bw,avx512vl,avx512dq,avx512vpopcntdq,bmi,bmi2,lzcnt,popcnt")))
+
+// ---- generator: one block step, out of place -------------------------------------------------------------------------
+#define CG_GEN_SPAN(a, src, dst, len)                                                          \
+  for (int t = 0; t < (len); ++t) {                                                            \
+    const uint32_t y = ((a)[t] & 0x80000000u) | ((a)[t + 1] & 0x7fffffffu);                    \
+    (dst)[t] = (src)[t] ^ (y >> 1) ^ ((uint32_t)(-(int32_t)(y & 1u)) & 0x9908b0dfu);           \
+  }
+
+#define CG_BLOCK_BODY                                                                                            \
+  {                                                                                                              \
+    const uint32_t* __restrict o = old;                                                                          \
+    uint32_t* __restrict n0 = neu;                                                                               \
+    CG_GEN_SPAN(o, o + MT_M, n0, MT_N - MT_M)                               /* kk =   0..226: mt[kk+397] is old */ \
+    { const uint32_t* __restrict s = neu; uint32_t* __restrict d = neu + 227; CG_GEN_SPAN(o + 227, s, d, 227) }  \
+    { const uint32_t* __restrict s = neu + 227; uint32_t* __restrict d = neu + 454; CG_GEN_SPAN(o + 454, s, d, 169) } \
+    const uint32_t y = (old[MT_N - 1] & 0x80000000u) | (neu[0] & 0x7fffffffu);                                   \
+    neu[MT_N - 1] = neu[MT_M - 1] ^ (y >> 1) ^ ((uint32_t)(-(int32_t)(y & 1u)) & 0x9908b0dfu);                   \
+    for (int t = 0; t < MT_N; ++t) {                                                                             \
+      uint32_t z = neu[t];                                                                                       \
+      z ^= (z >> 11); z ^= (z << 7) & 0x9d2c5680u; z ^= (z << 15) & 0xefc60000u; z ^= (z >> 18);                  \
+      tmp[t] = z;                                                                                                \
+    }                                                                                                            \
+  }
+
+// neu = the state block after `old` (numpy's mt19937_gen), tmp = neu tempered
+CG_T512 void next_block_512(const uint32_t* old, uint32_t* neu, uint32_t* __restrict tmp) CG_BLOCK_BODY
+void next_block_scalar(const uint32_t* old, uint32_t* neu, uint32_t* __restrict tmp) CG_BLOCK_BODY
+
+inline void temper_block(const uint32_t* key, uint32_t* tmp) {
+  for (int t = 0; t < MT_N; ++t) {
+    uint32_t z = key[t];
+    z ^= (z >> 11); z ^= (z << 7) & 0x9d2c5680u; z ^= (z << 15) & 0xefc60000u; z ^= (z >> 18);
+    tmp[t] = z;
+  }
+}
+
+// ---- the word source: raw + tempered blocks, produced in place or by a run-ahead thread ------------------------------
+struct Blocks {
+  uint32_t (*raw)[MT_N];                 // RING raw state blocks
+  uint32_t (*tmp)[MT_N + 16];            // the same blocks tempered (+16 words of slack for whole-vector loads)
+  bool wide;                             // AVX-512 block step
+  bool threaded;
+  alignas(64) std::atomic<long> produced{1};    // blocks 0 .. produced-1 exist (block 0 = the caller's state); written by the producer
+  alignas(64) std::atomic<long> released{0};    // blocks < released may be overwritten; written by the consumer
+  std::atomic<int> stop{0};
+  alignas(64) long cur = 0;                     // the block the consumer reads
+
+  void step(long b) {                    // block b from block b-1
+    const uint32_t* o = raw[(b - 1) % RING];
+    if (wide) next_block_512(o, raw[b % RING], tmp[b % RING]); else next_block_scalar(o, raw[b % RING], tmp[b % RING]);
+  }
+  void producer() {
+    long b = 1;
+    while (!stop.load(std::memory_order_relaxed)) {
+      if (b - released.load(std::memory_order_acquire) >= RING - 1) { _mm_pause(); continue; }   // slot of block b-RING+1.. still in use
+      step(b);
+      produced.store(++b, std::memory_order_release);
+    }
+  }
+  const uint32_t* advance() {            // consumer: done with block `cur`, hand out the next one
+    const long b = ++cur;
+    if (threaded) {
+      released.store(b - 1, std::memory_order_release);        // block b-1 stays readable (step b+.. reads only newer ones; its slot is reused RING later)
+      while (produced.load(std::memory_order_acquire) <= b) _mm_pause();
+    } else {
+      step(b);
+    }
+    return tmp[b % RING];
+  }
+};
+
+// ---- per-row work, AVX-512 ------------------------------------------------------------------------------------------
+struct Cursor { const uint32_t* tb; int pos; };
+
+// Fisher-Yates partners of one permutation(n) pass: o[s] = j_i, s = n-1-i, i = n-1 .. 1.  o needs 16 entries of slack.
+CG_T512 inline void partners_512(Blocks& B, Cursor& c, int n, uint16_t* o) {
+  const __m512i lane_low = _mm512_setr_epi32(0, 1, 3, 7, 15, 31, 63, 127, 255, 511, 1023, 2047, 4095, 8191, 16383, 32767);
+  uint32_t i = (uint32_t)(n - 1), mask = i;
+  mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+  int s = 0;
+  while (i > 0) {
+    const uint32_t lim = mask >> 1;                       // this mask serves the steps i in (lim, mask]
+    if (i <= lim) { mask = lim; continue; }
+    const __m512i vmask = _mm512_set1_epi32((int)mask);
+    while (i > lim) {
+      if (c.pos == MT_N) { c.tb = B.advance(); c.pos = 0; }
+      const int avail = MT_N - c.pos;
+      const __mmask16 kav = avail >= 16 ? (__mmask16)0xffff : (__mmask16)((1u << avail) - 1u);
+      const __m512i v = _mm512_and_si512(_mm512_loadu_si512((const void*)(c.tb + c.pos)), vmask);   // slack words are masked out of `a`
+      const __m512i vi = _mm512_set1_epi32((int)i);
+      __mmask16 a = _mm512_mask_cmple_epu32_mask(kav, v, vi);
+      for (;;) {                                          // accept(t) = v_t <= i - #accepts before t
+        const __m512i cnt = _mm512_popcnt_epi32(_mm512_and_si512(_mm512_set1_epi32((int)(uint32_t)a), lane_low));
+        const __mmask16 a2 = _mm512_mask_cmple_epu32_mask(kav, _mm512_add_epi32(v, cnt), vi);
+        if (a2 == a) break;
+        a = a2;
+      }
+      uint32_t nacc = (uint32_t)_mm_popcnt_u32((uint32_t)a);
+      int used = avail >= 16 ? 16 : avail;
+      const uint32_t room = i - lim;                      // accepts left under this mask
+      if (nacc >= room) {                                 // cut behind the accept that reaches the boundary
+        const uint32_t lane = (uint32_t)_tzcnt_u32(_pdep_u32(1u << (room - 1), (uint32_t)a));
+        a &= (__mmask16)((2u << lane) - 1u);
+        used = (int)lane + 1;
+        nacc = room;
+      }
+      _mm256_storeu_si256((__m256i*)(o + s), _mm512_cvtepi32_epi16(_mm512_maskz_compress_epi32(a, v)));
+      s += (int)nacc; i -= nacc; c.pos += used;
+    }
+  }
+}
+
+// heads[t] = permutation(n)[t], t < k, from the partner row: undo the swaps i = 1 .. n-1 for the k tracked positions
+CG_T512 inline void heads_512(const uint16_t* o, int n, int k, int* heads) {
+  uint32_t p[16];
+  for (int t = 0; t < k; ++t) p[t] = (uint32_t)t;
+  const int kk = k < n ? k : n;
+  for (int i = 1; i < kk; ++i) {                          // below k a tracked position can sit ON i: the full swap rule
+    const uint32_t j = o[n - 1 - i];
+    for (int t = 0; t < k; ++t) p[t] = p[t] == (uint32_t)i ? j : (p[t] == j ? (uint32_t)i : p[t]);
+  }
+  const int S = n - 1 - k;                                // the partners of i = k .. n-1 sit at s = S .. 0
+  if (S >= 0) {
+    __m512i bp[16];
+    for (int t = 0; t < k; ++t) bp[t] = _mm512_set1_epi16((short)p[t]);
+    for (int b = S & ~31; b >= 0; b -= 32) {
+      const int top = S - b;                              // highest valid lane of this chunk
+      const __mmask32 valid = top >= 31 ? 0xffffffffu : ((2u << top) - 1u);
+      const __m512i vec = _mm512_maskz_loadu_epi16(valid, o + b);
+      __mmask32 any = 0;
+      for (int t = 0; t < k; ++t) any |= _mm512_mask_cmpeq_epi16_mask(valid, vec, bp[t]);
+      if (!any) continue;
+      for (int t = 0; t < k; ++t) {                       // rare (~ln n chunks per head): walk this head through the chunk, high lane first
+        __mmask32 m = _mm512_mask_cmpeq_epi16_mask(valid, vec, bp[t]);
+        while (m) {
+          const int h = 31 - (int)_lzcnt_u32((uint32_t)m);
+          p[t] = (uint32_t)(n - 1 - (b + h));
+          bp[t] = _mm512_set1_epi16((short)p[t]);
+          m = h ? _mm512_mask_cmpeq_epi16_mask(valid & (((__mmask32)1u << h) - 1u), vec, bp[t]) : 0;
+        }
+      }
+    }
+  }
+  for (int t = 0; t < k; ++t) heads[t] = (int)p[t];
+}
+
+CG_T512 void rows_512(Blocks& B, Cursor& c, int n, int k, long count, uint16_t* o, int* out) {
+  for (long r = 0; r < count; ++r) {
+    partners_512(B, c, n, o);
+    heads_512(o, n, k, out + r * k);
+  }
+}
+
+// ---- per-row work, scalar twin ---------------------------------------------------------------------------------------
+void rows_scalar(Blocks& B, Cursor& c, int n, int k, long count, uint16_t* o, int* out) {
+  const uint32_t n1 = (uint32_t)(n - 1);
+  uint32_t mask0 = n1;
+  mask0 |= mask0 >> 1; mask0 |= mask0 >> 2; mask0 |= mask0 >> 4; mask0 |= mask0 >> 8; mask0 |= mask0 >> 16;
+  for (long r = 0; r < count; ++r) {
+    uint32_t i = n1, mask = mask0;
+    while (i > 0) {
+      const uint32_t lim = mask >> 1;
+      if (i <= lim) { mask = lim; continue; }
+      if (c.pos == MT_N) { c.tb = B.advance(); c.pos = 0; }
+      const uint32_t* w = c.tb + c.pos;
+      const int avail = MT_N - c.pos;
+      int t = 0;
+      for (; t < avail && i > lim; ++t) {                 // branch-free rejection: store, advance by the accept bit
+        const uint32_t v = w[t] & mask;
+        o[n1 - i] = (uint16_t)v;
+        i = i - 1 + (i < v);
+      }
+      c.pos += t;
+    }
+    uint32_t p[16];
+    for (int t = 0; t < k; ++t) p[t] = (uint32_t)t;
+    for (int i2 = 1; i2 < n; ++i2) {
+      const uint32_t j = o[n - 1 - i2], ii = (uint32_t)i2;
+      for (int t = 0; t < k; ++t) p[t] = p[t] == ii ? j : (p[t] == j ? ii : p[t]);
+    }
+    for (int t = 0; t < k; ++t) out[r * k + t] = (int)p[t];
+  }
+}
+
+bool cpu_has_avx512() {
+  return __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512vl") &&
+         __builtin_cpu_supports("avx512dq") && __builtin_cpu_supports("avx512vpopcntdq") && __builtin_cpu_supports("bmi2");
+}
+
+}  // namespace
+
+// `count` draws of np.random.choice(n, size=k, replace=False) = permutation(n)[:k] from the generator state (key, pos) of
+// np.random.get_state(); the state is advanced exactly as numpy would have.  2 <= n <= 65536, 1 <= k <= min(n, 16).
+// threads >= 2: the generator runs ahead on a second thread.  isa: 0 = pick at run time, 1 = force the scalar twin (tests).
+extern "C" int cg_host_numpy_choice_heads(uint32_t* h_mt_key624, int* h_mt_pos, int n, int k, long count, int threads, int isa, int* h_out) {
+  if (!h_mt_key624 || !h_mt_pos || n < 2 || n > 65536 || k < 1 || k > 16 || k > n || count < 0 || *h_mt_pos < 0 || *h_mt_pos > MT_N)
+    return CG_ERR_ARG;
+  if (count == 0) return CG_OK;
+  if (!h_out) return CG_ERR_ARG;
+  Blocks B;
+  B.raw = (uint32_t(*)[MT_N]) new uint32_t[(size_t)RING * MT_N];
+  B.tmp = (uint32_t(*)[MT_N + 16]) new uint32_t[(size_t)RING * (MT_N + 16)]();
+  uint16_t* row = new uint16_t[(size_t)n + 64];
+  B.wide = isa != 1 && cpu_has_avx512();
+  B.threaded = threads >= 2 && count * (long)n >= (1L << 20);        // a thread start costs more than a small draw
+  memcpy(B.raw[0], h_mt_key624, sizeof(uint32_t) * MT_N);
+  temper_block(B.raw[0], B.tmp[0]);
+  Cursor c{B.tmp[0], *h_mt_pos};
+  std::thread th;
+  if (B.threaded) th = std::thread([&B] { B.producer(); });
+  if (B.wide) rows_512(B, c, n, k, count, row, h_out); else rows_scalar(B, c, n, k, count, row, h_out);
+  if (B.threaded) { B.stop.store(1); th.join(); }
+  memcpy(h_mt_key624, B.raw[B.cur % RING], sizeof(uint32_t) * MT_N);
+  *h_mt_pos = c.pos;
+  delete[] row; delete[] (uint32_t*)B.tmp; delete[] (uint32_t*)B.raw;
+  return CG_OK;
+}

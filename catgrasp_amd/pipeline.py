@@ -48,14 +48,19 @@ def canonical_fields(canonical):
 
 
 def evaluate_object(ob_pts, ob_normals, scene_pts, K, gripper, grasp_predicter, nunocs_predicter, canonical=None, symmetry_tfs=None,
-                    n_surface_samples=50, sphere_pts=None, approach_step=0.004, resolution=0.0005, cam_in_world=None, timings=None, ik=None):
+                    n_surface_samples=50, sphere_pts=None, approach_step=0.004, resolution=0.0005, cam_in_world=None, timings=None, ik=None,
+                    rng=None, nocs_pose_override=None):
     """Returns dict(poses (n,4,4) f32, p_G, p_T_given_G, p_T_G, order) for the surviving candidates, best first.
     `gripper`: dict with vertices/faces/enclosed_vertices/enclosed_faces/gripper_in_grasp/hand_depth/init_bite/diameter and
     finger_vertices (list of 2 arrays), grip_dirs.  `canonical`: optional dict(cloud, normals, affordance, grasps (m,4,4))
     in the canonical (NUNOCS-scaled) frame, or the reference's `{class}_canonical.pkl` dict as grasp_sampler.load_canonical returns it
     (canonical_fields); without it P(T|G) = 1 and only cone-sampled candidates are produced.
     `ik`: optional dict(ee_in_grasp 4x4, upper[7], lower[7]) -> filter_ik=True with the device iiwa14 solver (cam_in_world must
-    then be the camera pose in the robot base frame, common.cpp:214-226)."""
+    then be the camera pose in the robot base frame, common.cpp:214-226).
+    `rng`: the per-candidate resampling draw of the grasp-Q stage -- 'numpy' (numpy's global stream, as predict_batch's default),
+    'device' (counter-based device draw); default: the predicter's own setting.  `nocs_pose_override`: use this 4x4 for the canonical
+    branch instead of the RANSAC result (NunocsPredicter.predict still runs and is timed): random-init weights cannot recover a pose.
+    `timings` additionally receives the split of the NUNOCS stage that NunocsPredicter.predict records (net / id draw / RANSAC)."""
     dev = grasp_predicter.device
     t = time.perf_counter
     canonical = canonical_fields(canonical)
@@ -77,6 +82,11 @@ def evaluate_object(ob_pts, ob_normals, scene_pts, K, gripper, grasp_predicter, 
     data = {'cloud_xyz': ob_pts, 'cloud_normal': ob_normals}
     nocs_cloud, nocs_pose = nunocs_predicter.predict(data)
     lap('nunocs+ransac', t0)
+    if timings is not None:
+        for k, v in getattr(nunocs_predicter, 'timings', {}).items():
+            timings[k] = timings.get(k, 0.0) + v
+    if nocs_pose_override is not None:
+        nocs_pose = np.asarray(nocs_pose_override, dtype=np.float64)
     # --- candidates ---
     t0 = t()
     rng_ids = np.random.choice(len(ob_pts), size=min(n_surface_samples, len(ob_pts)), replace=False)
@@ -126,10 +136,18 @@ def evaluate_object(ob_pts, ob_normals, scene_pts, K, gripper, grasp_predicter, 
     # --- grasp quality ---
     t0 = t()
     cloud = transforms.DeviceCloud(ob_pts, ob_normals, dev)
-    ids = transforms.draw_ids_device(cloud.n, grasp_predicter.cfg['n_pts'], n, dev)
+    rng = rng or getattr(grasp_predicter, 'rng', 'device')
+    if rng == 'numpy':         # the reference's stream (dataset_grasp.py:72-73), replayed one chunk ahead of the device
+        ids = grasp_predicter._numpy_id_chunks(cloud.n, grasp_predicter.cfg['n_pts'], n)
+    else:
+        ids = transforms.draw_ids_device(cloud.n, grasp_predicter.cfg['n_pts'], n, dev)
     pinv = torch.from_numpy(transforms.pose_inverse_rows(surv_np, cloud.center)).to(dev)
-    _, _, _, p_g = grasp_predicter.score_on_device(cloud.xyz, cloud.normal, ids, pinv)
-    p_g = p_g.cpu().numpy().astype(np.float64)
+    try:
+        _, _, _, p_g = grasp_predicter.score_on_device(cloud.xyz, cloud.normal, ids, pinv)
+        p_g = p_g.cpu().numpy().astype(np.float64)
+    finally:
+        if hasattr(ids, 'close'):
+            ids.close()
     lap('grasp-Q scoring', t0)
     valid = np.isfinite(p_t_g)                    # the reference drops grasps without a finger contact (:68-70)
     p_tg = np.where(valid, p_t_g, 0.0) * p_g

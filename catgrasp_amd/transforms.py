@@ -74,6 +74,63 @@ class NumpyChoiceStream:
         np.random.set_state(('MT19937', self._key, int(self._pos.value)) + self._rest)
 
 
+class NumpyHeadsDraw:
+    """`count` consecutive draws of `np.random.choice(n, size=k, replace=False)` from numpy's GLOBAL generator, replayed in C
+    (cg_host_numpy_choice_heads, csrc/nprng_heads.hip: only the k heads of each permutation are materialised).  The state is taken
+    at construction; with `pool` (a ThreadPoolExecutor) the draw runs there without the GIL while the caller queues device work.
+    result() -> (count,k) int32 and puts the advanced state back into numpy; cancel() waits and leaves numpy's state alone."""
+
+    HEAD_MAX, N_MAX = 16, 65536
+
+    def __init__(self, n, k, count, pool=None, threads=None, isa=0):
+        import ctypes
+        import os
+        from . import _lib as L
+        if not (2 <= n <= self.N_MAX and 1 <= k <= min(n, self.HEAD_MAX)):
+            raise ValueError(f'NumpyHeadsDraw: n={n}, k={k} outside 2 <= n <= {self.N_MAX}, 1 <= k <= min(n, {self.HEAD_MAX})')
+        st = np.random.get_state()
+        if st[0] != 'MT19937':
+            raise RuntimeError(f'numpy global generator is {st[0]}, expected the legacy MT19937')
+        self._rest = (st[3], st[4])
+        self._key = np.ascontiguousarray(st[1], dtype=np.uint32).copy()
+        self._pos = ctypes.c_int(int(st[2]))
+        self._out = np.empty((count, k), dtype=np.int32)
+        if threads is None:
+            threads = int(os.environ.get('CATGRASP_AMD_RNG_THREADS', '1'))
+        fn, ct = L.lib().cg_host_numpy_choice_heads, ctypes
+
+        self.seconds = None                  # duration of the C call (on whichever thread ran it)
+
+        def run():
+            import time
+            t0 = time.perf_counter()
+            rc = fn(self._key.ctypes.data_as(ct.c_void_p), ct.byref(self._pos), ct.c_int(n), ct.c_int(k), ct.c_long(count),
+                    ct.c_int(threads), ct.c_int(isa), self._out.ctypes.data_as(ct.c_void_p))
+            self.seconds = time.perf_counter() - t0
+            if rc != 0:
+                raise RuntimeError(f'cg_host_numpy_choice_heads failed with status {rc}')
+            return self._out
+        self._future = pool.submit(run) if pool is not None else None
+        self._run = run
+
+    def result(self):
+        out = self._future.result() if self._future is not None else self._run()
+        np.random.set_state(('MT19937', self._key, int(self._pos.value)) + self._rest)
+        return out
+
+    def cancel(self):
+        if self._future is not None:
+            self._future.exception()
+
+
+def draw_choice_heads(n, k, count):
+    """[np.random.choice(n, size=k, replace=False) for _ in range(count)] from numpy's global generator (same rows, same state
+    afterwards).  -> (count,k) int32.  Shapes outside NumpyHeadsDraw's take the full-row replay."""
+    if 2 <= n <= NumpyHeadsDraw.N_MAX and 1 <= k <= min(n, NumpyHeadsDraw.HEAD_MAX):
+        return NumpyHeadsDraw(n, k, count).result()
+    return draw_ids_reference(n, k, count)
+
+
 def draw_ids_reference(n_valid, n_pts, count):
     """Resample indices drawn exactly as the reference does: one `np.random.choice` per sample from
     numpy's GLOBAL generator (dataset_grasp.py:72-73), with replacement iff n_valid < n_pts.

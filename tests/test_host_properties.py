@@ -2,7 +2,10 @@
 evaluation segments, the cut of a shard through segments and through (pose x symmetry) rectangles.  Whatever the sizes, every
 evaluation must be computed exactly once, by exactly one rank, in the global order -- and the replay of numpy's random stream."""
 import numpy as np
-from hypothesis import given, settings, strategies as st
+import pytest
+
+pytest.importorskip('hypothesis')          # not a declared dependency of the package: skip, do not abort collection, where it is absent
+from hypothesis import given, settings, strategies as st  # noqa: E402
 
 from catgrasp_amd import distributed as cgd
 from catgrasp_amd import workload
@@ -82,4 +85,20 @@ def test_numpy_stream_replay_at_arbitrary_sizes_and_positions(n_valid, n_pts, se
     else:
         got = stream.draw(count)
     stream.close()
+    assert np.array_equal(got, want) and np.array_equal(np.random.randint(0, 2 ** 31, 3), after_want)
+
+
+@settings(max_examples=150, deadline=None)
+@given(n=st.one_of(st.integers(2, 3000), st.sampled_from([255, 256, 257, 4095, 4096, 4097, 8191, 8192, 8193, 65535, 65536])),
+       k=st.integers(1, 16), seed=st.integers(0, 2 ** 32 - 1), burn=st.integers(0, 1300), count=st.integers(1, 6), isa=st.integers(0, 1))
+def test_numpy_choice_heads_at_arbitrary_sizes_and_positions(n, k, seed, burn, count, isa):
+    """cg_host_numpy_choice_heads (the RANSAC hypothesis draw) against numpy itself around the rejection-mask boundaries, from
+    arbitrary positions of the Mersenne-Twister block, for both instruction sets: same heads, same generator state afterwards."""
+    from catgrasp_amd import transforms
+    k = min(k, n)
+    np.random.seed(seed); np.random.randint(0, 7, burn)
+    want = np.stack([np.random.choice(n, size=k, replace=False) for _ in range(count)])
+    after_want = np.random.randint(0, 2 ** 31, 3)
+    np.random.seed(seed); np.random.randint(0, 7, burn)
+    got = transforms.NumpyHeadsDraw(n, k, count, isa=isa).result()
     assert np.array_equal(got, want) and np.array_equal(np.random.randint(0, 2 ** 31, 3), after_want)
