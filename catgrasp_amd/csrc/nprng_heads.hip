@@ -10,13 +10,16 @@
 // and drops everything that is not needed for the k heads:
 //   1. generator: blocks of 624 words produced OUT OF PLACE (new[kk] reads old[kk], old[kk+1] and either old[kk+397] or
 //      new[kk-227]: three spans without a loop-carried dependence inside a vector) and tempered a block at a time, 16 words per
-//      instruction; optionally on a second thread that runs ahead through a ring of blocks (the recurrence does not depend on
-//      how the words are consumed);
-//   2. rejection walk: 16 words per step.  accept(t) = (v_t <= i - #accepts before t) is resolved as the fixed point of
-//      a <- (v + prefix_count(a) <= i) started from the upper bound (v <= i): lane 0 is exact at once, lane t after t rounds,
-//      and in all but ~1 % of the vectors the first round already repeats its input.  The mask only changes when i crosses a
-//      power of two; a vector that crosses is cut at the accept that reaches the boundary (pdep/tzcnt on the accept mask).
-//      Accepted partners are compressed (vpcompressd) into a 16-bit row buffer that stays in L1;
+//      instruction.  (A second thread generating ahead through the ring was measured and dropped: handing 2.5 KB blocks from core
+//      to core costs more than producing them -- 164 vs 80 ms per 20,000 draws on the EPYC 9575F host of the GPU box);
+//   2. rejection walk: 16 .. 128 words per step.  accept(t) = (v_t <= i - #accepts before t) is resolved as the fixed point of
+//      a <- (v + prefix_count(a) <= i) started from the upper bound (v <= i): word 0 is exact at once, word t after t rounds, and
+//      the second round almost always repeats the first (an earlier word must have flipped AND this word must sit in the
+//      one-wide gap that opens).  The loop-carried dependence is i alone (broadcast -> compare -> mask -> popcount, ~16 cycles):
+//      the wider the step, the fewer trips through it, so the large masks -- where the chance of a third round stays ~1 % -- walk
+//      128 / 64 words at a time.  The mask only changes when i crosses a power of two; a vector that crosses is cut at the accept
+//      that reaches the boundary (pdep/tzcnt on the accept mask).  Accepted partners are compressed (vpcompressd) into a 16-bit
+//      row buffer that stays in L1;
 //   3. no permutation is ever built.  a[p] after the pass is found by undoing the swaps from the last to the first for the k
 //      tracked positions only: for i >= k the tracked position is < i, so the only swap that moves it is one whose partner
 //      j_i equals it -- a vector equality search over the partner row (32 partners per compare), ~ln(n) hits per head.
@@ -25,14 +28,14 @@
 #include <immintrin.h>
 #include <stdint.h>
 #include <string.h>
-#include <atomic>
-#include <thread>
 #include "../../include/catgrasp_amd.h"
 
 namespace {
 
 constexpr int MT_N = 624, MT_M = 397;
-constexpr int RING = 32;                                   // blocks the producer may run ahead (2 x 80 KB, L2 resident)
+constexpr int RING = 8;                                    // generator blocks kept (2 x 20 KB, L1/L2 resident)
+constexpr long RING_WORDS = (long)RING * 624;
+constexpr int MIRROR = 256;                                // words of slot 0 repeated behind the ring: a step may read across the wrap
 
 #define CG_T512 __attribute__((target("avx512f,avx512bw,avx512vl,avx512dq,avx512vpopcntdq,bmi,bmi2,lzcnt,popcnt")))
 
@@ -71,47 +74,78 @@ inline void temper_block(const uint32_t* key, uint32_t* tmp) {
   }
 }
 
-// ---- the word source: raw + tempered blocks, produced in place or by a run-ahead thread ------------------------------
-struct Blocks {
-  uint32_t (*raw)[MT_N];                 // RING raw state blocks
-  uint32_t (*tmp)[MT_N + 16];            // the same blocks tempered (+16 words of slack for whole-vector loads)
+// ---- the word source: a ring of raw + tempered generator blocks addressed by the GLOBAL word index -------------------
+// Word g of the stream (g = 0 is word 0 of the caller's block) lives at tmp[g % RING_WORDS]; block b = words [624 b, 624 b + 624).
+struct Stream {
+  uint32_t* raw;                         // RING raw state blocks, flat
+  uint32_t* tmp;                         // the same words tempered, + MIRROR words of slot 0 repeated behind the ring
   bool wide;                             // AVX-512 block step
-  bool threaded;
-  alignas(64) std::atomic<long> produced{1};    // blocks 0 .. produced-1 exist (block 0 = the caller's state); written by the producer
-  alignas(64) std::atomic<long> released{0};    // blocks < released may be overwritten; written by the consumer
-  std::atomic<int> stop{0};
-  alignas(64) long cur = 0;                     // the block the consumer reads
+  long fpos = 0;                         // global index of the next word
+  long have = 1;                         // blocks 0 .. have-1 exist
+  long start = 0;
 
   void step(long b) {                    // block b from block b-1
-    const uint32_t* o = raw[(b - 1) % RING];
-    if (wide) next_block_512(o, raw[b % RING], tmp[b % RING]); else next_block_scalar(o, raw[b % RING], tmp[b % RING]);
+    uint32_t* t = tmp + (b % RING) * MT_N;
+    if (wide) next_block_512(raw + ((b - 1) % RING) * MT_N, raw + (b % RING) * MT_N, t);
+    else next_block_scalar(raw + ((b - 1) % RING) * MT_N, raw + (b % RING) * MT_N, t);
+    if (b % RING == 0) memcpy(tmp + RING_WORDS, t, sizeof(uint32_t) * MIRROR);
   }
-  void producer() {
-    long b = 1;
-    while (!stop.load(std::memory_order_relaxed)) {
-      if (b - released.load(std::memory_order_acquire) >= RING - 1) { _mm_pause(); continue; }   // slot of block b-RING+1.. still in use
-      step(b);
-      produced.store(++b, std::memory_order_release);
-    }
-  }
-  const uint32_t* advance() {            // consumer: done with block `cur`, hand out the next one
-    const long b = ++cur;
-    if (threaded) {
-      released.store(b - 1, std::memory_order_release);        // block b-1 stays readable (step b+.. reads only newer ones; its slot is reused RING later)
-      while (produced.load(std::memory_order_acquire) <= b) _mm_pause();
-    } else {
-      step(b);
-    }
-    return tmp[b % RING];
+  // words [fpos, upto) are about to be read: make them exist; -> pointer to word fpos
+  inline const uint32_t* need(long upto) {
+    const long last = (upto - 1) / MT_N;                 // last block touched
+    while (__builtin_expect(have <= last, 0)) step(have++);      // at most a block or two ahead of fpos: the block of the last
+    return tmp + fpos % RING_WORDS;                              // consumed word (the final state) is never overwritten
   }
 };
 
 // ---- per-row work, AVX-512 ------------------------------------------------------------------------------------------
-struct Cursor { const uint32_t* tb; int pos; };
+#define CG_LANE_LOW _mm512_setr_epi32(0, 1, 3, 7, 15, 31, 63, 127, 255, 511, 1023, 2047, 4095, 8191, 16383, 32767)
+
+// one round of the accept recurrence over NV vectors: b = (v + #accepts of `a` before the word <= i)
+template <int NV>
+CG_T512 inline void accept_round(const __m512i* v, const __mmask16* a, __mmask16* b, __m512i vi) {
+  const __m512i lane_low = CG_LANE_LOW;
+  uint32_t base = 0;
+#pragma unroll
+  for (int q = 0; q < NV; ++q) {
+    __m512i cnt = _mm512_popcnt_epi32(_mm512_and_si512(_mm512_set1_epi32((int)(uint32_t)a[q]), lane_low));
+    if (q) cnt = _mm512_add_epi32(cnt, _mm512_set1_epi32((int)base));
+    b[q] = _mm512_cmple_epu32_mask(_mm512_add_epi32(v[q], cnt), vi);
+    base += (uint32_t)_mm_popcnt_u32((uint32_t)a[q]);
+  }
+}
+
+// NV x 16 words under one mask, none of which can reach the mask boundary (the caller checks i - lim > 16 NV)
+template <int NV>
+CG_T512 inline void walk_group(const uint32_t* w, __m512i vmask, uint32_t& i, uint16_t* o, int& s) {
+  const __m512i vi = _mm512_set1_epi32((int)i);
+  __m512i v[NV];
+  __mmask16 a[NV], b[NV];
+#pragma unroll
+  for (int q = 0; q < NV; ++q) {
+    v[q] = _mm512_and_si512(_mm512_loadu_si512((const void*)(w + 16 * q)), vmask);
+    b[q] = _mm512_cmple_epu32_mask(v[q], vi);            // upper bound: as if nothing had been accepted before the word
+  }
+  accept_round<NV>(v, b, a, vi);                          // lower bound; exact unless an earlier word of the group flipped
+  for (;;) {       // always checked by a further round (skipping it when the first round changed nothing costs more in mispredicted branches)
+    accept_round<NV>(v, a, b, vi);
+    uint32_t diff = 0;
+#pragma unroll
+    for (int q = 0; q < NV; ++q) { diff |= (uint32_t)(a[q] ^ b[q]); a[q] = b[q]; }
+    if (__builtin_expect(diff == 0, 1)) break;            // a fixed point of the recurrence is the sequential answer
+  }
+  uint32_t nacc = 0;
+#pragma unroll
+  for (int q = 0; q < NV; ++q) {
+    _mm256_storeu_si256((__m256i*)(o + s), _mm512_cvtepi32_epi16(_mm512_maskz_compress_epi32(a[q], v[q])));
+    const uint32_t c = (uint32_t)_mm_popcnt_u32((uint32_t)a[q]);
+    s += (int)c; nacc += c;
+  }
+  i -= nacc;
+}
 
 // Fisher-Yates partners of one permutation(n) pass: o[s] = j_i, s = n-1-i, i = n-1 .. 1.  o needs 16 entries of slack.
-CG_T512 inline void partners_512(Blocks& B, Cursor& c, int n, uint16_t* o) {
-  const __m512i lane_low = _mm512_setr_epi32(0, 1, 3, 7, 15, 31, 63, 127, 255, 511, 1023, 2047, 4095, 8191, 16383, 32767);
+CG_T512 inline void partners_512(Stream& S, int n, uint16_t* o) {
   uint32_t i = (uint32_t)(n - 1), mask = i;
   mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
   int s = 0;
@@ -119,21 +153,21 @@ CG_T512 inline void partners_512(Blocks& B, Cursor& c, int n, uint16_t* o) {
     const uint32_t lim = mask >> 1;                       // this mask serves the steps i in (lim, mask]
     if (i <= lim) { mask = lim; continue; }
     const __m512i vmask = _mm512_set1_epi32((int)mask);
-    while (i > lim) {
-      if (c.pos == MT_N) { c.tb = B.advance(); c.pos = 0; }
-      const int avail = MT_N - c.pos;
-      const __mmask16 kav = avail >= 16 ? (__mmask16)0xffff : (__mmask16)((1u << avail) - 1u);
-      const __m512i v = _mm512_and_si512(_mm512_loadu_si512((const void*)(c.tb + c.pos)), vmask);   // slack words are masked out of `a`
+    if (mask >= 4095)
+      while (i - lim > 128) { walk_group<8>(S.need(S.fpos + 128), vmask, i, o, s); S.fpos += 128; }
+    if (mask >= 1023)
+      while (i - lim > 64) { walk_group<4>(S.need(S.fpos + 64), vmask, i, o, s); S.fpos += 64; }
+    while (i > lim) {                                     // one vector at a time, cut where the mask changes
+      const __m512i v = _mm512_and_si512(_mm512_loadu_si512((const void*)S.need(S.fpos + 16)), vmask);
       const __m512i vi = _mm512_set1_epi32((int)i);
-      __mmask16 a = _mm512_mask_cmple_epu32_mask(kav, v, vi);
-      for (;;) {                                          // accept(t) = v_t <= i - #accepts before t
-        const __m512i cnt = _mm512_popcnt_epi32(_mm512_and_si512(_mm512_set1_epi32((int)(uint32_t)a), lane_low));
-        const __mmask16 a2 = _mm512_mask_cmple_epu32_mask(kav, _mm512_add_epi32(v, cnt), vi);
+      __mmask16 a = _mm512_cmple_epu32_mask(v, vi), a2;
+      for (;;) {
+        accept_round<1>(&v, &a, &a2, vi);
         if (a2 == a) break;
         a = a2;
       }
       uint32_t nacc = (uint32_t)_mm_popcnt_u32((uint32_t)a);
-      int used = avail >= 16 ? 16 : avail;
+      int used = 16;
       const uint32_t room = i - lim;                      // accepts left under this mask
       if (nacc >= room) {                                 // cut behind the accept that reaches the boundary
         const uint32_t lane = (uint32_t)_tzcnt_u32(_pdep_u32(1u << (room - 1), (uint32_t)a));
@@ -142,11 +176,10 @@ CG_T512 inline void partners_512(Blocks& B, Cursor& c, int n, uint16_t* o) {
         nacc = room;
       }
       _mm256_storeu_si256((__m256i*)(o + s), _mm512_cvtepi32_epi16(_mm512_maskz_compress_epi32(a, v)));
-      s += (int)nacc; i -= nacc; c.pos += used;
+      s += (int)nacc; i -= nacc; S.fpos += used;
     }
   }
 }
-
 // heads[t] = permutation(n)[t], t < k, from the partner row: undo the swaps i = 1 .. n-1 for the k tracked positions
 CG_T512 inline void heads_512(const uint16_t* o, int n, int k, int* heads) {
   uint32_t p[16];
@@ -181,15 +214,15 @@ CG_T512 inline void heads_512(const uint16_t* o, int n, int k, int* heads) {
   for (int t = 0; t < k; ++t) heads[t] = (int)p[t];
 }
 
-CG_T512 void rows_512(Blocks& B, Cursor& c, int n, int k, long count, uint16_t* o, int* out) {
+CG_T512 void rows_512(Stream& S, int n, int k, long count, uint16_t* o, int* out) {
   for (long r = 0; r < count; ++r) {
-    partners_512(B, c, n, o);
+    partners_512(S, n, o);
     heads_512(o, n, k, out + r * k);
   }
 }
 
 // ---- per-row work, scalar twin ---------------------------------------------------------------------------------------
-void rows_scalar(Blocks& B, Cursor& c, int n, int k, long count, uint16_t* o, int* out) {
+void rows_scalar(Stream& S, int n, int k, long count, uint16_t* o, int* out) {
   const uint32_t n1 = (uint32_t)(n - 1);
   uint32_t mask0 = n1;
   mask0 |= mask0 >> 1; mask0 |= mask0 >> 2; mask0 |= mask0 >> 4; mask0 |= mask0 >> 8; mask0 |= mask0 >> 16;
@@ -198,16 +231,15 @@ void rows_scalar(Blocks& B, Cursor& c, int n, int k, long count, uint16_t* o, in
     while (i > 0) {
       const uint32_t lim = mask >> 1;
       if (i <= lim) { mask = lim; continue; }
-      if (c.pos == MT_N) { c.tb = B.advance(); c.pos = 0; }
-      const uint32_t* w = c.tb + c.pos;
-      const int avail = MT_N - c.pos;
+      const int avail = MT_N - (int)(S.fpos % MT_N);      // to the end of this generator block
+      const uint32_t* w = S.need(S.fpos + avail);
       int t = 0;
       for (; t < avail && i > lim; ++t) {                 // branch-free rejection: store, advance by the accept bit
         const uint32_t v = w[t] & mask;
         o[n1 - i] = (uint16_t)v;
         i = i - 1 + (i < v);
       }
-      c.pos += t;
+      S.fpos += t;
     }
     uint32_t p[16];
     for (int t = 0; t < k; ++t) p[t] = (uint32_t)t;
@@ -228,27 +260,26 @@ bool cpu_has_avx512() {
 
 // `count` draws of np.random.choice(n, size=k, replace=False) = permutation(n)[:k] from the generator state (key, pos) of
 // np.random.get_state(); the state is advanced exactly as numpy would have.  2 <= n <= 65536, 1 <= k <= min(n, 16).
-// threads >= 2: the generator runs ahead on a second thread.  isa: 0 = pick at run time, 1 = force the scalar twin (tests).
-extern "C" int cg_host_numpy_choice_heads(uint32_t* h_mt_key624, int* h_mt_pos, int n, int k, long count, int threads, int isa, int* h_out) {
+// isa: 0 = pick at run time, 1 = force the scalar twin (tests).
+extern "C" int cg_host_numpy_choice_heads(uint32_t* h_mt_key624, int* h_mt_pos, int n, int k, long count, int isa, int* h_out) {
   if (!h_mt_key624 || !h_mt_pos || n < 2 || n > 65536 || k < 1 || k > 16 || k > n || count < 0 || *h_mt_pos < 0 || *h_mt_pos > MT_N)
     return CG_ERR_ARG;
   if (count == 0) return CG_OK;
   if (!h_out) return CG_ERR_ARG;
-  Blocks B;
-  B.raw = (uint32_t(*)[MT_N]) new uint32_t[(size_t)RING * MT_N];
-  B.tmp = (uint32_t(*)[MT_N + 16]) new uint32_t[(size_t)RING * (MT_N + 16)]();
+  Stream S;
+  S.raw = new uint32_t[(size_t)RING_WORDS];
+  S.tmp = new uint32_t[(size_t)RING_WORDS + MIRROR];
   uint16_t* row = new uint16_t[(size_t)n + 64];
-  B.wide = isa != 1 && cpu_has_avx512();
-  B.threaded = threads >= 2 && count * (long)n >= (1L << 20);        // a thread start costs more than a small draw
-  memcpy(B.raw[0], h_mt_key624, sizeof(uint32_t) * MT_N);
-  temper_block(B.raw[0], B.tmp[0]);
-  Cursor c{B.tmp[0], *h_mt_pos};
-  std::thread th;
-  if (B.threaded) th = std::thread([&B] { B.producer(); });
-  if (B.wide) rows_512(B, c, n, k, count, row, h_out); else rows_scalar(B, c, n, k, count, row, h_out);
-  if (B.threaded) { B.stop.store(1); th.join(); }
-  memcpy(h_mt_key624, B.raw[B.cur % RING], sizeof(uint32_t) * MT_N);
-  *h_mt_pos = c.pos;
-  delete[] row; delete[] (uint32_t*)B.tmp; delete[] (uint32_t*)B.raw;
+  S.wide = isa != 1 && cpu_has_avx512();
+  memcpy(S.raw, h_mt_key624, sizeof(uint32_t) * MT_N);
+  temper_block(S.raw, S.tmp);
+  S.fpos = S.start = *h_mt_pos;
+  if (S.wide) rows_512(S, n, k, count, row, h_out); else rows_scalar(S, n, k, count, row, h_out);
+  if (S.fpos > S.start) {                 // numpy regenerates lazily: after the last word of a block the state is (that block, 624)
+    const long b = (S.fpos - 1) / MT_N;
+    memcpy(h_mt_key624, S.raw + (b % RING) * MT_N, sizeof(uint32_t) * MT_N);
+    *h_mt_pos = (int)(S.fpos - b * MT_N);
+  }
+  delete[] row; delete[] S.tmp; delete[] S.raw;
   return CG_OK;
 }

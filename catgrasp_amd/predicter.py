@@ -419,7 +419,7 @@ class NunocsPredicter:
         coords, conf = ops.nunocs_decode(logits.view(B * N, 3 * nb), nb)
         return coords.view(B, N, 3), conf.view(B, N), logits
 
-    def predict_nocs(self, data, ids=None, _after_draw=None):
+    def predict_nocs(self, data, ids=None):
         """The network + decode part of predict (predicter.py:135-150): returns (nocs_cloud (n_pts,3) float32,
         confidence_z (n_pts,), data_transformed dict with 'cloud_xyz_original', 'keep_ids')."""
         with torch.no_grad():
@@ -429,8 +429,9 @@ class NunocsPredicter:
             ids = np.ascontiguousarray(ids, dtype=np.int32).reshape(1, -1)
             if ids.size and (ids.min() < 0 or ids.max() >= cloud.n):         # the device gather does no bounds checking
                 raise IndexError(f'resample index out of range for a cloud of {cloud.n} valid points')
-            if _after_draw is not None:       # numpy's stream now stands where the reference's first estimate9DTransform finds it
-                _after_draw(ids.shape[1])
+            hook, self._after_draw = getattr(self, '_after_draw', None), None
+            if hook is not None:              # numpy's stream now stands where the reference's first estimate9DTransform finds it
+                hook(ids.shape[1])
             coords, conf, _ = self.nocs_on_device(cloud.xyz, cloud.normal, torch.from_numpy(ids).to(self.device))
             self.data_transformed = {'cloud_xyz_original': cloud.xyz64[ids[0]].copy(), 'keep_ids': cloud.keep_ids[ids[0]],
                                      'cloud_normal': cloud.normal64[ids[0]].copy()}
@@ -450,12 +451,15 @@ class NunocsPredicter:
                 draw.append(transforms.NumpyHeadsDraw(n, 4, len(thresholds) * max_iter, pool=_draw_worker()))
         import time
         t0 = time.perf_counter()
+        self._after_draw = start_hypothesis_draw          # one-shot hook of predict_nocs (an overridden predict_nocs simply never calls it)
         try:
-            nocs_cloud, _, dt = self.predict_nocs(data, ids, _after_draw=start_hypothesis_draw)
+            nocs_cloud, _, dt = self.predict_nocs(data, ids)
         except BaseException:
             for d in draw:
                 d.cancel()                     # the reference would not have reached its hypothesis draws either
             raise
+        finally:
+            self._after_draw = None
         t1 = time.perf_counter()
         hyp = draw[0].result() if draw else None
         t2 = time.perf_counter()

@@ -82,9 +82,8 @@ class NumpyHeadsDraw:
 
     HEAD_MAX, N_MAX = 16, 65536
 
-    def __init__(self, n, k, count, pool=None, threads=None, isa=0):
+    def __init__(self, n, k, count, pool=None, isa=0):
         import ctypes
-        import os
         from . import _lib as L
         if not (2 <= n <= self.N_MAX and 1 <= k <= min(n, self.HEAD_MAX)):
             raise ValueError(f'NumpyHeadsDraw: n={n}, k={k} outside 2 <= n <= {self.N_MAX}, 1 <= k <= min(n, {self.HEAD_MAX})')
@@ -95,8 +94,6 @@ class NumpyHeadsDraw:
         self._key = np.ascontiguousarray(st[1], dtype=np.uint32).copy()
         self._pos = ctypes.c_int(int(st[2]))
         self._out = np.empty((count, k), dtype=np.int32)
-        if threads is None:
-            threads = int(os.environ.get('CATGRASP_AMD_RNG_THREADS', '1'))
         fn, ct = L.lib().cg_host_numpy_choice_heads, ctypes
 
         self.seconds = None                  # duration of the C call (on whichever thread ran it)
@@ -105,7 +102,7 @@ class NumpyHeadsDraw:
             import time
             t0 = time.perf_counter()
             rc = fn(self._key.ctypes.data_as(ct.c_void_p), ct.byref(self._pos), ct.c_int(n), ct.c_int(k), ct.c_long(count),
-                    ct.c_int(threads), ct.c_int(isa), self._out.ctypes.data_as(ct.c_void_p))
+                    ct.c_int(isa), self._out.ctypes.data_as(ct.c_void_p))
             self.seconds = time.perf_counter() - t0
             if rc != 0:
                 raise RuntimeError(f'cg_host_numpy_choice_heads failed with status {rc}')

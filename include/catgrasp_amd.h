@@ -237,9 +237,8 @@ int cg_host_numpy_choice_rows(unsigned int* h_mt_key624, int* h_mt_pos, int n_va
  * 2 x 10,000 iterations per object, predicter.py:167-170) replayed from numpy's stream: `count` consecutive draws of
  * permutation(n)[:k], 2 <= n <= 65536, 1 <= k <= min(n,16), into h_out (count,k) int32; the generator state advances exactly as
  * numpy's would.  Nothing but the k heads is materialised (csrc/nprng_heads.hip): vectorised generator blocks, a 16-word
- * rejection walk, and the swaps undone for the k tracked positions only.  threads >= 2 lets the generator run ahead on a second
- * thread; isa 0 = AVX-512 when the CPU has it, 1 = the scalar twin.  HOST pointers, no device work. */
-int cg_host_numpy_choice_heads(unsigned int* h_mt_key624, int* h_mt_pos, int n, int k, long count, int threads, int isa, int* h_out);
+ * rejection walk, and the swaps undone for the k tracked positions only.  isa 0 = AVX-512 when the CPU has it, 1 = the scalar twin.  HOST pointers, no device work. */
+int cg_host_numpy_choice_heads(unsigned int* h_mt_key624, int* h_mt_pos, int n, int k, long count, int isa, int* h_out);
 
 /* The same draw with the swap chain on the device (n_pts <= n_valid <= 65536, the replace=False branch): the HOST part is only
  * what makes numpy's stream sequential -- the rejection-sampled Fisher-Yates swap partners j(i), i = n_valid-1 .. 1, of `count`

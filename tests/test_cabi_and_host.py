@@ -69,11 +69,11 @@ def test_argument_errors_are_reported_not_crashed():
     assert lib.cg_host_numpy_shuffle_partners(one, ctypes.byref(ok_pos), 70000, L(1), L(70000), one) == -1        # > 65536: u16 partners
     assert lib.cg_host_numpy_shuffle_partners(one, ctypes.byref(ok_pos), 2500, L(1), L(2000), one) == -1          # stride < n_valid - 1
     assert lib.cg_host_numpy_shuffle_partners(one, ctypes.byref(ok_pos), 2500, L(0), L(2504), None) == 0
-    assert lib.cg_host_numpy_choice_heads(one, ctypes.byref(bad_pos), 8192, 4, L(1), 1, 0, one) == -1             # MT position > 624
-    assert lib.cg_host_numpy_choice_heads(one, ctypes.byref(ok_pos), 70000, 4, L(1), 1, 0, one) == -1             # > 65536: u16 partners
-    assert lib.cg_host_numpy_choice_heads(one, ctypes.byref(ok_pos), 3, 4, L(1), 1, 0, one) == -1                 # k > n (numpy raises too)
-    assert lib.cg_host_numpy_choice_heads(one, ctypes.byref(ok_pos), 8192, 17, L(1), 1, 0, one) == -1             # more heads than tracked
-    assert lib.cg_host_numpy_choice_heads(one, ctypes.byref(ok_pos), 8192, 4, L(0), 1, 0, None) == 0
+    assert lib.cg_host_numpy_choice_heads(one, ctypes.byref(bad_pos), 8192, 4, L(1), 0, one) == -1             # MT position > 624
+    assert lib.cg_host_numpy_choice_heads(one, ctypes.byref(ok_pos), 70000, 4, L(1), 0, one) == -1             # > 65536: u16 partners
+    assert lib.cg_host_numpy_choice_heads(one, ctypes.byref(ok_pos), 3, 4, L(1), 0, one) == -1                 # k > n (numpy raises too)
+    assert lib.cg_host_numpy_choice_heads(one, ctypes.byref(ok_pos), 8192, 17, L(1), 0, one) == -1             # more heads than tracked
+    assert lib.cg_host_numpy_choice_heads(one, ctypes.byref(ok_pos), 8192, 4, L(0), 0, None) == 0
     assert lib.cg_apply_shuffle_rows(one, L(2504), 2500, 2048, L(-1), 0, one, null) == -1
     assert lib.cg_apply_shuffle_rows(one, L(2501), 2500, 2048, L(1), 0, one, null) == -1                          # stride not a multiple of 8
     assert lib.cg_apply_shuffle_rows(one, L(2504), 2500, 4096, L(1), 0, one, null) == -1                          # n_pts > n_valid
@@ -254,17 +254,17 @@ def test_numpy_shuffle_partners_replay(n_valid, n_pts):
 def test_numpy_choice_heads_replay_is_bit_identical_to_numpy(n, k):
     """The RANSAC hypothesis draw (aligning.py:89-93, `np.random.choice(n, size=4, replace=False)` x 2 x 10,000 per object) replayed
     without ever building a permutation (cg_host_numpy_choice_heads): rows == numpy's call after call and numpy's generator ends in
-    the same state, from arbitrary block positions, for the AVX-512 walk and its scalar twin, with and without the generator thread."""
+    the same state, from arbitrary block positions, for the AVX-512 walk and its scalar twin."""
     count = 3 if n > 20000 else 25
     for seed, burn in ((0, 0), (3, 623), (2 ** 31 - 1, 1250)):
         np.random.seed(seed); np.random.randint(0, 10, burn)
         want = np.stack([np.random.choice(n, size=k, replace=False) for _ in range(count)])
         after_want = np.random.randint(0, 2 ** 31, 5); g_want = np.random.normal()
-        for threads, isa in ((1, 0), (1, 1), (2, 0)):
+        for isa in (0, 1):
             np.random.seed(seed); np.random.randint(0, 10, burn)
-            got = transforms.NumpyHeadsDraw(n, k, count, threads=threads, isa=isa).result()
+            got = transforms.NumpyHeadsDraw(n, k, count, isa=isa).result()
             after_got = np.random.randint(0, 2 ** 31, 5); g_got = np.random.normal()
-            assert np.array_equal(got, want) and np.array_equal(after_got, after_want) and g_got == g_want, (threads, isa)
+            assert np.array_equal(got, want) and np.array_equal(after_got, after_want) and g_got == g_want, isa
     # on a worker thread; cancel() leaves numpy's state where it was
     from concurrent.futures import ThreadPoolExecutor
     with ThreadPoolExecutor(max_workers=1) as pool:
@@ -275,14 +275,14 @@ def test_numpy_choice_heads_replay_is_bit_identical_to_numpy(n, k):
         np.random.seed(8); assert x == np.random.rand()
 
 
-def test_numpy_choice_heads_long_run_with_generator_thread():
-    """A draw long enough for the run-ahead generator thread to lap its ring of blocks many times (2,000 x 8,192: ~36,000 blocks
-    through a 32-block ring), against numpy itself."""
+def test_numpy_choice_heads_long_run():
+    """A draw long enough to lap the ring of generator blocks thousands of times (2,000 x 8,192: ~36,000 blocks through an 8-block
+    ring, wide steps reading across the wrap), against numpy itself."""
     np.random.seed(123)
     want = np.stack([np.random.choice(8192, size=4, replace=False) for _ in range(2000)]); tail = np.random.randint(0, 2 ** 31, 4)
-    for threads in (1, 2):
+    for isa in (0, 1):
         np.random.seed(123)
-        got = transforms.NumpyHeadsDraw(8192, 4, 2000, threads=threads).result()
+        got = transforms.NumpyHeadsDraw(8192, 4, 2000, isa=isa).result()
         assert np.array_equal(got, want) and np.array_equal(np.random.randint(0, 2 ** 31, 4), tail)
     with pytest.raises(ValueError):
         from catgrasp_amd import aligning
