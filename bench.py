@@ -70,20 +70,6 @@ DTYPE = {'f32': 'f32 (exact-f32 MFMA: every product and accumulation in float32,
                      'all other wide layers f16x3'}
 
 
-def subdivide(V, F, times):
-    """Loop-free 1:4 midpoint subdivision (the api block wants a >= 5k-triangle gripper: 36 x 4^4 = 9216)."""
-    V = np.asarray(V, dtype=np.float32); F = np.asarray(F, dtype=np.int32)
-    for _ in range(times):
-        a, b, c = V[F[:, 0]], V[F[:, 1]], V[F[:, 2]]
-        n0 = len(V)
-        mids = np.stack([(a + b) / 2, (b + c) / 2, (c + a) / 2], axis=1).reshape(-1, 3).astype(np.float32)
-        i = n0 + 3 * np.arange(len(F))
-        F = np.concatenate([np.stack([F[:, 0], i, i + 2], 1), np.stack([i, F[:, 1], i + 1], 1), np.stack([i + 2, i + 1, F[:, 2]], 1),
-                            np.stack([i, i + 1, i + 2], 1)]).astype(np.int32)
-        V = np.concatenate([V, mids])
-    return V, F
-
-
 def api_block(batch, gp, device, n=50000):
     """Wall-clock of the REFERENCE entry points exactly as run_grasp_simulation.py:176,310 call them (python lists / numpy arrays in,
     python lists out; includes every host-side conversion, upload, download and list build), next to the device-resident number."""
@@ -122,8 +108,7 @@ def api_block(batch, gp, device, n=50000):
     out['predict_batch'] = pb
     # filterGraspPose, 20 positional arguments, >= 5k-triangle gripper meshes, nut symmetries, pose nudging on
     g = batch.gripper
-    V, F = subdivide(g['vertices'], g['faces'], 4)
-    Ve, Fe = subdivide(g['enclosed_vertices'], g['enclosed_faces'], 4)
+    V, F, Ve, Fe = g['vertices'], g['faces'], g['enclosed_vertices'], g['enclosed_faces']       # the batch's gripper: 9,216 / 12,288 triangles
     from catgrasp_amd import transforms
     sym = transforms.get_symmetry_tfs('nut')
     n_can = (n + len(sym) - 1) // len(sym)
@@ -143,6 +128,49 @@ def api_block(batch, gp, device, n=50000):
                               'note': 'cold = first call on these meshes/clouds (device mesh-grid build + voxelisation); warm = the '
                                       'content-keyed scene cache is hit, as on the second per-object call of grasp_sampler.py'}
     return out
+
+
+GRIPPER_SUBDIVISIONS = 4                                # the step's gripper meshes: 36 / 48 box triangles x 4^4 = 9,216 / 12,288
+PEAK_L2_GBS = 34500.0                                   # MI355X_MICROARCH.md: L2 4 MiB per XCD, ~34.5 TB/s aggregate
+
+
+def filter_roofline_block(batch, device, reps=5):
+    """roofline_filter: the collision filter of the step, object 0's two segments (canonical grasps x symmetries with nudging; cone poses),
+    alone on the stream: HIP-event time of the three launches of a call (pose composition, grid kernel, exhaustive finisher) against the
+    CACHE-LEVEL bytes the grid kernel itself counts (cg_filter_grasp_pose_accel work_stats: 8 B per voxel key read, 8 B per grid cell
+    looked up, 48 B of triangle + 4 B of list entry per (voxel, triangle) pair tested) plus the algorithmic HBM bytes (64 B pose in,
+    66 B out per evaluation).  HBM-wise the kernel is trivial; the voxel keys, cell table and triangles are L2 / L1 resident."""
+    from catgrasp_amd import my_cpp
+    I4 = np.eye(4, dtype=np.float32)
+    g = batch.gripper
+    tot_ms, tot_bytes, E_tot, w_tot = 0.0, 0, 0, np.zeros(3, dtype=np.int64)
+    for seg in [s for s in batch.segs if s.obj == 0 and s.replica == 0]:
+        P = batch.segment_poses(seg)
+        sym, nocs = (batch.syms[batch.cats[0]], batch.nocs_pose[0]) if seg.kind == 'nocs' else (batch.eye, I4)
+        call = lambda ws=None: my_cpp.filter_on_device(batch.scenes[0], P, sym, nocs, I4, I4, I4, g['gripper_in_grasp'], True, False, seg.adjust,
+                                                       keep_rejected_pose=True, work_stats=ws)
+        stats = torch.zeros(3, dtype=torch.int64, device=device)
+        out = call(stats)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            call()
+        e1.record(); torch.cuda.synchronize()
+        w = stats.cpu().numpy()
+        E = int(out[0].numel())
+        tot_ms += e0.elapsed_time(e1) / reps; E_tot += E; w_tot += w
+        tot_bytes += int(8 * w[0] + 8 * w[1] + 52 * w[2] + 130 * E)
+    gbs = tot_bytes / (tot_ms * 1e-3) / 1e9
+    return {'bound': 'l2', 'kernel': 'compose_grasp_pose_kernel + filter_grasp_pose_kernel<true> (+ the exhaustive finisher, which finds nothing to do)',
+            'achieved': round(gbs, 1), 'peak': PEAK_L2_GBS, 'unit': 'GB/s', 'frac': round(gbs / PEAK_L2_GBS, 4),
+            'traffic': None, 'cache_level_bytes': tot_bytes, 'evaluations': E_tot, 'ms': round(tot_ms, 4),
+            'evaluations_per_s': round(E_tot / (tot_ms * 1e-3), 1),
+            'voxel_keys_read': int(w_tot[0]), 'grid_cells_looked_up': int(w_tot[1]), 'pairs_tested': int(w_tot[2]),
+            'gripper_triangles': [int(len(g['faces'])), int(len(g['enclosed_faces']))],
+            'hbm_algorithmic_bytes': 130 * E_tot,
+            'note': 'cache-level figure (what the lanes load from L1 / L2), not HBM; `traffic` (HBM by PMC) and the issue-side counters of the same call '
+                    'shapes are in profiles/r4_pmc_*_filter.csv: the kernel is bound by vector-instruction issue (broad-phase arithmetic per voxel, '
+                    'the 13-axis SAT per pair), not by bytes'}
 
 
 def pick_cycle_block(batch, gp, npred, device, n_canonical=2000):
@@ -191,7 +219,7 @@ def pick_cycle_block(batch, gp, npred, device, n_canonical=2000):
     return res
 
 
-def cpu_baseline(batch, sd_cls, sd_seg, n_score=100, n_coll=4096):
+def cpu_baseline(batch, sd_cls, sd_seg, n_score=100, n_coll=1024):
     """BASELINE.md §3 on this box's host cores, bounded to ~30 s: the reference's op sequence (F.conv1d / F.batch_norm / F.linear
     port, oracle/pointnet_ref.py -- the reference package cannot travel to the GPU box) in chunks of 200 (predicter.py:69) fed by
     the restated per-candidate GraspDataset.transform python loop; the C/OpenMP filterGraspPose restatement over all cores with
@@ -255,6 +283,8 @@ def cpu_baseline(batch, sd_cls, sd_seg, n_score=100, n_coll=4096):
     per_rank = batch.n_total
     per_cand = t_transform + t_netonly + t_coll + t_nunocs_obj * len(batch.objs) / per_rank
     return {'value': round(1.0 / per_cand, 2), 'unit': 'candidates/s', 'cores': nthreads, 'host_cores': host, 'kind': 'port',
+            'kind_note': 'port pinned to reference goldens: the F.conv1d / F.batch_norm op sequence of oracle/pointnet_ref.py is checked against outputs of the '
+                         'imported /root/reference/pointnet2.py (tests/golden/make_golden*.py); the reference package itself cannot travel to the GPU box',
             'collision_threads': co.num_threads(),
             'sample': f'{n_score} candidates x (3 warm-ups, median of 5): python transform loop + PointNetCls fp32 in chunks of 200 through '
                       f'F.conv1d/F.batch_norm/F.linear on {nthreads} torch threads (best of the scan); {n_can * len(sym) + n_coll // 2} '
@@ -446,11 +476,12 @@ def main():
         if scaling == 'weak':
             n = args.candidates * world
             return SceneBatch(device, gps, npreds, kind='nut', n_objects=8, pts_per_object=2500, per_replica=args.candidates, replicas=world,
-                              materialize=(rank * args.candidates, (rank + 1) * args.candidates)), n
+                              materialize=(rank * args.candidates, (rank + 1) * args.candidates), gripper_subdivisions=GRIPPER_SUBDIVISIONS), n
         n = args.candidates if args.workload == 'C3' else args.candidates_total
         _, bounds = cgd.shard_bounds(n, world)
         kind, n_obj = {'C3': ('nut', 8), 'C4': ('screw', 16), 'C5': ('bin', 24)}[args.workload]
-        return SceneBatch(device, gps, npreds, kind=kind, n_objects=n_obj, pts_per_object=2500, per_replica=n, replicas=1, materialize=bounds[rank]), n
+        return SceneBatch(device, gps, npreds, kind=kind, n_objects=n_obj, pts_per_object=2500, per_replica=n, replicas=1, materialize=bounds[rank],
+                          gripper_subdivisions=GRIPPER_SUBDIVISIONS), n
 
     batch, n_total = make_batch(args.scaling)
     assert batch.n_total == n_total
@@ -608,7 +639,8 @@ def main():
                                     'C5': 'C5 (BASELINE.json configs[4]): mixed-category bin, 60k-pt scene (24 objects x 2500 pts: nut / hnm / screw '
                                           'in turn, one GraspPredicter + NunocsPredicter per category), '
                                           f'{n_total} candidates in total over {world} GPU(s)'}[args.workload] +
-                                   f': NUNOCS PointNetSeg(8192x6) per object + filterGraspPose [canonical grasps x {sym_txt} symmetries with '
+                                   f': NUNOCS PointNetSeg(8192x6) per object + filterGraspPose [{len(batch.gripper["faces"])} / {len(batch.gripper["enclosed_faces"])}-triangle '
+                                   f'gripper meshes; canonical grasps x {sym_txt} symmetries with '
                                    'adjust_collision_pose=True (grasp_sampler.py:345) and cone poses with symmetry=[I] (grasp_sampler.py:216)] + '
                                    'device pose inverse + per-candidate resampling draw + grasp-Q PointNetCls(2048x6) + softmax/p_G for EVERY candidate',
                        'candidates_per_gpu': n_total // world, 'candidates_total': n_total, 'scene_points': int(batch.cloud_xyz.shape[0]),
@@ -625,6 +657,11 @@ def main():
             line['rccl_selftest'] = selftest
         if 'bgi' in prim:
             line['roofline_hbm'] = prim['bgi']
+        if world == 1:
+            try:
+                line['roofline_filter'] = filter_roofline_block(batch, device)
+            except Exception as e:          # an extra: never let it take the bench line down
+                line['roofline_filter'] = {'error': f'{type(e).__name__}: {e}'[:300]}
         if secondary:
             line['secondary'] = secondary
         if api is not None:

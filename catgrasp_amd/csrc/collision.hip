@@ -6,9 +6,10 @@
 // of occupied octomap depth-16 leaves (key = floor(x/res) + 32768 in double); a posed mesh collides with
 // it iff some occupied leaf box intersects some posed triangle (13-axis SAT in float32).  One wavefront
 // evaluates one (grasp pose, symmetry transform) pair: its 64 lanes stride over the occupied voxels
-// (8-byte int16x4 keys, coalesced), the posed triangles of the gripper live in LDS, and a wave ballot
-// gives the early exit.  HBM traffic is 64 B of pose in and 66 B out per evaluation; the voxel and
+// (8-byte int16x4 keys, coalesced), queue the (voxel, triangle) pairs the mesh-frame grid hands them in LDS and
+// test the queue 64 pairs at a time; a wave ballot gives the early exit.  HBM traffic is 64 B of pose in and 66 B out per evaluation; the voxel and
 // mesh arrays are L2 resident.
+#include <stddef.h>
 #include "cg_common.hpp"
 #include "../../include/catgrasp_amd.h"
 
@@ -31,34 +32,32 @@ __device__ __forceinline__ void mat4_mul(const float* A, const float* B, float* 
   for (int i = 0; i < 16; ++i) C[i] = t[i];
 }
 
+// A value every lane of the wave holds identically, moved to a scalar register.  The 4x4 matrices of an evaluation are wave-uniform
+// but computed by the vector ALU (gfx950 has no scalar float unit): left in VGPRs they cost ~100 registers per lane across the
+// collision loops; as SGPRs they are free operands of the lanes' v_fma.
+__device__ __forceinline__ float uni(float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); }
+
 __device__ __forceinline__ void normalize_col(float* M, int col) {
   const float x = M[0 * 4 + col], y = M[1 * 4 + col], z = M[2 * 4 + col];
   const float s = (x * x + y * y) + z * z;
   if (s > 0.0f) { const float n = sqrtf(s); M[0 * 4 + col] = x / n; M[1 * 4 + col] = y / n; M[2 * 4 + col] = z / n; }
 }
 
-__device__ __forceinline__ bool plane_box_overlap(const float* n, const float* v, float h) {
-  float vmin[3], vmax[3];
-#pragma unroll
-  for (int q = 0; q < 3; ++q) {
-    if (n[q] > 0.0f) { vmin[q] = -h - v[q]; vmax[q] = h - v[q]; }
-    else { vmin[q] = h - v[q]; vmax[q] = -h - v[q]; }
-  }
-  if ((n[0] * vmin[0] + n[1] * vmin[1]) + n[2] * vmin[2] > 0.0f) return false;
-  if ((n[0] * vmax[0] + n[1] * vmax[1]) + n[2] * vmax[2] >= 0.0f) return true;
-  return false;
-}
-
+// Exact float32 triangle / axis-aligned cube overlap (separating axes: 9 edge crosses, 3 box axes, plane), BRANCH-FREE: every axis
+// is evaluated and the "separated" bits are OR-ed.  In a wavefront the lanes test different (voxel, triangle) pairs, so an early
+// exit per axis saves nothing unless all 64 lanes take it, while each `return` costs an exec-mask save in SGPRs (the version with
+// 13 early exits spilled 364 of them).  Every expression is the one the early-exit version evaluated (same operation order, no
+// FMA contraction), so the predicate is bit-identical to it and to oracle/collision_ref.c.
 #define CG_AXIS(pa, pb, rad) { const float _a = (pa), _b = (pb), _r = (rad); \
-    const float mn = fminf(_a, _b), mx = fmaxf(_a, _b); if (mn > _r || mx < -_r) return false; }
+    sep = fminf(_a, _b) > _r ? 1 : sep; sep = fmaxf(_a, _b) < -_r ? 1 : sep; }
 
-// exact float32 triangle / axis-aligned cube overlap (separating axes: 9 edge crosses, 3 box axes, plane)
 __device__ __forceinline__ bool tri_box_overlap(const float* c, float h, const float* a, const float* b, const float* d) {
   float v0[3], v1[3], v2[3], e0[3], e1[3], e2[3];
 #pragma unroll
   for (int i = 0; i < 3; ++i) { v0[i] = a[i] - c[i]; v1[i] = b[i] - c[i]; v2[i] = d[i] - c[i]; }
 #pragma unroll
   for (int i = 0; i < 3; ++i) { e0[i] = v1[i] - v0[i]; e1[i] = v2[i] - v1[i]; e2[i] = v0[i] - v2[i]; }
+  int sep = 0;
   float fex, fey, fez;
   fex = fabsf(e0[0]); fey = fabsf(e0[1]); fez = fabsf(e0[2]);
   CG_AXIS(e0[2] * v0[1] - e0[1] * v0[2], e0[2] * v2[1] - e0[1] * v2[2], fez * h + fey * h);
@@ -73,94 +72,176 @@ __device__ __forceinline__ bool tri_box_overlap(const float* c, float h, const f
   CG_AXIS(-e2[2] * v0[0] + e2[0] * v0[2], -e2[2] * v1[0] + e2[0] * v1[2], fez * h + fex * h);
   CG_AXIS(e2[1] * v1[0] - e2[0] * v1[1], e2[1] * v2[0] - e2[0] * v2[1], fey * h + fex * h);
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    if (fminf(fminf(v0[i], v1[i]), v2[i]) > h || fmaxf(fmaxf(v0[i], v1[i]), v2[i]) < -h) return false;
-  }
+  for (int i = 0; i < 3; ++i)
+  { sep = fminf(fminf(v0[i], v1[i]), v2[i]) > h ? 1 : sep; sep = fmaxf(fmaxf(v0[i], v1[i]), v2[i]) < -h ? 1 : sep; }
   float n[3];
   n[0] = e0[1] * e1[2] - e0[2] * e1[1];
   n[1] = e0[2] * e1[0] - e0[0] * e1[2];
   n[2] = e0[0] * e1[1] - e0[1] * e1[0];
-  return plane_box_overlap(n, v0, h);
+  // plane / box: the box vertex extremal along n, on either side (vmin: most negative, vmax: most positive)
+  float vmin[3], vmax[3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const bool pos = n[q] > 0.0f;
+    vmin[q] = (pos ? -h : h) - v0[q];
+    vmax[q] = (pos ? h : -h) - v0[q];
+  }
+  const float dmin = (n[0] * vmin[0] + n[1] * vmin[1]) + n[2] * vmin[2];
+  const float dmax = (n[0] * vmax[0] + n[1] * vmax[1]) + n[2] * vmax[2];
+  return !sep && !(dmin > 0.0f) && (dmax >= 0.0f);
 }
 
 // Optional broad phase: a uniform grid in the MESH frame; cell (i,j,k) lists every triangle whose box, inflated by the
-// grid's build margin, overlaps the cell (CSR: cell_start, tri_ids).  Built on the host (my_cpp.build_mesh_grid).
-struct Grid { float ox, oy, oz, inv_cell; int nx, ny, nz; const int* cell_start; const int* tri_ids; float res_built; };
+// grid's build margin, overlaps the cell (CSR: cell_start, tri_ids).  Built on the device (cg_mesh_grid_count / _fill).
+// tri_verts (optional): the triangles as a flat (nf,12) float array [v0 v1 v2 pad] -- one indirection less than F -> V.
+struct Grid { float ox, oy, oz, inv_cell; int nx, ny, nz; const int* cell_start; const int* tri_ids; const float* tri_verts; float res_built; };
 struct Mesh { const float* V; const int* F; int nf; Grid grid; int has_grid; };
 struct Voxels { const short* keys; int nk; };   // (nk,4) int16: key-32768 per axis, 4th unused
 
-// wave-level: does the mesh posed by T (row-major 4x4, wave-uniform) hit any occupied voxel?
-// Broad-phase path.  The grid lists are built for voxels of resolution `res_built` and poses whose linear part A
-// satisfies sigma_min(A) >= 0.5: a leaf box that touches a posed triangle has its centre within r = res*sqrt(3)/2 of it
-// in the camera frame, hence within r/sigma_min <= 2r in the mesh frame, which is the build margin (plus slack for the
-// float32 inverse).  The narrow phase is the SAME float32 SAT on the SAME posed vertices as the exhaustive path, so the
-// result is identical; poses that do not satisfy the bound take the exhaustive path.
-__device__ bool wave_grid_collide(const Mesh& mesh, const float* T, const Voxels& vox, float res, int lane, bool* usable) {
-  const Grid& g = mesh.grid;
+constexpr int PAIR_CAP = 512;              // (voxel, triangle) pairs a wave queues in LDS before it tests them
+constexpr int PAIR_DRAIN = 256;            // ... and the fill from which it does (a test round occupies all 64 lanes but the last)
+struct alignas(16) PairList { short4 key[PAIR_CAP]; int tri[PAIR_CAP]; float T[12]; };   // + the posed-gripper matrix (rows 0..2) of the test in flight
+
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// The grid lists are built for voxels of resolution `res_built` and poses whose linear part A satisfies sigma_min(A) >= 0.5: a leaf
+// box that touches a posed triangle has its centre within r = res*sqrt(3)/2 of it in the camera frame, hence within
+// r/sigma_min <= 2r in the mesh frame, which is the build margin (plus slack for the float32 inverse).  -> usable, and I = A^-1.
+__device__ __forceinline__ bool grid_usable(const Grid& g, const float* T, float res, float* I) {
   const float a00 = T[0], a01 = T[1], a02 = T[2], a10 = T[4], a11 = T[5], a12 = T[6], a20 = T[8], a21 = T[9], a22 = T[10];
   const float c00 = a11 * a22 - a12 * a21, c01 = a12 * a20 - a10 * a22, c02 = a10 * a21 - a11 * a20;
   const float det = a00 * c00 + a01 * c01 + a02 * c02;
-  *usable = false;
   if (!(fabsf(det) > 1e-12f) || res != g.res_built) return false;
   const float id = 1.0f / det;
-  float I[9];
   I[0] = c00 * id; I[1] = (a02 * a21 - a01 * a22) * id; I[2] = (a01 * a12 - a02 * a11) * id;
   I[3] = c01 * id; I[4] = (a00 * a22 - a02 * a20) * id; I[5] = (a02 * a10 - a00 * a12) * id;
   I[6] = c02 * id; I[7] = (a01 * a20 - a00 * a21) * id; I[8] = (a00 * a11 - a01 * a10) * id;
   float fro = 0.f;
 #pragma unroll
   for (int k = 0; k < 9; ++k) fro += I[k] * I[k];
-  if (!(fro <= 3.96f)) return false;            // 1/||A^-1||_F >= 0.5025  =>  sigma_min(A) >= 0.5 (with margin)
-  *usable = true;
+  return fro <= 3.96f;                                     // 1/||A^-1||_F >= 0.5025  =>  sigma_min(A) >= 0.5 (with margin)
+}
+
+// voxel key -> grid coordinate as ONE affine map: f = inv_cell (I (res (k + 1/2) - t) - origin) = A k + b.  (12 scalars and 9 FMAs per
+// voxel instead of centre, difference, 3x3 product, offset and scale: the broad phase is 60 % of the grid kernel's instructions.  The
+// rounding differs from the step-by-step form by ~1e-7 m, against a list margin of 3e-5 m.)
+__device__ __forceinline__ void grid_affine(const Grid& g, const float* T, const float* I, float res, float* A, float* b) {
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const float o = r == 0 ? g.ox : (r == 1 ? g.oy : g.oz);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) A[r * 3 + c] = uni((I[r * 3 + c] * res) * g.inv_cell);
+    b[r] = uni(((I[r * 3] * (0.5f * res - T[3]) + I[r * 3 + 1] * (0.5f * res - T[7])) + I[r * 3 + 2] * (0.5f * res - T[11]) - o) * g.inv_cell);
+  }
+}
+
+// narrow phase over the queued pairs, 64 at a time: every lane poses ITS triangle by T and runs the float32 SAT against ITS voxel
+__device__ __forceinline__ bool wave_test_pairs(const Mesh& mesh, const PairList* pl, int fill, float res, int lane, unsigned* work) {
   const float h = 0.5f * res;
-  const float tx = T[3], ty = T[7], tz = T[11];
-  for (int v0 = 0; v0 < vox.nk; v0 += 64) {
-    const int v = v0 + lane;
+  wave_lds_sync();
+  // The pose is read back from LDS here (a broadcast read per queue flush) instead of being held in 12 scalar registers across the
+  // voxel loop: scalar registers are what this kernel is short of.
+  float T[12];
+#pragma unroll
+  for (int k = 0; k < 12; k += 4) *(float4*)(T + k) = *(const float4*)(pl->T + k);
+  for (int p0 = 0; p0 < fill; p0 += 64) {
+    const int p = p0 + lane;
     bool hv = false;
-    if (v < vox.nk) {
-      const short4 k = ((const short4*)vox.keys)[v];
-      float c[3];
+    if (p < fill) {
+      work[2] += 1u;
+      const short4 k = pl->key[p];
+      const float4* tv = (const float4*)(mesh.grid.tri_verts + (size_t)pl->tri[p] * 12);
+      const float4 q0 = tv[0], q1 = tv[1], q2 = tv[2];
+      float c[3], pv[9];
+      const float m[9] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x};
       c[0] = ((float)k.x + 0.5f) * res; c[1] = ((float)k.y + 0.5f) * res; c[2] = ((float)k.z + 0.5f) * res;
-      const float dx = c[0] - tx, dy = c[1] - ty, dz = c[2] - tz;
-      const float qx = I[0] * dx + I[1] * dy + I[2] * dz, qy = I[3] * dx + I[4] * dy + I[5] * dz, qz = I[6] * dx + I[7] * dy + I[8] * dz;
-      const float fx = (qx - g.ox) * g.inv_cell, fy = (qy - g.oy) * g.inv_cell, fz = (qz - g.oz) * g.inv_cell;
-      if (fx >= 0.f && fy >= 0.f && fz >= 0.f && fx < (float)g.nx && fy < (float)g.ny && fz < (float)g.nz) {
-        const int cell = ((int)fx * g.ny + (int)fy) * g.nz + (int)fz;
-        const int e0 = g.cell_start[cell], e1 = g.cell_start[cell + 1];
-        for (int e = e0; e < e1 && !hv; ++e) {
-          const int t = g.tri_ids[e];
-          float pv[9];
 #pragma unroll
-          for (int kk = 0; kk < 3; ++kk) {
-            const float* vtx = mesh.V + 3 * (size_t)mesh.F[(size_t)t * 3 + kk];
-            const float vx = vtx[0], vy = vtx[1], vz = vtx[2];
+      for (int kk = 0; kk < 3; ++kk)
 #pragma unroll
-            for (int r = 0; r < 3; ++r)
-              pv[kk * 3 + r] = fmaf(T[r * 4 + 0], vx, fmaf(T[r * 4 + 1], vy, fmaf(T[r * 4 + 2], vz, T[r * 4 + 3])));
-          }
-          hv = tri_box_overlap(c, h, pv, pv + 3, pv + 6);
-        }
-      }
+        for (int r = 0; r < 3; ++r)
+          pv[kk * 3 + r] = fmaf(T[r * 4 + 0], m[kk * 3], fmaf(T[r * 4 + 1], m[kk * 3 + 1], fmaf(T[r * 4 + 2], m[kk * 3 + 2], T[r * 4 + 3])));
+      hv = tri_box_overlap(c, h, pv, pv + 3, pv + 6);
     }
     if (__ballot(hv) != 0ull) return true;
   }
+  wave_lds_sync();                                         // the list is refilled next
   return false;
 }
 
+// wave-level: does the mesh posed by T (row-major 4x4, wave-uniform; I = inverse of its linear part) hit any occupied voxel?
+// Broad phase: the lanes stride over the voxels, move each centre into the mesh frame and look its grid cell up; the triangles
+// listed there are QUEUED as (voxel, triangle) pairs in LDS rather than tested by the lane that found them -- the lists are short,
+// uneven and most voxels have none (6 % of the lane slots of a per-lane loop did useful work on the 9k-triangle gripper), so the
+// narrow phase runs over the flat queue with every lane busy.  The narrow phase is the SAME float32 SAT on the SAME posed vertices
+// as the exhaustive kernel, and "any pair hits" does not depend on the order of the pairs: identical results.
+__device__ __forceinline__ bool wave_grid_collide(const Mesh& mesh, const float* A, const float* b, const Voxels& vox, float res, PairList* pl,
+                                                  int lane, unsigned* work) {
+  const Grid& g = mesh.grid;
+  int fill = 0;
+  // One loop, one place where the queue is tested: a pass either looks up the next 128 voxels (two per lane: the two dependent
+  // load chains key -> cell -> list run side by side) or, once the voxels are exhausted, only flushes what is queued.
+  for (int v0 = 0;; v0 += 128) {
+    const bool last = v0 >= vox.nk;
+    int cnt[2] = {0, 0}, e0[2] = {0, 0};
+    short4 k[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int v = v0 + 64 * u + lane;
+      k[u] = make_short4(0, 0, 0, 0);
+      if (v < vox.nk) {
+        k[u] = ((const short4*)vox.keys)[v];
+        work[0] += 1u;
+        const float kx = (float)k[u].x, ky = (float)k[u].y, kz = (float)k[u].z;
+        const float fx = fmaf(A[0], kx, fmaf(A[1], ky, fmaf(A[2], kz, b[0])));
+        const float fy = fmaf(A[3], kx, fmaf(A[4], ky, fmaf(A[5], kz, b[1])));
+        const float fz = fmaf(A[6], kx, fmaf(A[7], ky, fmaf(A[8], kz, b[2])));
+        if (fx >= 0.f && fy >= 0.f && fz >= 0.f && fx < (float)g.nx && fy < (float)g.ny && fz < (float)g.nz) {
+          const int cell = ((int)fx * g.ny + (int)fy) * g.nz + (int)fz;
+          e0[u] = g.cell_start[cell];
+          cnt[u] = g.cell_start[cell + 1] - e0[u];
+          work[1] += 1u;
+        }
+      }
+    }
+    const int total = cnt[0] + cnt[1];
+    for (int r = 0;;) {                                    // entry r of every lane's two lists, compacted into the queue
+      const bool act = total > r;
+      const unsigned long long m = __ballot(act);
+      if (m != 0ull && fill + 64 <= PAIR_CAP) {
+        if (act) {
+          const int slot = fill + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+          const bool first = r < cnt[0];
+          pl->key[slot] = first ? k[0] : k[1];
+          pl->tri[slot] = g.tri_ids[first ? e0[0] + r : e0[1] + (r - cnt[0])];
+        }
+        fill += __popcll(m);
+        ++r;
+        continue;
+      }
+      // the lists of this pass are queued (m == 0), or the queue is full: test it when full, worth a round, or at the very end
+      if (fill && (m != 0ull || last || fill >= PAIR_DRAIN)) {
+        if (wave_test_pairs(mesh, pl, fill, res, lane, work)) return true;
+        fill = 0;
+      }
+      if (m == 0ull) break;
+    }
+    if (last) return false;
+  }
+}
+
+// Exhaustive form (no grid, or a pose outside the grid's validity): posed triangles staged in LDS, every voxel against every
+// triangle whose box it touches.
 __device__ bool wave_mesh_voxels_collide(const Mesh& mesh, const float* T, const Voxels& vox, float res, float* tl, int lane) {
   if (vox.nk == 0 || mesh.nf == 0) return false;
-  if (mesh.has_grid) {
-    bool usable;
-    const bool r = wave_grid_collide(mesh, T, vox, res, lane, &usable);
-    if (usable) return r;
-  }
   const float h = 0.5f * res;
   const float slack = 1e-5f;     // conservative culls only; never changes the predicate
   bool hit = false;
   for (int c0 = 0; c0 < mesh.nf && !hit; c0 += TRI_CHUNK) {
     const int nt = min(TRI_CHUNK, mesh.nf - c0);
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    wave_lds_sync();
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (int t = lane; t < nt; t += 64) {
       float tlo[3] = {INFINITY, INFINITY, INFINITY}, thi[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -186,8 +267,7 @@ __device__ bool wave_mesh_voxels_collide(const Mesh& mesh, const float* T, const
       for (int o = 32; o > 0; o >>= 1) { lo[r] = fminf(lo[r], __shfl_xor(lo[r], o)); hi[r] = fmaxf(hi[r], __shfl_xor(hi[r], o)); }
       lo[r] -= slack; hi[r] += slack;
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    wave_lds_sync();
     for (int v0 = 0; v0 < vox.nk; v0 += 64) {
       const int v = v0 + lane;
       bool hv = false;
@@ -195,13 +275,16 @@ __device__ bool wave_mesh_voxels_collide(const Mesh& mesh, const float* T, const
         const short4 k = ((const short4*)vox.keys)[v];
         float c[3];
         c[0] = ((float)k.x + 0.5f) * res; c[1] = ((float)k.y + 0.5f) * res; c[2] = ((float)k.z + 0.5f) * res;
-        const bool out = (c[0] - h > hi[0]) || (c[0] + h < lo[0]) || (c[1] - h > hi[1]) || (c[1] + h < lo[1]) ||
-                         (c[2] - h > hi[2]) || (c[2] + h < lo[2]);
+        int out = 0;                                   // (selects, not ||: a chain of boolean ORs lives in scalar register pairs)
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { out = c[r] - h > hi[r] ? 1 : out; out = c[r] + h < lo[r] ? 1 : out; }
         if (!out) {
           for (int t = 0; t < nt && !hv; ++t) {
             const float* q = tl + t * TRI_FLOATS;
-            if ((c[0] - h > q[12]) || (c[0] + h < q[9]) || (c[1] - h > q[13]) || (c[1] + h < q[10]) ||
-                (c[2] - h > q[14]) || (c[2] + h < q[11])) continue;
+            int cull = 0;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) { cull = c[r] - h > q[12 + r] ? 1 : cull; cull = c[r] + h < q[9 + r] ? 1 : cull; }
+            if (cull) continue;
             hv = tri_box_overlap(c, h, q, q + 3, q + 6);
           }
         }
@@ -212,91 +295,177 @@ __device__ bool wave_mesh_voxels_collide(const Mesh& mesh, const float* T, const
   return hit;
 }
 
-struct FilterArgs {
+
+// ---- stage 1: pose composition, one THREAD per evaluation (common.cpp:184-231) -------------------------------------------------
+// grasp_in_cam = nocs_pose . canonical_to_nocs . symmetry_j . grasp_pose_i with unit rotation columns; the approach-direction test;
+// the IK verdict of the host/device solver.  Writes the composed pose into poses_out and the code so far (0 / 1 / 2) into codes;
+// stage 2 reads both.  (Every lane of a wave used to repeat this wave-uniform arithmetic ahead of its collision loops.)
+struct ComposeArgs {
   const float* grasp_poses; int n_pose;       // (n_pose,16)
   const float* symmetry_tfs; int n_sym;       // (n_sym,16)
-  Mat4 nocs_pose, canonical_to_nocs, cam_in_world, ee_in_grasp, gripper_in_grasp;
-  int filter_dir, adjust;
+  Mat4 c2c, cam_in_world, ee_in_grasp;        // c2c = nocs_pose . canonical_to_nocs (host, same float32 operation order)
+  int filter_dir;
   const unsigned char* ik_ok;                 // optional (E): 0 -> IK reject
-  Mesh open_mesh, enc_mesh;
-  Voxels vox_open, vox_bg;
-  float res;
   signed char* codes; float* poses_out; signed char* nudge;
-  float* ee_out;                              // optional (E,16): ee_in_base for the host IK pass; stops after the dir test
-  int keep_rejected_pose;                     // poses_out of a rejected evaluation: 0 -> zeros, 1 -> its (un-nudged) grasp_in_cam
+  float* ee_out;                              // optional (E,16): ee_in_base for the IK pass (then nothing else is written but codes)
 };
 
-__global__ __launch_bounds__(64 * WAVES) void filter_grasp_pose_kernel(FilterArgs a) {
-  __shared__ float tl_all[WAVES][TRI_CHUNK * TRI_FLOATS];
-  const int lane = threadIdx.x & 63;
-  const int wv = threadIdx.x >> 6;
-  float* tl = tl_all[wv];
+__global__ __launch_bounds__(256) void compose_grasp_pose_kernel(ComposeArgs a) {
   const long E = (long)a.n_pose * a.n_sym;
-  float c2c[16];
-  mat4_mul(a.nocs_pose.m, a.canonical_to_nocs.m, c2c);
-  for (long e = (long)blockIdx.x * WAVES + wv; e < E; e += (long)gridDim.x * WAVES) {
-    const int i = (int)(e / a.n_sym), j = (int)(e - (long)i * a.n_sym);
-    float P[16], S[16], tmp[16], gic[16];
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  const int i = (int)(e / a.n_sym), j = (int)(e - (long)i * a.n_sym);
+  float P[16], S[16], tmp[16], gic[16];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) { P[k] = a.grasp_poses[(size_t)i * 16 + k]; S[k] = a.symmetry_tfs[(size_t)j * 16 + k]; }
-    mat4_mul(S, P, tmp);
-    mat4_mul(c2c, tmp, gic);
-    normalize_col(gic, 0); normalize_col(gic, 1); normalize_col(gic, 2);
-    int code = 0, nud = -1;
-    if (a.filter_dir && gic[2 * 4 + 0] < 0.0f) code = 1;
-    if (a.ee_out) {
-      if (lane < 16) {
-        float t2[16], ee[16];
-        mat4_mul(a.cam_in_world.m, gic, t2);
-        mat4_mul(t2, a.ee_in_grasp.m, ee);
-        float v = 0.f;
+  for (int k = 0; k < 16; k += 4) {
+    *(float4*)(P + k) = *(const float4*)(a.grasp_poses + (size_t)i * 16 + k);
+    *(float4*)(S + k) = *(const float4*)(a.symmetry_tfs + (size_t)j * 16 + k);
+  }
+  mat4_mul(S, P, tmp);
+  mat4_mul(a.c2c.m, tmp, gic);
+  normalize_col(gic, 0); normalize_col(gic, 1); normalize_col(gic, 2);
+  int code = 0;
+  if (a.filter_dir && gic[2 * 4 + 0] < 0.0f) code = 1;
+  if (a.ee_out) {
+    float t2[16], ee[16];
+    mat4_mul(a.cam_in_world.m, gic, t2);
+    mat4_mul(t2, a.ee_in_grasp.m, ee);
 #pragma unroll
-        for (int k = 0; k < 16; ++k) if (lane == k) v = ee[k];
-        a.ee_out[e * 16 + lane] = v;
-      }
-      if (lane == 0) a.codes[e] = (signed char)code;
+    for (int k = 0; k < 16; k += 4) *(float4*)(a.ee_out + e * 16 + k) = *(float4*)(ee + k);
+    a.codes[e] = (signed char)code;
+    return;
+  }
+  if (code == 0 && a.ik_ok && a.ik_ok[e] == 0) code = 2;
+#pragma unroll
+  for (int k = 0; k < 16; k += 4) *(float4*)(a.poses_out + e * 16 + k) = *(float4*)(gic + k);
+  a.codes[e] = (signed char)code;
+  a.nudge[e] = (signed char)-1;
+}
+
+// ---- stage 2: collision, one WAVEFRONT per evaluation that is still alive (common.cpp:233-299) -------------------------------
+constexpr signed char CODE_PENDING = -128;    // written by the grid kernel for an evaluation it leaves to the exhaustive kernel
+
+struct FilterArgs {
+  long E;
+  Mat4 gripper_in_grasp;
+  int adjust;
+  Mesh mesh[2];                               // open gripper, enclosed gripper
+  Voxels vox[2];                              // ... against the object's own voxels, the background voxels
+  float res;
+  signed char* codes; float* poses_out; signed char* nudge;
+  int keep_rejected_pose;                     // poses_out of a rejected evaluation: 0 -> zeros, 1 -> its (un-nudged) grasp_in_cam
+  int only_pending;                           // exhaustive kernel: evaluate only what the grid kernel marked CODE_PENDING
+  unsigned long long* work_stats;             // optional (3): voxel keys read, grid cells looked up, (voxel, triangle) pairs tested
+};
+
+// GRID: both meshes through their broad-phase grids (an evaluation whose pose a grid does not cover is marked CODE_PENDING);
+// !GRID: the exhaustive collider.
+// Fields of the kernel argument block that are touched once per evaluation (output pointers, flags) are read from the kernarg segment
+// WHERE they are used (a volatile scalar load the compiler may not hoist): loaded up front they sat in ~20 scalar registers across
+// the collision loops and were spilled to VGPR lanes.
+#define CG_KARG(field) (*(volatile const __attribute__((address_space(4))) decltype(FilterArgs::field)*)(kargs + offsetof(FilterArgs, field)))
+
+template <bool GRID>
+__global__ __launch_bounds__(64 * WAVES, 4) void filter_grasp_pose_kernel(FilterArgs a) {
+  const __attribute__((address_space(4))) char* kargs = (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
+  __shared__ char lds_raw[WAVES * (GRID ? sizeof(PairList) : sizeof(float) * TRI_CHUNK * TRI_FLOATS)];
+  __shared__ float gig_lds[16];                // gripper_in_grasp: read back (broadcast) where a pose is composed, costs no register between
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  PairList* pl = (PairList*)lds_raw + wv;
+  float* tl = (float*)lds_raw + wv * TRI_CHUNK * TRI_FLOATS;
+  if (threadIdx.x < 16) gig_lds[threadIdx.x] = a.gripper_in_grasp.m[threadIdx.x];
+  __syncthreads();
+  unsigned work[3] = {0u, 0u, 0u};             // per-lane counts of the grid kernel's memory work (reported only when asked for)
+  // One wavefront per evaluation.  (One WORKGROUP per evaluation, its wavefronts dealing the voxel passes among themselves, was
+  // measured: 2.92 instead of 2.38 ms per 50,004 evaluations -- the kernel is bound by the number of vector instructions it issues
+  // (~40 % of the VALU issue rate of the whole chip), not by the length of one evaluation's dependent chain.)
+  for (long e = (long)blockIdx.x * WAVES + wv; e < CG_KARG(E); e += (long)gridDim.x * WAVES) {
+    const int code0 = CG_KARG(codes)[e];
+    if (GRID ? (code0 != 0) : (CG_KARG(only_pending) ? code0 != CODE_PENDING : code0 != 0)) {
+      if (code0 > 0 && !CG_KARG(keep_rejected_pose) && lane < 16) CG_KARG(poses_out)[e * 16 + lane] = 0.f;   // rejected in stage 1
       continue;
     }
-    if (code == 0 && a.ik_ok && a.ik_ok[e] == 0) code = 2;
-    if (code == 0) {
-      if (!a.adjust) {
-        float gcam[16];
-        mat4_mul(gic, a.gripper_in_grasp.m, gcam);
-        if (wave_mesh_voxels_collide(a.open_mesh, gcam, a.vox_open, a.res, tl, lane)) code = 3;
-        else if (wave_mesh_voxels_collide(a.enc_mesh, gcam, a.vox_bg, a.res, tl, lane)) code = 4;
-        else nud = 0;
-      } else {
-        const float major[3] = {gic[1], gic[5], gic[9]};
-        bool found = false;
-        int idx = 0;
-        for (float step = 0.0f; (double)step <= 0.003 && !found; step += 0.001f) {
-          const int nsign = (step == 0.0f) ? 1 : 2;
-          for (int s = 0; s < nsign; ++s, ++idx) {
-            const float sign = (s == 0) ? 1.0f : -1.0f;
-            float cur[16], gcam[16];
+    // the nudge loop of common.cpp:255-288 (float accumulation 0, 0.001f, 0.002f; +step before -step); without
+    // adjust_collision_pose only its first pose is tried and the mesh that collided names the code (common.cpp:233-253)
+    int code = 0, nud = -1;
+    float acc_t[3] = {0.f, 0.f, 0.f};
+    bool found = false, stop = false;
+    int idx = 0;
+    for (float step = 0.0f; (double)step <= 0.003 && !found && !stop; step += 0.001f) {
+      const int nsign = (step == 0.0f) ? 1 : 2;
+      for (int s = 0; s < nsign && !found && !stop; ++s, ++idx) {
+        const float sign = (s == 0) ? 1.0f : -1.0f;
+        // grasp_in_cam (stage 1 left it in poses_out) is re-read per tried pose rather than kept: scalar registers are what the
+        // collision loops are short of
+        float cur[16], gig[16], gcam[16], cur_t[3];
 #pragma unroll
-            for (int k = 0; k < 16; ++k) cur[k] = gic[k];
+        for (int k = 0; k < 12; k += 4) *(float4*)(cur + k) = *(const float4*)(CG_KARG(poses_out) + e * 16 + k);
+        cur[12] = 0.f; cur[13] = 0.f; cur[14] = 0.f; cur[15] = 1.f;      // rows 0..2 of cur . gig do not read row 3 of cur
 #pragma unroll
-            for (int r = 0; r < 3; ++r) cur[r * 4 + 3] = cur[r * 4 + 3] + (step * major[r]) * sign;
-            mat4_mul(cur, a.gripper_in_grasp.m, gcam);
-            if (wave_mesh_voxels_collide(a.open_mesh, gcam, a.vox_open, a.res, tl, lane)) continue;
-            if (wave_mesh_voxels_collide(a.enc_mesh, gcam, a.vox_bg, a.res, tl, lane)) continue;
+        for (int r = 0; r < 3; ++r) { cur[r * 4 + 3] = cur[r * 4 + 3] + (step * cur[r * 4 + 1]) * sign; cur_t[r] = cur[r * 4 + 3]; }
 #pragma unroll
-            for (int k = 0; k < 16; ++k) gic[k] = cur[k];
-            found = true; nud = idx;
-            break;
+        for (int k = 0; k < 16; ++k) gig[k] = gig_lds[k];
+        mat4_mul(cur, gig, gcam);
+        if (GRID) {          // the posed-gripper matrix goes to LDS and is read back where it is used
+          wave_lds_sync();
+          if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 12; k += 4) *(float4*)(pl->T + k) = *(float4*)(gcam + k);
+          }
+          wave_lds_sync();
+        }
+        int hit = 0;
+#pragma unroll 1
+        for (int m = 0; m < 2 && !hit; ++m) {
+          const Mesh& mesh = a.mesh[m];
+          const Voxels& vox = a.vox[m];
+          if (vox.nk == 0 || mesh.nf == 0) continue;
+          if (GRID) {
+            float T[12];
+#pragma unroll
+            for (int k = 0; k < 12; k += 4) *(float4*)(T + k) = *(const float4*)(pl->T + k);
+            float I[9], A[9], b[3];
+            const bool ok = mesh.has_grid && grid_usable(mesh.grid, T, a.res, I);
+            if (!ok) { code = CODE_PENDING; stop = true; break; }
+            grid_affine(mesh.grid, T, I, a.res, A, b);
+            if (wave_grid_collide(mesh, A, b, vox, a.res, pl, lane, work)) hit = 3 + m;
+          } else {
+            if (wave_mesh_voxels_collide(mesh, gcam, vox, a.res, tl, lane)) hit = 3 + m;
           }
         }
-        if (!found) code = 3;
+        if (stop) break;
+        if (!hit) {
+#pragma unroll
+          for (int r = 0; r < 3; ++r) acc_t[r] = cur_t[r];              // cur differs from grasp_in_cam in its translation only
+          found = true; nud = idx;
+        } else if (!CG_KARG(adjust)) {
+          code = hit; stop = true;
+        }
       }
     }
-    if (lane < 16) {
-      float v = 0.f;
-#pragma unroll
-      for (int k = 0; k < 16; ++k) if (lane == k) v = gic[k];
-      a.poses_out[e * 16 + lane] = (code == 0 || a.keep_rejected_pose) ? v : 0.f;
+    if (!found && !stop) code = 3;
+    if (GRID && code == CODE_PENDING) {
+      if (lane == 0) CG_KARG(codes)[e] = CODE_PENDING;
+      continue;
     }
-    if (lane == 0) { a.codes[e] = (signed char)code; a.nudge[e] = (signed char)nud; }
+    if (code == 0) {                                                    // the accepted (possibly nudged) translation
+      if (lane == 0) {
+        float* po = CG_KARG(poses_out) + e * 16;
+        po[3] = acc_t[0]; po[7] = acc_t[1]; po[11] = acc_t[2];
+      }
+    } else if (!CG_KARG(keep_rejected_pose)) {
+      if (lane < 16) CG_KARG(poses_out)[e * 16 + lane] = 0.f;
+    }
+    if (lane == 0) { CG_KARG(codes)[e] = (signed char)code; CG_KARG(nudge)[e] = (signed char)nud; }
+  }
+  if (GRID && CG_KARG(work_stats)) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      unsigned w = work[q];
+      for (int o = 32; o > 0; o >>= 1) w += __shfl_xor(w, o);
+      if (lane == 0 && w) atomicAdd(CG_KARG(work_stats) + q, (unsigned long long)w);
+    }
   }
 }
 
@@ -305,7 +474,7 @@ __global__ __launch_bounds__(64 * WAVES) void mesh_voxels_collide_kernel(Mesh me
                                                                          float res, unsigned char* out) {
   __shared__ float tl_all[WAVES][TRI_CHUNK * TRI_FLOATS];
   const int lane = threadIdx.x & 63;
-  const int wv = threadIdx.x >> 6;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   for (long e = (long)blockIdx.x * WAVES + wv; e < E; e += (long)gridDim.x * WAVES) {
     float T[16];
 #pragma unroll
@@ -345,15 +514,22 @@ __global__ void unpack_keys_kernel(const long long* __restrict__ packed, long n,
 
 inline Mesh make_mesh(const float* V, const int* F, int nf, const cg_mesh_grid* hg) {
   Mesh m; m.V = V; m.F = F; m.nf = nf; m.has_grid = 0; m.grid = Grid{};
-  if (hg && hg->cell_start && hg->tri_ids && hg->cell > 0.f) {
+  if (hg && hg->cell_start && hg->tri_ids && hg->tri_verts && hg->cell > 0.f) {      // a grid without the flat triangle array is not used
     m.grid = Grid{hg->origin[0], hg->origin[1], hg->origin[2], 1.0f / hg->cell, hg->dims[0], hg->dims[1], hg->dims[2], hg->cell_start,
-                  hg->tri_ids, hg->resolution};
+                  hg->tri_ids, hg->tri_verts, hg->resolution};
     m.has_grid = 1;
   }
   return m;
 }
 
 inline Mat4 load_mat(const float* h) { Mat4 m; for (int i = 0; i < 16; ++i) m.m[i] = h[i]; return m; }
+
+// mat4_mul of the device code on the host: the same float32 expression per element (this file is compiled with -ffp-contract=off)
+inline void host_mat4_mul(const float* A, const float* B, float* C) {
+  for (int r = 0; r < 4; ++r)
+    for (int c = 0; c < 4; ++c)
+      C[r * 4 + c] = ((A[r * 4 + 0] * B[0 * 4 + c] + A[r * 4 + 1] * B[1 * 4 + c]) + A[r * 4 + 2] * B[2 * 4 + c]) + A[r * 4 + 3] * B[3 * 4 + c];
+}
 
 }  // namespace
 
@@ -367,7 +543,7 @@ extern "C" int cg_filter_grasp_pose_accel(const float* grasp_poses, int n_pose, 
                                     const short* open_keys, int n_open_keys, const short* bg_keys, int n_bg_keys,
                                     float resolution, signed char* codes, float* poses_out, signed char* nudge,
                                     float* ee_in_base_out, const cg_mesh_grid* h_open_grid, const cg_mesh_grid* h_enc_grid,
-                                    int keep_rejected_pose, void* stream) {
+                                    int keep_rejected_pose, unsigned long long* work_stats, void* stream) {
   if (n_pose < 0 || n_sym < 0) return CG_ERR_ARG;
   if ((long)n_pose * n_sym == 0) return CG_OK;
   if (!grasp_poses || !symmetry_tfs || !h_nocs_pose || !h_canonical_to_nocs || !h_cam_in_world || !h_ee_in_grasp ||
@@ -381,20 +557,38 @@ extern "C" int cg_filter_grasp_pose_accel(const float* grasp_poses, int n_pose, 
   if (!(resolution > 0.f)) return CG_ERR_ARG;
   const long E = (long)n_pose * n_sym;
   if (E == 0) return CG_OK;
+  hipStream_t st = (hipStream_t)stream;
+  ComposeArgs c;
+  c.grasp_poses = grasp_poses; c.n_pose = n_pose; c.symmetry_tfs = symmetry_tfs; c.n_sym = n_sym;
+  host_mat4_mul(h_nocs_pose, h_canonical_to_nocs, c.c2c.m);
+  c.cam_in_world = load_mat(h_cam_in_world); c.ee_in_grasp = load_mat(h_ee_in_grasp);
+  c.filter_dir = filter_approach_dir_face_camera; c.ik_ok = ik_ok;
+  c.codes = codes; c.poses_out = poses_out; c.nudge = nudge; c.ee_out = ee_in_base_out;
+  hipLaunchKernelGGL(compose_grasp_pose_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, st, c);
+  if (ee_in_base_out) return cg_hip_status(hipGetLastError());
   FilterArgs a;
-  a.grasp_poses = grasp_poses; a.n_pose = n_pose; a.symmetry_tfs = symmetry_tfs; a.n_sym = n_sym;
-  a.nocs_pose = load_mat(h_nocs_pose); a.canonical_to_nocs = load_mat(h_canonical_to_nocs);
-  a.cam_in_world = load_mat(h_cam_in_world); a.ee_in_grasp = load_mat(h_ee_in_grasp);
+  a.E = E;
   a.gripper_in_grasp = load_mat(h_gripper_in_grasp);
-  a.filter_dir = filter_approach_dir_face_camera; a.adjust = adjust_collision_pose; a.ik_ok = ik_ok;
-  a.open_mesh = make_mesh(gripper_vertices, gripper_faces, n_gripper_faces, h_open_grid);
-  a.enc_mesh = make_mesh(enclosed_vertices, enclosed_faces, n_enclosed_faces, h_enc_grid);
-  a.vox_open = Voxels{open_keys, n_open_keys}; a.vox_bg = Voxels{bg_keys, n_bg_keys};
-  a.res = resolution; a.codes = codes; a.poses_out = poses_out; a.nudge = nudge; a.ee_out = ee_in_base_out;
-  a.keep_rejected_pose = keep_rejected_pose;
+  a.adjust = adjust_collision_pose;
+  a.mesh[0] = make_mesh(gripper_vertices, gripper_faces, n_gripper_faces, h_open_grid);
+  a.mesh[1] = make_mesh(enclosed_vertices, enclosed_faces, n_enclosed_faces, h_enc_grid);
+  a.vox[0] = Voxels{open_keys, n_open_keys}; a.vox[1] = Voxels{bg_keys, n_bg_keys};
+  a.res = resolution; a.codes = codes; a.poses_out = poses_out; a.nudge = nudge;
+  a.keep_rejected_pose = keep_rejected_pose; a.work_stats = work_stats;
   long blocks = (E + WAVES - 1) / WAVES;
   if (blocks > 256 * 16) blocks = 256 * 16;      // grid-stride: 16 blocks per CU
-  hipLaunchKernelGGL(filter_grasp_pose_kernel, dim3((unsigned)blocks), dim3(64 * WAVES), 0, (hipStream_t)stream, a);
+  // Meshes that collide with anything (non-empty mesh against a non-empty voxel set) must all carry a grid for the grid kernel;
+  // evaluations it cannot cover (a pose outside a grid's validity) come back CODE_PENDING and the exhaustive kernel, which skips
+  // everything else, finishes them.  Without grids the exhaustive kernel does all of it.
+  bool grids = true;
+  for (int m = 0; m < 2; ++m)
+    if (a.mesh[m].nf > 0 && a.vox[m].nk > 0 && !a.mesh[m].has_grid) grids = false;
+  a.only_pending = 0;
+  if (grids) {
+    hipLaunchKernelGGL(filter_grasp_pose_kernel<true>, dim3((unsigned)blocks), dim3(64 * WAVES), 0, st, a);
+    a.only_pending = 1;
+  }
+  hipLaunchKernelGGL(filter_grasp_pose_kernel<false>, dim3((unsigned)blocks), dim3(64 * WAVES), 0, st, a);
   return cg_hip_status(hipGetLastError());
 }
 
@@ -442,5 +636,5 @@ extern "C" int cg_filter_grasp_pose(const float* grasp_poses, int n_pose, const 
   return cg_filter_grasp_pose_accel(grasp_poses, n_pose, symmetry_tfs, n_sym, h_nocs_pose, h_canonical_to_nocs, h_cam_in_world, h_ee_in_grasp,
                                     h_gripper_in_grasp, filter_approach_dir_face_camera, adjust_collision_pose, ik_ok, gripper_vertices,
                                     gripper_faces, n_gripper_faces, enclosed_vertices, enclosed_faces, n_enclosed_faces, open_keys, n_open_keys,
-                                    bg_keys, n_bg_keys, resolution, codes, poses_out, nudge, ee_in_base_out, nullptr, nullptr, 0, stream);
+                                    bg_keys, n_bg_keys, resolution, codes, poses_out, nudge, ee_in_base_out, nullptr, nullptr, 0, nullptr, stream);
 }

@@ -15,6 +15,7 @@ ValueError is raised instead -- wrong shapes are never silently accepted.
 All collision arithmetic runs in the HIP library; there is no CPU fallback.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -150,7 +151,7 @@ class CollisionManager:
 class _MeshGridC(ctypes.Structure):
     """cg_mesh_grid (include/catgrasp_amd.h)."""
     _fields_ = [('origin', ctypes.c_float * 3), ('cell', ctypes.c_float), ('dims', ctypes.c_int * 3),
-                ('cell_start', ctypes.c_void_p), ('tri_ids', ctypes.c_void_p), ('resolution', ctypes.c_float)]
+                ('cell_start', ctypes.c_void_p), ('tri_ids', ctypes.c_void_p), ('resolution', ctypes.c_float), ('tri_verts', ctypes.c_void_p)]
 
 
 class MeshGrid:
@@ -163,8 +164,8 @@ class MeshGrid:
         V = np.asarray(V, dtype=np.float64); F = np.asarray(F, dtype=np.int64)
         res = float(np.float32(resolution))
         inflate = 2.0 * (res * np.sqrt(3.0) / 2.0) + 3e-5          # sigma_min >= 0.5, plus float32 slack
-        if cell is None:
-            cell = max(4.0 * res, 0.002)
+        if cell is None:      # finely tessellated meshes get finer cells: half the candidate pairs per voxel for 8x the (small) cell table
+            cell = float(os.environ.get('CATGRASP_AMD_GRID_CELL', 0)) or (max(2.0 * res, 0.001) if len(F) >= 2000 else max(4.0 * res, 0.002))
         lo = V.min(axis=0) - inflate - 1e-6
         hi = V.max(axis=0) + inflate + 1e-6
         dims = np.maximum(np.ceil((hi - lo) / cell).astype(np.int64), 1)
@@ -190,7 +191,14 @@ class MeshGrid:
             counts.zero_()
             check(L.lib().cg_mesh_grid_fill(_p(Vd), _p(Fd), _c_int(len(F)), org, ctypes.c_double(cell), ctypes.c_double(inflate), dm,
                                             _p(start), _p(counts), _p(self.tri_ids), _stream()), 'cg_mesh_grid_fill')
+        # the triangles as a flat (nf,12) array [v0 v1 v2 pad]: the narrow phase fetches a triangle with three 16-byte loads
+        Vf = V_dev if V_dev is not None else torch.from_numpy(np.ascontiguousarray(V, dtype=np.float32)).to(device)
+        Ff = F_dev if F_dev is not None else torch.from_numpy(np.ascontiguousarray(F, dtype=np.int32)).to(device)
+        self.tri_verts = torch.zeros((max(len(F), 1), 12), dtype=torch.float32, device=device)
+        if len(F):
+            self.tri_verts[:, :9] = Vf[Ff.long()].reshape(len(F), 9)
         self.c = _MeshGridC()
+        self.c.tri_verts = self.tri_verts.data_ptr()
         for i in range(3):
             self.c.origin[i] = float(lo[i]); self.c.dims[i] = int(dims[i])
         self.c.cell = float(cell); self.c.resolution = res
@@ -291,10 +299,12 @@ class GripperScene:
 
 def filter_on_device(scene, grasp_poses, symmetry_tfs, nocs_pose, canonical_to_nocs_transform, cam_in_world, ee_in_grasp,
                      gripper_in_grasp, filter_approach_dir_face_camera, filter_ik, adjust_collision_pose, upper=None, lower=None,
-                     keep_rejected_pose=False):
+                     keep_rejected_pose=False, work_stats=None):
     """Device-tensor form: grasp_poses (n,4,4)/(n,16) and symmetry_tfs (m,4,4) float32 cuda tensors (or arrays).
     Returns codes (E) int8, poses (E,4,4) float32, nudge (E) int8 as cuda tensors, E = n*m in input order.
-    keep_rejected_pose: rejected evaluations keep their composed grasp_in_cam in `poses` instead of zeros."""
+    keep_rejected_pose: rejected evaluations keep their composed grasp_in_cam in `poses` instead of zeros.
+    work_stats: optional (3,) int64 cuda tensor the grid kernel adds its memory work to (voxel keys read, grid cells looked up,
+    (voxel, triangle) pairs tested) -- measurement only."""
     dev = scene.device
 
     def dev_poses(x, name):
@@ -328,7 +338,7 @@ def filter_on_device(scene, grasp_poses, symmetry_tfs, nocs_pose, canonical_to_n
             _c_int(int(bool(filter_approach_dir_face_camera))), _c_int(int(bool(adjust_collision_pose))), _p(ik_ok),
             _p(scene.V), _p(scene.F), _c_int(scene.F.shape[0]), _p(scene.Ve), _p(scene.Fe), _c_int(scene.Fe.shape[0]),
             _p(scene.keys_open), _c_int(scene.keys_open.shape[0]), _p(scene.keys_bg), _c_int(scene.keys_bg.shape[0]),
-            ctypes.c_float(scene.res), _p(codes), _p(poses), _p(nudge), _p(ee_out), go, ge, _c_int(int(bool(keep_rejected_pose))), _stream()),
+            ctypes.c_float(scene.res), _p(codes), _p(poses), _p(nudge), _p(ee_out), go, ge, _c_int(int(bool(keep_rejected_pose))), _p(work_stats), _stream()),
               'cg_filter_grasp_pose_accel')
 
     ik_ok = None

@@ -117,7 +117,7 @@ class SceneBatch:
     pose inversion + resampling draw + grasp-Q net -> packed (p_G, code) records."""
 
     def __init__(self, device, grasp_predicter, nunocs_predicter, kind='nut', n_objects=8, pts_per_object=2500, per_replica=50000,
-                 replicas=1, scene_seed=0, nocs_scale=0.02, materialize=None):
+                 replicas=1, scene_seed=0, nocs_scale=0.02, materialize=None, gripper_subdivisions=0):
         # materialize: (lo, hi) global evaluation range whose candidate poses are generated up front (default: all)
         # kind: one category ('nut' | 'hnm' | 'screw'), or a mixed bin of synth.MIXED_BINS ('bin' = nut + hnm + screw, BASELINE.json
         # configs[4]); for a mixed bin the two predicters are dicts {category: predicter} -- the reference keeps one GraspPredicter /
@@ -126,7 +126,8 @@ class SceneBatch:
         from . import my_cpp, synth, transforms
         self.device, self.kind = device, kind
         self.objs = synth.make_scene(n_objects, pts_per_object, seed=scene_seed, kind=kind)       # same scene on every rank
-        self.gripper = synth.make_gripper()
+        # gripper_subdivisions: 0 = the 36 / 48-triangle box gripper, 4 = the same surfaces as 9,216 / 12,288 triangles (bench.py)
+        self.gripper = synth.make_gripper(subdivisions=gripper_subdivisions)
         self.cats = [ob['kind'] for ob in self.objs]                                               # category of every object
         self.gps = grasp_predicter if isinstance(grasp_predicter, dict) else {c: grasp_predicter for c in set(self.cats)}
         self.npreds = nunocs_predicter if isinstance(nunocs_predicter, dict) else {c: nunocs_predicter for c in set(self.cats)}

@@ -162,6 +162,8 @@ typedef struct cg_mesh_grid {
   const int* cell_start;   /* device, prod(dims)+1 */
   const int* tri_ids;      /* device */
   float resolution;
+  const float* tri_verts;  /* device, optional (NULL: gather through faces -> vertices): the triangles as (n_faces,12) float32
+                              [v0.xyz v1.xyz v2.xyz 0 0 0], 16-byte aligned -- one dependent load less per narrow-phase test */
 } cg_mesh_grid;
 
 /* filterGraspPose (my_cpp/common.cpp:156-321; declaration my_cpp/common.h:60) for every
@@ -189,7 +191,12 @@ int cg_filter_grasp_pose(const float* grasp_poses, int n_pose, const float* symm
                          float* ee_in_base_out, void* stream);
 /* Same, with optional broad-phase grids (HOST descriptors, NULL = exhaustive) for the open / enclosed gripper mesh.
  * keep_rejected_pose != 0: poses_out of a REJECTED evaluation holds its composed, column-normalised (un-nudged) grasp_in_cam
- * (common.cpp:191-197) instead of zeros, so a fixed-size batch can be scored without a compaction step. */
+ * (common.cpp:191-197) instead of zeros, so a fixed-size batch can be scored without a compaction step.
+ * work_stats: optional DEVICE pointer to 3 uint64 counters the grid kernel ADDS to (measurement only): voxel keys read (8 B each),
+ * grid cells looked up (8 B each), (voxel, triangle) pairs run through the narrow phase (48 B of triangle each) -- the
+ * cache-level byte count bench.py's roofline_filter block is priced on.
+ * Three launches: pose composition (one thread per evaluation), the grid kernel (one wavefront per live evaluation), and the
+ * exhaustive kernel, which only finishes evaluations whose pose a grid does not cover (all of them when there are no grids). */
 int cg_filter_grasp_pose_accel(const float* grasp_poses, int n_pose, const float* symmetry_tfs, int n_sym,
                                const float* h_nocs_pose, const float* h_canonical_to_nocs, const float* h_cam_in_world,
                                const float* h_ee_in_grasp, const float* h_gripper_in_grasp,
@@ -200,7 +207,7 @@ int cg_filter_grasp_pose_accel(const float* grasp_poses, int n_pose, const float
                                const short* open_keys, int n_open_keys, const short* bg_keys, int n_bg_keys,
                                float resolution, signed char* codes, float* poses_out, signed char* nudge,
                                float* ee_in_base_out, const cg_mesh_grid* h_open_grid, const cg_mesh_grid* h_enc_grid,
-                               int keep_rejected_pose, void* stream);
+                               int keep_rejected_pose, unsigned long long* work_stats, void* stream);
 
 /* Device build of cg_mesh_grid (replaces a per-triangle host loop): triangle t is listed in every cell its bounding box,
  * inflated by `inflate`, overlaps (float64 cell arithmetic).  h_origin[3], h_dims[3]: HOST.  Two passes around a host-side
