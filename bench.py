@@ -87,13 +87,13 @@ def api_block(batch, gp, device, n=50000):
             torch.cuda.synchronize(); t0 = time.perf_counter(); r = fn(); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
         return float(np.median(ts)), r
     pb = []
-    for prec in dict.fromkeys([engine.PRECISION, 'f16x3']):
+    for prec in dict.fromkeys([engine.current_precision(), 'f16x3']):
         with engine.precision(prec):
             gp.predict_batch(data, poses[:2000], rng='device')        # warm-up
             t, ret = wall(lambda: gp.predict_batch(data, poses, rng='device'), 3)
         assert len(ret) == n and len(ret[0]) == 3 and ret[0][2].shape == (10,)
         pb.append({'poses': n, 'rng': 'device', 'precision': prec, 'wall_s': round(t, 4), 'candidates_per_s': round(n / t, 1)})
-    for prec in dict.fromkeys([engine.PRECISION, 'f16x3']):
+    for prec in dict.fromkeys([engine.current_precision(), 'f16x3']):
         with engine.precision(prec):
             gp.predict_batch(data, poses[:2000], rng='numpy')         # warm-up of this mode too (worker thread, stream replay, swap-chain kernel)
             ts = []
@@ -219,7 +219,12 @@ def pick_cycle_block(batch, gp, npred, device, n_canonical=2000):
     return res
 
 
-def cpu_baseline(batch, sd_cls, sd_seg, n_score=100, n_coll=1024):
+def ctypes_float0():
+    import ctypes
+    return ctypes.c_float(0.0)
+
+
+def cpu_baseline(batch, sd_cls, sd_seg, n_score=100, n_coll=4096):
     """BASELINE.md §3 on this box's host cores, bounded to ~30 s: the reference's op sequence (F.conv1d / F.batch_norm / F.linear
     port, oracle/pointnet_ref.py -- the reference package cannot travel to the GPU box) in chunks of 200 (predicter.py:69) fed by
     the restated per-candidate GraspDataset.transform python loop; the C/OpenMP filterGraspPose restatement over all cores with
@@ -227,7 +232,13 @@ def cpu_baseline(batch, sd_cls, sd_seg, n_score=100, n_coll=1024):
     from oracle import collision_oracle as co
     from oracle import pointnet_ref as oref
     from oracle import transforms_ref as tref
-    ob = batch.objs[0]; g = batch.gripper
+    from catgrasp_amd import synth as _synth
+    ob = batch.objs[0]
+    # The step's gripper meshes are the box gripper's surfaces subdivided to 9,216 / 12,288 triangles.  The CPU restatement has no BVH
+    # (FCL has), so it is timed on the SAME surfaces un-subdivided (36 / 48 triangles: identical verdicts) and with the float32
+    # separating-axis narrow phase -- the cheapest form of the predicate, not the oracle's float64 clipping.
+    g = _synth.make_gripper()
+    co.lib().cr_set_variant(0, ctypes_float0(), 1)
     seg_nocs = next(s for s in batch.segs if s.kind == 'nocs' and s.obj == 0)
     seg_cone = next(s for s in batch.segs if s.kind == 'cone' and s.obj == 0)
     P = batch.host_poses(seg_cone)
@@ -272,6 +283,7 @@ def cpu_baseline(batch, sd_cls, sd_seg, n_score=100, n_coll=1024):
     co.filter_grasp_pose(P[:n_coll // 2], [I4], I4, I4, I4, I4, g['gripper_in_grasp'], 1, 0, 0, g['vertices'], g['faces'],
                          g['enclosed_vertices'], g['enclosed_faces'], ob['xyz'], bg, 0.0005)
     t_coll = (time.perf_counter() - t0) / (n_can * len(sym) + n_coll // 2)
+    co.lib().cr_set_variant(0, ctypes_float0(), 0)
     pss = oref.prepared_state_dict(sd_seg)
     t0 = time.perf_counter()
     ids = tref.draw_ids(len(ob['xyz']), 8192)
@@ -288,8 +300,9 @@ def cpu_baseline(batch, sd_cls, sd_seg, n_score=100, n_coll=1024):
             'collision_threads': co.num_threads(),
             'sample': f'{n_score} candidates x (3 warm-ups, median of 5): python transform loop + PointNetCls fp32 in chunks of 200 through '
                       f'F.conv1d/F.batch_norm/F.linear on {nthreads} torch threads (best of the scan); {n_can * len(sym) + n_coll // 2} '
-                      f'evaluations collision-filtered by the C/OpenMP oracle on {co.num_threads()} threads (both call shapes, structure build '
-                      f'included); 1 NUNOCS forward amortised over {per_rank} candidates',
+                      f'evaluations collision-filtered by the C/OpenMP restatement on {co.num_threads()} threads (both call shapes, structure build '
+                      f'included; un-subdivided 36 / 48-triangle meshes of the same gripper surfaces, float32 SAT: the restatement has no BVH); '
+                      f'1 NUNOCS forward amortised over {per_rank} candidates',
             'net_only_ms_per_candidate': round(t_netonly * 1e3, 3), 'transform_ms_per_candidate': round(t_transform * 1e3, 3),
             'net_plus_transform_candidates_per_s': round(1.0 / (t_transform + t_netonly), 2),
             'collision_ms_per_evaluation': round(t_coll * 1e3, 5), 'nunocs_ms_per_object': round(t_nunocs_obj * 1e3, 1),

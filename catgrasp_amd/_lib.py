@@ -54,7 +54,10 @@ def _stream():
     """hipStream_t of torch's current stream on the current device.  torch.cuda.current_stream() builds a Stream object through four
     layers of python (8 us under a profiler, per launch -- a tenth of a 16-candidate predict_batch call); the raw handle is what
     torch's own compiled backends fetch."""
-    return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
+    try:
+        return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
+    except AttributeError:          # a torch build without the private accessor: the public (slower) route
+        return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
 def check(status, what):

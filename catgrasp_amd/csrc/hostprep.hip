@@ -160,11 +160,14 @@ __global__ __launch_bounds__(256) void pose_inverse_rows_kernel(const TIn* __res
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= E) return;
   const TIn* P = poses + e * 16;
-  if (bad) {                    // the reference's np.linalg.inv propagates NaN / Inf into the network input; here the call is refused
+  int flags = 0;                // bit 0: NaN / Inf in the pose; bit 1: singular (np.linalg.inv raises LinAlgError) or an inverse beyond
+                                // float32; bit 2: last row is not 0 0 0 1 (the closed form below inverts an AFFINE matrix)
+  {
     bool ok = true;
 #pragma unroll
     for (int k = 0; k < 16; ++k) ok = ok && isfinite((double)P[k]);
-    if (!ok) *bad = 1;
+    if (!ok) flags |= 1;
+    if (!((double)P[12] == 0.0 && (double)P[13] == 0.0 && (double)P[14] == 0.0 && (double)P[15] == 1.0)) flags |= 4;
   }
   const double a00 = P[0], a01 = P[1], a02 = P[2], t0 = P[3];
   const double a10 = P[4], a11 = P[5], a12 = P[6], t1 = P[7];
@@ -172,6 +175,7 @@ __global__ __launch_bounds__(256) void pose_inverse_rows_kernel(const TIn* __res
   const double c00 = a11 * a22 - a12 * a21, c01 = a12 * a20 - a10 * a22, c02 = a10 * a21 - a11 * a20;
   const double det = a00 * c00 + a01 * c01 + a02 * c02;
   const double id = 1.0 / det;
+  if (det == 0.0 || !isfinite(id)) flags |= 2;
   double I[9];
   I[0] = c00 * id; I[1] = (a02 * a21 - a01 * a22) * id; I[2] = (a01 * a12 - a02 * a11) * id;
   I[3] = c01 * id; I[4] = (a00 * a22 - a02 * a20) * id; I[5] = (a02 * a10 - a00 * a12) * id;
@@ -183,7 +187,10 @@ __global__ __launch_bounds__(256) void pose_inverse_rows_kernel(const TIn* __res
   for (int r = 0; r < 3; ++r) {
     o[r * 4 + 0] = (float)I[r * 3 + 0]; o[r * 4 + 1] = (float)I[r * 3 + 1]; o[r * 4 + 2] = (float)I[r * 3 + 2];
     o[r * 4 + 3] = (float)(I[r * 3 + 0] * d0 + I[r * 3 + 1] * d1 + I[r * 3 + 2] * d2);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (!isfinite(o[r * 4 + k])) flags |= 2;
   }
+  if (bad && flags) atomicOr(bad, flags);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -29,6 +29,8 @@ from . import ops
 # on Ampere and later.
 MODES = ('f32', 'bf16x3', 'f16x3', 'f16fp8x2')
 _default = os.environ.get('CATGRASP_AMD_PRECISION', 'f32')      # process-wide default (set_precision)
+if _default not in MODES:
+    raise ValueError(f'CATGRASP_AMD_PRECISION={_default!r}: expected one of {MODES}')
 _tls = threading.local()                                        # per-thread override stack of the `precision` context manager
 TILE_POINTS = 256   # bf16x3 kernel geometry: points per workgroup tile (8 waves, one workgroup per CU)
 
@@ -298,3 +300,17 @@ def seg_forward(W, x, status=None):
     h = _dense(W, 'seg.c3', h, 128, W['seg.c3b'], relu=True, status=status)
     y = _dense(W, 'seg.c4', h, W.n_out, W['seg.c4b'], status=status)
     return y.view(B, N, W.n_out), t64.view(B, 64, 64).transpose(1, 2)
+
+
+class _EngineModule(type(os)):
+    """`engine.PRECISION = ...` used to be how older scripts switched arithmetic; it would now create a real attribute that shadows the
+    module __getattr__ above while the kernels keep dispatching on current_precision().  Refuse it instead of ignoring it."""
+
+    def __setattr__(self, name, value):
+        if name == 'PRECISION':
+            raise AttributeError("engine.PRECISION is read-only: use engine.set_precision(mode) or `with engine.precision(mode):`")
+        super().__setattr__(name, value)
+
+
+import sys as _sys          # noqa: E402
+_sys.modules[__name__].__class__ = _EngineModule

@@ -1,6 +1,7 @@
 """Thin torch-tensor wrappers over the C ABI (device memory + stream plumbing only)."""
 import ctypes
 
+import numpy as np
 import torch
 
 from . import _lib as L
@@ -90,14 +91,26 @@ def group_max(x, groups):
 
 def pose_inverse_rows_f64(poses, center, bad=None):
     """poses (E,16) float64 cuda (row-major 4x4, the caller's own numbers) -> (E,12) float32 rows of inv(pose) re-expressed for a cloud
-    shifted by -center (cg_pose_inverse_rows_f64: float64 arithmetic, rounded once).  bad: optional (1,) int32 cuda flag, set when a
-    pose holds NaN / Inf."""
+    shifted by -center (cg_pose_inverse_rows_f64: float64 arithmetic, rounded once).  bad: optional (1,) int32 cuda flag collecting
+    bits 1 (NaN / Inf in a pose), 2 (singular pose / inverse beyond float32), 4 (last row not 0 0 0 1); raise_bad_poses() turns it into
+    the exception the reference's np.linalg.inv path would have ended in."""
     require_cuda(poses)
     assert poses.dtype == torch.float64 and poses.is_contiguous() and poses.shape[1] == 16
     out = torch.empty((poses.shape[0], 12), dtype=torch.float32, device=poses.device)
     c = (ctypes.c_double * 3)(*[float(v) for v in center])
     check(L.lib().cg_pose_inverse_rows_f64(_p(poses), _c_long(poses.shape[0]), c, _p(out), _p(bad), _stream()), 'cg_pose_inverse_rows_f64')
     return out
+
+
+def raise_bad_poses(bits):
+    """The exception for a non-zero flag word of pose_inverse_rows_f64 (dataset_grasp.py:69-70: np.linalg.inv(grasp_pose))."""
+    bits = int(bits)
+    if bits & 1:
+        raise ValueError('grasp_poses contain NaN or Inf')
+    if bits & 2:
+        raise np.linalg.LinAlgError('Singular matrix')          # what np.linalg.inv raises in the reference's transform
+    if bits & 4:
+        raise ValueError('grasp_poses must be affine 4x4 transforms (last row 0 0 0 1)')
 
 
 def softmax_pg(logits):

@@ -132,7 +132,7 @@ class GraspPredicter:
         each chunk of candidates in order, exactly once; pose_inv (G,12) f32 cuda.
         -> probs (G,C), label (G) i32, confidence (G), p_G (G) cuda tensors."""
         G = pose_inv.shape[0]
-        guard = engine.PRECISION in engine.HALF_MODES
+        guard = engine.current_precision() in engine.HALF_MODES
         id_chunks = {}      # chunks of a callable id source, kept ONLY under the half-range guard (a tripped chunk is scored again)
 
         def ids_of(s, e):
@@ -189,8 +189,10 @@ class GraspPredicter:
         ring, uploaded = [None, None], [None, None]     # two page-locked staging buffers, chunk k goes through ring[k & 1]
 
         def set_plan(bounds):
+            assert not pending, 're-planning with draws in flight'
             plan.clear(); plan.update(dict(bounds))
             order.clear(); order.update({s: k for k, (s, _) in enumerate(bounds)})
+            ring[:] = [None, None]; uploaded[:] = [None, None]      # staging buffers are sized for ONE plan
             rows = max(e - s for s, e in bounds)
             if rows * width * (2 if on_device else 4) <= _PIN_LIMIT:
                 ring[:] = [_pin((rows, width), dtype) for _ in range(min(2, len(bounds)))] + [None] * (2 - min(2, len(bounds)))
@@ -289,7 +291,7 @@ class GraspPredicter:
                 if rng == 'device':
                     ids_d = transforms.draw_ids_device(cloud.n, n_pts, G, self.device, seed=int(np.random.randint(0, 2 ** 31)))
                 elif rng == 'numpy':
-                    self._poses_f64(grasp_poses, 0, min(G, 64))      # a malformed pose list fails before the generator is touched
+                    self._poses_f64(grasp_poses, 0, G)               # a malformed pose list fails before the generator is touched
                     ids_d = self._numpy_id_chunks(cloud.n, n_pts, G)
                 else:
                     raise ValueError(f"rng must be 'numpy' or 'device', not {rng!r}")
@@ -310,7 +312,7 @@ class GraspPredicter:
     def _predict_chunks(self, cloud, grasp_poses, ids_d, G):
         bounds = self._chunk_plan(G, ids_d)
         C = len(self.cfg['classes']) - 1
-        guard = engine.PRECISION in engine.HALF_MODES
+        guard = engine.current_precision() in engine.HALF_MODES
         bad = torch.zeros((1,), dtype=torch.int32, device=self.device)
         stage = {'probs': _pin((G, C), torch.float32), 'label': _pin((G,), torch.int32), 'conf': _pin((G,), torch.float32),
                  'flags': _pin((len(bounds), 2), torch.int32).zero_(), 'poses': _pin((G, 16), torch.float64)}
@@ -338,7 +340,7 @@ class GraspPredicter:
         def drain(k, s, e, ev, idc):
             ev.synchronize()
             if flags_h[k, 0]:
-                raise ValueError('grasp_poses contain NaN or Inf')
+                ops.raise_bad_poses(flags_h[k, 0])
             if guard and flags_h[k, 1]:                 # this chunk left the half range: score it again with bf16 pieces (rare)
                 engine.warn_range(int(flags_h[k, 1]))
                 with engine.precision('bf16x3'):

@@ -263,8 +263,9 @@ int cg_apply_shuffle_rows(const unsigned short* partners, long row_stride, int n
  * 3 doubles).  float64 arithmetic, rounded once (same contract as the host helper transforms.pose_inverse_rows). */
 int cg_pose_inverse_rows(const float* poses, long n_poses, const double* h_center, float* out, void* stream);
 /* The same for the caller's float64 poses (predict_batch's grasp_poses list, predicter.py:67: uploaded unconverted, so the inverse
- * is taken of the very numbers np.linalg.inv sees at dataset_grasp.py:69-70).  *bad_flag (optional device int, pre-zeroed) is set
- * when a pose holds NaN / Inf. */
+ * is taken of the very numbers np.linalg.inv sees at dataset_grasp.py:69-70).  *bad_flag (optional device int, pre-zeroed) collects
+ * bits: 1 a pose holds NaN / Inf; 2 a pose is singular (np.linalg.inv raises LinAlgError) or its inverse does not fit float32;
+ * 4 a pose's last row is not 0 0 0 1 (the closed form inverts an affine matrix, np.linalg.inv the full 4x4). */
 int cg_pose_inverse_rows_f64(const double* poses, long n_poses, const double* h_center, float* out, int* bad_flag, void* stream);
 
 /* ---------------------------------------------------------------------------------------------

@@ -12,9 +12,13 @@
  *     floor(x * (1/res)) + 32768 evaluated in double, depth-16 leaves, a leaf is occupied after one
  *     updateNode(p,true); out-of-range points are ignored) and
  *   - FCL's mesh-vs-octree result as the exact predicate  "some occupied leaf box intersects some
- *     posed mesh triangle"  (surface-only, as BVH-vs-octree is), evaluated with the 13-axis
- *     triangle/box separating-axis test in float32 instead of FCL's GJK.
- * Bit-exactness of the HIP path is defined against THIS predicate.
+ *     posed mesh triangle"  (surface-only, as BVH-vs-octree is).  The oracle decides it by CLIPPING the
+ *     triangle against the box's six half-spaces in float64 (cr_tri_box_clip64: no separating axes) -- a
+ *     different decision procedure from the HIP kernel's 13-axis float32 separating-axis test, so that
+ *     kernel == oracle is not one formulation compared with itself.  The float32 SAT twin of the kernel
+ *     (cr_tri_box_overlap) and libccd's MPR as FCL's default solver runs it (cr_tri_box_mpr) are selectable
+ *     through cr_set_variant for the sensitivity study (oracle/collision_sensitivity.py).
+ * Bit-exactness of the HIP path's codes / nudges / poses is defined against THIS file's default predicate.
  *
  * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off -fopenmp -shared).
  */
@@ -120,16 +124,22 @@ int cr_tri_box_overlap(const float c[3], float h, const float a[3], const float 
   return plane_box_overlap(n, v0, h);
 }
 
-/* ---------------- alternative formulations of the same predicate (sensitivity study, profiles/r3_collision_sensitivity.json) --------
+/* ---------------- formulations of the predicate (sensitivity study, profiles/r4_collision_sensitivity.json) ----------------------
  * FCL and octomap are absent, so what CAN be measured is how much the answer depends on the details this restatement had to choose:
  *   leaf_mode 1  the leaf box FCL actually hands to its narrow phase: not ((float)k + 0.5f) * res, but the box reached by 16
  *                float halvings of the root BV [-d, d]^3, d = (float)((1 << 16) * resolution / 2) (fcl::OcTree<float>::getRootBV,
  *                computeChildBV: child.min/max = (bv.min + bv.max) * 0.5 per set / unset bit of the child index), then
  *                constructBox(): side = max - min, centre = (min + max) * 0.5 -- a different rounding path, ~1 ulp of 0.6 m;
- *   dh           the cube's half edge grown / shrunk by dh metres (+-1e-6 m: the scale of libccd's GJK tolerances at contact);
- *   narrow 1     closed-set intersection by Sutherland-Hodgman clipping of the triangle against the six half-spaces in float64 -- no
- *                separating axes at all (the C twin of oracle/tribox_exact.py, fast enough for whole batches).
- * cr_set_variant(0, 0, 0) (the default) leaves every code path of the parity oracle exactly as it was. */
+ *   dh           the cube's half edge grown / shrunk by dh metres (+-1e-6 m: the scale of libccd's tolerances at contact);
+ *   narrow 0     (DEFAULT, the parity oracle) closed-set intersection by Sutherland-Hodgman clipping of the triangle against the six
+ *                half-spaces in float64 -- no separating axes at all (the C twin of oracle/tribox_exact.py);
+ *   narrow 1     the 13-axis separating-axis test in float32, operation for operation what csrc/collision.hip evaluates;
+ *   narrow 2     libccd's MPR (Minkowski portal refinement) intersection test on {box, triangle} support functions, as FCL's default
+ *                GJKSolver_libccd runs shapeTriangleIntersect without contact output: ccdMPRIntersect, mpr_tolerance 1e-6 (FCL's
+ *                collision_tolerance), double precision -- restated from the published algorithm (libccd src/mpr.c, FCL
+ *                narrowphase/detail/convexity_based_algorithm/gjk_libccd-inl.h: supportBox / supportTriangle / centerShape /
+ *                centerTriangle); the sources are not in this container, so this is a restatement from general knowledge, not a pin.
+ * cr_set_variant(0, 0, 0) is the parity oracle. */
 static struct { int leaf_mode; float dh; int narrow; } g_variant = {0, 0.0f, 0};
 void cr_set_variant(int leaf_mode, float dh, int narrow) { g_variant.leaf_mode = leaf_mode; g_variant.dh = dh; g_variant.narrow = narrow; }
 
@@ -204,6 +214,109 @@ int cr_tri_box_clip64(const float c[3], const float h[3], const float a[3], cons
   return 1;
 }
 
+/* ---- libccd MPR on {box centred at c with half sides h, triangle a b d}, everything in double (ccd_real_t of a CCD_DOUBLE build) ---- */
+#define MPR_EPS 2.220446049250313e-16          /* CCD_EPS = DBL_EPSILON */
+typedef struct { double v[3]; } mv3;
+static inline int mpr_is_zero(double x) { return fabs(x) < MPR_EPS; }
+static inline int mpr_eq(double a, double b) {
+  const double ab = fabs(a - b);
+  if (ab < MPR_EPS) return 1;
+  const double fa = fabs(a), fb = fabs(b);
+  return fb > fa ? ab < MPR_EPS * fb : ab < MPR_EPS * fa;
+}
+static inline double mpr_dot(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+static inline void mpr_cross(const double* a, const double* b, double* o) {
+  o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0];
+}
+static inline void mpr_normalize(double* a) { const double n = sqrt(mpr_dot(a, a)); a[0] /= n; a[1] /= n; a[2] /= n; }
+typedef struct { double c[3], h[3], tri[3][3], tc[3]; } mpr_pair;
+/* Minkowski-difference support point box - triangle in direction dir (__ccdSupport: v1 = support1(dir), v2 = support2(-dir), v = v1 - v2) */
+static void mpr_support(const mpr_pair* p, const double* dir, double* out) {
+  double s1[3], s2[3];
+  for (int k = 0; k < 3; ++k) {                       /* supportBox: ccdSign(dir) * half side, + centre */
+    const double sg = mpr_is_zero(dir[k]) ? 0.0 : (dir[k] < 0.0 ? -1.0 : 1.0);
+    s1[k] = sg * p->h[k] + p->c[k];
+  }
+  double best = -1.7976931348623157e308; int bi = 0;  /* supportTriangle: the vertex with the largest dot of (vertex - centroid) */
+  for (int i = 0; i < 3; ++i) {
+    double q[3] = {p->tri[i][0] - p->tc[0], p->tri[i][1] - p->tc[1], p->tri[i][2] - p->tc[2]};
+    const double d = -(dir[0] * q[0] + dir[1] * q[1] + dir[2] * q[2]);
+    if (d > best) { best = d; bi = i; }
+  }
+  for (int k = 0; k < 3; ++k) { s2[k] = p->tri[bi][k]; out[k] = s1[k] - s2[k]; }
+}
+/* -> 1 intersect, 0 not (ccdMPRIntersect: discoverPortal + refinePortal) */
+int cr_tri_box_mpr(const float c[3], const float h[3], const float a[3], const float b[3], const float d[3]) {
+  mpr_pair p;
+  for (int k = 0; k < 3; ++k) {
+    p.c[k] = c[k]; p.h[k] = h[k]; p.tri[0][k] = a[k]; p.tri[1][k] = b[k]; p.tri[2][k] = d[k];
+    p.tc[k] = (p.tri[0][k] + p.tri[1][k] + p.tri[2][k]) / 3.0;
+  }
+  const double tol = 1e-6;                             /* FCL GJKSolver_libccd: collision_tolerance -> ccd.mpr_tolerance */
+  double v0[3], v1[3], v2[3], v3[3], v4[3], dir[3], va[3], vb[3], dot;
+  for (int k = 0; k < 3; ++k) v0[k] = p.c[k] - p.tc[k];                                  /* findOrigin: centre1 - centre2 */
+  if (mpr_eq(v0[0], 0.0) && mpr_eq(v0[1], 0.0) && mpr_eq(v0[2], 0.0)) v0[0] += MPR_EPS * 10.0;
+  for (int k = 0; k < 3; ++k) dir[k] = -v0[k];
+  mpr_normalize(dir);
+  mpr_support(&p, dir, v1);
+  dot = mpr_dot(v1, dir);
+  if (mpr_is_zero(dot) || dot < 0.0) return 0;
+  mpr_cross(v0, v1, dir);
+  if (mpr_is_zero(mpr_dot(dir, dir))) return 1;        /* origin on v1, or on the segment v0-v1: both count as intersection */
+  mpr_normalize(dir);
+  mpr_support(&p, dir, v2);
+  dot = mpr_dot(v2, dir);
+  if (mpr_is_zero(dot) || dot < 0.0) return 0;
+  for (int k = 0; k < 3; ++k) { va[k] = v1[k] - v0[k]; vb[k] = v2[k] - v0[k]; }
+  mpr_cross(va, vb, dir); mpr_normalize(dir);
+  if (mpr_dot(dir, v0) > 0.0) {                        /* portal faces oriented "outside" the origin */
+    for (int k = 0; k < 3; ++k) { const double t = v1[k]; v1[k] = v2[k]; v2[k] = t; dir[k] = -dir[k]; }
+  }
+  for (int it = 0;; ++it) {                            /* discoverPortal: until (v1, v2, v3) encloses the ray v0 -> origin */
+    if (it > 500) return 0;                            /* (libccd loops unbounded here; FCL's max_collision_iterations as a guard) */
+    mpr_support(&p, dir, v3);
+    dot = mpr_dot(v3, dir);
+    if (mpr_is_zero(dot) || dot < 0.0) return 0;
+    int cont = 0;
+    mpr_cross(v1, v3, va); dot = mpr_dot(va, v0);
+    if (dot < 0.0 && !mpr_is_zero(dot)) { memcpy(v2, v3, sizeof v2); cont = 1; }
+    if (!cont) {
+      mpr_cross(v3, v2, va); dot = mpr_dot(va, v0);
+      if (dot < 0.0 && !mpr_is_zero(dot)) { memcpy(v1, v3, sizeof v1); cont = 1; }
+    }
+    if (!cont) break;
+    for (int k = 0; k < 3; ++k) { va[k] = v1[k] - v0[k]; vb[k] = v2[k] - v0[k]; }
+    mpr_cross(va, vb, dir); mpr_normalize(dir);
+  }
+  for (int it = 0;; ++it) {                            /* refinePortal */
+    if (it > 500) return 0;
+    for (int k = 0; k < 3; ++k) { va[k] = v2[k] - v1[k]; vb[k] = v3[k] - v1[k]; }
+    mpr_cross(va, vb, dir); mpr_normalize(dir);        /* portalDir */
+    dot = mpr_dot(dir, v1);
+    if (mpr_is_zero(dot) || dot > 0.0) return 1;       /* portalEncapsulesOrigin */
+    mpr_support(&p, dir, v4);
+    dot = mpr_dot(v4, dir);
+    if (!(mpr_is_zero(dot) || dot > 0.0)) return 0;   /* !portalCanEncapsuleOrigin */
+    {                                                  /* portalReachTolerance */
+      const double dv4 = dot;
+      double m = dv4 - mpr_dot(v1, dir);
+      const double m2 = dv4 - mpr_dot(v2, dir), m3 = dv4 - mpr_dot(v3, dir);
+      if (m2 < m) m = m2;
+      if (m3 < m) m = m3;
+      if (mpr_eq(m, tol) || m < tol) return 0;
+    }
+    mpr_cross(v4, v0, va);                             /* expandPortal */
+    dot = mpr_dot(v1, va);
+    if (dot > 0.0) {
+      dot = mpr_dot(v2, va);
+      if (dot > 0.0) memcpy(v1, v4, sizeof v1); else memcpy(v3, v4, sizeof v3);
+    } else {
+      dot = mpr_dot(v3, va);
+      if (dot > 0.0) memcpy(v2, v4, sizeof v2); else memcpy(v1, v4, sizeof v1);
+    }
+  }
+}
+
 /* ---------------- CollisionManager (collision_manager.cpp:15-111) ---------------- */
 
 /* posed vertex: R v + t with the pose's upper 3x4 (setTransform(pose.block(0,0,3,3), pose.block(0,3,3,1))) */
@@ -225,37 +338,36 @@ int cr_mesh_voxels_collide(const float* V, int nv, const int* F, int nf, const f
       pose_vertex(pose, V + 3 * F[f * 3 + k], tri + f * 9 + k * 3);
       for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], tri[f * 9 + k * 3 + a]); hi[a] = fmaxf(hi[a], tri[f * 9 + k * 3 + a]); }
     }
-  int hit = 0;
-  if (g_variant.leaf_mode || g_variant.dh != 0.0f || g_variant.narrow) {       /* sensitivity study only; see cr_set_variant */
-    for (int i = 0; i < nk && !hit; ++i) {
-      float c[3], h3[3];
-      if (g_variant.leaf_mode == 1) fcl_leaf_box(keys + i * 3, resolution, c, h3);
-      else for (int a = 0; a < 3; ++a) { c[a] = ((float)keys[i * 3 + a] + 0.5f) * resolution; h3[a] = h; }
-      int out = 0;
-      for (int a = 0; a < 3; ++a) {
-        h3[a] += g_variant.dh;
-        if (c[a] - h3[a] > hi[a] + 1e-5f || c[a] + h3[a] < lo[a] - 1e-5f) out = 1;
-      }
-      if (out) continue;
-      for (int f = 0; f < nf; ++f)
-        if (g_variant.narrow ? cr_tri_box_clip64(c, h3, tri + f * 9, tri + f * 9 + 3, tri + f * 9 + 6)
-                             : cr_tri_box_overlap_h3(c, h3, tri + f * 9, tri + f * 9 + 3, tri + f * 9 + 6)) { hit = 1; break; }
+  /* per-triangle bounds for a conservative cull (1e-5 m slack >> any rounding in the predicates; never changes a result) */
+  float* tb = (float*)malloc(sizeof(float) * 6 * (size_t)nf);
+  for (int f = 0; f < nf; ++f)
+    for (int a = 0; a < 3; ++a) {
+      tb[f * 6 + a] = min3f(tri[f * 9 + a], tri[f * 9 + 3 + a], tri[f * 9 + 6 + a]) - 1e-5f;
+      tb[f * 6 + 3 + a] = max3f(tri[f * 9 + a], tri[f * 9 + 3 + a], tri[f * 9 + 6 + a]) + 1e-5f;
     }
-    free(tri);
-    return hit;
-  }
+  int hit = 0;
   for (int i = 0; i < nk && !hit; ++i) {
-    float c[3];
+    float c[3], h3[3];
+    if (g_variant.leaf_mode == 1) fcl_leaf_box(keys + i * 3, resolution, c, h3);
+    else for (int a = 0; a < 3; ++a) { c[a] = ((float)keys[i * 3 + a] + 0.5f) * resolution; h3[a] = h; }
     int out = 0;
     for (int a = 0; a < 3; ++a) {
-      c[a] = ((float)keys[i * 3 + a] + 0.5f) * resolution;
-      /* conservative early-out only (1e-5 m slack >> float rounding of the SAT); never changes the result */
-      if (c[a] - h > hi[a] + 1e-5f || c[a] + h < lo[a] - 1e-5f) out = 1;
+      h3[a] += g_variant.dh;
+      if (c[a] - h3[a] > hi[a] + 1e-5f || c[a] + h3[a] < lo[a] - 1e-5f) out = 1;
     }
     if (out) continue;
-    for (int f = 0; f < nf; ++f)
-      if (cr_tri_box_overlap(c, h, tri + f * 9, tri + f * 9 + 3, tri + f * 9 + 6)) { hit = 1; break; }
+    for (int f = 0; f < nf; ++f) {
+      const float* q = tb + f * 6;
+      if (c[0] - h3[0] > q[3] || c[0] + h3[0] < q[0] || c[1] - h3[1] > q[4] || c[1] + h3[1] < q[1] || c[2] - h3[2] > q[5] || c[2] + h3[2] < q[2])
+        continue;
+      const float* t = tri + f * 9;
+      const int o = g_variant.narrow == 0 ? cr_tri_box_clip64(c, h3, t, t + 3, t + 6)
+                  : g_variant.narrow == 1 ? cr_tri_box_overlap_h3(c, h3, t, t + 3, t + 6)
+                                          : cr_tri_box_mpr(c, h3, t, t + 3, t + 6);
+      if (o) { hit = 1; break; }
+    }
   }
+  free(tb);
   free(tri);
   return hit;
 }

@@ -4,15 +4,18 @@ The reference's `CollisionManager::isAnyCollision` is FCL's BVHModel<OBBRSSf> vs
 63-70, 93-111); neither library is available here (PARITY UNPINNED, oracle/collision_ref.c).  This study runs the SAME filterGraspPose
 control flow (common.cpp:156-321, both live call shapes, nudging on) over the WHOLE C3 batch of BASELINE.json configs[2] -- 50,000
 evaluations, every object of the scene -- under alternative formulations of the leaf-box-vs-triangle predicate
-(collision_ref.c: cr_set_variant) and counts what changes against the parity oracle:
+(collision_ref.c: cr_set_variant) and counts what changes against the parity oracle (float64 polygon clipping, no separating axes):
 
+  sat_f32       the 13-axis separating-axis test in float32 -- what csrc/collision.hip evaluates, operation for operation
+  mpr_libccd    libccd's MPR intersection test on box / triangle support functions with FCL's defaults (mpr_tolerance 1e-6, double):
+                the narrow phase FCL's default solver actually runs for a BVH-triangle / octree-leaf pair (restated, not linked)
   fcl_halving   leaf boxes from FCL's 16 float halvings of the root BV instead of ((float)k + 0.5f) * res
-  grow_1um      box half edge + 1e-6 m   (libccd / GJK contact tolerance scale)
+  fcl_halving+mpr_libccd   both: the closest this container can get to what the reference's FCL call computes
+  grow_1um      box half edge + 1e-6 m   (libccd contact tolerance scale)
   shrink_1um    box half edge - 1e-6 m
-  clip64        closed-set intersection by polygon clipping in float64, no separating axes (independent narrow phase)
 
-plus 100,000 synthetic grazing triangle/box pairs per variant.  Output: profiles/r3_collision_sensitivity.json.
-    python -m oracle.collision_sensitivity [--out profiles/r3_collision_sensitivity.json]
+plus 100,000 synthetic grazing triangle/box pairs per variant.  Output: profiles/r4_collision_sensitivity.json.
+    python -m oracle.collision_sensitivity [--out profiles/r4_collision_sensitivity.json]
 """
 import argparse
 import ctypes
@@ -30,8 +33,10 @@ if ROOT not in sys.path:
 from catgrasp_amd import synth, transforms, workload      # noqa: E402  (host-side scene / candidate generators only: no device code)
 from oracle import collision_oracle as co                 # noqa: E402
 
-VARIANTS = {'fcl_halving': (1, 0.0, 0), 'grow_1um': (0, 1e-6, 0), 'shrink_1um': (0, -1e-6, 0), 'clip64': (0, 0.0, 1),
-            'fcl_halving+clip64': (1, 0.0, 1)}
+# (leaf_mode, half-edge delta, narrow phase: 0 float64 clipping = the parity oracle, 1 float32 SAT = the kernel's twin, 2 libccd MPR)
+VARIANTS = {'sat_f32': (0, 0.0, 1), 'mpr_libccd': (0, 0.0, 2), 'fcl_halving': (1, 0.0, 0), 'fcl_halving+mpr_libccd': (1, 0.0, 2),
+            'fcl_halving+sat_f32': (1, 0.0, 1), 'grow_1um': (0, 1e-6, 0), 'shrink_1um': (0, -1e-6, 0)}
+NARROW_NAME = {0: 'clip64', 1: 'sat_f32', 2: 'mpr_libccd'}
 I4 = np.eye(4)
 
 
@@ -107,7 +112,7 @@ def main(out_path, per_replica=50000, n_grazing=100000):
     set_variant()
     base = run_batch(batch, objs, gripper, nocs, cats)
     report = {'what': 'sensitivity of the filterGraspPose result to the formulation of the leaf-box / triangle predicate (FCL and octomap absent: '
-                      'PARITY UNPINNED); baseline = oracle/collision_ref.c = csrc/collision.hip',
+                      'PARITY UNPINNED); baseline = oracle/collision_ref.c (float64 clipping); sat_f32 = the arithmetic of csrc/collision.hip',
               'workload': f'C3 (BASELINE.json configs[2]): {len(objs)} objects x {len(objs[0]["xyz"])} pts, {n_total} evaluations in the global order of '
                           'catgrasp_amd/workload.py, both call shapes (grasp_sampler.py:345 with 12 symmetries and pose nudging; :216), resolution 0.0005',
               'baseline_code_histogram_0keep_1dir_2ik_3open_4enclosed': np.bincount(base[0], minlength=5).tolist(),
@@ -123,9 +128,9 @@ def main(out_path, per_replica=50000, n_grazing=100000):
         both_keep = (c == 0) & (base[0] == 0)
         pose_diff = both_keep & (np.abs(p - base[2]).reshape(n_total, -1).max(1) > 0)
         any_change = code_flip | nudge_flip | pose_diff
-        if name != 'fcl_halving+clip64':
+        if '+' not in name:
             union |= any_change
-        report['variants'][name] = {'leaf_mode': lm, 'half_edge_delta_m': dh, 'narrow_phase': 'clip64' if nar else 'sat_f32',
+        report['variants'][name] = {'leaf_mode': lm, 'half_edge_delta_m': dh, 'narrow_phase': NARROW_NAME[nar],
                                     'codes_flipped': int(code_flip.sum()), 'nudge_index_changed': int(nudge_flip.sum()),
                                     'survivor_set_changed': int(surv.sum()), 'kept_pose_changed': int(pose_diff.sum()),
                                     'evaluations_with_any_change': int(any_change.sum()),
@@ -133,7 +138,7 @@ def main(out_path, per_replica=50000, n_grazing=100000):
                                                                     for a in range(5) for b in range(5) if a != b and ((base[0] == a) & (c == b)).any()}}
     report['evaluations_inside_the_fcl_uncertainty_band'] = int(union.sum())
     report['evaluations_total'] = int(n_total)
-    report['band_definition'] = 'an evaluation is inside the band if its code, its accepted nudge or its kept pose changes under ANY of: fcl_halving, grow_1um, shrink_1um, clip64'
+    report['band_definition'] = 'an evaluation is inside the band if its code, its accepted nudge or its kept pose changes under ANY of: sat_f32, mpr_libccd, fcl_halving, grow_1um, shrink_1um'
     keys, a, b, e = grazing_pairs(n_grazing)
     gbase = grazing_decisions(keys, a, b, e, 0, 0.0, 0)
     gz = {'pairs': int(n_grazing), 'gap_range_m': [-2e-6, 2e-6], 'baseline_overlaps': int(gbase.sum())}
@@ -151,7 +156,7 @@ def main(out_path, per_replica=50000, n_grazing=100000):
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
-    ap.add_argument('--out', default=os.path.join(ROOT, 'profiles', 'r3_collision_sensitivity.json'))
+    ap.add_argument('--out', default=os.path.join(ROOT, 'profiles', 'r4_collision_sensitivity.json'))
     ap.add_argument('--evaluations', type=int, default=50000)
     ap.add_argument('--grazing', type=int, default=100000)
     a = ap.parse_args()

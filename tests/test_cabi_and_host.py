@@ -568,6 +568,9 @@ def test_precision_override_is_thread_local():
         assert seen == {'before': 'f32', 'during': 'f32', 'own': 'f16x3'} and engine.PRECISION == 'f32'
         with pytest.raises(AssertionError):
             engine.precision('fp64')
+        with pytest.raises(AttributeError):          # assignment would shadow the module __getattr__ and be silently ignored by the kernels
+            engine.PRECISION = 'f16x3'
+        assert engine.PRECISION == 'f32'
     finally:
         engine.set_precision(old)
 
@@ -602,4 +605,11 @@ def test_hot_kernels_stay_out_of_scratch():
                 seen += 1
                 assert r['private_segment_fixed_size'] == 0 and r['vgpr_spill_count'] == 0, r
     assert seen >= 100          # 3 + 117 set-abstraction signatures + 4 FPS geometries + ...
+    # the collision kernels additionally keep every scalar register: their wave-uniform state (posed matrices, grid geometry, output
+    # pointers) is laid out so that nothing is spilled to VGPR lanes (round 3: 364 spilled SGPRs in filter_grasp_pose_kernel)
+    rows = kr.resources(os.path.join(root, 'catgrasp_amd', 'csrc', 'collision.o'))
+    names = [r['kernel'] for r in rows]
+    assert any('filter_grasp_pose_kernel<true>' in n for n in names) and any('compose_grasp_pose_kernel' in n for n in names)
+    for r in rows:
+        assert r['sgpr_spill_count'] == 0 and r['vgpr_spill_count'] == 0 and r['private_segment_fixed_size'] == 0, r
 

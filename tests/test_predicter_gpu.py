@@ -294,3 +294,17 @@ def test_predict_batch_device_rng_and_id_validation(cuda_device):
     bad = ids[:len(P)].copy(); bad[3, 5] = 2500
     with pytest.raises(IndexError):
         gp.predict_batch(data, list(P), ids=bad)
+    # poses np.linalg.inv (dataset_grasp.py:69-70) would refuse or that the device's closed-form affine inverse cannot represent:
+    # a singular pose raises LinAlgError like the reference, a non-affine last row and a NaN are refused -- none is pooled away into
+    # finite-looking probabilities; numpy's generator is left untouched by the failed call (all poses are converted before the draw)
+    for bad_pose, exc in ((np.diag([1.0, 1.0, 0.0, 1.0]), np.linalg.LinAlgError), (np.zeros((4, 4)), (np.linalg.LinAlgError, ValueError)),
+                          (np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0], [0, 0, 0.5, 1.0]]), ValueError),
+                          (np.full((4, 4), np.nan), ValueError)):
+        for rng_mode in ('device', 'numpy'):
+            Pb = [p.copy() for p in P]; Pb[17] = bad_pose
+            with pytest.raises(exc):
+                gp.predict_batch(data, Pb, rng=rng_mode)
+    np.random.seed(3); st = np.random.get_state()[1].copy()
+    with pytest.raises(ValueError):
+        gp.predict_batch(data, list(P[:30]) + [np.eye(3)], rng='numpy')         # malformed pose late in the list
+    assert np.array_equal(np.random.get_state()[1], st)
