@@ -219,6 +219,30 @@ def pick_cycle_block(batch, gp, npred, device, n_canonical=2000):
     return res
 
 
+def projected_scaling_block(batch, n_total, ms_full_s, steps=3):
+    """What ONE GPU needs for the slice a rank of an N-rank job would get (strong scaling: contiguous slices of the same batch, rank 0's
+    and the last rank's, whichever is slower), measured in this run -> the speed-up the N-rank job can reach before its one all_gather.
+    A projection from single-GPU timings: no multi-GPU hardware was available to the builder; the driver's SCALE run is the measurement."""
+    from catgrasp_amd import distributed as cgd
+    out = {'what': 'single-GPU time of the slice one rank of an N-rank strong-scaling job scores (max of the first and the last rank\'s slice), '
+                   'this run; speed-up = full-batch step / slice step, before the all_gather of the 8 B records',
+           'status': 'projection -- unmeasured on multi-GPU hardware', 'full_batch_ms': round(ms_full_s * 1e3, 3), 'ranks': {}}
+    with torch.no_grad():
+        for world in (2, 4, 8):
+            _, bounds = cgd.shard_bounds(n_total, world)
+            worst = 0.0
+            for lo, hi in (bounds[0], bounds[-1]):
+                batch.score_slice(lo, hi); torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    batch.score_slice(lo, hi)
+                torch.cuda.synchronize()
+                worst = max(worst, (time.perf_counter() - t0) / steps)
+            out['ranks'][str(world)] = {'slice_candidates': bounds[0][1] - bounds[0][0], 'slice_ms': round(worst * 1e3, 3),
+                                        'projected_speedup': round(ms_full_s / worst, 3)}
+    return out
+
+
 def ctypes_float0():
     import ctypes
     return ctypes.c_float(0.0)
@@ -437,6 +461,7 @@ def main():
                     help='measure roofline.traffic for this run with two rocprofv3 --pmc child passes (N = 1 only; adds ~1 min).  Default: on '
                          'when rocprofv3 is present')
     ap.add_argument('--no-pmc-traffic', dest='pmc_traffic', action='store_false', help='quote the constant from profiles/ instead')
+    ap.add_argument('--no-projection', action='store_true', help='skip the projected_scaling block (N = 1: slice timings of the 2 / 4 / 8-rank shards)')
     ap.add_argument('--no-rccl-selftest', action='store_true', help='skip the one-rank RCCL all-gather check after the timed region (N = 1)')
     ap.add_argument('--pmc-child', action='store_true', help=argparse.SUPPRESS)      # the child run of --pmc-traffic: workload only
     args = ap.parse_args()
@@ -621,6 +646,9 @@ def main():
         del wbatch, r
     engine.set_precision(args.precision)
 
+    projected = None
+    if world == 1 and rank == 0 and args.scaling == 'strong' and not args.no_projection:
+        projected = projected_scaling_block(batch, n_total, prim['dt'] / args.steps)
     selftest = None
     if world == 1 and not args.no_rccl_selftest and backend == 'nccl':
         selftest = rccl_selftest(batch, n_total, ref_out, device)
@@ -666,6 +694,10 @@ def main():
             'per_rank_ms': {'columns': ['local scoring (HIP events)', 'all_gather of the (p_G, code) records (HIP events)', 'step wall-clock'],
                             'ranks': [[round(v, 3) for v in pr] for pr in prim['per_rank']]},
         }
+        import hashlib
+        line['records_sha256'] = hashlib.sha256(ref_out.cpu().numpy().tobytes()).hexdigest()      # (p_G, code) of every candidate, global order
+        if projected is not None:
+            line['projected_scaling'] = projected
         if selftest is not None:
             line['rccl_selftest'] = selftest
         if 'bgi' in prim:

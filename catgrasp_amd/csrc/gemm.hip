@@ -6,6 +6,7 @@
 // segmentation head of PointNetSeg (pointnet2.py:324-328; one row per point).  BatchNorm is folded
 // into W / bias on the host.  W is pre-packed into MFMA B-fragment order (see pack_b in
 // catgrasp_amd/folding.py): Wp[nb][ks][lane][4] = W[nb*32 + (lane&31)][ks*8 + (lane>>5)*4 + j].
+#include <stdlib.h>
 #include "cg_common.hpp"
 #include "../../include/catgrasp_amd.h"
 
@@ -83,6 +84,50 @@ __global__ __launch_bounds__(256) void gemm_bias_act_kernel(GemmArgs a) {
   }
 }
 
+// The same layer for FEW rows (the FC tails of a predict_batch call of 1 .. ~1,000 poses: the reference scores a few hundred per
+// object, predicter.py:67-94).  The tile kernel above gives a 64 x 128 output tile to a workgroup: at M <= 64 and N = 512 that is 4
+// workgroups on 4 of 256 CUs, each streaming 128 KB of weights through one MFMA chain per wave -- 42-53 us per launch, nine launches
+// per call, i.e. 0.4 ms of a 1 ms call whatever the number of poses.  Here ONE WAVEFRONT owns a 32 x 32 output tile and walks the
+// whole K itself, operands straight from global memory (the x rows are L1 / L2 resident, the weights are read once per row tile):
+// ceil(M/32) x ceil(N/32) independent wavefronts.  Per output element the sequence of MFMAs and their operands is the one the tile
+// kernel issues, so a row's result does not depend on which kernel -- i.e. on how many rows -- it was computed with.
+__global__ __launch_bounds__(256) void gemm_bias_act_small_kernel(GemmArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int tiles_m = (a.M + 31) / 32;
+  if (tile >= tiles_m * a.nblocks) return;
+  const int tm = tile / a.nblocks, nb = tile - tm * a.nblocks;     // neighbouring wavefronts share their x rows, not their weights
+  const int ksteps = a.K / 8;
+  int xrow = tm * 32 + l31; if (xrow >= a.M) xrow = a.M - 1;
+  const float* xr = a.x + (size_t)xrow * a.ldx + lhi * 4;
+  const f32x4* bp = (const f32x4*)a.wp + (size_t)nb * ksteps * 64 + lane;
+  f32x16 c = {0};
+#pragma unroll 8
+  for (int ks = 0; ks < ksteps; ++ks) {
+    const f32x4 bv = bp[(size_t)ks * 64];
+    const f32x4 av = *(const f32x4*)(xr + ks * 8);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c = mfma32(av[j], bv[j], c);
+  }
+  const int col = nb * 32 + l31;
+  if (col >= a.N) return;
+  float bias = a.bias ? a.bias[col] : 0.f;
+  if (a.eye_k > 0 && (col % (a.eye_k + 1)) == 0) bias += 1.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = tm * 32 + acc_row(r, lane);
+    if (row < a.M) {
+      float v = c[r] + bias;
+      if (a.row_bias) v += a.row_bias[(size_t)(row / a.rows_per_group) * a.ld_rb + col];
+      if (a.relu) v = fmaxf(v, 0.f);
+      a.y[(size_t)row * a.ldy + col] = v;
+    }
+  }
+}
+
+constexpr int SMALL_M = 1024;      // rows up to which the wavefront-per-tile kernel is used (measured: profiles/r4_gemm_small.txt)
+
 }  // namespace
 
 extern "C" int cg_gemm_bias_act(const float* x, int M, int K, int ldx, const float* w_packed, int N,
@@ -94,6 +139,12 @@ extern "C" int cg_gemm_bias_act(const float* x, int M, int K, int ldx, const flo
   if (row_bias && (rows_per_group <= 0 || ld_rb < N)) return CG_ERR_ARG;
   if (M == 0) return CG_OK;
   GemmArgs a{x, M, K, ldx, w_packed, N, (N + 31) / 32, bias, row_bias, rows_per_group, ld_rb, relu, eye_k, y, ldy};
+  static const int small_m = getenv("CATGRASP_AMD_GEMM_SMALL_M") ? atoi(getenv("CATGRASP_AMD_GEMM_SMALL_M")) : SMALL_M;   // dev knob
+  if (M <= small_m) {
+    const long tiles = (long)((M + 31) / 32) * a.nblocks;
+    hipLaunchKernelGGL(gemm_bias_act_small_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
+    return cg_hip_status(hipGetLastError());
+  }
   dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((a.nblocks + 3) / 4)), block(256);
   hipLaunchKernelGGL(gemm_bias_act_kernel, grid, block, 0, (hipStream_t)stream, a);
   return cg_hip_status(hipGetLastError());

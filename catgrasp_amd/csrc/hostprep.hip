@@ -100,6 +100,41 @@ __global__ __launch_bounds__(64) void draw_ids_perm_kernel(int n_valid, int n_pt
   }
 }
 
+// The same draw as a SORT: one workgroup per row.  Every point index gets a 48-bit random key (two Philox words; a tie between two of
+// 2,500 keys has probability 1e-8 per row and is then decided by the index), the (key, index) pairs are bitonic-sorted in LDS and the
+// first n_pts indices are the row: a uniform n_pts-subset in uniform order, like np.random.choice(replace=False).  The Fisher-Yates
+// kernel above runs ONE LANE per row down a chain of n_pts dependent LDS swaps: ~250 us for a row however few rows there are (a
+// quarter of a one-pose predict_batch call), and 61 GB/s of ids at full occupancy.  Here a row is 78 barrier-separated rounds of 8
+// compare-exchanges per thread (N = 4096): microseconds per row, and several workgroups per CU overlap each other's barriers.
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void draw_ids_sort_kernel(int n_valid, int n_pts, int N, long count, unsigned k0, unsigned k1, int base,
+                                                                long row_offset, int* __restrict__ out) {
+  extern __shared__ unsigned long long keys[];
+  const long row = blockIdx.x;
+  const long grow = row + row_offset;          // the stream is a function of the GLOBAL row: a shard draws what the whole would
+  const unsigned c0 = (unsigned)grow, c2 = (unsigned)(grow >> 32);
+  for (int p = threadIdx.x; p < N / 2; p += THREADS) {            // one Philox block keys two points
+    const U4 w = philox4x32_10(U4{c0, (unsigned)p, c2, 0x50525453u}, k0, k1);
+    const int i0 = 2 * p, i1 = 2 * p + 1;
+    keys[i0] = i0 < n_valid ? ((unsigned long long)w.x << 32 | (unsigned long long)(w.y & 0xffff0000u)) | (unsigned)i0 : ~0ull;
+    keys[i1] = i1 < n_valid ? ((unsigned long long)w.z << 32 | (unsigned long long)(w.w & 0xffff0000u)) | (unsigned)i1 : ~0ull;
+  }
+  for (int k = 2; k <= N; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      __syncthreads();
+      for (int t = threadIdx.x; t < N / 2; t += THREADS) {
+        const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;       // the t-th pair of this round
+        const unsigned long long a = keys[lo], b = keys[hi];
+        const bool up = (lo & k) == 0;
+        if ((a > b) == up) { keys[lo] = b; keys[hi] = a; }
+      }
+    }
+  }
+  __syncthreads();
+  int* o = out + row * n_pts;
+  for (int i = threadIdx.x; i < n_pts; i += THREADS) o[i] = (int)(keys[i] & 0xffffu) + base;
+}
+
 // The swap chain of numpy's permutation(n_valid) for `count` rows whose swap partners the host extracted from numpy's generator
 // (cg_host_numpy_shuffle_partners): a[i] <-> a[j(i)] for i = n_valid-1 .. 1 on a = arange(n_valid), out = a[:n_pts] + base.
 // One lane per row, the row's array in LDS as u16, rows interleaved like draw_ids_perm_kernel (the LDS operations of a lane
@@ -263,6 +298,13 @@ extern "C" int cg_draw_resample_ids(int n_valid, int n_pts, long count, unsigned
   if (!out) return CG_ERR_ARG;
   const unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
   hipStream_t s = (hipStream_t)stream;
+  if (n_valid >= n_pts && n_valid <= 8192) {             // (key, index) pairs of the whole cloud fit 64 KB of LDS: the sort kernel
+    int N = 2;
+    while (N < n_valid) N <<= 1;
+    hipLaunchKernelGGL(draw_ids_sort_kernel<256>, dim3((unsigned)count), dim3(256), (size_t)N * 8, s, n_valid, n_pts, N, count, k0, k1, base,
+                       row_offset, out);
+    return cg_hip_status(hipGetLastError());
+  }
   if (n_valid >= n_pts && n_valid <= 65535) {
     constexpr size_t LDS = 128 * 1024;
     int R = (int)(LDS / ((size_t)n_valid * 2));

@@ -98,6 +98,8 @@ struct Stream {
   }
 };
 
+template <bool WIDE> void perm_rows(struct Stream& S, int n, int n_pts, long count, uint16_t* o, uint16_t* a, int* out);
+
 // ---- per-row work, AVX-512 ------------------------------------------------------------------------------------------
 #define CG_LANE_LOW _mm512_setr_epi32(0, 1, 3, 7, 15, 31, 63, 127, 255, 511, 1023, 2047, 4095, 8191, 16383, 32767)
 
@@ -214,6 +216,8 @@ CG_T512 inline void heads_512(const uint16_t* o, int n, int k, int* heads) {
   for (int t = 0; t < k; ++t) heads[t] = (int)p[t];
 }
 
+CG_T512 void perm_rows_512(Stream& S, int n, int n_pts, long count, uint16_t* o, uint16_t* a, int* out) { perm_rows<true>(S, n, n_pts, count, o, a, out); }
+
 CG_T512 void rows_512(Stream& S, int n, int k, long count, uint16_t* o, int* out) {
   for (long r = 0; r < count; ++r) {
     partners_512(S, n, o);
@@ -222,25 +226,28 @@ CG_T512 void rows_512(Stream& S, int n, int k, long count, uint16_t* o, int* out
 }
 
 // ---- per-row work, scalar twin ---------------------------------------------------------------------------------------
-void rows_scalar(Stream& S, int n, int k, long count, uint16_t* o, int* out) {
+void partners_scalar(Stream& S, int n, uint16_t* o) {
   const uint32_t n1 = (uint32_t)(n - 1);
-  uint32_t mask0 = n1;
-  mask0 |= mask0 >> 1; mask0 |= mask0 >> 2; mask0 |= mask0 >> 4; mask0 |= mask0 >> 8; mask0 |= mask0 >> 16;
-  for (long r = 0; r < count; ++r) {
-    uint32_t i = n1, mask = mask0;
-    while (i > 0) {
-      const uint32_t lim = mask >> 1;
-      if (i <= lim) { mask = lim; continue; }
-      const int avail = MT_N - (int)(S.fpos % MT_N);      // to the end of this generator block
-      const uint32_t* w = S.need(S.fpos + avail);
-      int t = 0;
-      for (; t < avail && i > lim; ++t) {                 // branch-free rejection: store, advance by the accept bit
-        const uint32_t v = w[t] & mask;
-        o[n1 - i] = (uint16_t)v;
-        i = i - 1 + (i < v);
-      }
-      S.fpos += t;
+  uint32_t i = n1, mask = n1;
+  mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+  while (i > 0) {
+    const uint32_t lim = mask >> 1;
+    if (i <= lim) { mask = lim; continue; }
+    const int avail = MT_N - (int)(S.fpos % MT_N);      // to the end of this generator block
+    const uint32_t* w = S.need(S.fpos + avail);
+    int t = 0;
+    for (; t < avail && i > lim; ++t) {                 // branch-free rejection: store, advance by the accept bit
+      const uint32_t v = w[t] & mask;
+      o[n1 - i] = (uint16_t)v;
+      i = i - 1 + (i < v);
     }
+    S.fpos += t;
+  }
+}
+
+void rows_scalar(Stream& S, int n, int k, long count, uint16_t* o, int* out) {
+  for (long r = 0; r < count; ++r) {
+    partners_scalar(S, n, o);
     uint32_t p[16];
     for (int t = 0; t < k; ++t) p[t] = (uint32_t)t;
     for (int i2 = 1; i2 < n; ++i2) {
@@ -248,6 +255,21 @@ void rows_scalar(Stream& S, int n, int k, long count, uint16_t* o, int* out) {
       for (int t = 0; t < k; ++t) p[t] = p[t] == ii ? j : (p[t] == j ? ii : p[t]);
     }
     for (int t = 0; t < k; ++t) out[r * k + t] = (int)p[t];
+  }
+}
+
+// whole rows: permutation(n)[:n_pts] from the partner row (the swap chain itself, 2 ns a step on a row that sits in L1)
+template <bool WIDE>
+void perm_rows(Stream& S, int n, int n_pts, long count, uint16_t* o, uint16_t* a, int* out) {
+  for (long r = 0; r < count; ++r) {
+    if (WIDE) partners_512(S, n, o); else partners_scalar(S, n, o);
+    for (int i = 0; i < n; ++i) a[i] = (uint16_t)i;
+    for (int i = n - 1; i > 0; --i) {
+      const uint16_t j = o[n - 1 - i], t = a[i];
+      a[i] = a[j]; a[j] = t;
+    }
+    int* q = out + r * n_pts;
+    for (int i = 0; i < n_pts; ++i) q[i] = a[i];
   }
 }
 
@@ -281,5 +303,33 @@ extern "C" int cg_host_numpy_choice_heads(uint32_t* h_mt_key624, int* h_mt_pos, 
     *h_mt_pos = (int)(S.fpos - b * MT_N);
   }
   delete[] row; delete[] S.tmp; delete[] S.raw;
+  return CG_OK;
+}
+
+// `count` draws of np.random.choice(n, size=n_pts, replace=False) = permutation(n)[:n_pts] as WHOLE rows on the host, 2 <= n <= 65536,
+// 1 <= n_pts <= n: the vectorised partner extraction above + the swap chain on a row that sits in L1 (~6 us per row at n = 2,500
+// against ~14 us for cg_host_numpy_choice_rows).  What a small predict_batch call uses instead of shipping partners to the device:
+// a swap chain is a dependent sequence wherever it runs, and one lane of the device needs ~250 us for it.
+extern "C" int cg_host_numpy_permutation_rows(uint32_t* h_mt_key624, int* h_mt_pos, int n, int n_pts, long count, int isa, int* h_out) {
+  if (!h_mt_key624 || !h_mt_pos || n < 2 || n > 65536 || n_pts < 1 || n_pts > n || count < 0 || *h_mt_pos < 0 || *h_mt_pos > MT_N)
+    return CG_ERR_ARG;
+  if (count == 0) return CG_OK;
+  if (!h_out) return CG_ERR_ARG;
+  Stream S;
+  S.raw = new uint32_t[(size_t)RING_WORDS];
+  S.tmp = new uint32_t[(size_t)RING_WORDS + MIRROR];
+  uint16_t* row = new uint16_t[(size_t)n + 64];
+  uint16_t* perm = new uint16_t[(size_t)n];
+  S.wide = isa != 1 && cpu_has_avx512();
+  memcpy(S.raw, h_mt_key624, sizeof(uint32_t) * MT_N);
+  temper_block(S.raw, S.tmp);
+  S.fpos = S.start = *h_mt_pos;
+  if (S.wide) perm_rows_512(S, n, n_pts, count, row, perm, h_out); else perm_rows<false>(S, n, n_pts, count, row, perm, h_out);
+  if (S.fpos > S.start) {
+    const long b = (S.fpos - 1) / MT_N;
+    memcpy(h_mt_key624, S.raw + (b % RING) * MT_N, sizeof(uint32_t) * MT_N);
+    *h_mt_pos = (int)(S.fpos - b * MT_N);
+  }
+  delete[] perm; delete[] row; delete[] S.tmp; delete[] S.raw;
   return CG_OK;
 }

@@ -67,6 +67,11 @@ def _pin(shape, dtype):
 _PIN_LIMIT = 512 << 20       # per staging buffer; a larger chunk of swap partners (a > 30k-point cloud at 16,384 poses) goes pageable
 
 
+# Chunks of up to this many poses draw their resampling rows entirely on the host (numpy stream replay + swap chain, ~6 us per row)
+# instead of sending swap partners to the device: a swap chain is a dependent sequence wherever it runs, one lane of the device
+# needs ~250 us for it however few rows there are, so the device only wins when it runs thousands of chains side by side.
+_HOST_ROWS_MAX = 32
+
 _WORKER = []
 
 
@@ -198,6 +203,8 @@ class GraspPredicter:
                 ring[:] = [_pin((rows, width), dtype) for _ in range(min(2, len(bounds)))] + [None] * (2 - min(2, len(bounds)))
 
         def task(k, count):
+            if on_device and count <= _HOST_ROWS_MAX:      # a few poses: whole rows on the host (see _HOST_ROWS_MAX)
+                return torch.from_numpy(stream.draw(count))
             buf = ring[k & 1]
             if buf is None:
                 return torch.from_numpy(draw(count))
@@ -219,7 +226,7 @@ class GraspPredicter:
             submit(e)                                   # the next chunk is drawn while this one is uploaded and scored
             up = host.to(dev, non_blocking=True)
             uploaded[order[s] & 1] = _event()
-            return ops.apply_shuffle_rows(up, n_valid, n_pts) if on_device else up
+            return ops.apply_shuffle_rows(up, n_valid, n_pts) if host.dtype == torch.uint16 else up
 
         ids.ramp = (2048, 4096, 8192)
         ids.plan = set_plan

@@ -38,6 +38,13 @@ class NumpyChoiceStream:
         if out is None:
             out = np.empty((count, self.n_pts), dtype=np.int32)
         assert out.shape == (count, self.n_pts) and out.dtype == np.int32 and out.flags.c_contiguous
+        if self.on_device_chain:         # replace=False, n_valid <= 65536: vectorised partner extraction + the swap chain in L1
+            from . import _lib as L
+            rc = L.lib().cg_host_numpy_permutation_rows(self._key.ctypes.data_as(ct.c_void_p), ct.byref(self._pos), ct.c_int(self.n_valid),
+                                                        ct.c_int(self.n_pts), ct.c_long(count), ct.c_int(0), out.ctypes.data_as(ct.c_void_p))
+            if rc != 0:
+                raise RuntimeError(f'cg_host_numpy_permutation_rows failed with status {rc}')
+            return out
         rc = self._fn(self._key.ctypes.data_as(ct.c_void_p), ct.byref(self._pos), ct.c_int(self.n_valid), ct.c_int(self.n_pts),
                       ct.c_long(count), self._scratch.ctypes.data_as(ct.c_void_p), out.ctypes.data_as(ct.c_void_p))
         if rc != 0:

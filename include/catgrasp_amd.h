@@ -247,6 +247,11 @@ int cg_host_numpy_choice_rows(unsigned int* h_mt_key624, int* h_mt_pos, int n_va
  * rejection walk, and the swaps undone for the k tracked positions only.  isa 0 = AVX-512 when the CPU has it, 1 = the scalar twin.  HOST pointers, no device work. */
 int cg_host_numpy_choice_heads(unsigned int* h_mt_key624, int* h_mt_pos, int n, int k, long count, int isa, int* h_out);
 
+/* Whole rows of permutation(n)[:n_pts] on the host (2 <= n <= 65536, 1 <= n_pts <= n): the vectorised partner extraction of
+ * cg_host_numpy_choice_heads + the swap chain in L1, ~2x faster than cg_host_numpy_choice_rows.  Used for SMALL draws (a predict_batch
+ * call of a few poses), where shipping partners to the device would wait ~250 us for one lane's swap chain.  HOST pointers. */
+int cg_host_numpy_permutation_rows(unsigned int* h_mt_key624, int* h_mt_pos, int n, int n_pts, long count, int isa, int* h_out);
+
 /* The same draw with the swap chain on the device (n_pts <= n_valid <= 65536, the replace=False branch): the HOST part is only
  * what makes numpy's stream sequential -- the rejection-sampled Fisher-Yates swap partners j(i), i = n_valid-1 .. 1, of `count`
  * consecutive permutation(n_valid) calls, written as u16 at h_partners + r*row_stride + (n_valid-1-i) (row_stride >= n_valid-1,
