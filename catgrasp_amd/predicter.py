@@ -293,12 +293,14 @@ class GraspPredicter:
                 return []
             cloud = self.upload_cloud(data)
             n_pts = self.cfg['n_pts']
+            rng_state = None
             if ids is None:
                 rng = rng or self.rng
                 if rng == 'device':
                     ids_d = transforms.draw_ids_device(cloud.n, n_pts, G, self.device, seed=int(np.random.randint(0, 2 ** 31)))
                 elif rng == 'numpy':
-                    self._poses_f64(grasp_poses, 0, G)               # a malformed pose list fails before the generator is touched
+                    self._poses_f64(grasp_poses, 0, min(G, 64))      # the usual malformed pose list fails before the generator is touched
+                    rng_state = np.random.get_state()                # ... and a failure further down puts the generator back (below)
                     ids_d = self._numpy_id_chunks(cloud.n, n_pts, G)
                 else:
                     raise ValueError(f"rng must be 'numpy' or 'device', not {rng!r}")
@@ -312,6 +314,12 @@ class GraspPredicter:
             try:
                 with _gc_paused():
                     return self._predict_chunks(cloud, grasp_poses, ids_d, G)
+            except BaseException:
+                if hasattr(ids_d, 'close'):
+                    ids_d.close(); ids_d.close = lambda: None
+                if rng_state is not None:        # the worker had drawn ahead of the failing chunk: a failed call consumes nothing
+                    np.random.set_state(rng_state)
+                raise
             finally:
                 if hasattr(ids_d, 'close'):
                     ids_d.close()
