@@ -105,36 +105,51 @@ template <bool WIDE> void perm_rows(struct Stream& S, int n, int n_pts, long cou
 
 // one round of the accept recurrence over NV vectors: b = (v + #accepts of `a` before the word <= i)
 template <int NV>
-CG_T512 inline void accept_round(const __m512i* v, const __mmask16* a, __mmask16* b, __m512i vi) {
+CG_T512 inline uint32_t accept_round(const __m512i* v, const __mmask16* a, __mmask16* b, __m512i vi, __m512i* sum = nullptr) {
   const __m512i lane_low = CG_LANE_LOW;
   uint32_t base = 0;
 #pragma unroll
   for (int q = 0; q < NV; ++q) {
     __m512i cnt = _mm512_popcnt_epi32(_mm512_and_si512(_mm512_set1_epi32((int)(uint32_t)a[q]), lane_low));
     if (q) cnt = _mm512_add_epi32(cnt, _mm512_set1_epi32((int)base));
-    b[q] = _mm512_cmple_epu32_mask(_mm512_add_epi32(v[q], cnt), vi);
+    const __m512i sm = _mm512_add_epi32(v[q], cnt);
+    if (sum) sum[q] = sm;
+    b[q] = _mm512_cmple_epu32_mask(sm, vi);
     base += (uint32_t)_mm_popcnt_u32((uint32_t)a[q]);
   }
+  return base;                                           // number of accepts in `a`
 }
 
 // NV x 16 words under one mask, none of which can reach the mask boundary (the caller checks i - lim > 16 NV)
 template <int NV>
 CG_T512 inline void walk_group(const uint32_t* w, __m512i vmask, uint32_t& i, uint16_t* o, int& s) {
   const __m512i vi = _mm512_set1_epi32((int)i);
-  __m512i v[NV];
+  __m512i v[NV], sum[NV];
   __mmask16 a[NV], b[NV];
 #pragma unroll
   for (int q = 0; q < NV; ++q) {
     v[q] = _mm512_and_si512(_mm512_loadu_si512((const void*)(w + 16 * q)), vmask);
-    b[q] = _mm512_cmple_epu32_mask(v[q], vi);            // upper bound: as if nothing had been accepted before the word
+    b[q] = _mm512_cmple_epu32_mask(v[q], vi);            // a0, upper bound: as if nothing had been accepted before the word
   }
-  accept_round<NV>(v, b, a, vi);                          // lower bound; exact unless an earlier word of the group flipped
-  for (;;) {       // always checked by a further round (skipping it when the first round changed nothing costs more in mispredicted branches)
-    accept_round<NV>(v, a, b, vi);
-    uint32_t diff = 0;
+  const uint32_t n0 = accept_round<NV>(v, b, a, vi, sum); // a1 = (v + count0 <= i), a subset of a0 and a lower bound of the answer
+  // Is a1 the answer?  With f = |a0 \ a1| words flipped, a word's true count lies in [count0 - f, count0]: the answer can differ from
+  // a1 only in a word with v + count0 in (i, i + f].  One more compare per vector, at threshold i + f, rules that out (and repeats a1
+  // outright when f = 0) -- instead of a whole further round of prefix counts.
+  uint32_t n1 = 0;
 #pragma unroll
-    for (int q = 0; q < NV; ++q) { diff |= (uint32_t)(a[q] ^ b[q]); a[q] = b[q]; }
-    if (__builtin_expect(diff == 0, 1)) break;            // a fixed point of the recurrence is the sequential answer
+  for (int q = 0; q < NV; ++q) n1 += (uint32_t)_mm_popcnt_u32((uint32_t)a[q]);
+  const __m512i vif = _mm512_set1_epi32((int)(i + (n0 - n1)));
+  uint32_t diff = 0;
+#pragma unroll
+  for (int q = 0; q < NV; ++q) diff |= (uint32_t)(_mm512_cmple_epu32_mask(sum[q], vif) ^ a[q]);
+  if (__builtin_expect(diff != 0, 0)) {                   // rare: iterate to the fixed point of the recurrence = the sequential answer
+    for (;;) {
+      accept_round<NV>(v, a, b, vi);
+      diff = 0;
+#pragma unroll
+      for (int q = 0; q < NV; ++q) { diff |= (uint32_t)(a[q] ^ b[q]); a[q] = b[q]; }
+      if (diff == 0) break;
+    }
   }
   uint32_t nacc = 0;
 #pragma unroll

@@ -44,8 +44,9 @@ __device__ void jacobi3(double S[3][3], double V[3][3], double e[3]) {
 }
 
 // hypothesis model from 4 correspondences; returns false if rejected.  T: row-major [R diag(s) | t] (3x4), Ti its inverse.
-__device__ bool hypothesis(const RansacArgs& a, const int* id, double T[12], double Ti[12]) {
-  double M[4][7];   // [sx sy sz 1 | dx dy dz]
+// M: the 4 x 7 system [sx sy sz 1 | dx dy dz] in LDS -- the pivot search indexes its rows dynamically, which as a private array put the
+// kernel into scratch memory (240 B private segment)
+__device__ bool hypothesis(const RansacArgs& a, const int* id, double T[12], double Ti[12], double (*M)[7]) {
   for (int r = 0; r < 4; ++r) {
     const double* s = a.src + (size_t)id[r] * 3; const double* d = a.dst + (size_t)id[r] * 3;
     M[r][0] = s[0]; M[r][1] = s[1]; M[r][2] = s[2]; M[r][3] = 1.0; M[r][4] = d[0]; M[r][5] = d[1]; M[r][6] = d[2];
@@ -96,14 +97,14 @@ __device__ __forceinline__ double wave_min(double v) { for (int o = 32; o > 0; o
 __device__ __forceinline__ double wave_max(double v) { for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o)); return v; }
 
 __global__ __launch_bounds__(256) void ransac_9d_kernel(RansacArgs a) {
-  __shared__ double sT[12], sTi[12];
+  __shared__ double sT[12], sTi[12], sM[4][7];
   __shared__ int s_ok;
   __shared__ double red[4][6];
   __shared__ int redc[4];
   const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   if (tid == 0) {
     double T[12], Ti[12];
-    const bool ok = hypothesis(a, a.ids + (size_t)h * 4, T, Ti);
+    const bool ok = hypothesis(a, a.ids + (size_t)h * 4, T, Ti, sM);
     s_ok = ok;
     if (ok) for (int k = 0; k < 12; ++k) { sT[k] = T[k]; sTi[k] = Ti[k]; }
   }

@@ -104,10 +104,11 @@ def voxelize(pts, resolution, device=None):
 
 
 class CollisionManager:
-    """my_cpp.CollisionManager (collision_manager.h:55-69).  Objects are triangle meshes (posed by
-    setTransform) and voxelised point clouds (identity pose only: the reference never moves the octree).
-    isAnyCollision tests every mesh/cloud pair; mesh/mesh and cloud/cloud pairs, which the reference
-    pipeline never registers together, raise NotImplementedError."""
+    """my_cpp.CollisionManager (collision_manager.h:55-69).  Objects are triangle meshes and voxelised point clouds (octomap leaves at
+    the registered resolution), each posed by setTransform.  isAnyCollision tests every {mesh, cloud} pair -- the only kind the
+    reference registers together (common.cpp:176-182) -- with the mesh expressed in the cloud's frame, inv(cloud pose) . mesh pose (the
+    reference never moves its octrees; a posed cloud is the same leaf boxes seen from another frame).  mesh/mesh and cloud/cloud
+    pairs raise NotImplementedError instead of answering something else (contract table)."""
 
     def __init__(self):
         self._obs = []
@@ -127,8 +128,8 @@ class CollisionManager:
     def setTransform(self, pose, ob_id):
         pose = _mat4(pose, 'pose')
         ob = self._obs[ob_id]
-        if ob['kind'] == 'cloud' and not np.array_equal(pose, np.eye(4, dtype=np.float32)):
-            raise NotImplementedError('posing a registered point cloud is not supported (reference never does)')
+        if ob['kind'] == 'cloud' and abs(float(np.linalg.det(pose[:3, :3].astype(np.float64))) - 1.0) > 1e-3:
+            raise ValueError('a registered point cloud can only be posed rigidly (its leaf boxes are re-expressed, not re-sampled)')
         ob['pose'] = pose
 
     def isAnyCollision(self):
@@ -138,7 +139,10 @@ class CollisionManager:
                 if a['kind'] == b['kind']:
                     raise NotImplementedError(f"{a['kind']}/{b['kind']} pairs are not supported")
                 mesh, cloud = (a, b) if a['kind'] == 'mesh' else (b, a)
-                pose = torch.from_numpy(mesh['pose'].reshape(1, 16)).to(self._dev)
+                rel = mesh['pose']
+                if not np.array_equal(cloud['pose'], np.eye(4, dtype=np.float32)):        # the mesh as seen from the cloud's frame
+                    rel = (np.linalg.inv(cloud['pose'].astype(np.float64)) @ mesh['pose'].astype(np.float64)).astype(np.float32)
+                pose = torch.from_numpy(np.ascontiguousarray(rel).reshape(1, 16)).to(self._dev)
                 out = torch.zeros((1,), dtype=torch.uint8, device=self._dev)
                 check(L.lib().cg_mesh_voxels_collide(_p(mesh['V']), _p(mesh['F']), _c_int(mesh['F'].shape[0]), _p(pose), _c_long(1),
                                                      _p(cloud['keys']), _c_int(cloud['keys'].shape[0]), ctypes.c_float(cloud['res']),

@@ -221,8 +221,11 @@ class GraspPredicter:
             if not plan:
                 set_plan([(a, min(G, a + chunk)) for a in range(0, G, chunk)])
             assert plan.get(s) == e, 'chunks must be asked for in the planned order'
-            submit(s)
-            host = pending.pop(s).result()
+            if s not in pending and e - s <= _HOST_ROWS_MAX:      # a few rows: drawn right here, a thread hand-over costs more than the draw
+                host = task(order[s], e - s)
+            else:
+                submit(s)
+                host = pending.pop(s).result()
             submit(e)                                   # the next chunk is drawn while this one is uploaded and scored
             up = host.to(dev, non_blocking=True)
             uploaded[order[s] & 1] = _event()

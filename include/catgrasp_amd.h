@@ -11,6 +11,8 @@
  */
 #ifndef CATGRASP_AMD_H
 #define CATGRASP_AMD_H
+#include <stddef.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -90,6 +92,25 @@ int cg_pointmlp_max_f16fp8x2(const float* x, int B, int N, const float* t3, cons
 int cg_gemm_bias_act(const float* x, int M, int K, int ldx, const float* w_packed, int N,
                      const float* bias, const float* row_bias, int rows_per_group, int ld_rb,
                      int relu, int eye_k, float* y, int ldy, void* stream);
+
+/* PointNetCls.forward (pointnet2.py:289-299; eval mode, exact-f32 kernels) as ONE call: the three cg_pointmlp_max passes and nine
+ * cg_gemm_bias_act layers issued back to back -- the launch chain of a predict_batch call of a few poses without ~10 us of caller-side
+ * work per launch.  Same kernels, arguments and order as issuing them one by one: identical results.
+ * w: HOST struct of DEVICE pointers to the BatchNorm-folded, packed weights (catgrasp_amd.folding.prepare_cls; names as there).
+ * ws: caller-owned device workspace of cg_pointnet_cls_workspace_floats(B) floats, 16-byte aligned.  logits: (B, n_out).
+ * *trans_feat_t (optional, HOST pointer to a device pointer): receives the address, inside ws, of the (B,64,64) feature transform,
+ * TRANSPOSED like cg_pointmlp_max's t64 (PointNetCls returns it as trans_feat, pointnet2.py:299). */
+typedef struct cg_cls_weights {
+  const float *stn_w1, *stn_b1, *stn_w2, *stn_b2, *stn_w3, *stn_b3, *stn_fc1, *stn_fc1b, *stn_fc2, *stn_fc2b, *stn_fc3, *stn_fc3b;
+  const float *enc_w1, *enc_b1, *fstn_wm, *fstn_bm, *fstn_w2, *fstn_b2, *fstn_w3, *fstn_b3;
+  const float *fstn_fc1, *fstn_fc1b, *fstn_fc2, *fstn_fc2b, *fstn_fc3, *fstn_fc3b;
+  const float *enc_w2, *enc_b2, *enc_w3, *enc_b3;
+  const float *head_fc1, *head_fc1b, *head_fc2, *head_fc2b, *head_fc3, *head_fc3b;
+  int n_out;
+} cg_cls_weights;
+size_t cg_pointnet_cls_workspace_floats(int B);
+int cg_pointnet_cls_forward(const float* x, int B, int N, const cg_cls_weights* h_weights, int nsplit, float* workspace, float* logits,
+                            float** trans_feat_t, void* stream);
 
 /* Split-precision ("bf16x3") variant of cg_gemm_bias_act for the wide FC tails / segmentation head: every product block
  * is three bf16 MFMAs with f32 accumulation, X is split on the fly, W is split-packed on the host

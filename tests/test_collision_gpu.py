@@ -169,6 +169,25 @@ def test_collision_manager_api(cuda_device):
         cm.setTransform(np.eye(3), gid)
     with pytest.raises(ValueError):
         cm.registerMesh(np.zeros((4, 2)), np.zeros((1, 3), dtype=np.int32))
+    # a rigidly posed cloud (collision_manager.cpp:81-91 lets any object be posed): the same leaf boxes seen from another frame, i.e.
+    # the oracle's answer for the mesh pose inv(cloud pose) . mesh pose
+    Tc = np.eye(4); Tc[:3, :3] = synth.random_rotation(np.random.default_rng(3)); Tc[:3, 3] = [0.02, -0.01, 0.03]
+    cm.setTransform(Tc.astype(np.float32), cid)
+    n_hit = 0
+    for p in P:
+        pose_w = (Tc @ p @ g['gripper_in_grasp']).astype(np.float32)                  # the gripper moved along with the cloud ...
+        cm.setTransform(pose_w, gid)
+        rel = (np.linalg.inv(Tc.astype(np.float32).astype(np.float64)) @ pose_w.astype(np.float64)).astype(np.float32)
+        got = cm.isAnyCollision()
+        assert got == co.mesh_voxels_collide(g['vertices'], g['faces'], rel, okeys, 0.0005)
+        n_hit += int(got)
+    assert 0 < n_hit < len(P)                                                          # ... so the verdicts are those of the unposed scene
+    with pytest.raises(ValueError):                     # a cloud can be moved, not scaled
+        cm.setTransform(np.diag([2.0, 2.0, 2.0, 1.0]).astype(np.float32), cid)
+    cm2 = my_cpp.CollisionManager()
+    cm2.registerMesh(g['vertices'], g['faces']); cm2.registerMesh(g['vertices'], g['faces'])
+    with pytest.raises(NotImplementedError):            # documented contract limit: mesh / mesh and cloud / cloud pairs
+        cm2.isAnyCollision()
 
 
 def test_tri_box_predicate_random_and_grazing(cuda_device):
