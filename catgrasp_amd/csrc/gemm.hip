@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void gemm_bias_act_kernel(GemmArgs a) {
   }
 }
 
-// The same layer for FEW rows (the FC tails of a predict_batch call of 1 .. ~1,000 poses: the reference scores a few hundred per
+// The same layer for FEW output tiles (the FC tails of a predict_batch call of 1 .. ~1,000 poses: the reference scores a few hundred per
 // object, predicter.py:67-94).  The tile kernel above gives a 64 x 128 output tile to a workgroup: at M <= 64 and N = 512 that is 4
 // workgroups on 4 of 256 CUs, each streaming 128 KB of weights through one MFMA chain per wave -- 42-53 us per launch, nine launches
 // per call, i.e. 0.4 ms of a 1 ms call whatever the number of poses.  Here ONE WAVEFRONT owns a 32 x 32 output tile and walks the
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void gemm_bias_act_small_kernel(GemmArgs a) {
   }
 }
 
-constexpr int SMALL_M = 1024;      // rows up to which the wavefront-per-tile kernel is used (measured: profiles/r4_gemm_small.txt)
+constexpr long SMALL_TILES = 2048;  // 32 x 32 output tiles up to which the wavefront-per-tile kernel is used (measured: profiles/r4_gemm_small.txt)
 
 }  // namespace
 
@@ -167,9 +167,9 @@ extern "C" int cg_gemm_bias_act(const float* x, int M, int K, int ldx, const flo
   if (row_bias && (rows_per_group <= 0 || ld_rb < N)) return CG_ERR_ARG;
   if (M == 0) return CG_OK;
   GemmArgs a{x, M, K, ldx, w_packed, N, (N + 31) / 32, bias, row_bias, rows_per_group, ld_rb, relu, eye_k, y, ldy};
-  static const int small_m = getenv("CATGRASP_AMD_GEMM_SMALL_M") ? atoi(getenv("CATGRASP_AMD_GEMM_SMALL_M")) : SMALL_M;   // dev knob
-  if (M <= small_m) {
-    const long tiles = (long)((M + 31) / 32) * a.nblocks;
+  static const long small_tiles = getenv("CATGRASP_AMD_GEMM_SMALL_TILES") ? atol(getenv("CATGRASP_AMD_GEMM_SMALL_TILES")) : SMALL_TILES;   // dev knob
+  const long tiles = (long)((M + 31) / 32) * a.nblocks;
+  if (tiles <= small_tiles) {
     hipLaunchKernelGGL(gemm_bias_act_small_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
     return cg_hip_status(hipGetLastError());
   }

@@ -1,5 +1,5 @@
 """dev: the FC-tail layers (1024->512, 512->256, 256->4096) for M = 1 .. 16384 rows through cg_gemm_bias_act, HIP events, 50 launches;
-CATGRASP_AMD_GEMM_SMALL_M=0 forces the tile kernel, a large value the wavefront-per-tile kernel: the crossover behind SMALL_M."""
+CATGRASP_AMD_GEMM_SMALL_TILES=0 forces the tile kernel, a large value the wavefront-per-tile kernel: the crossover behind SMALL_M."""
 import sys
 import numpy as np, torch
 sys.path.insert(0, '.')

@@ -11,6 +11,6 @@ done
 timeout 300 python scripts/sa_layer_time.py $O/sa_layer.json > $O/sa_layer.txt 2>&1
 timeout 300 python scripts/bf16_single_product_hw.py $O/bf16_single_product.json > $O/bf16_single_product.txt 2>&1
 for m in 0 100000; do
-echo "== CATGRASP_AMD_GEMM_SMALL_M=$m" >> $O/gemm_small.txt
-CATGRASP_AMD_GEMM_SMALL_M=$m timeout 200 python scripts/gemm_small_time.py >> $O/gemm_small.txt 2>&1
+echo "== CATGRASP_AMD_GEMM_SMALL_TILES=$m" >> $O/gemm_small.txt
+CATGRASP_AMD_GEMM_SMALL_TILES=$m timeout 200 python scripts/gemm_small_time.py >> $O/gemm_small.txt 2>&1
 done

@@ -4,7 +4,7 @@ export TMPDIR=/tmp
 O=gpurun_out/r4batch3; rm -rf $O; mkdir -p $O
 timeout 900 python -m pytest tests/test_primitives_gpu.py tests/test_pointnet_gpu.py tests/test_pointnet_blocks_gpu.py tests/test_predicter_gpu.py tests/test_collision_gpu.py tests/test_aligning_gpu.py -x -q > $O/tests.txt 2>&1; tail -4 $O/tests.txt
 timeout 300 python scripts/time_predict_small.py > $O/predict_small.txt 2>&1
-CATGRASP_AMD_GEMM_SMALL_M=100000 timeout 200 python scripts/gemm_small_time.py > $O/gemm_small.txt 2>&1
+CATGRASP_AMD_GEMM_SMALL_TILES=100000 timeout 200 python scripts/gemm_small_time.py > $O/gemm_small.txt 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/tr1 -- python scripts/prof_predict_small2.py 1 device > $O/tr1.log 2>&1
 find $O/tr1 -name '*kernel_stats.csv' -exec cp {} $O/kernel_stats_1.csv \; ; rm -rf $O/tr1
 python scripts/time_heads_draw.py > $O/heads_draw.txt 2>&1

@@ -60,3 +60,41 @@ def test_seg_forward_matches_oracle(cuda_device, B, N):
     assert y.shape == (B, N, 300)
     _close(y.cpu(), ref_y, 'seg logits')
     _close(tf.cpu(), ref_tf, 'trans_feat')
+
+
+def test_dense_layer_bits_do_not_depend_on_the_kernel_or_the_batch(cuda_device):
+    """cg_gemm_bias_act takes a wavefront-per-tile kernel for few output tiles (<= 2,048 of 32 x 32) and the workgroup-tile kernel
+    beyond; both issue the same sequence of exact-f32 MFMAs per output element, so a row's result must not depend on how many rows
+    were computed with it -- bit for bit, against a float64 product within float32 rounding, for the FC shapes of the networks, odd K
+    tails (K = 72: not a multiple of the 8-k-step pipeline) and every epilogue option.  And the one-call PointNetCls forward
+    (cg_pointnet_cls_forward, batches <= 1,024) == the launch-by-launch chain."""
+    from catgrasp_amd import engine, folding, ops
+    rng = np.random.default_rng(3)
+    for K, N, relu, eye in ((1024, 512, True, 0), (512, 256, True, 0), (256, 4096, False, 64), (256, 10, False, 0), (72, 96, True, 0)):
+        w = rng.normal(0, 0.05, (N, K)).astype(np.float32); b = rng.normal(0, 0.1, N).astype(np.float32)
+        wp = torch.from_numpy(folding.pack_b(w)).to(cuda_device); bd = torch.from_numpy(b).to(cuda_device)
+        nb = (N + 31) // 32
+        m_small = max(32, (2048 // nb) * 32)                  # the largest row count the wavefront-per-tile kernel takes
+        M = m_small + 64                                       # ... and one the tile kernel takes
+        x = torch.from_numpy(rng.normal(0, 1, (M, K)).astype(np.float32)).to(cuda_device)
+        y_big = ops.gemm_bias_act(x, wp, N, bd, relu=relu, eye_k=eye)
+        for m in (1, 5, 33, m_small):
+            y = ops.gemm_bias_act(x[:m].contiguous(), wp, N, bd, relu=relu, eye_k=eye)
+            assert torch.equal(y, y_big[:m]), (K, N, m)
+        ref = x[:64].double().cpu().numpy() @ w.astype(np.float64).T + b
+        if eye:
+            ref += np.eye(eye).reshape(-1)
+        if relu:
+            ref = np.maximum(ref, 0)
+        assert np.abs(y_big[:64].double().cpu().numpy() - ref).max() < 2e-4
+    sd = synth.make_state_dict('cls', 6, 10, seed=9)
+    W = folding.prepare_cls(sd, cuda_device)
+    x = torch.from_numpy(rng.normal(0, 0.3, (37, 300, 6)).astype(np.float32)).to(cuda_device)
+    with engine.precision('f32'):
+        one_call = engine.cls_forward(W, x)
+        old, engine.FUSED_LAUNCH_MAX_B = engine.FUSED_LAUNCH_MAX_B, 0
+        try:
+            chain = engine.cls_forward(W, x)
+        finally:
+            engine.FUSED_LAUNCH_MAX_B = old
+    assert torch.equal(one_call[0], chain[0]) and torch.equal(one_call[1], chain[1])
