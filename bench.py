@@ -586,16 +586,18 @@ def main():
     measured_traffic = {}
 
     def roofline(precision, r):
-        per = PMC_HBM_BYTES_PER_CANDIDATE[precision]
-        source = ('constant from profiles/r2_pmc_hbm_pointmlp_{f32,split,f16fp8x2}.csv (2*FETCH_SIZE + WRITE_SIZE per candidate at B=4096) x candidates per '
-                  'launch -- not a counter read in this run; algorithmic bytes are 69,632 B/candidate')
+        # traffic is reported only when it was MEASURED for this run (primary precision, N = 1, rocprofv3 present); otherwise null plus
+        # the round-2 PMC constant under its own name -- not a counter read in this run
+        per, source = None, ('not measured in this run; `traffic_round2_constant` = profiles/r2_pmc_hbm_pointmlp_{f32,split,f16fp8x2}.csv '
+                             '(2*FETCH_SIZE + WRITE_SIZE per candidate at B=4096) x candidates per launch; algorithmic bytes are 69,632 B/candidate')
         if precision in measured_traffic:
             per, source = measured_traffic[precision]
         hbm_gbs = ALG_HBM_BYTES_PER_CANDIDATE * r['avg_cand'] / (r['avg_ms'] * 1e-3) / 1e9
         common = {'achieved': round(r['tflops'], 2), 'unit': 'TFLOP/s', 'avg_launch_ms': round(r['avg_ms'], 4), 'launches': r['launches'],
                   'candidates_per_launch': round(r['avg_cand'], 1), 'flop_per_candidate_launch': 2 * MAC_PER_POINT_ENC * 2048,
-                  'traffic': int(per * r['avg_cand']),
+                  'traffic': int(per * r['avg_cand']) if per is not None else None,
                   'traffic_source': source,
+                  'traffic_round2_constant': int(PMC_HBM_BYTES_PER_CANDIDATE[precision] * r['avg_cand']),
                   'hbm_achieved_gbs': round(hbm_gbs, 1), 'hbm_frac': round(hbm_gbs / PEAK_HBM_GBS, 5)}
         if precision == 'f32':
             return dict({'bound': 'mfma', 'kernel': 'pointmlp_max_kernel<2> (encoder pass: conv1, x.T64, conv2, conv3, max; exact-f32 MFMA)',

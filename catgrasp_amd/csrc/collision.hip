@@ -94,13 +94,16 @@ __device__ __forceinline__ bool tri_box_overlap(const float* c, float h, const f
 // Optional broad phase: a uniform grid in the MESH frame; cell (i,j,k) lists every triangle whose box, inflated by the
 // grid's build margin, overlaps the cell (CSR: cell_start, tri_ids).  Built on the device (cg_mesh_grid_count / _fill).
 // tri_verts (optional): the triangles as a flat (nf,12) float array [v0 v1 v2 pad] -- one indirection less than F -> V.
-struct Grid { float ox, oy, oz, inv_cell; int nx, ny, nz; const int* cell_start; const int* tri_ids; const float* tri_verts; float res_built; };
+struct Grid { float ox, oy, oz, inv_cell; int nx, ny, nz; const int* cell_start; const int* tri_ids; const float* tri_verts; float res_built;
+              const unsigned char* coarse; };    // coarse (optional): 1 per 4 x 4 x 4 block of cells that holds a non-empty cell
 struct Mesh { const float* V; const int* F; int nf; Grid grid; int has_grid; };
-struct Voxels { const short* keys; int nk; };   // (nk,4) int16: key-32768 per axis, 4th unused
+struct Voxels { const short* keys; int nk; const short* blocks; };   // keys (nk,4) int16: key-32768 per axis, 4th unused; blocks (optional):
+                                                                     // (ceil(nk/64), 2, 4) int16 = lowest / highest key of every run of 64 keys
 
 constexpr int PAIR_CAP = 512;              // (voxel, triangle) pairs a wave queues in LDS before it tests them
 constexpr int PAIR_DRAIN = 256;            // ... and the fill from which it does (a test round occupies all 64 lanes but the last)
-struct alignas(16) PairList { short4 key[PAIR_CAP]; int tri[PAIR_CAP]; float T[12]; };   // + the posed-gripper matrix (rows 0..2) of the test in flight
+constexpr int BMASK_WORDS = 64;           // voxel blocks whose relevance is decided up front: 64 x 64 blocks = 262,144 voxels per set
+struct alignas(16) PairList { short4 key[PAIR_CAP]; int tri[PAIR_CAP]; float T[12]; float Ab[12]; unsigned long long bmask[BMASK_WORDS]; };   // Ab: the key -> cell map   // + the posed-gripper matrix (rows 0..2) of the test in flight
 
 __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -128,14 +131,24 @@ __device__ __forceinline__ bool grid_usable(const Grid& g, const float* T, float
 // voxel key -> grid coordinate as ONE affine map: f = inv_cell (I (res (k + 1/2) - t) - origin) = A k + b.  (12 scalars and 9 FMAs per
 // voxel instead of centre, difference, 3x3 product, offset and scale: the broad phase is 60 % of the grid kernel's instructions.  The
 // rounding differs from the step-by-step form by ~1e-7 m, against a list margin of 3e-5 m.)
-__device__ __forceinline__ void grid_affine(const Grid& g, const float* T, const float* I, float res, float* A, float* b) {
+// Written to LDS (pl->Ab: A row-major, then b) and read back per pass of the voxel loop: as 12 scalars it would sit in scalar registers
+// across the whole loop, which has none to spare.
+__device__ __forceinline__ void grid_affine(const Grid& g, const float* T, const float* I, float res, PairList* pl, int lane) {
+  float A[9], b[3];
 #pragma unroll
   for (int r = 0; r < 3; ++r) {
     const float o = r == 0 ? g.ox : (r == 1 ? g.oy : g.oz);
 #pragma unroll
-    for (int c = 0; c < 3; ++c) A[r * 3 + c] = uni((I[r * 3 + c] * res) * g.inv_cell);
-    b[r] = uni(((I[r * 3] * (0.5f * res - T[3]) + I[r * 3 + 1] * (0.5f * res - T[7])) + I[r * 3 + 2] * (0.5f * res - T[11]) - o) * g.inv_cell);
+    for (int c = 0; c < 3; ++c) A[r * 3 + c] = (I[r * 3 + c] * res) * g.inv_cell;
+    b[r] = ((I[r * 3] * (0.5f * res - T[3]) + I[r * 3 + 1] * (0.5f * res - T[7])) + I[r * 3 + 2] * (0.5f * res - T[11]) - o) * g.inv_cell;
   }
+  wave_lds_sync();
+  if (lane == 0) {
+    *(float4*)(pl->Ab) = make_float4(A[0], A[1], A[2], A[3]);
+    *(float4*)(pl->Ab + 4) = make_float4(A[4], A[5], A[6], A[7]);
+    *(float4*)(pl->Ab + 8) = make_float4(A[8], b[0], b[1], b[2]);
+  }
+  wave_lds_sync();
 }
 
 // narrow phase over the queued pairs, 64 at a time: every lane poses ITS triangle by T and runs the float32 SAT against ITS voxel
@@ -177,21 +190,90 @@ __device__ __forceinline__ bool wave_test_pairs(const Mesh& mesh, const PairList
 // uneven and most voxels have none (6 % of the lane slots of a per-lane loop did useful work on the 9k-triangle gripper), so the
 // narrow phase runs over the flat queue with every lane busy.  The narrow phase is the SAME float32 SAT on the SAME posed vertices
 // as the exhaustive kernel, and "any pair hits" does not depend on the order of the pairs: identical results.
-__device__ __forceinline__ bool wave_grid_collide(const Mesh& mesh, const float* A, const float* b, const Voxels& vox, float res, PairList* pl,
-                                                  int lane, unsigned* work) {
+// Which of the 64 voxel blocks bb .. bb+63 can hold a voxel whose cell has a triangle list?  Lane j looks at block bb + j: the box of
+// its keys, mapped into grid coordinates (centre by the affine map, extent by |A|), against the grid's bounds and -- when the box covers
+// at most 3 x 3 x 3 coarse cells -- against the coarse occupancy.  Conservative (1e-3 cells of slack for the two roundings of f).
+__device__ __forceinline__ unsigned long long relevant_blocks(const Grid& g, const PairList* pl, const Voxels& vox, int nblocks, int bb, int lane) {
+  float A[9], b[3];
+  { const float4 q0 = *(const float4*)(pl->Ab), q1 = *(const float4*)(pl->Ab + 4), q2 = *(const float4*)(pl->Ab + 8);
+    A[0] = q0.x; A[1] = q0.y; A[2] = q0.z; A[3] = q0.w; A[4] = q1.x; A[5] = q1.y; A[6] = q1.z; A[7] = q1.w; A[8] = q2.x; b[0] = q2.y; b[1] = q2.z; b[2] = q2.w; }
+  const int blk = bb + lane;
+  bool keep = blk < nblocks;
+  if (keep && vox.blocks) {
+    const short4 lo = ((const short4*)vox.blocks)[2 * blk], hi = ((const short4*)vox.blocks)[2 * blk + 1];
+    const float cx = 0.5f * ((float)lo.x + (float)hi.x), cy = 0.5f * ((float)lo.y + (float)hi.y), cz = 0.5f * ((float)lo.z + (float)hi.z);
+    const float hx = 0.5f * ((float)hi.x - (float)lo.x), hy = 0.5f * ((float)hi.y - (float)lo.y), hz = 0.5f * ((float)hi.z - (float)lo.z);
+    int c0[3], c1[3];
+    const int n[3] = {g.nx, g.ny, g.nz};
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const float fc = fmaf(A[r * 3], cx, fmaf(A[r * 3 + 1], cy, fmaf(A[r * 3 + 2], cz, b[r])));
+      const float rad = fmaf(fabsf(A[r * 3]), hx, fmaf(fabsf(A[r * 3 + 1]), hy, fabsf(A[r * 3 + 2]) * hz)) + 1e-3f;
+      const float f0 = fc - rad, f1 = fc + rad;
+      if (f1 < 0.f || f0 >= (float)n[r]) keep = false;
+      c0[r] = f0 > 0.f ? (int)f0 : 0;
+      c1[r] = f1 < (float)(n[r] - 1) ? (int)f1 : n[r] - 1;
+    }
+    if (keep && g.coarse) {
+      const int s0x = c0[0] >> 2, s1x = c1[0] >> 2, s0y = c0[1] >> 2, s1y = c1[1] >> 2, s0z = c0[2] >> 2, s1z = c1[2] >> 2;
+      if ((s1x - s0x) <= 2 && (s1y - s0y) <= 2 && (s1z - s0z) <= 2) {
+        const int nsy = (g.ny + 3) >> 2, nsz = (g.nz + 3) >> 2;
+        int occ = 0;
+        for (int x = s0x; x <= s1x; ++x)
+          for (int y = s0y; y <= s1y; ++y)
+            for (int z = s0z; z <= s1z; ++z) occ |= g.coarse[(x * nsy + y) * nsz + z];
+        keep = occ != 0;
+      }
+    }
+  }
+  return __ballot(keep);
+}
+
+__device__ __forceinline__ bool wave_grid_collide(const Mesh& mesh, const Voxels& vox, float res, PairList* pl, int lane, unsigned* work) {
   const Grid& g = mesh.grid;
   int fill = 0;
-  // One loop, one place where the queue is tested: a pass either looks up the next 128 voxels (two per lane: the two dependent
-  // load chains key -> cell -> list run side by side) or, once the voxels are exhausted, only flushes what is queued.
-  for (int v0 = 0;; v0 += 128) {
-    const bool last = v0 >= vox.nk;
-    int cnt[2] = {0, 0}, e0[2] = {0, 0};
-    short4 k[2];
+  const int nblocks = (vox.nk + 63) >> 6;
+  // which blocks of 64 voxels are worth a visit: decided for the whole set up front (a bit per block, kept in LDS), so that the state of
+  // that decision -- block boxes, coarse occupancy -- is not alive in the loop below
+  const int nwords = (nblocks + 63) >> 6;
+  wave_lds_sync();
+  for (int wd = 0; wd < nwords && wd < BMASK_WORDS; ++wd) {
+    const unsigned long long m = relevant_blocks(g, pl, vox, nblocks, wd * 64, lane);
+    if (lane == 0) pl->bmask[wd] = m;
+  }
+  wave_lds_sync();
+  int bb = -64;                                            // the 64 blocks under consideration: bb .. bb+63, `km` = those still to visit
+  unsigned long long km = 0ull;
+  // One loop, one place where the queue is tested: a pass either looks up the 2 x 64 voxels of the next two relevant blocks (two per
+  // lane: the two dependent load chains key -> cell -> list run side by side) or, once the blocks are exhausted, only flushes the queue.
+  for (;;) {
+    int blk[2] = {-1, -1};
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      const int v = v0 + 64 * u + lane;
+      while (km == 0ull && bb + 64 < nblocks) {
+        bb += 64;
+        const int wd = bb >> 6;
+        const int left = nblocks - bb;                     // blocks beyond the up-front table (a set of > 262,144 voxels) are all visited
+        unsigned long long w = left >= 64 ? ~0ull : ((1ull << left) - 1ull);
+        if (wd < BMASK_WORDS) {
+          const unsigned long long t = pl->bmask[wd];        // the same word in every lane: keep it in scalar registers
+          w = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(t >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)t);
+        }
+        km = w;
+      }
+      if (km != 0ull) { blk[u] = bb + __builtin_ctzll(km); km &= km - 1ull; }
+    }
+    const bool last = blk[0] < 0;
+    int cnt[2] = {0, 0}, e0[2] = {0, 0};
+    short4 k[2];
+    float A[9], b[3];
+    { const float4 q0 = *(const float4*)(pl->Ab), q1 = *(const float4*)(pl->Ab + 4), q2 = *(const float4*)(pl->Ab + 8);
+      A[0] = q0.x; A[1] = q0.y; A[2] = q0.z; A[3] = q0.w; A[4] = q1.x; A[5] = q1.y; A[6] = q1.z; A[7] = q1.w; A[8] = q2.x; b[0] = q2.y; b[1] = q2.z; b[2] = q2.w; }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int v = blk[u] * 64 + lane;
       k[u] = make_short4(0, 0, 0, 0);
-      if (v < vox.nk) {
+      if (blk[u] >= 0 && v < vox.nk) {
         k[u] = ((const short4*)vox.keys)[v];
         work[0] += 1u;
         const float kx = (float)k[u].x, ky = (float)k[u].y, kz = (float)k[u].z;
@@ -363,7 +445,22 @@ struct FilterArgs {
 // Fields of the kernel argument block that are touched once per evaluation (output pointers, flags) are read from the kernarg segment
 // WHERE they are used (a volatile scalar load the compiler may not hoist): loaded up front they sat in ~20 scalar registers across
 // the collision loops and were spilled to VGPR lanes.
-#define CG_KARG(field) (*(volatile const __attribute__((address_space(4))) decltype(FilterArgs::field)*)(kargs + offsetof(FilterArgs, field)))
+// (an explicit s_load at a constant offset from the kernarg pointer: as a C++ volatile load the compiler materialised every field's
+// ADDRESS in a scalar register pair and kept those alive instead)
+template <typename T, int OFF>
+__device__ __forceinline__ T karg_load(const __attribute__((address_space(4))) char* kargs) {
+  static_assert(sizeof(T) == 4 || sizeof(T) == 8, "dword or qword fields");
+  if constexpr (sizeof(T) == 8) {
+    unsigned long long v;
+    asm volatile("s_load_dwordx2 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(kargs), "n"(OFF));
+    if constexpr (__is_pointer(T)) return reinterpret_cast<T>(v); else return (T)v;
+  } else {
+    unsigned v;
+    asm volatile("s_load_dword %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(kargs), "n"(OFF));
+    return (T)v;
+  }
+}
+#define CG_KARG(field) karg_load<decltype(FilterArgs::field), (int)offsetof(FilterArgs, field)>(kargs)
 
 template <bool GRID>
 __global__ __launch_bounds__(64 * WAVES, 4) void filter_grasp_pose_kernel(FilterArgs a) {
@@ -380,10 +477,13 @@ __global__ __launch_bounds__(64 * WAVES, 4) void filter_grasp_pose_kernel(Filter
   // One wavefront per evaluation.  (One WORKGROUP per evaluation, its wavefronts dealing the voxel passes among themselves, was
   // measured: 2.92 instead of 2.38 ms per 50,004 evaluations -- the kernel is bound by the number of vector instructions it issues
   // (~40 % of the VALU issue rate of the whole chip), not by the length of one evaluation's dependent chain.)
-  for (long e = (long)blockIdx.x * WAVES + wv; e < CG_KARG(E); e += (long)gridDim.x * WAVES) {
+  for (int e = (int)blockIdx.x * WAVES + wv; e < (int)CG_KARG(E); e += (int)gridDim.x * WAVES) {      // E < 2^31 (checked by the launcher)
     const int code0 = CG_KARG(codes)[e];
     if (GRID ? (code0 != 0) : (CG_KARG(only_pending) ? code0 != CODE_PENDING : code0 != 0)) {
-      if (code0 > 0 && !CG_KARG(keep_rejected_pose) && lane < 16) CG_KARG(poses_out)[e * 16 + lane] = 0.f;   // rejected in stage 1
+      if (code0 > 0 && !CG_KARG(keep_rejected_pose) && lane == 0) {                                        // rejected in stage 1
+        float4* po = (float4*)(CG_KARG(poses_out) + (size_t)e * 16);
+        po[0] = po[1] = po[2] = po[3] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
       continue;
     }
     // the nudge loop of common.cpp:255-288 (float accumulation 0, 0.001f, 0.002f; +step before -step); without
@@ -392,15 +492,19 @@ __global__ __launch_bounds__(64 * WAVES, 4) void filter_grasp_pose_kernel(Filter
     float acc_t[3] = {0.f, 0.f, 0.f};
     bool found = false, stop = false;
     int idx = 0;
-    for (float step = 0.0f; (double)step <= 0.003 && !found && !stop; step += 0.001f) {
-      const int nsign = (step == 0.0f) ? 1 : 2;
+    // common.cpp:255: `for (float step = 0; step <= 0.003; step += 0.001f)` visits 0, 0.001f and 0.001f + 0.001f -- the third
+    // addition gives 0.0030000000261 > 0.003 (the comparison is in double) -- so the loop is counted here and `step` takes exactly
+    // those three float values (one float compare and one conversion less per trip, both evaluated by the vector unit)
+    for (int si = 0; si < 3 && !found && !stop; ++si) {
+      const float step = si == 0 ? 0.0f : (si == 1 ? 0.001f : 0.001f + 0.001f);
+      const int nsign = si == 0 ? 1 : 2;
       for (int s = 0; s < nsign && !found && !stop; ++s, ++idx) {
         const float sign = (s == 0) ? 1.0f : -1.0f;
         // grasp_in_cam (stage 1 left it in poses_out) is re-read per tried pose rather than kept: scalar registers are what the
         // collision loops are short of
         float cur[16], gig[16], gcam[16], cur_t[3];
 #pragma unroll
-        for (int k = 0; k < 12; k += 4) *(float4*)(cur + k) = *(const float4*)(CG_KARG(poses_out) + e * 16 + k);
+        for (int k = 0; k < 12; k += 4) *(float4*)(cur + k) = *(const float4*)(CG_KARG(poses_out) + (size_t)e * 16 + k);
         cur[12] = 0.f; cur[13] = 0.f; cur[14] = 0.f; cur[15] = 1.f;      // rows 0..2 of cur . gig do not read row 3 of cur
 #pragma unroll
         for (int r = 0; r < 3; ++r) { cur[r * 4 + 3] = cur[r * 4 + 3] + (step * cur[r * 4 + 1]) * sign; cur_t[r] = cur[r * 4 + 3]; }
@@ -425,11 +529,11 @@ __global__ __launch_bounds__(64 * WAVES, 4) void filter_grasp_pose_kernel(Filter
             float T[12];
 #pragma unroll
             for (int k = 0; k < 12; k += 4) *(float4*)(T + k) = *(const float4*)(pl->T + k);
-            float I[9], A[9], b[3];
+            float I[9];
             const bool ok = mesh.has_grid && grid_usable(mesh.grid, T, a.res, I);
             if (!ok) { code = CODE_PENDING; stop = true; break; }
-            grid_affine(mesh.grid, T, I, a.res, A, b);
-            if (wave_grid_collide(mesh, A, b, vox, a.res, pl, lane, work)) hit = 3 + m;
+            grid_affine(mesh.grid, T, I, a.res, pl, lane);
+            if (wave_grid_collide(mesh, vox, a.res, pl, lane, work)) hit = 3 + m;
           } else {
             if (wave_mesh_voxels_collide(mesh, gcam, vox, a.res, tl, lane)) hit = 3 + m;
           }
@@ -451,11 +555,14 @@ __global__ __launch_bounds__(64 * WAVES, 4) void filter_grasp_pose_kernel(Filter
     }
     if (code == 0) {                                                    // the accepted (possibly nudged) translation
       if (lane == 0) {
-        float* po = CG_KARG(poses_out) + e * 16;
+        float* po = CG_KARG(poses_out) + (size_t)e * 16;
         po[3] = acc_t[0]; po[7] = acc_t[1]; po[11] = acc_t[2];
       }
     } else if (!CG_KARG(keep_rejected_pose)) {
-      if (lane < 16) CG_KARG(poses_out)[e * 16 + lane] = 0.f;
+      if (lane == 0) {
+        float4* po = (float4*)(CG_KARG(poses_out) + (size_t)e * 16);
+        po[0] = po[1] = po[2] = po[3] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
     }
     if (lane == 0) { CG_KARG(codes)[e] = (signed char)code; CG_KARG(nudge)[e] = (signed char)nud; }
   }
@@ -516,7 +623,7 @@ inline Mesh make_mesh(const float* V, const int* F, int nf, const cg_mesh_grid* 
   Mesh m; m.V = V; m.F = F; m.nf = nf; m.has_grid = 0; m.grid = Grid{};
   if (hg && hg->cell_start && hg->tri_ids && hg->tri_verts && hg->cell > 0.f) {      // a grid without the flat triangle array is not used
     m.grid = Grid{hg->origin[0], hg->origin[1], hg->origin[2], 1.0f / hg->cell, hg->dims[0], hg->dims[1], hg->dims[2], hg->cell_start,
-                  hg->tri_ids, hg->tri_verts, hg->resolution};
+                  hg->tri_ids, hg->tri_verts, hg->resolution, hg->coarse_occupancy};
     m.has_grid = 1;
   }
   return m;
@@ -543,7 +650,8 @@ extern "C" int cg_filter_grasp_pose_accel(const float* grasp_poses, int n_pose, 
                                     const short* open_keys, int n_open_keys, const short* bg_keys, int n_bg_keys,
                                     float resolution, signed char* codes, float* poses_out, signed char* nudge,
                                     float* ee_in_base_out, const cg_mesh_grid* h_open_grid, const cg_mesh_grid* h_enc_grid,
-                                    int keep_rejected_pose, unsigned long long* work_stats, void* stream) {
+                                    int keep_rejected_pose, unsigned long long* work_stats, const short* open_blocks, const short* bg_blocks,
+                                    void* stream) {
   if (n_pose < 0 || n_sym < 0) return CG_ERR_ARG;
   if ((long)n_pose * n_sym == 0) return CG_OK;
   if (!grasp_poses || !symmetry_tfs || !h_nocs_pose || !h_canonical_to_nocs || !h_cam_in_world || !h_ee_in_grasp ||
@@ -557,6 +665,7 @@ extern "C" int cg_filter_grasp_pose_accel(const float* grasp_poses, int n_pose, 
   if (!(resolution > 0.f)) return CG_ERR_ARG;
   const long E = (long)n_pose * n_sym;
   if (E == 0) return CG_OK;
+  if (E >= (1L << 31) - 64 * 1024) return CG_ERR_ARG;      // evaluation indices are 32-bit in the kernels
   hipStream_t st = (hipStream_t)stream;
   ComposeArgs c;
   c.grasp_poses = grasp_poses; c.n_pose = n_pose; c.symmetry_tfs = symmetry_tfs; c.n_sym = n_sym;
@@ -572,7 +681,7 @@ extern "C" int cg_filter_grasp_pose_accel(const float* grasp_poses, int n_pose, 
   a.adjust = adjust_collision_pose;
   a.mesh[0] = make_mesh(gripper_vertices, gripper_faces, n_gripper_faces, h_open_grid);
   a.mesh[1] = make_mesh(enclosed_vertices, enclosed_faces, n_enclosed_faces, h_enc_grid);
-  a.vox[0] = Voxels{open_keys, n_open_keys}; a.vox[1] = Voxels{bg_keys, n_bg_keys};
+  a.vox[0] = Voxels{open_keys, n_open_keys, open_blocks}; a.vox[1] = Voxels{bg_keys, n_bg_keys, bg_blocks};
   a.res = resolution; a.codes = codes; a.poses_out = poses_out; a.nudge = nudge;
   a.keep_rejected_pose = keep_rejected_pose; a.work_stats = work_stats;
   long blocks = (E + WAVES - 1) / WAVES;
@@ -601,7 +710,7 @@ extern "C" int cg_mesh_voxels_collide(const float* vertices, const int* faces, i
   long blocks = (n_poses + WAVES - 1) / WAVES;
   if (blocks > 256 * 16) blocks = 256 * 16;
   hipLaunchKernelGGL(mesh_voxels_collide_kernel, dim3((unsigned)blocks), dim3(64 * WAVES), 0, (hipStream_t)stream,
-                     make_mesh(vertices, faces, n_faces, nullptr), poses, n_poses, Voxels{keys, n_keys}, resolution, out);
+                     make_mesh(vertices, faces, n_faces, nullptr), poses, n_poses, Voxels{keys, n_keys, nullptr}, resolution, out);
   return cg_hip_status(hipGetLastError());
 }
 
@@ -636,5 +745,5 @@ extern "C" int cg_filter_grasp_pose(const float* grasp_poses, int n_pose, const 
   return cg_filter_grasp_pose_accel(grasp_poses, n_pose, symmetry_tfs, n_sym, h_nocs_pose, h_canonical_to_nocs, h_cam_in_world, h_ee_in_grasp,
                                     h_gripper_in_grasp, filter_approach_dir_face_camera, adjust_collision_pose, ik_ok, gripper_vertices,
                                     gripper_faces, n_gripper_faces, enclosed_vertices, enclosed_faces, n_enclosed_faces, open_keys, n_open_keys,
-                                    bg_keys, n_bg_keys, resolution, codes, poses_out, nudge, ee_in_base_out, nullptr, nullptr, 0, nullptr, stream);
+                                    bg_keys, n_bg_keys, resolution, codes, poses_out, nudge, ee_in_base_out, nullptr, nullptr, 0, nullptr, nullptr, nullptr, stream);
 }

@@ -101,38 +101,88 @@ __global__ __launch_bounds__(64) void draw_ids_perm_kernel(int n_valid, int n_pt
 }
 
 // The same draw as a SORT: one workgroup per row.  Every point index gets a 48-bit random key (two Philox words; a tie between two of
-// 2,500 keys has probability 1e-8 per row and is then decided by the index), the (key, index) pairs are bitonic-sorted in LDS and the
-// first n_pts indices are the row: a uniform n_pts-subset in uniform order, like np.random.choice(replace=False).  The Fisher-Yates
-// kernel above runs ONE LANE per row down a chain of n_pts dependent LDS swaps: ~250 us for a row however few rows there are (a
-// quarter of a one-pose predict_batch call), and 61 GB/s of ids at full occupancy.  Here a row is 78 barrier-separated rounds of 8
-// compare-exchanges per thread (N = 4096): microseconds per row, and several workgroups per CU overlap each other's barriers.
-template <int THREADS>
-__global__ __launch_bounds__(THREADS) void draw_ids_sort_kernel(int n_valid, int n_pts, int N, long count, unsigned k0, unsigned k1, int base,
-                                                                long row_offset, int* __restrict__ out) {
-  extern __shared__ unsigned long long keys[];
+// 2,500 keys has probability 1e-8 per row and is then decided by the index), the (key, index) pairs are bitonic-sorted and the first
+// n_pts indices are the row: a uniform n_pts-subset in uniform order, like np.random.choice(replace=False).  The Fisher-Yates kernel
+// above runs ONE LANE per row down a chain of n_pts dependent LDS swaps: ~250 us for a row however few rows there are (a quarter of a
+// one-pose predict_batch call).  Here a row is N = 2^LOG_N pairs on 256 threads, E = N / 256 per thread IN REGISTERS: a
+// compare-exchange round with partner distance 2^p runs inside the registers of a thread whenever bit p of the element index is one of
+// the thread's register bits, and the elements are re-dealt through LDS (write E, barrier, read E) only when the next round's bit is
+// not -- three deals per merge stage instead of a trip through LDS per round (78 rounds at N = 4096: the first version of this kernel,
+// 1.77 ms per 6,250 rows against 0.84 for the Fisher-Yates kernel it replaced).
+template <int LOG_N>
+struct SortGeo {
+  static constexpr int LOG_T = 8, LOG_E = LOG_N - LOG_T, E = 1 << LOG_E, N = 1 << LOG_N;
+  static_assert(LOG_E >= 2 && LOG_E <= 5, "2,048 .. 8,192 ... pairs per row on 256 threads");
+  // lowest register bit of the layout that holds element-index bit p in a thread's registers
+  static constexpr int lo_of(int p) { return (p / LOG_E) * LOG_E > LOG_N - LOG_E ? LOG_N - LOG_E : (p / LOG_E) * LOG_E; }
+};
+
+template <int LOG_N, int LO>
+__device__ __forceinline__ int sort_index(int t, int r) {          // element index of register r of thread t when the register bits are [LO, LO + LOG_E)
+  constexpr int LOG_E = SortGeo<LOG_N>::LOG_E;
+  return ((t >> LO) << (LO + LOG_E)) | (r << LO) | (t & ((1 << LO) - 1));
+}
+
+template <int LOG_N, int FROM, int TO>
+__device__ __forceinline__ void sort_deal(unsigned long long (&e)[1 << (LOG_N - 8)], unsigned long long* keys, int t) {
+  constexpr int E = SortGeo<LOG_N>::E;
+  __syncthreads();                                                 // whoever still reads the previous deal is done
+#pragma unroll
+  for (int r = 0; r < E; ++r) keys[sort_index<LOG_N, FROM>(t, r)] = e[r];
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < E; ++r) e[r] = keys[sort_index<LOG_N, TO>(t, r)];
+}
+
+// rounds p = P .. 0 of merge stage S (blocks of 2^S: ascending where bit S of the index is 0; the last stage is ascending throughout)
+template <int LOG_N, int S, int P, int LO>
+__device__ __forceinline__ void sort_rounds(unsigned long long (&e)[1 << (LOG_N - 8)], unsigned long long* keys, int t) {
+  constexpr int LOG_E = SortGeo<LOG_N>::LOG_E, E = SortGeo<LOG_N>::E;
+  constexpr int NEED = SortGeo<LOG_N>::lo_of(P);
+  if constexpr (NEED != LO) sort_deal<LOG_N, LO, NEED>(e, keys, t);
+  constexpr int RB = 1 << (P - NEED);                              // the register bit of this round
+  bool up_t = true;                                                // direction when bit S lies in the thread part of the index
+  if constexpr (S < LOG_N && !(S >= NEED && S < NEED + LOG_E)) up_t = ((sort_index<LOG_N, NEED>(t, 0) >> S) & 1) == 0;
+#pragma unroll
+  for (int r = 0; r < E; ++r) {
+    if ((r & RB) == 0) {
+      bool up = up_t;
+      if constexpr (S < LOG_N && S >= NEED && S < NEED + LOG_E) up = ((r >> (S - NEED)) & 1) == 0;
+      const unsigned long long a = e[r], b = e[r | RB];
+      const bool sw = (a > b) == up;
+      e[r] = sw ? b : a; e[r | RB] = sw ? a : b;
+    }
+  }
+  if constexpr (P > 0) sort_rounds<LOG_N, S, P - 1, NEED>(e, keys, t);
+  else if constexpr (S < LOG_N) sort_rounds<LOG_N, S + 1, S, NEED>(e, keys, t);
+  else if constexpr (NEED != 0) sort_deal<LOG_N, NEED, 0>(e, keys, t);          // leave the sorted row in consecutive order
+}
+
+template <int LOG_N>
+__global__ __launch_bounds__(256) void draw_ids_sort_kernel(int n_valid, int n_pts, long count, unsigned k0, unsigned k1, int base,
+                                                            long row_offset, int* __restrict__ out) {
+  constexpr int E = SortGeo<LOG_N>::E, N = SortGeo<LOG_N>::N;
+  __shared__ unsigned long long keys[N];
+  const int t = threadIdx.x;
   const long row = blockIdx.x;
   const long grow = row + row_offset;          // the stream is a function of the GLOBAL row: a shard draws what the whole would
   const unsigned c0 = (unsigned)grow, c2 = (unsigned)(grow >> 32);
-  for (int p = threadIdx.x; p < N / 2; p += THREADS) {            // one Philox block keys two points
-    const U4 w = philox4x32_10(U4{c0, (unsigned)p, c2, 0x50525453u}, k0, k1);
-    const int i0 = 2 * p, i1 = 2 * p + 1;
-    keys[i0] = i0 < n_valid ? ((unsigned long long)w.x << 32 | (unsigned long long)(w.y & 0xffff0000u)) | (unsigned)i0 : ~0ull;
-    keys[i1] = i1 < n_valid ? ((unsigned long long)w.z << 32 | (unsigned long long)(w.w & 0xffff0000u)) | (unsigned)i1 : ~0ull;
+  unsigned long long e[E];                     // elements t*E .. t*E + E-1 (layout with register bits [0, LOG_E))
+#pragma unroll
+  for (int r = 0; r < E; r += 2) {             // one Philox block keys two points
+    const int i0 = t * E + r, i1 = i0 + 1;
+    const U4 w = philox4x32_10(U4{c0, (unsigned)(i0 >> 1), c2, 0x50525453u}, k0, k1);
+    e[r] = i0 < n_valid ? ((unsigned long long)w.x << 32 | (unsigned long long)(w.y & 0xffff0000u)) | (unsigned)i0 : ~0ull;
+    e[r + 1] = i1 < n_valid ? ((unsigned long long)w.z << 32 | (unsigned long long)(w.w & 0xffff0000u)) | (unsigned)i1 : ~0ull;
   }
-  for (int k = 2; k <= N; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      __syncthreads();
-      for (int t = threadIdx.x; t < N / 2; t += THREADS) {
-        const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;       // the t-th pair of this round
-        const unsigned long long a = keys[lo], b = keys[hi];
-        const bool up = (lo & k) == 0;
-        if ((a > b) == up) { keys[lo] = b; keys[hi] = a; }
-      }
-    }
-  }
+  sort_rounds<LOG_N, 1, 0, 0>(e, keys, t);
+  // registers hold elements t*E + r of the sorted row again: the first n_pts indices leave through LDS for coalesced stores
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < E; ++r) keys[t * E + r] = e[r];
   __syncthreads();
   int* o = out + row * n_pts;
-  for (int i = threadIdx.x; i < n_pts; i += THREADS) o[i] = (int)(keys[i] & 0xffffu) + base;
+  for (int i = t; i < n_pts; i += 256) o[i] = (int)(keys[i] & 0xffffu) + base;
 }
 
 // The swap chain of numpy's permutation(n_valid) for `count` rows whose swap partners the host extracted from numpy's generator
@@ -299,10 +349,11 @@ extern "C" int cg_draw_resample_ids(int n_valid, int n_pts, long count, unsigned
   const unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
   hipStream_t s = (hipStream_t)stream;
   if (n_valid >= n_pts && n_valid <= 8192) {             // (key, index) pairs of the whole cloud fit 64 KB of LDS: the sort kernel
-    int N = 2;
-    while (N < n_valid) N <<= 1;
-    hipLaunchKernelGGL(draw_ids_sort_kernel<256>, dim3((unsigned)count), dim3(256), (size_t)N * 8, s, n_valid, n_pts, N, count, k0, k1, base,
-                       row_offset, out);
+    const dim3 grid((unsigned)count), block(256);
+    if (n_valid <= 1024) hipLaunchKernelGGL(draw_ids_sort_kernel<10>, grid, block, 0, s, n_valid, n_pts, count, k0, k1, base, row_offset, out);
+    else if (n_valid <= 2048) hipLaunchKernelGGL(draw_ids_sort_kernel<11>, grid, block, 0, s, n_valid, n_pts, count, k0, k1, base, row_offset, out);
+    else if (n_valid <= 4096) hipLaunchKernelGGL(draw_ids_sort_kernel<12>, grid, block, 0, s, n_valid, n_pts, count, k0, k1, base, row_offset, out);
+    else hipLaunchKernelGGL(draw_ids_sort_kernel<13>, grid, block, 0, s, n_valid, n_pts, count, k0, k1, base, row_offset, out);
     return cg_hip_status(hipGetLastError());
   }
   if (n_valid >= n_pts && n_valid <= 65535) {

@@ -103,6 +103,31 @@ def voxelize(pts, resolution, device=None):
     return keys
 
 
+def voxel_blocks(keys):
+    """keys (n,4) int16 (voxelize) -> (the keys sorted by Morton code, (ceil(n/64), 2, 4) int16 lowest / highest key of every run of 64):
+    with a space-filling order a run of 64 consecutive voxels is a compact blob of space."""
+    n = keys.shape[0]
+    if n == 0:
+        return keys, torch.zeros((0, 2, 4), dtype=torch.int16, device=keys.device)
+
+    def spread(x):                     # 16 bits -> every third bit of 48
+        x = x & 0xFFFF
+        x = (x | (x << 32)) & 0x1F00000000FFFF
+        x = (x | (x << 16)) & 0x1F0000FF0000FF
+        x = (x | (x << 8)) & 0x100F00F00F00F00F
+        x = (x | (x << 4)) & 0x10C30C30C30C30C3
+        x = (x | (x << 2)) & 0x1249249249249249
+        return x
+    k = keys[:, :3].to(torch.int64) + 32768
+    code = (spread(k[:, 0]) << 2) | (spread(k[:, 1]) << 1) | spread(k[:, 2])
+    keys = keys[torch.argsort(code)].contiguous()
+    nb = (n + 63) // 64
+    padded = torch.cat([keys, keys[-1:].expand(nb * 64 - n, 4)]) if nb * 64 != n else keys
+    runs = padded.view(nb, 64, 4)
+    blocks = torch.stack([runs.min(dim=1).values, runs.max(dim=1).values], dim=1).contiguous()
+    return keys, blocks
+
+
 class CollisionManager:
     """my_cpp.CollisionManager (collision_manager.h:55-69).  Objects are triangle meshes and voxelised point clouds (octomap leaves at
     the registered resolution), each posed by setTransform.  isAnyCollision tests every {mesh, cloud} pair -- the only kind the
@@ -155,7 +180,8 @@ class CollisionManager:
 class _MeshGridC(ctypes.Structure):
     """cg_mesh_grid (include/catgrasp_amd.h)."""
     _fields_ = [('origin', ctypes.c_float * 3), ('cell', ctypes.c_float), ('dims', ctypes.c_int * 3),
-                ('cell_start', ctypes.c_void_p), ('tri_ids', ctypes.c_void_p), ('resolution', ctypes.c_float), ('tri_verts', ctypes.c_void_p)]
+                ('cell_start', ctypes.c_void_p), ('tri_ids', ctypes.c_void_p), ('resolution', ctypes.c_float), ('tri_verts', ctypes.c_void_p),
+                ('coarse_occupancy', ctypes.c_void_p)]
 
 
 class MeshGrid:
@@ -201,8 +227,16 @@ class MeshGrid:
         self.tri_verts = torch.zeros((max(len(F), 1), 12), dtype=torch.float32, device=device)
         if len(F):
             self.tri_verts[:, :9] = Vf[Ff.long()].reshape(len(F), 9)
+        # coarse occupancy: one byte per 4 x 4 x 4 block of cells, 1 iff some cell of it has a triangle list (voxel-block culling)
+        nx, ny, nz = (int(v) for v in dims)
+        nonempty = (self.cell_start[1:] != self.cell_start[:-1]).view(nx, ny, nz)
+        pad = [(-nx) % 4, (-ny) % 4, (-nz) % 4]
+        nonempty = torch.nn.functional.pad(nonempty, (0, pad[2], 0, pad[1], 0, pad[0]))
+        sx, sy, sz = (nx + 3) // 4, (ny + 3) // 4, (nz + 3) // 4
+        self.coarse = nonempty.view(sx, 4, sy, 4, sz, 4).permute(0, 2, 4, 1, 3, 5).reshape(sx, sy, sz, 64).any(dim=3).to(torch.uint8).contiguous()
         self.c = _MeshGridC()
         self.c.tri_verts = self.tri_verts.data_ptr()
+        self.c.coarse_occupancy = self.coarse.data_ptr()
         for i in range(3):
             self.c.origin[i] = float(lo[i]); self.c.dims[i] = int(dims[i])
         self.c.cell = float(cell); self.c.resolution = res
@@ -287,18 +321,21 @@ class GripperScene:
             return _mesh_cache.get((_digest(V, F), self.res, str(dev), bool(accel)), make) if cache else make()
 
         def cloud(pts):
+            # -> (voxel keys in Morton order, key box of every run of 64): see voxel_blocks
             if isinstance(pts, torch.Tensor) or not cache:
-                return voxelize(pts, self.res, dev)
+                return voxel_blocks(voxelize(pts, self.res, dev))
             a = np.asarray(pts)
             if a.ndim != 2 or a.shape[1] != 3:
                 raise ValueError(f'point cloud shape wrong: {a.shape}')
             a = np.ascontiguousarray(a, dtype=np.float32)
-            return _cloud_cache.get((_digest(a), self.res, str(dev)), lambda: voxelize(a, self.res, dev))
+            return _cloud_cache.get((_digest(a), self.res, str(dev)), lambda: voxel_blocks(voxelize(a, self.res, dev)))
 
         self.V, self.F, self.grid_open = mesh(gripper_vertices, gripper_faces, 'gripper')
         self.Ve, self.Fe, self.grid_enc = mesh(gripper_enclosed_vertices, gripper_enclosed_faces, 'gripper_enclosed')
-        self.keys_open = cloud(gripper_collision_pts)
-        self.keys_bg = cloud(gripper_enclosed_collision_pts)
+        # the voxel sets in Morton order + the key box of every run of 64 (voxel_blocks): the grid kernel skips runs that cannot touch a
+        # triangle list.  Which voxels collide does not depend on their order.
+        self.keys_open, self.blocks_open = cloud(gripper_collision_pts)
+        self.keys_bg, self.blocks_bg = cloud(gripper_enclosed_collision_pts)
 
 
 def filter_on_device(scene, grasp_poses, symmetry_tfs, nocs_pose, canonical_to_nocs_transform, cam_in_world, ee_in_grasp,
@@ -342,7 +379,8 @@ def filter_on_device(scene, grasp_poses, symmetry_tfs, nocs_pose, canonical_to_n
             _c_int(int(bool(filter_approach_dir_face_camera))), _c_int(int(bool(adjust_collision_pose))), _p(ik_ok),
             _p(scene.V), _p(scene.F), _c_int(scene.F.shape[0]), _p(scene.Ve), _p(scene.Fe), _c_int(scene.Fe.shape[0]),
             _p(scene.keys_open), _c_int(scene.keys_open.shape[0]), _p(scene.keys_bg), _c_int(scene.keys_bg.shape[0]),
-            ctypes.c_float(scene.res), _p(codes), _p(poses), _p(nudge), _p(ee_out), go, ge, _c_int(int(bool(keep_rejected_pose))), _p(work_stats), _stream()),
+            ctypes.c_float(scene.res), _p(codes), _p(poses), _p(nudge), _p(ee_out), go, ge, _c_int(int(bool(keep_rejected_pose))), _p(work_stats),
+            _p(getattr(scene, 'blocks_open', None)), _p(getattr(scene, 'blocks_bg', None)), _stream()),
               'cg_filter_grasp_pose_accel')
 
     ik_ok = None

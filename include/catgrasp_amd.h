@@ -183,8 +183,10 @@ typedef struct cg_mesh_grid {
   const int* cell_start;   /* device, prod(dims)+1 */
   const int* tri_ids;      /* device */
   float resolution;
-  const float* tri_verts;  /* device, optional (NULL: gather through faces -> vertices): the triangles as (n_faces,12) float32
-                              [v0.xyz v1.xyz v2.xyz 0 0 0], 16-byte aligned -- one dependent load less per narrow-phase test */
+  const float* tri_verts;  /* device: the triangles as (n_faces,12) float32 [v0.xyz v1.xyz v2.xyz 0 0 0], 16-byte aligned -- one
+                              dependent load less per narrow-phase test (a grid without it is not used) */
+  const unsigned char* coarse_occupancy;  /* device, optional: (ceil(dims/4)) bytes, z fastest: 1 iff some cell of the 4 x 4 x 4 block
+                              of cells has a non-empty list -- lets the kernel skip whole blocks of voxels (see open_blocks) */
 } cg_mesh_grid;
 
 /* filterGraspPose (my_cpp/common.cpp:156-321; declaration my_cpp/common.h:60) for every
@@ -216,6 +218,10 @@ int cg_filter_grasp_pose(const float* grasp_poses, int n_pose, const float* symm
  * work_stats: optional DEVICE pointer to 3 uint64 counters the grid kernel ADDS to (measurement only): voxel keys read (8 B each),
  * grid cells looked up (8 B each), (voxel, triangle) pairs run through the narrow phase (48 B of triangle each) -- the
  * cache-level byte count bench.py's roofline_filter block is priced on.
+ * open_blocks / bg_blocks: optional DEVICE (ceil(n_keys/64), 2, 4) int16 -- lowest and highest key (per axis) of every run of 64
+ * consecutive keys of the voxel set.  With keys in a space-filling order (my_cpp.GripperScene sorts them by Morton code) a run is a
+ * compact blob, and the grid kernel skips runs whose box lies outside the grid or over empty coarse cells: a pure accelerator, the
+ * set of (voxel, triangle) pairs that reach the narrow phase is unchanged.
  * Three launches: pose composition (one thread per evaluation), the grid kernel (one wavefront per live evaluation), and the
  * exhaustive kernel, which only finishes evaluations whose pose a grid does not cover (all of them when there are no grids). */
 int cg_filter_grasp_pose_accel(const float* grasp_poses, int n_pose, const float* symmetry_tfs, int n_sym,
@@ -228,7 +234,8 @@ int cg_filter_grasp_pose_accel(const float* grasp_poses, int n_pose, const float
                                const short* open_keys, int n_open_keys, const short* bg_keys, int n_bg_keys,
                                float resolution, signed char* codes, float* poses_out, signed char* nudge,
                                float* ee_in_base_out, const cg_mesh_grid* h_open_grid, const cg_mesh_grid* h_enc_grid,
-                               int keep_rejected_pose, unsigned long long* work_stats, void* stream);
+                               int keep_rejected_pose, unsigned long long* work_stats, const short* open_blocks, const short* bg_blocks,
+                               void* stream);
 
 /* Device build of cg_mesh_grid (replaces a per-triangle host loop): triangle t is listed in every cell its bounding box,
  * inflated by `inflate`, overlaps (float64 cell arithmetic).  h_origin[3], h_dims[3]: HOST.  Two passes around a host-side

@@ -105,13 +105,12 @@ row('filter_grasp_pose_kernel (broad-phase grid)', t_f, Pn * (64 + 66), '64 B po
 G50 = 50000
 ids_out = torch.empty((G50, 2048), dtype=torch.int32, device=dev)
 t_d = timed(lambda: transforms.draw_ids_device(2500, 2048, G50, dev, seed=7, out=ids_out), iters=10)
-row('draw_ids_perm_kernel (resampling draw, 50k candidates)', t_d, G50 * 2048 * 4, '2048 x 4 B ids written per candidate', bound='LDS latency (sequential Fisher-Yates per row)',
-    extra={'rows_per_s': round(G50 / t_d), 'note': 'one lane per candidate, permutation array in LDS; the reference draws these on the host: ~75 us per candidate'})
+row('draw_ids_sort_kernel (resampling draw, 50k candidates)', t_d, G50 * 2048 * 4, '2048 x 4 B ids written per candidate', bound='LDS (bitonic sort of 4096 (key, index) pairs per row: 78 barrier-separated rounds)',
+    extra={'rows_per_s': round(G50 / t_d), 'note': 'one workgroup per candidate: 48-bit Philox keys, bitonic sort in LDS (round 3: one lane per candidate down a Fisher-Yates chain, 0.835 ms per 6,250 rows); the reference draws these on the host: ~75 us per candidate'})
 poses50 = torch.from_numpy(synth.make_candidates(objs[0], 2000, np.random.default_rng(1)).astype(np.float32).reshape(-1, 16)).to(dev).repeat(25, 1).contiguous()
 t_pi = timed(lambda: transforms.pose_inverse_rows_device(poses50, np.zeros(3)))
 row('pose_inverse_rows_kernel', t_pi, G50 * (64 + 48), '64 B pose in + 48 B rows out per candidate (launch-latency bound at this size)')
-import bench as _bench          # noqa: E402  (subdivide)
-Vb, Fb = _bench.subdivide(gr['vertices'], gr['faces'], 4)
+Vb, Fb = synth.subdivide(gr['vertices'], gr['faces'], 4)
 Vd, Fd = torch.from_numpy(Vb).to(dev), torch.from_numpy(Fb).to(dev)
 t_mg = timed(lambda: my_cpp.MeshGrid(Vb, Fb, 0.0005, dev, V_dev=Vd, F_dev=Fd), iters=5, warm=1)
 row('mesh_grid_count/fill/sort (9216-triangle gripper)', t_mg, len(Fb) * 36, 'wall time of the whole device build incl. its one read-back', bound='launch latency',
