@@ -659,6 +659,7 @@ extern "C" int cg_filter_grasp_pose_accel(const float* grasp_poses, int n_pose, 
     return CG_ERR_ARG;
   if ( n_gripper_faces < 0 || n_enclosed_faces < 0 || n_open_keys < 0 || n_bg_keys < 0) return CG_ERR_ARG;
   if (!ee_in_base_out && (!poses_out || !nudge)) return CG_ERR_ARG;
+  if ((((uintptr_t)grasp_poses | (uintptr_t)symmetry_tfs | (uintptr_t)poses_out | (uintptr_t)ee_in_base_out) & 15) != 0) return CG_ERR_ARG;   // 16-byte rows
   if ((n_gripper_faces > 0 && (!gripper_vertices || !gripper_faces)) || (n_enclosed_faces > 0 && (!enclosed_vertices || !enclosed_faces)))
     return CG_ERR_ARG;
   if ((n_open_keys > 0 && !open_keys) || (n_bg_keys > 0 && !bg_keys)) return CG_ERR_ARG;

@@ -214,8 +214,12 @@ class DeviceCloud:
         self.normal64 = nrm[m].reshape(-1, 3)
         self.n = len(self.xyz64)
         self.center = self.xyz64.mean(axis=0) if self.n else np.zeros(3)
-        self.xyz = torch.from_numpy((self.xyz64 - self.center).astype(np.float32)).to(device)
-        self.normal = torch.from_numpy(self.normal64.astype(np.float32)).to(device)
+        n_pad = (self.n + 3) & ~3                                   # ONE upload for coordinates and normals (a pageable copy blocks the
+        both = np.zeros((2, n_pad, 3), dtype=np.float32)            # caller); rows padded to 4 points so that both halves stay 16-byte aligned
+        both[0, :self.n] = self.xyz64 - self.center
+        both[1, :self.n] = self.normal64
+        both = torch.from_numpy(both).to(device)
+        self.xyz, self.normal = both[0, :self.n], both[1, :self.n]
         self.device = device
 
 

@@ -191,7 +191,7 @@ typedef struct cg_mesh_grid {
 
 /* filterGraspPose (my_cpp/common.cpp:156-321; declaration my_cpp/common.h:60) for every
  * (grasp pose i, symmetry transform j) pair, in input order e = i*n_sym + j.
- *  grasp_poses (n_pose,16), symmetry_tfs (n_sym,16): device, row-major float32 4x4.
+ *  grasp_poses (n_pose,16), symmetry_tfs (n_sym,16): device, row-major float32 4x4, 16-byte aligned (as are poses_out / ee_in_base_out).
  *  h_*: HOST pointers to 16 floats (row-major 4x4): nocs_pose, canonical_to_nocs_transform, cam_in_world,
  *       ee_in_grasp, gripper_in_grasp.
  *  ik_ok: optional (E) u8 produced by the host IK pass (0 => rejected with code 2); NULL => filter_ik=false.

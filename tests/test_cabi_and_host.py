@@ -289,6 +289,27 @@ def test_numpy_choice_heads_long_run():
         aligning.draw_hypothesis_ids(3, 5)            # numpy: "Cannot take a larger sample than population when replace is False"
 
 
+def test_voxel_blocks_are_a_reordering_with_tight_boxes():
+    """my_cpp.voxel_blocks (the collision kernel's block skip rests on it): the Morton-ordered keys are a permutation of the input, the box
+    of every run of 64 bounds exactly its keys, and on a surface-like voxel set the runs are compact blobs, not slabs."""
+    from catgrasp_amd import my_cpp
+    rng = np.random.default_rng(2)
+    uv = rng.uniform(0, 1, (6000, 2))                                      # a curved sheet sampled densely at voxel pitch
+    pts = np.stack([uv[:, 0] * 60, uv[:, 1] * 60, 8 * np.sin(uv[:, 0] * 3) + 1200], 1)
+    k = np.unique(np.floor(pts).astype(np.int16), axis=0)
+    keys = torch.from_numpy(np.concatenate([k, np.zeros((len(k), 1), np.int16)], 1))
+    ks, blocks = my_cpp.voxel_blocks(keys)
+    assert ks.shape == keys.shape and blocks.shape == ((len(k) + 63) // 64, 2, 4) and blocks.dtype == torch.int16
+    assert sorted(map(tuple, ks.tolist())) == sorted(map(tuple, keys.tolist()))
+    for b in range(blocks.shape[0]):
+        run = ks[b * 64:(b + 1) * 64, :3]
+        assert torch.equal(blocks[b, 0, :3], run.min(0).values) and torch.equal(blocks[b, 1, :3], run.max(0).values)
+    ext = (blocks[:, 1, :3].int() - blocks[:, 0, :3].int()).float()
+    assert float(ext.max(dim=1).values.median()) <= 16                      # ~8 x 8 voxels of sheet per run; a lexicographic order gives 60-wide slabs
+    e, eb = my_cpp.voxel_blocks(keys[:0])
+    assert e.shape == (0, 4) and eb.shape == (0, 2, 4)
+
+
 def test_device_cloud_applies_z_mask_and_centres():
     xyz = np.array([[0, 0, 0.05], [0.01, 0, 0.6], [0, 0.02, 0.62], [0, 0, 0.099]], dtype=np.float64)
     dc = transforms.DeviceCloud(xyz, np.ones_like(xyz), torch.device('cpu'))
@@ -383,7 +404,7 @@ def test_symmetry_sets_form_groups():
         transforms.get_symmetry_tfs('bolt')
 
 
-@pytest.mark.parametrize('name', ['r1_bench_line.json', 'r2_bench_line.json', 'r3_bench_line.json'])
+@pytest.mark.parametrize('name', ['r1_bench_line.json', 'r2_bench_line.json', 'r3_bench_line.json', 'r4_bench_line.json'])
 def test_committed_bench_line_honours_the_contract(name):
     """profiles/r<N>_bench_line.json is the JSON line bench.py printed on the MI355X in that round: every field of the driver's
     contract (and the roofline / cpu_baseline objects) must be present and self-consistent; from round 2 on the line is measured
@@ -401,12 +422,23 @@ def test_committed_bench_line_honours_the_contract(name):
     for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype',
               'data', 'config', 'roofline', 'cpu_baseline'):
         assert k in d, k
-    if name.startswith('r3'):        # round 3: traffic measured inside the run, RCCL exercised on the step's records, API within 5 % of `value`
+    if name[:2] in ('r3', 'r4'):     # round 3: traffic measured inside the run, RCCL exercised on the step's records, API within 5 % of `value`
         assert d['roofline']['traffic_source'].startswith('measured for this run') and 1.0 <= d['roofline']['traffic'] / (69632 * d['roofline']['candidates_per_launch']) < 1.1
         assert d['rccl_selftest']['ok'] is True and d['rccl_selftest']['backend'] == 'nccl' and d['rccl_selftest']['records'] == 50000
         numpy_f32 = [x for x in d['api']['predict_batch'] if x['rng'].startswith('numpy') and x['precision'] == 'f32'][0]
         assert numpy_f32['candidates_per_s'] >= 0.95 * d['value']
-    assert d['unit'] == 'candidates/s' and d['higher_is_better'] is True and d['scaling'] == ('strong' if name.startswith('r3') else 'weak') and d['vs_baseline'] is None
+    if name.startswith('r4'):        # round 4: the realistic gripper in the timed step, the filter's own roofline block, the default-mode pick cycle
+        assert min(d['roofline_filter']['gripper_triangles']) >= 5000 and d['roofline_filter']['bound'] == 'l2'
+        rf = d['roofline_filter']
+        assert abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-3 and rf['cache_level_bytes'] == 8 * rf['voxel_keys_read'] + 8 * rf['grid_cells_looked_up'] + 52 * rf['pairs_tested'] + 130 * rf['evaluations']
+        pc = d['api']['pick_cycle']
+        assert pc['precision'] == 'f32' and pc['objects'] == 8 and set(pc['default']['ms_per_object_by_stage']) >= {'occupancy', 'nunocs net + decode', 'ransac id draw', 'ransac kernels + selection', 'candidate generation', 'filterGraspPose', 'affordance', 'grasp-Q scoring'}
+        assert pc['default']['ms_per_object_by_stage']['ransac id draw'] <= 120.0          # <= 0.12 s per object (round 3: ~610 ms)
+        ps = d['projected_scaling']
+        assert ps['status'].startswith('projection') and 6.0 < ps['ranks']['8']['projected_speedup'] <= 8.0
+        assert all(x['roofline']['traffic'] is None for x in d['secondary']) and len(d['records_sha256']) == 64
+        assert d['cpu_baseline']['kind'] == 'port' and 'goldens' in d['cpu_baseline']['kind_note']
+    assert d['unit'] == 'candidates/s' and d['higher_is_better'] is True and d['scaling'] == ('strong' if name[:2] in ('r3', 'r4') else 'weak') and d['vs_baseline'] is None
     assert 'workload' in d['config'] and 'model' not in d['config']
     per_gpu = d['config']['candidates_per_gpu']
     assert abs(d['value'] - d['n_gpus'] * per_gpu / (d['ms_per_step'] * 1e-3)) / d['value'] < 1e-3
