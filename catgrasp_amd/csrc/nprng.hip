@@ -102,47 +102,5 @@ extern "C" int cg_host_numpy_choice_rows(uint32_t* h_mt_key624, int* h_mt_pos, i
   return CG_OK;
 }
 
-// The sequential part of `count` calls of permutation(n_valid) alone: the Fisher-Yates swap partners j(i), i = n_valid-1 .. 1, of
-// every row, as u16 (row r at h_j + r*row_stride, step s = n_valid-1-i at [s]; the tail of the stride is zero-filled).  Consumes
-// the generator exactly like cg_host_numpy_choice_rows' replace=False branch -- the rejection loop is what makes the stream
-// sequential -- but leaves the memory-bound swap chain itself to the device (cg_apply_shuffle_rows), which runs one chain per
-// lane: ~3x less host time per pose and 5 KB instead of 8 KB uploaded per pose at n_valid = 2500.
-extern "C" int cg_host_numpy_shuffle_partners(uint32_t* h_mt_key624, int* h_mt_pos, int n_valid, long count, long row_stride,
-                                              uint16_t* h_j) {
-  if (!h_mt_key624 || !h_mt_pos || n_valid < 2 || n_valid > 65536 || count < 0 || row_stride < n_valid - 1 || *h_mt_pos < 0 ||
-      *h_mt_pos > MT_N)
-    return CG_ERR_ARG;
-  if (count == 0) return CG_OK;
-  if (!h_j) return CG_ERR_ARG;
-  MT s;
-  s.key = h_mt_key624; s.pos = *h_mt_pos;
-  temper_block(s);
-  const uint32_t mask0 = gen_mask((uint32_t)(n_valid - 1));
-  // Branch-free rejection: every generator word is masked and stored at the cursor, and the step index advances by the accept
-  // bit (the rejection branch of the textbook loop mispredicts on ~30 % of the words and costs more than the arithmetic).  The
-  // mask only changes when i crosses a power of two, so the steps are walked one mask segment (mask/2, mask] at a time and the
-  // loop-carried chain is the compare + subtract on i alone.
-  const uint32_t n1 = (uint32_t)(n_valid - 1);
-  for (long r = 0; r < count; ++r) {
-    uint16_t* o = h_j + r * row_stride;
-    uint32_t i = n1, mask = mask0;
-    while (i > 0) {
-      const uint32_t lim = mask >> 1;             // this mask serves the steps i in (lim, mask]
-      if (i <= lim) { mask = lim; continue; }
-      if (s.pos == MT_N) { mt_gen(s.key); temper_block(s); s.pos = 0; }
-      const uint32_t* w = s.tb + s.pos;
-      const int avail = MT_N - s.pos;
-      int t = 0;
-      for (; t < avail && i > lim; ++t) {
-        const uint32_t v = w[t] & mask;
-        o[n1 - i] = (uint16_t)v;                  // overwritten by the next word if this one is rejected
-        i = i - 1 + (i < v);                      // i -= (v <= i) as compare + add-with-carry
-      }
-      s.pos += t;
-    }
-    o += n1;
-    for (long k = n_valid - 1; k < row_stride; ++k) *o++ = 0;
-  }
-  *h_mt_pos = s.pos;
-  return CG_OK;
-}
+// cg_host_numpy_shuffle_partners (the sequential part of permutation(n_valid) alone: the swap partners, for the device's swap chains) lives in
+// nprng_heads.hip with the vectorised generator and rejection walk it shares with the hypothesis draw.

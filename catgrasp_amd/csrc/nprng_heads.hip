@@ -232,6 +232,7 @@ CG_T512 inline void heads_512(const uint16_t* o, int n, int k, int* heads) {
 }
 
 CG_T512 void perm_rows_512(Stream& S, int n, int n_pts, long count, uint16_t* o, uint16_t* a, int* out) { perm_rows<true>(S, n, n_pts, count, o, a, out); }
+CG_T512 void partners_rows_512(Stream& S, int n, uint16_t* o) { partners_512(S, n, o); }
 
 CG_T512 void rows_512(Stream& S, int n, int k, long count, uint16_t* o, int* out) {
   for (long r = 0; r < count; ++r) {
@@ -346,5 +347,38 @@ extern "C" int cg_host_numpy_permutation_rows(uint32_t* h_mt_key624, int* h_mt_p
     *h_mt_pos = (int)(S.fpos - b * MT_N);
   }
   delete[] perm; delete[] row; delete[] S.tmp; delete[] S.raw;
+  return CG_OK;
+}
+
+// The sequential part of `count` calls of permutation(n_valid) alone: the Fisher-Yates swap partners j(i), i = n_valid-1 .. 1, of
+// every row, as u16 (row r at h_j + r*row_stride, step s = n_valid-1-i at [s]; the tail of the stride is zero-filled).  Consumes the
+// generator exactly like cg_host_numpy_choice_rows' replace=False branch -- the rejection loop is what makes the stream sequential --
+// and leaves the swap chain itself to the device (cg_apply_shuffle_rows), which runs one chain per lane.  Same vectorised generator
+// and rejection walk as the hypothesis draw above (~1.5 us per row at n_valid = 2,500 on the AVX-512 path; the scalar walk: ~5 us).
+extern "C" int cg_host_numpy_shuffle_partners(uint32_t* h_mt_key624, int* h_mt_pos, int n_valid, long count, long row_stride, uint16_t* h_j) {
+  if (!h_mt_key624 || !h_mt_pos || n_valid < 2 || n_valid > 65536 || count < 0 || row_stride < n_valid - 1 || *h_mt_pos < 0 || *h_mt_pos > MT_N)
+    return CG_ERR_ARG;
+  if (count == 0) return CG_OK;
+  if (!h_j) return CG_ERR_ARG;
+  Stream S;
+  S.raw = new uint32_t[(size_t)RING_WORDS];
+  S.tmp = new uint32_t[(size_t)RING_WORDS + MIRROR];
+  uint16_t* row = new uint16_t[(size_t)n_valid + 64];      // the walk stores whole vectors: a row is produced here and copied out
+  S.wide = cpu_has_avx512();
+  memcpy(S.raw, h_mt_key624, sizeof(uint32_t) * MT_N);
+  temper_block(S.raw, S.tmp);
+  S.fpos = S.start = *h_mt_pos;
+  for (long r = 0; r < count; ++r) {
+    if (S.wide) partners_rows_512(S, n_valid, row); else partners_scalar(S, n_valid, row);
+    uint16_t* o = h_j + r * row_stride;
+    memcpy(o, row, sizeof(uint16_t) * (size_t)(n_valid - 1));
+    for (long k = n_valid - 1; k < row_stride; ++k) o[k] = 0;
+  }
+  if (S.fpos > S.start) {
+    const long b = (S.fpos - 1) / MT_N;
+    memcpy(h_mt_key624, S.raw + (b % RING) * MT_N, sizeof(uint32_t) * MT_N);
+    *h_mt_pos = (int)(S.fpos - b * MT_N);
+  }
+  delete[] row; delete[] S.tmp; delete[] S.raw;
   return CG_OK;
 }
