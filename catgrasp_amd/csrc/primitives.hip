@@ -274,6 +274,317 @@ __global__ __launch_bounds__(NT) void fps_kernel(const float* __restrict__ xyz, 
   }
 }
 
+// ---------------------------------------------------------------- farthest point sampling that skips what cannot change
+// The same rounds, the same arithmetic per point, fewer points per round.  A point's running distance only changes when the new centre
+// is nearer than its present value, so a set of points whose bounding box lies farther from the centre than the set's LARGEST running
+// distance needs no update at all.  The lower bound is evaluated with the very instruction sequence of the update -- sub, mul, add, add
+// on the box's nearest corner -- and every one of those float operations is monotone in |argument|, so the bound is exact in float
+// arithmetic, not merely in real arithmetic: skipped points would have computed d >= bound >= their running value and stayed as they
+// are (pointnet2.py:70-72 `mask = dist < distance`).  Samples stay bit-identical to the plain loop (tests/test_primitives_gpu.py;
+// scripts/fps_blob_sim.py is the host emulation, which also counts the work: 20 % of the blobs per round for a uniform volume, 13 % for
+// a surface, at 512 points per blob).
+//  * prologue (once per cloud, in the same launch): the points are binned into 16 x 16 x 16 cells of the cloud's box, cells in Morton
+//    order (LDS histogram, scan, scatter; the order inside a cell is whatever the atomics give -- any order yields the same samples);
+//    `perm` (LDS, 16-bit) maps a sorted position back to the point index;
+//  * a blob = the GS slots x 64 lanes of one (wavefront, group) = 64 GS consecutive sorted positions; consecutive blobs go to different
+//    wavefronts (a round lasts as long as its busiest SIMD, and the blobs a centre touches are neighbours);
+//  * per round each wavefront tests its NG blobs in lanes 0..NG-1 at once (box and running maximum live there), and updates the ones the
+//    ballot names; an updated group reduces its new maximum over the wave (kept wave-uniform, bm[g]) -- so the wave's winner is known from
+//    scalars, no reduction at the end of the round;
+//  * ties (equal running distances: duplicates, lattices) must resolve to the smallest POINT index, and sorted order is not index order:
+//    any tie -- two groups, two lanes or two slots at the maximum -- takes a wave-uniform slow path that looks the indices up in `perm`;
+//  * the exchange between wavefronts is the one of fps_kernel, carrying sorted positions; the samples are translated through `perm` when
+//    the rounds are over.
+constexpr int FPS_CELL_BITS = 4, FPS_BINS = 1 << (3 * FPS_CELL_BITS);
+
+__device__ __forceinline__ int fps_cell(float x, float y, float z, const float (&lo)[3], const float (&inv)[3]) {
+  constexpr float TOP = (float)((1 << FPS_CELL_BITS) - 1);
+  const unsigned a = (unsigned)fminf(fmaxf((x - lo[0]) * inv[0], 0.f), TOP);      // NaN -> 0: every point lands in some cell
+  const unsigned b = (unsigned)fminf(fmaxf((y - lo[1]) * inv[1], 0.f), TOP);
+  const unsigned c = (unsigned)fminf(fmaxf((z - lo[2]) * inv[2], 0.f), TOP);
+  auto spread = [](unsigned v) {       // 4 bits -> bits 0, 3, 6, 9
+    v = (v | (v << 4)) & 0x0c3u;
+    return (v | (v << 2)) & 0x249u;
+  };
+  static_assert(FPS_CELL_BITS == 4, "spread() is written for 4 bits per axis");
+  return (int)(spread(a) | (spread(b) << 1) | (spread(c) << 2));
+}
+
+// sorted position of slot k of (wavefront wv, lane): blob (k / GS) * NW + wv, then slot-major inside the blob
+template <int NW, int GS>
+__device__ __forceinline__ int fps_slot_pos(int wv, int lane, int k) {
+  return (((((k / GS) * NW + wv) * GS) + (k % GS)) << 6) + lane;
+}
+
+// the winner of the wave inside group gw (wave-uniform; binary search over the groups): its lane, slot and coordinates, and whether
+// anything else in the group holds the same value (`tie` != 0)
+template <int GLO, int GHI, int GS, int PPT, int H>
+__device__ __forceinline__ void fps_blob_find(int gw, unsigned wmax, const unsigned (&gmax)[PPT / GS], const unsigned (&dist)[PPT],
+                                              const f32x2 (&px)[H], const f32x2 (&py)[H], const f32x2 (&pz)[H], int& wl, int& kw, int& tie,
+                                              float& x, float& y, float& z) {
+  if constexpr (GHI - GLO == 1) {
+    constexpr int G = GLO;
+    unsigned bv = wmax;
+    asm volatile("" : "+v"(bv));                            // the search stays inside its branch
+    const unsigned long long cand = __ballot(gmax[G] == bv);
+    wl = __builtin_ctzll(cand);
+    int k = G * GS + GS - 1, cnt = 0;
+#pragma unroll
+    for (int j = GS - 1; j >= 0; --j) {
+      const bool eq = dist[G * GS + j] == bv;
+      k = eq ? G * GS + j : k;
+      cnt += eq ? 1 : 0;
+    }
+    kw = __builtin_amdgcn_readlane(k, wl);
+    tie = (__builtin_popcountll(cand) - 1) | (__builtin_amdgcn_readlane(cnt, wl) - 1);
+    fps_pick<G * GS, G * GS + GS, H>(kw, px, py, pz, x, y, z);
+  } else {
+    constexpr int MID = (GLO + GHI) / 2;
+    if (gw < MID) fps_blob_find<GLO, MID, GS, PPT, H>(gw, wmax, gmax, dist, px, py, pz, wl, kw, tie, x, y, z);
+    else fps_blob_find<MID, GHI, GS, PPT, H>(gw, wmax, gmax, dist, px, py, pz, wl, kw, tie, x, y, z);
+  }
+}
+
+template <int NT, int PPT, int GS>
+__global__ __launch_bounds__(NT) void fps_blob_kernel(const float* __restrict__ xyz, const long long* __restrict__ start, int N, int npoint,
+                                                      long long* __restrict__ out) {
+  static_assert(NT % 64 == 0 && NT <= 1024 && GS % 2 == 0 && PPT % GS == 0 && (GS & (GS - 1)) == 0, "geometry");
+  static_assert(FPS_BINS % NT == 0 && NT * PPT < 0xffff, "one scan chunk per thread; 16-bit point indices with 0xffff = none");
+  constexpr int H = PPT / 2, NG = PPT / GS, NW = NT / 64, CAP = NT * PPT, BPT = FPS_BINS / NT;
+  static_assert(NG <= 64, "one lane per group for the skip test");
+  __shared__ __attribute__((aligned(16))) unsigned short perm[CAP];   // sorted position -> point index (0xffff: padding)
+  __shared__ __attribute__((aligned(16))) int scr[FPS_BINS];   // prologue: box partials, then the cell histogram; rounds: the wave records
+  int* wsum = reinterpret_cast<int*>(perm);                // the scan's wave totals (perm is written after the scan); 64 KB of LDS in all at 48 slots
+  f32x4 (*red_v)[16] = reinterpret_cast<f32x4 (*)[16]>(scr);         // [2][16]: (bits of the best distance, x, y, z) of each wave's winner
+  int (*red_i)[16] = reinterpret_cast<int (*)[16]>(scr + 128);       // [2][16]: its sorted position
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const float* xb = xyz + (size_t)b * N * 3;
+  long long* ob = out + (size_t)b * npoint;
+
+  // ---- prologue 1: the cloud's box (the thread's share of the cloud in index order, CH points in flight at a time) ----
+  constexpr int CH = PPT / 2;
+  float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+#pragma unroll
+  for (int k0 = 0; k0 < PPT; k0 += CH) {
+    float r[CH][3];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      const int p = tid + (k0 + j) * NT, q = p < N ? p : N - 1;      // beyond N: the last point again, the box does not mind
+#pragma unroll
+      for (int a = 0; a < 3; ++a) r[j][a] = xb[q * 3 + a];
+    }
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], r[j][a]); hi[a] = fmaxf(hi[a], r[j][a]); }
+    }
+    asm volatile("" ::: "memory");
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], __shfl_xor(lo[a], o)); hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], o)); }
+  }
+  float* fscr = reinterpret_cast<float*>(scr);
+  if (lane == 0) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { fscr[wv * 8 + a] = lo[a]; fscr[wv * 8 + 4 + a] = hi[a]; }
+  }
+  __syncthreads();
+  float inv[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    for (int w = 0; w < NW; ++w) { lo[a] = fminf(lo[a], fscr[w * 8 + a]); hi[a] = fmaxf(hi[a], fscr[w * 8 + 4 + a]); }
+    inv[a] = (float)(1 << FPS_CELL_BITS) / fmaxf(hi[a] - lo[a], 1e-30f);
+  }
+  __syncthreads();
+  // ---- prologue 2: counting sort by cell ----
+  for (int i = tid; i < FPS_BINS; i += NT) scr[i] = 0;
+  __syncthreads();
+  unsigned cell[H];                    // the cells of the thread's points, two per register
+  int tid2 = tid;
+  asm volatile("" : "+v"(tid2));       // the addresses are formed again here (kept from the first pass they would be 2 registers per point)
+#pragma unroll
+  for (int k0 = 0; k0 < PPT; k0 += CH) {
+    float r[CH][3];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      const int p = tid2 + (k0 + j) * NT, q = p < N ? p : N - 1;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) r[j][a] = xb[q * 3 + a];
+    }
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      const int k = k0 + j;
+      const unsigned c = (unsigned)fps_cell(r[j][0], r[j][1], r[j][2], lo, inv);
+      cell[k >> 1] = (k & 1) ? (cell[k >> 1] | (c << 16)) : c;
+      if (tid + k * NT < N) atomicAdd(&scr[c], 1);
+    }
+    asm volatile("" ::: "memory");
+  }
+  __syncthreads();
+  {
+    int c[BPT], s = 0;
+#pragma unroll
+    for (int i = 0; i < BPT; ++i) { c[i] = scr[tid * BPT + i]; s += c[i]; }
+    int inc = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    int base = inc - s;
+    for (int w = 0; w < wv; ++w) base += wsum[w];
+#pragma unroll
+    for (int i = 0; i < BPT; ++i) { scr[tid * BPT + i] = base; base += c[i]; }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < PPT; ++k) {
+    const int p = tid + k * NT;
+    if (p < N) perm[atomicAdd(&scr[(cell[k >> 1] >> (16 * (k & 1))) & 0xffffu], 1)] = (unsigned short)p;
+  }
+  for (int s = N + tid; s < CAP; s += NT) perm[s] = 0xffffu;
+  __syncthreads();
+  // ---- prologue 3: the thread's slots (again all loads in flight), the blob boxes (lane g of every wave holds group g's), the maxima ----
+  f32x2 px[H], py[H], pz[H];
+  unsigned dist[PPT];                  // bit patterns of the running distances (all >= +0)
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {       // a group at a time: GS positions out of LDS, then GS gathers in flight
+    int sp[GS];
+#pragma unroll
+    for (int j = 0; j < GS; ++j) sp[j] = perm[fps_slot_pos<NW, GS>(wv, lane, g * GS + j)];
+#pragma unroll
+    for (int j = 0; j < GS; ++j) {
+      const int k = g * GS + j;
+      const bool real = sp[j] != 0xffff;
+      const int q = real ? sp[j] : 0;
+      const float x = xb[q * 3 + 0], y = xb[q * 3 + 1], z = xb[q * 3 + 2];
+      // padding: at the origin with running distance 0, which never shrinks and never beats a real point (its index reads 0xffff)
+      px[k >> 1][k & 1] = real ? x : 0.f; py[k >> 1][k & 1] = real ? y : 0.f; pz[k >> 1][k & 1] = real ? z : 0.f;
+      dist[k] = real ? __float_as_uint(1e10f) : 0u;
+    }
+    asm volatile("" ::: "memory");     // keeps the groups apart (all at once would need every register twice)
+  }
+  unsigned gmax[NG];                   // per lane: the largest running distance among the GS slots of group g
+  unsigned bm[NG];                     // wave-uniform: the largest of the whole blob
+  float blo[3] = {0.f, 0.f, 0.f}, bhi[3] = {0.f, 0.f, 0.f}, bmaxv = 0.f;   // lane g < NG: blob g's box and running maximum
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    float l3[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, h3[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+    unsigned m = 0u;
+#pragma unroll
+    for (int k = g * GS; k < (g + 1) * GS; ++k) {
+      if (dist[k] != 0u) {             // a real point
+        l3[0] = fminf(l3[0], px[k >> 1][k & 1]); h3[0] = fmaxf(h3[0], px[k >> 1][k & 1]);
+        l3[1] = fminf(l3[1], py[k >> 1][k & 1]); h3[1] = fmaxf(h3[1], py[k >> 1][k & 1]);
+        l3[2] = fminf(l3[2], pz[k >> 1][k & 1]); h3[2] = fmaxf(h3[2], pz[k >> 1][k & 1]);
+      }
+      m = m > dist[k] ? m : dist[k];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) { l3[a] = fminf(l3[a], __shfl_xor(l3[a], o)); h3[a] = fmaxf(h3[a], __shfl_xor(h3[a], o)); }
+    }
+    gmax[g] = m;
+    bm[g] = wave_max_u32(m);
+    if (lane == g) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) { blo[a] = l3[a]; bhi[a] = h3[a]; }
+      bmaxv = __uint_as_float(bm[g]);
+    }
+  }
+  if (tid < 32) { red_v[tid >> 4][tid & 15] = f32x4{0.f, 0.f, 0.f, 0.f}; red_i[tid >> 4][tid & 15] = 0x7fffffff; }   // absent waves: distance 0, position "none"
+  __syncthreads();
+
+  const int first = (int)start[b];
+  float cx = xb[first * 3 + 0], cy = xb[first * 3 + 1], cz = xb[first * 3 + 2];
+  if (tid == 0 && npoint > 0) ob[0] = first;
+  for (int it = 1; it < npoint; ++it) {
+    // ---- which of the wave's blobs can change: distance from the centre to the blob's box, rounded exactly like a point's ----
+    const float qx = fmaxf(fmaxf(blo[0] - cx, cx - bhi[0]), 0.f), qy = fmaxf(fmaxf(blo[1] - cy, cy - bhi[1]), 0.f),
+                qz = fmaxf(fmaxf(blo[2] - cz, cz - bhi[2]), 0.f);
+    const float lb = (qx * qx + qy * qy) + qz * qz;
+    const unsigned need = (unsigned)(__ballot(lane < NG && lb < bmaxv));
+    const f32x2 c2x = {cx, cx}, c2y = {cy, cy}, c2z = {cz, cz};
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      if ((need >> g) & 1u) {
+        unsigned m = 0u;
+#pragma unroll
+        for (int h = g * (GS / 2); h < (g + 1) * (GS / 2); ++h) {
+          const f32x2 dx = px[h] - c2x, dy = py[h] - c2y, dz = pz[h] - c2z;
+          const f32x2 d = (dx * dx + dy * dy) + dz * dz;      // torch.sum((xyz - centroid) ** 2, -1), two points per instruction
+          const unsigned d0 = __float_as_uint(d[0]), d1 = __float_as_uint(d[1]);
+          const unsigned n0 = d0 < dist[2 * h] ? d0 : dist[2 * h];              // mask = dist < distance; distance[mask] = dist[mask]
+          const unsigned n1 = d1 < dist[2 * h + 1] ? d1 : dist[2 * h + 1];
+          dist[2 * h] = n0; dist[2 * h + 1] = n1;
+          const unsigned a = m > n0 ? m : n0;
+          m = a > n1 ? a : n1;
+        }
+        gmax[g] = m;
+        const unsigned wm = wave_max_u32(m);
+        bm[g] = wm;
+        // lane g keeps blob g's maximum for the skip test (the wait states cover the SGPR just written by v_readlane)
+        asm volatile("s_nop 3\n\tv_writelane_b32 %0, %1, %2" : "+v"(bmaxv) : "s"(wm), "n"(g));
+      }
+    }
+    // ---- the wave's winner, from the blob maxima ----
+    unsigned wmax = bm[0];
+#pragma unroll
+    for (int g = 1; g < NG; ++g) wmax = wmax > bm[g] ? wmax : bm[g];
+    int gw = NG - 1, cntg = 0;
+#pragma unroll
+    for (int g = NG - 1; g >= 0; --g) { const bool eq = bm[g] == wmax; gw = eq ? g : gw; cntg += eq ? 1 : 0; }
+    int wl, kw, tie; float bx, by, bz;
+    fps_blob_find<0, NG, GS, PPT, H>(gw, wmax, gmax, dist, px, py, pz, wl, kw, tie, bx, by, bz);
+    if (tie | (cntg - 1)) {                                  // equal maxima somewhere in the wave: the smallest point index wins
+      int bi = 0x7fffffff, bk = 0;
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        if (bm[g] == wmax) {
+          int oi[GS];
+#pragma unroll
+          for (int j = 0; j < GS; ++j) oi[j] = perm[fps_slot_pos<NW, GS>(wv, lane, g * GS + j)];
+#pragma unroll
+          for (int j = 0; j < GS; ++j) {
+            const bool better = dist[g * GS + j] == wmax && oi[j] < bi;
+            bi = better ? oi[j] : bi; bk = better ? g * GS + j : bk;
+          }
+        }
+      }
+      const int mi = wave_min_i32(bi);
+      wl = __builtin_ctzll(__ballot(bi == mi));
+      kw = __builtin_amdgcn_readlane(bk, wl);
+      fps_pick<0, PPT, H>(kw, px, py, pz, bx, by, bz);
+    }
+    const int iw = fps_slot_pos<NW, GS>(wv, wl, kw);
+    const int buf = it & 1;
+    if (lane == wl) { red_v[buf][wv] = f32x4{__uint_as_float(wmax), bx, by, bz}; red_i[buf][wv] = iw; }
+    __syncthreads();
+    // ---- workgroup: the same over the wave winners; every wave redoes it on its own copy ----
+    const f32x4 e = red_v[buf][lane & 15];
+    const int ei = red_i[buf][lane & 15];
+    const unsigned ev = __float_as_uint(e[0]);
+    const unsigned best = row_max_u32(ev);
+    unsigned c16 = (unsigned)__ballot(ev == best) & 0xffffu;
+    if (__builtin_popcount(c16) != 1) {
+      const int oi = (unsigned)ei < (unsigned)CAP ? (int)perm[ei] : 0x7fffffff;
+      const int mi = row_min_i32(ev == best ? oi : 0x7fffffff);
+      c16 = (unsigned)__ballot(ev == best && oi == mi) & 0xffffu;
+    }
+    const int win = __builtin_ctz(c16);
+    const int farthest = __builtin_amdgcn_readlane(ei, win);
+    cx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e[1]), win));
+    cy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e[2]), win));
+    cz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e[3]), win));
+    if (tid == 0) ob[it] = farthest;                         // a sorted position for now
+  }
+  __syncthreads();                                           // thread 0's stores are visible to the workgroup
+  for (int i = 1 + tid; i < npoint; i += NT) ob[i] = perm[(int)ob[i]];
+}
+
 // generic fallback for clouds larger than the register path: running distances live in a global scratch row.
 __global__ __launch_bounds__(1024) void fps_kernel_global(const float* __restrict__ xyz, const long long* __restrict__ start, int N, int npoint,
                                                           float* __restrict__ dist_scratch, long long* __restrict__ out) {
@@ -409,6 +720,13 @@ extern "C" int cg_index_points(const float* points, const long long* idx, int B,
   return cg_hip_status(hipGetLastError());
 }
 
+// CATGRASP_AMD_FPS = plain | blob8 | blob4: which kernel samples clouds of 8,193 .. 24,576 points
+static int fps_variant() {
+  const char* e = getenv("CATGRASP_AMD_FPS");
+  if (!e || e[0] != 'b') return 0;
+  return e[1] && e[2] && e[3] && e[4] == '8' ? 8 : e[1] && e[2] && e[3] && e[4] == '4' ? 4 : 0;
+}
+
 extern "C" int cg_farthest_point_sample(const float* xyz, const long long* start, int B, int N, int npoint, float* dist_scratch,
                                         long long* out, void* stream) {
   if (B < 0 || N <= 0 || npoint < 0) return CG_ERR_ARG;
@@ -422,8 +740,17 @@ extern "C" int cg_farthest_point_sample(const float* xyz, const long long* start
   else if (N <= 1024 * 8) hipLaunchKernelGGL((fps_kernel<1024, 8>), grid, block, 0, s, xyz, start, N, npoint, out);
   // 8,193 .. 24,576 points: 512 threads x 40 / 48 points (two waves per SIMD).  Measured at N = 20,000: 1.47 us per round against
   // 1.65 us for 1024 threads x 20 points -- more waves only add exchange work.
-  else if (N <= 512 * 40) hipLaunchKernelGGL((fps_kernel<512, 40>), grid, dim3(512), 0, s, xyz, start, N, npoint, out);
-  else if (N <= 512 * 48) hipLaunchKernelGGL((fps_kernel<512, 48>), grid, dim3(512), 0, s, xyz, start, N, npoint, out);
+  else if (N <= 512 * 40) {
+    const int v = fps_variant();
+    if (v == 8) hipLaunchKernelGGL((fps_blob_kernel<512, 40, 8>), grid, dim3(512), 0, s, xyz, start, N, npoint, out);
+    else if (v == 4) hipLaunchKernelGGL((fps_blob_kernel<512, 40, 4>), grid, dim3(512), 0, s, xyz, start, N, npoint, out);
+    else hipLaunchKernelGGL((fps_kernel<512, 40>), grid, dim3(512), 0, s, xyz, start, N, npoint, out);
+  } else if (N <= 512 * 48) {
+    const int v = fps_variant();
+    if (v == 8) hipLaunchKernelGGL((fps_blob_kernel<512, 48, 8>), grid, dim3(512), 0, s, xyz, start, N, npoint, out);
+    else if (v == 4) hipLaunchKernelGGL((fps_blob_kernel<512, 48, 4>), grid, dim3(512), 0, s, xyz, start, N, npoint, out);
+    else hipLaunchKernelGGL((fps_kernel<512, 48>), grid, dim3(512), 0, s, xyz, start, N, npoint, out);
+  }
   else {
     if (!dist_scratch) return CG_ERR_ARG;   // (B,N) floats needed for clouds beyond the register path
     hipLaunchKernelGGL(fps_kernel_global, grid, block, 0, s, xyz, start, N, npoint, dist_scratch, out);
