@@ -276,25 +276,29 @@ __global__ __launch_bounds__(NT) void fps_kernel(const float* __restrict__ xyz, 
 
 // ---------------------------------------------------------------- farthest point sampling that skips what cannot change
 // The same rounds, the same arithmetic per point, fewer points per round.  A point's running distance only changes when the new centre
-// is nearer than its present value, so a set of points whose bounding box lies farther from the centre than the set's LARGEST running
-// distance needs no update at all.  The lower bound is evaluated with the very instruction sequence of the update -- sub, mul, add, add
-// on the box's nearest corner -- and every one of those float operations is monotone in |argument|, so the bound is exact in float
-// arithmetic, not merely in real arithmetic: skipped points would have computed d >= bound >= their running value and stayed as they
-// are (pointnet2.py:70-72 `mask = dist < distance`).  Samples stay bit-identical to the plain loop (tests/test_primitives_gpu.py;
-// scripts/fps_blob_sim.py is the host emulation, which also counts the work: 20 % of the blobs per round for a uniform volume, 13 % for
-// a surface, at 512 points per blob).
+// is nearer than its present value, and no running distance exceeds the one the new centre had when it was chosen (it was the maximum):
+// a set of points whose bounding box lies farther from the centre than that needs no update at all.  The lower bound is evaluated with
+// the very instruction sequence of the update -- sub, mul, add, add on the box's nearest corner -- and every one of those float
+// operations is monotone in |argument|, so the bound holds in float arithmetic, not merely in real arithmetic: a skipped point would
+// have computed d >= bound >= maximum >= its running value and stayed as it is (pointnet2.py:70-72 `mask = dist < distance`).  Samples
+// stay bit-identical to the plain loop (tests/test_primitives_gpu.py; scripts/fps_blob_lane_sim.py is the host emulation lane by lane,
+// scripts/fps_blob_sim.py counts the work: 21 % of the blobs per round for a uniform volume, 14 % for a surface, at 512 points per blob).
 //  * prologue (once per cloud, in the same launch): the points are binned into 16 x 16 x 16 cells of the cloud's box, cells in Morton
 //    order (LDS histogram, scan, scatter; the order inside a cell is whatever the atomics give -- any order yields the same samples);
 //    `perm` (LDS, 16-bit) maps a sorted position back to the point index;
 //  * a blob = the GS slots x 64 lanes of one (wavefront, group) = 64 GS consecutive sorted positions; consecutive blobs go to different
-//    wavefronts (a round lasts as long as its busiest SIMD, and the blobs a centre touches are neighbours);
-//  * per round each wavefront tests its NG blobs in lanes 0..NG-1 at once (box and running maximum live there), and updates the ones the
-//    ballot names; an updated group reduces its new maximum over the wave (kept wave-uniform, bm[g]) -- so the wave's winner is known from
-//    scalars, no reduction at the end of the round;
+//    wavefronts: a round lasts as long as its busiest SIMD, and the blobs a centre touches are neighbours (measured with a wavefront's
+//    blobs adjacent instead: 1.29 us per round against 1.06);
+//  * per round each wavefront tests its NG blobs in lanes 0..NG-1 at once (the boxes live there) and updates the groups the ballot names;
+//    the winner is found as in fps_kernel (lane maxima, one wave reduction, the winner lane's group and slot);
 //  * ties (equal running distances: duplicates, lattices) must resolve to the smallest POINT index, and sorted order is not index order:
-//    any tie -- two groups, two lanes or two slots at the maximum -- takes a wave-uniform slow path that looks the indices up in `perm`;
+//    any tie -- two lanes, two groups or two slots at the maximum -- takes a wave-uniform slow path that looks the indices up in `perm`;
 //  * the exchange between wavefronts is the one of fps_kernel, carrying sorted positions; the samples are translated through `perm` when
 //    the rounds are over.
+// Measured and rejected (profiles/r4_fps_blob.json holds the kept ones): the blob's own running maximum as the bound instead of the
+// cloud's (a wave reduction per updated group: 2 % fewer updates, 1.06 us per round against 1.05; with 256-point blobs 1.16 against
+// 1.07); 256-point blobs above 8,192 points (more skipped, more bookkeeping: 1.07 against 1.05); keeping a wavefront's previous winner
+// when it updated nothing (1.08 against 1.06: the branch costs more than the search it saves).
 constexpr int FPS_CELL_BITS = 4, FPS_BINS = 1 << (3 * FPS_CELL_BITS);
 
 __device__ __forceinline__ int fps_cell(float x, float y, float z, const float (&lo)[3], const float (&inv)[3]) {
@@ -316,18 +320,15 @@ __device__ __forceinline__ int fps_slot_pos(int wv, int lane, int k) {
   return (((((k / GS) * NW + wv) * GS) + (k % GS)) << 6) + lane;
 }
 
-// the winner of the wave inside group gw (wave-uniform; binary search over the groups): its lane, slot and coordinates, and whether
-// anything else in the group holds the same value (`tie` != 0)
+// inside group gw of the winner lane wl (both wave-uniform; binary search over the groups): its first slot at the wave maximum, how
+// many of its slots hold it, the slot's coordinates
 template <int GLO, int GHI, int GS, int PPT, int H>
-__device__ __forceinline__ void fps_blob_find(int gw, unsigned wmax, const unsigned (&gmax)[PPT / GS], const unsigned (&dist)[PPT],
-                                              const f32x2 (&px)[H], const f32x2 (&py)[H], const f32x2 (&pz)[H], int& wl, int& kw, int& tie,
-                                              float& x, float& y, float& z) {
+__device__ __forceinline__ void fps_ball_find(int gw, int wl, unsigned wmax, const unsigned (&dist)[PPT], const f32x2 (&px)[H],
+                                              const f32x2 (&py)[H], const f32x2 (&pz)[H], int& kw, int& cw, float& x, float& y, float& z) {
   if constexpr (GHI - GLO == 1) {
     constexpr int G = GLO;
     unsigned bv = wmax;
     asm volatile("" : "+v"(bv));                            // the search stays inside its branch
-    const unsigned long long cand = __ballot(gmax[G] == bv);
-    wl = __builtin_ctzll(cand);
     int k = G * GS + GS - 1, cnt = 0;
 #pragma unroll
     for (int j = GS - 1; j >= 0; --j) {
@@ -336,12 +337,12 @@ __device__ __forceinline__ void fps_blob_find(int gw, unsigned wmax, const unsig
       cnt += eq ? 1 : 0;
     }
     kw = __builtin_amdgcn_readlane(k, wl);
-    tie = (__builtin_popcountll(cand) - 1) | (__builtin_amdgcn_readlane(cnt, wl) - 1);
+    cw = __builtin_amdgcn_readlane(cnt, wl);
     fps_pick<G * GS, G * GS + GS, H>(kw, px, py, pz, x, y, z);
   } else {
     constexpr int MID = (GLO + GHI) / 2;
-    if (gw < MID) fps_blob_find<GLO, MID, GS, PPT, H>(gw, wmax, gmax, dist, px, py, pz, wl, kw, tie, x, y, z);
-    else fps_blob_find<MID, GHI, GS, PPT, H>(gw, wmax, gmax, dist, px, py, pz, wl, kw, tie, x, y, z);
+    if (gw < MID) fps_ball_find<GLO, MID, GS, PPT, H>(gw, wl, wmax, dist, px, py, pz, kw, cw, x, y, z);
+    else fps_ball_find<MID, GHI, GS, PPT, H>(gw, wl, wmax, dist, px, py, pz, kw, cw, x, y, z);
   }
 }
 
@@ -467,8 +468,7 @@ __global__ __launch_bounds__(NT) void fps_blob_kernel(const float* __restrict__ 
     asm volatile("" ::: "memory");     // keeps the groups apart (all at once would need every register twice)
   }
   unsigned gmax[NG];                   // per lane: the largest running distance among the GS slots of group g
-  unsigned bm[NG];                     // wave-uniform: the largest of the whole blob
-  float blo[3] = {0.f, 0.f, 0.f}, bhi[3] = {0.f, 0.f, 0.f}, bmaxv = 0.f;   // lane g < NG: blob g's box and running maximum
+  float blo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, bhi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};   // lane g < NG: blob g's box
 #pragma unroll
   for (int g = 0; g < NG; ++g) {
     float l3[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, h3[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
@@ -488,11 +488,9 @@ __global__ __launch_bounds__(NT) void fps_blob_kernel(const float* __restrict__ 
       for (int a = 0; a < 3; ++a) { l3[a] = fminf(l3[a], __shfl_xor(l3[a], o)); h3[a] = fmaxf(h3[a], __shfl_xor(h3[a], o)); }
     }
     gmax[g] = m;
-    bm[g] = wave_max_u32(m);
     if (lane == g) {
 #pragma unroll
       for (int a = 0; a < 3; ++a) { blo[a] = l3[a]; bhi[a] = h3[a]; }
-      bmaxv = __uint_as_float(bm[g]);
     }
   }
   if (tid < 32) { red_v[tid >> 4][tid & 15] = f32x4{0.f, 0.f, 0.f, 0.f}; red_i[tid >> 4][tid & 15] = 0x7fffffff; }   // absent waves: distance 0, position "none"
@@ -501,12 +499,13 @@ __global__ __launch_bounds__(NT) void fps_blob_kernel(const float* __restrict__ 
   const int first = (int)start[b];
   float cx = xb[first * 3 + 0], cy = xb[first * 3 + 1], cz = xb[first * 3 + 2];
   if (tid == 0 && npoint > 0) ob[0] = first;
+  float rad = 1e10f;                   // the largest running distance of the whole cloud (= the new centre's, when it was chosen)
   for (int it = 1; it < npoint; ++it) {
     // ---- which of the wave's blobs can change: distance from the centre to the blob's box, rounded exactly like a point's ----
     const float qx = fmaxf(fmaxf(blo[0] - cx, cx - bhi[0]), 0.f), qy = fmaxf(fmaxf(blo[1] - cy, cy - bhi[1]), 0.f),
                 qz = fmaxf(fmaxf(blo[2] - cz, cz - bhi[2]), 0.f);
     const float lb = (qx * qx + qy * qy) + qz * qz;
-    const unsigned need = (unsigned)(__ballot(lane < NG && lb < bmaxv));
+    const unsigned need = (unsigned)(__ballot(lane < NG && lb < rad));
     const f32x2 c2x = {cx, cx}, c2y = {cy, cy}, c2z = {cz, cz};
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
@@ -524,26 +523,27 @@ __global__ __launch_bounds__(NT) void fps_blob_kernel(const float* __restrict__ 
           m = a > n1 ? a : n1;
         }
         gmax[g] = m;
-        const unsigned wm = wave_max_u32(m);
-        bm[g] = wm;
-        // lane g keeps blob g's maximum for the skip test (the wait states cover the SGPR just written by v_readlane)
-        asm volatile("s_nop 3\n\tv_writelane_b32 %0, %1, %2" : "+v"(bmaxv) : "s"(wm), "n"(g));
       }
     }
-    // ---- the wave's winner, from the blob maxima ----
-    unsigned wmax = bm[0];
+    // ---- the wave's winner: one reduction of the lanes' maxima, then the winner lane's group and slot ----
+    unsigned bv = gmax[0];
 #pragma unroll
-    for (int g = 1; g < NG; ++g) wmax = wmax > bm[g] ? wmax : bm[g];
-    int gw = NG - 1, cntg = 0;
+    for (int g = 1; g < NG; ++g) bv = bv > gmax[g] ? bv : gmax[g];
+    const unsigned wmax = wave_max_u32(bv);
+    const unsigned long long cand = __ballot(bv == wmax);
+    int wl = __builtin_ctzll(cand);
+    int gi = NG - 1, cg = 0;                                 // per lane: the first group at the lane's maximum, and how many are
 #pragma unroll
-    for (int g = NG - 1; g >= 0; --g) { const bool eq = bm[g] == wmax; gw = eq ? g : gw; cntg += eq ? 1 : 0; }
-    int wl, kw, tie; float bx, by, bz;
-    fps_blob_find<0, NG, GS, PPT, H>(gw, wmax, gmax, dist, px, py, pz, wl, kw, tie, bx, by, bz);
-    if (tie | (cntg - 1)) {                                  // equal maxima somewhere in the wave: the smallest point index wins
+    for (int g = NG - 1; g >= 0; --g) { const bool eq = gmax[g] == bv; gi = eq ? g : gi; cg += eq ? 1 : 0; }
+    const int gw = __builtin_amdgcn_readlane(gi, wl);
+    int kw, cw; float bx, by, bz;
+    fps_ball_find<0, NG, GS, PPT, H>(gw, wl, wmax, dist, px, py, pz, kw, cw, bx, by, bz);
+    const int tie = (__builtin_popcountll(cand) - 1) | (__builtin_amdgcn_readlane(cg, wl) - 1) | (cw - 1);
+    if (tie) {                                               // equal maxima somewhere in the wave: the smallest point index wins
       int bi = 0x7fffffff, bk = 0;
 #pragma unroll
       for (int g = 0; g < NG; ++g) {
-        if (bm[g] == wmax) {
+        if (__ballot(gmax[g] == wmax) != 0ull) {
           int oi[GS];
 #pragma unroll
           for (int j = 0; j < GS; ++j) oi[j] = perm[fps_slot_pos<NW, GS>(wv, lane, g * GS + j)];
@@ -579,6 +579,7 @@ __global__ __launch_bounds__(NT) void fps_blob_kernel(const float* __restrict__ 
     cx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e[1]), win));
     cy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e[2]), win));
     cz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e[3]), win));
+    rad = __uint_as_float(best);
     if (tid == 0) ob[it] = farthest;                         // a sorted position for now
   }
   __syncthreads();                                           // thread 0's stores are visible to the workgroup
@@ -720,11 +721,11 @@ extern "C" int cg_index_points(const float* points, const long long* idx, int B,
   return cg_hip_status(hipGetLastError());
 }
 
-// CATGRASP_AMD_FPS = plain | blob8 | blob4: which kernel samples clouds of 8,193 .. 24,576 points
-static int fps_variant() {
+// CATGRASP_AMD_FPS=plain (development switch, read per call): fps_kernel for every size, the round that updates every point -- what the
+// tests and scripts/fps_blob_check.py compare fps_blob_kernel with
+static bool fps_plain() {
   const char* e = getenv("CATGRASP_AMD_FPS");
-  if (!e || e[0] != 'b') return 0;
-  return e[1] && e[2] && e[3] && e[4] == '8' ? 8 : e[1] && e[2] && e[3] && e[4] == '4' ? 4 : 0;
+  return e && e[0] == 'p';
 }
 
 extern "C" int cg_farthest_point_sample(const float* xyz, const long long* start, int B, int N, int npoint, float* dist_scratch,
@@ -734,27 +735,30 @@ extern "C" int cg_farthest_point_sample(const float* xyz, const long long* start
   if (!xyz || !start || !out) return CG_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((unsigned)B), block(1024);
-  // <= 2,048 points: 512 threads x 4 points (0.60 us per round at N = 2,048 against 0.64 for 1,024 x 2 and 0.67 for 256 x 8: the round
-  // is all exchange there, and eight wave records are cheaper to reduce than sixteen)
-  if (N <= 512 * 4) hipLaunchKernelGGL((fps_kernel<512, 4>), grid, dim3(512), 0, s, xyz, start, N, npoint, out);
-  else if (N <= 1024 * 8) hipLaunchKernelGGL((fps_kernel<1024, 8>), grid, block, 0, s, xyz, start, N, npoint, out);
-  // 8,193 .. 24,576 points: 512 threads x 40 / 48 points (two waves per SIMD).  Measured at N = 20,000: 1.47 us per round against
-  // 1.65 us for 1024 threads x 20 points -- more waves only add exchange work.
-  else if (N <= 512 * 40) {
-    const int v = fps_variant();
-    if (v == 8) hipLaunchKernelGGL((fps_blob_kernel<512, 40, 8>), grid, dim3(512), 0, s, xyz, start, N, npoint, out);
-    else if (v == 4) hipLaunchKernelGGL((fps_blob_kernel<512, 40, 4>), grid, dim3(512), 0, s, xyz, start, N, npoint, out);
-    else hipLaunchKernelGGL((fps_kernel<512, 40>), grid, dim3(512), 0, s, xyz, start, N, npoint, out);
-  } else if (N <= 512 * 48) {
-    const int v = fps_variant();
-    if (v == 8) hipLaunchKernelGGL((fps_blob_kernel<512, 48, 8>), grid, dim3(512), 0, s, xyz, start, N, npoint, out);
-    else if (v == 4) hipLaunchKernelGGL((fps_blob_kernel<512, 48, 4>), grid, dim3(512), 0, s, xyz, start, N, npoint, out);
-    else hipLaunchKernelGGL((fps_kernel<512, 48>), grid, dim3(512), 0, s, xyz, start, N, npoint, out);
-  }
-  else {
-    if (!dist_scratch) return CG_ERR_ARG;   // (B,N) floats needed for clouds beyond the register path
+  if (N > 512 * 48) {
+    if (!dist_scratch) return CG_ERR_ARG;   // (B,N) floats needed for clouds beyond the register paths
     hipLaunchKernelGGL(fps_kernel_global, grid, block, 0, s, xyz, start, N, npoint, dist_scratch, out);
   }
+  // <= 2,048 points: 512 threads x 4 points (0.60 us per round at N = 2,048 against 0.64 for 1,024 x 2 and 0.67 for 256 x 8: the round
+  // is all exchange there, and eight wave records are cheaper to reduce than sixteen)
+  else if (N <= 512 * 4) hipLaunchKernelGGL((fps_kernel<512, 4>), grid, dim3(512), 0, s, xyz, start, N, npoint, out);
+  else if (fps_plain()) {
+    if (N <= 1024 * 8) hipLaunchKernelGGL((fps_kernel<1024, 8>), grid, block, 0, s, xyz, start, N, npoint, out);
+    else if (N <= 512 * 40) hipLaunchKernelGGL((fps_kernel<512, 40>), grid, dim3(512), 0, s, xyz, start, N, npoint, out);
+    else hipLaunchKernelGGL((fps_kernel<512, 48>), grid, dim3(512), 0, s, xyz, start, N, npoint, out);
+  }
+  // 2,049 .. 24,576 points: 512 threads (two waves per SIMD) x 8 .. 48 points, skipping the blobs a round cannot change; 256-point
+  // blobs up to 8,192 points, 512-point blobs above.  us per round, uniform volume / surface cloud, against fps_kernel (which updates
+  // every point every round; profiles/r4_fps_blob.json): 8,192 points 0.83 / 0.79 against 0.95; 12,288: 0.94 / 0.90 against 1.45;
+  // 20,000: 1.05 / 1.00 against 1.45; 24,576: 1.10 / 1.05 against 1.62.
+#define CG_FPS_BLOB(PPT, GS) hipLaunchKernelGGL((fps_blob_kernel<512, PPT, GS>), grid, dim3(512), 0, s, xyz, start, N, npoint, out)
+  else if (N <= 512 * 8) CG_FPS_BLOB(8, 4);
+  else if (N <= 512 * 16) CG_FPS_BLOB(16, 4);
+  else if (N <= 512 * 24) CG_FPS_BLOB(24, 8);
+  else if (N <= 512 * 32) CG_FPS_BLOB(32, 8);
+  else if (N <= 512 * 40) CG_FPS_BLOB(40, 8);
+  else CG_FPS_BLOB(48, 8);
+#undef CG_FPS_BLOB
   return cg_hip_status(hipGetLastError());
 }
 

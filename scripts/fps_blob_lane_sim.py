@@ -13,7 +13,7 @@ f32 = np.float32
 NONE = 0x7fffffff
 
 
-def kernel(xyz, npoint, start, NT=512, PPT=40, GS=8, rng=None, count=None):
+def kernel(xyz, npoint, start, NT=512, PPT=40, GS=8, rng=None, count=None, radius=False):
     N = len(xyz)
     NW, NG, CAP = NT // 64, PPT // GS, NT * PPT
     assert N <= CAP
@@ -41,12 +41,13 @@ def kernel(xyz, npoint, start, NT=512, PPT=40, GS=8, rng=None, count=None):
     out[0] = start
     cen = xyz[start]
     slow = 0
+    rad = f32(1e10)
     for it in range(1, npoint):
         rec_v = np.zeros(16, f32); rec_p = np.zeros((16, 3), f32); rec_i = np.full(16, NONE, np.int64)
         with np.errstate(invalid='ignore'):
             q = np.maximum(np.maximum(blo - cen, cen - bhi), f32(0))
         lb = (q[..., 0] * q[..., 0] + q[..., 1] * q[..., 1]) + q[..., 2] * q[..., 2]
-        need = lb < bm
+        need = (lb < rad) if radius else (lb < bm)
         for w in range(NW):
             for g in range(NG):
                 if need[w, g]:
@@ -56,21 +57,38 @@ def kernel(xyz, npoint, start, NT=512, PPT=40, GS=8, rng=None, count=None):
                     dist[w, :, s] = np.minimum(dist[w, :, s], d)
                     gm[w, :, g] = dist[w, :, s].max(1)
                     bm[w, g] = gm[w, :, g].max()
-            wmax = bm[w].max()
-            eqg = bm[w] == wmax
-            gw = int(np.argmax(eqg)); cntg = int(eqg.sum())
-            cand = gm[w, :, gw] == wmax
-            wl = int(np.argmax(cand))
-            eq = dist[w, :, gw * GS:(gw + 1) * GS] == wmax                 # (64,GS)
-            k = np.where(eq.any(1), gw * GS + np.argmax(eq, 1), gw * GS + GS - 1)
-            cnt = eq.sum(1)
-            kw = int(k[wl])
-            tie = (int(cand.sum()) - 1) | (int(cnt[wl]) - 1)
+            if radius:
+                bv = gm[w].max(1)                                            # per lane
+                wmax = bv.max()
+                cand = bv == wmax
+                wl = int(np.argmax(cand))
+                eqg = gm[w] == bv[:, None]                                   # (64,NG)
+                gi = np.argmax(eqg, 1); cg = eqg.sum(1)
+                gw = int(gi[wl])
+                eq = dist[w, :, gw * GS:(gw + 1) * GS] == wmax
+                k = np.where(eq.any(1), gw * GS + np.argmax(eq, 1), gw * GS + GS - 1)
+                cnt = eq.sum(1)
+                kw = int(k[wl])
+                tie = (int(cand.sum()) - 1) | (int(cg[wl]) - 1) | (int(cnt[wl]) - 1)
+                cntg = 1
+                slow_groups = (gm[w] == wmax).any(0)
+            else:
+                wmax = bm[w].max()
+                eqg = bm[w] == wmax
+                gw = int(np.argmax(eqg)); cntg = int(eqg.sum())
+                cand = gm[w, :, gw] == wmax
+                wl = int(np.argmax(cand))
+                eq = dist[w, :, gw * GS:(gw + 1) * GS] == wmax                 # (64,GS)
+                k = np.where(eq.any(1), gw * GS + np.argmax(eq, 1), gw * GS + GS - 1)
+                cnt = eq.sum(1)
+                kw = int(k[wl])
+                tie = (int(cand.sum()) - 1) | (int(cnt[wl]) - 1)
+                slow_groups = bm[w] == wmax
             if tie | (cntg - 1):
                 slow += 1
                 bi = np.full(64, NONE, np.int64); bk = np.zeros(64, np.int64)
                 for g in range(NG):
-                    if bm[w, g] == wmax:
+                    if slow_groups[g]:
                         for j in range(GS):
                             oi = perm[pos[w, :, g * GS + j]]
                             better = (dist[w, :, g * GS + j] == wmax) & (oi < bi)
@@ -85,7 +103,7 @@ def kernel(xyz, npoint, start, NT=512, PPT=40, GS=8, rng=None, count=None):
             mi = np.where(c16, oi, NONE).min()
             c16 = c16 & (oi == mi)
         win = int(np.argmax(c16))
-        out[it] = rec_i[win]; cen = rec_p[win].copy()
+        out[it] = rec_i[win]; cen = rec_p[win].copy(); rad = best
     out[1:] = perm[out[1:]]
     if count is not None:
         count['slow'] = slow
@@ -94,18 +112,19 @@ def kernel(xyz, npoint, start, NT=512, PPT=40, GS=8, rng=None, count=None):
 
 if __name__ == '__main__':
     GS = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+    RADIUS = len(sys.argv) > 2 and sys.argv[2] == 'radius'
     rng = np.random.default_rng(1)
     ok = True
     for N, PPT, S in ((20000, 40, 96), (8193, 40, 64), (22000, 48, 64), (24576, 48, 40), (20480, 40, 40)):
         for name, xyz in clouds(N, rng):
             cnt = {}
             st = int(rng.integers(0, N))
-            a = plain_fps(xyz, S, st); b = kernel(xyz, S, st, PPT=PPT, GS=GS, rng=rng, count=cnt)
+            a = plain_fps(xyz, S, st); b = kernel(xyz, S, st, PPT=PPT, GS=GS, rng=rng, count=cnt, radius=RADIUS)
             same = np.array_equal(a, b); ok &= same
             print(f'N={N:6d} PPT={PPT} GS={GS} {name:13s} equal={same}  slow-path wave-rounds={cnt["slow"]} of {(S - 1) * 8}', flush=True)
     # a cloud of identical points, and one point repeated with a single outlier
     for xyz in (np.full((9000, 3), f32(0.25)), np.concatenate([np.full((8999, 3), f32(0.25)), np.array([[1, 2, 3]], f32)])):
-        a = plain_fps(xyz, 20, 5); b = kernel(xyz, 20, 5, PPT=40, GS=GS, rng=rng)
+        a = plain_fps(xyz, 20, 5); b = kernel(xyz, 20, 5, PPT=40, GS=GS, rng=rng, radius=RADIUS)
         same = np.array_equal(a, b); ok &= same
         print('degenerate cloud equal=', same, a[:6], b[:6])
     print('ALL EQUAL' if ok else 'MISMATCH')

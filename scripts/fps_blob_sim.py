@@ -77,6 +77,16 @@ def blob_fps(xyz, npoint, start, cells=16, gs=8, nt=512, stats=None):
         wave_upd = np.bincount(need % nw, minlength=nw)
         simd = wave_upd.reshape(-1, 4).sum(0) if nw % 4 == 0 else wave_upd
         upd_total += len(need); simd_max_total += simd.max()
+        if stats is not None:
+            # instruction-count model of a round with the winner search skipped in wavefronts that updated nothing:
+            # idle wavefront 80, busy one 300 + 59 per updated group; a SIMD issues for its two wavefronts in turn
+            for name, wave_of in (('round_robin', need % nw), ('contiguous', need // ng)):
+                wu = np.bincount(wave_of, minlength=nw)
+                cost = np.where(wu > 0, 300 + 59 * wu, 80)
+                stats.setdefault('cost_' + name, []).append(cost.reshape(-1, 4).sum(0).max())
+                stats.setdefault('busy_' + name, []).append((wu > 0).sum())
+            wu = np.bincount(need % nw, minlength=nw)
+            stats.setdefault('cost_now', []).append((300 + 59 * wu).reshape(-1, 4).sum(0).max())
         m = bmax.max()
         cands = []
         for j in np.nonzero(bmax == m)[0]:
@@ -116,5 +126,7 @@ if __name__ == '__main__':
         per_group = 5.5 * gs + 15
         model = 2 * 17 + st['mean_simd_max'] * per_group
         full = 2 * (5.5 * st['ng'] * gs + 12)
+        print('   model (instructions per SIMD and round): now %.0f, skip-idle round-robin %.0f (%.1f busy waves), skip-idle contiguous %.0f (%.1f busy waves)' % (
+            np.mean(st['cost_now']), np.mean(st['cost_round_robin']), np.mean(st['busy_round_robin']), np.mean(st['cost_contiguous']), np.mean(st['busy_contiguous'])))
         print(f"{name:13s} equal={np.array_equal(a, b)}  blobs={st['nblob']} x {64 * gs}  updated/round={st['mean_updates']:.2f} ({st['frac']:.1%})  "
               f"busiest SIMD: {st['mean_simd_max']:.2f} groups  VALU/SIMD/round: {model:.0f} vs {full:.0f} now ({model / full:.2f})")

@@ -37,8 +37,20 @@ def test_index_points(cuda_device):
         p2.index_points(pts.to(cuda_device), torch.full((3, 2), 50, dtype=torch.long, device=cuda_device))
 
 
-@pytest.mark.parametrize('B,N,npoint', [(2, 1000, 64), (1, 5000, 128), (1, 20000, 256), (1, 30000, 40), (3, 64, 64)])
-def test_farthest_point_sample_exact(cuda_device, B, N, npoint):
+@pytest.fixture(params=['default', 'plain'])
+def fps_kernel(request, monkeypatch):
+    """Clouds of 2,049 .. 24,576 points are sampled by the blob-skipping kernel; CATGRASP_AMD_FPS=plain selects the round that updates
+    every point.  Both must reproduce the oracle."""
+    if request.param == 'plain':
+        monkeypatch.setenv('CATGRASP_AMD_FPS', 'plain')
+    else:
+        monkeypatch.delenv('CATGRASP_AMD_FPS', raising=False)
+    return request.param
+
+
+@pytest.mark.parametrize('B,N,npoint', [(2, 1000, 64), (1, 2049, 100), (2, 4096, 96), (1, 5000, 128), (1, 8192, 64), (2, 8193, 64), (1, 12288, 64),
+                                        (1, 15000, 64), (1, 20000, 256), (2, 20480, 48), (1, 24576, 48), (1, 30000, 40), (3, 64, 64)])
+def test_farthest_point_sample_exact(cuda_device, fps_kernel, B, N, npoint):
     from catgrasp_amd import pointnet2 as p2
     xyz = _cloud(B, N, 4 + N)
     start = torch.from_numpy(np.random.default_rng(5).integers(0, N, B))
@@ -48,11 +60,11 @@ def test_farthest_point_sample_exact(cuda_device, B, N, npoint):
     assert torch.equal(got, ref)
 
 
-@pytest.mark.parametrize('N,npoint', [(700, 200), (6000, 300), (20000, 200), (22000, 64)])
-def test_farthest_point_sample_ties_take_the_first_index(cuda_device, N, npoint):
+@pytest.mark.parametrize('N,npoint', [(700, 200), (3000, 200), (6000, 300), (10000, 100), (20000, 200), (22000, 64)])
+def test_farthest_point_sample_ties_take_the_first_index(cuda_device, fps_kernel, N, npoint):
     """Equal running distances -- duplicate points (a cloud resampled with replacement) and an integer lattice -- must resolve to the
     smallest point index like torch.max (pointnet2.py:74), in every kernel geometry, also when the tied points sit in different
-    lanes, slots and waves."""
+    lanes, slots, groups and waves (the blob-skipping kernel holds the points in spatial order, not index order)."""
     from catgrasp_amd import pointnet2 as p2
     rng = np.random.default_rng(N)
     base = rng.normal(0, 0.05, (N // 7, 3)).astype(np.float32)
@@ -63,6 +75,33 @@ def test_farthest_point_sample_ties_take_the_first_index(cuda_device, N, npoint)
     start = torch.tensor([3, N - 1])
     got = p2.farthest_point_sample(xyz.to(cuda_device), npoint, start=start).cpu()
     assert torch.equal(got, oref.farthest_point_sample(xyz, npoint, start))
+
+
+def test_farthest_point_sample_degenerate_clouds(cuda_device, fps_kernel):
+    """One point repeated (every running distance 0 after the first round: the padding slots of the kernel tie with the real points and
+    must lose), the same with a single outlier, and a cloud with more samples asked for than it has distinct points."""
+    from catgrasp_amd import pointnet2 as p2
+    same = np.full((9000, 3), 0.25, np.float32)
+    outlier = same.copy(); outlier[8999] = (1.0, 2.0, 3.0)
+    few = np.random.default_rng(0).normal(size=(5, 3)).astype(np.float32)[np.random.default_rng(1).integers(0, 5, 9000)]
+    xyz = torch.from_numpy(np.stack([same, outlier, few]))
+    start = torch.tensor([5, 5, 7])
+    got = p2.farthest_point_sample(xyz.to(cuda_device), 24, start=start).cpu()
+    assert torch.equal(got, oref.farthest_point_sample(xyz, 24, start))
+
+
+def test_farthest_point_sample_skips_nothing_it_should_not(cuda_device, fps_kernel):
+    """A cloud made of far-apart tight clusters plus a few stragglers: most blobs are skipped in most rounds, and the box test must stay
+    on the safe side at cluster borders (the bound is evaluated with the update's own float operations)."""
+    from catgrasp_amd import pointnet2 as p2
+    rng = np.random.default_rng(11)
+    centres = rng.uniform(-1, 1, (12, 3))
+    pts = (centres[rng.integers(0, 12, 18000)] + rng.normal(0, 1e-3, (18000, 3))).astype(np.float32)
+    pts[rng.integers(0, 18000, 40)] = rng.uniform(-1.5, 1.5, (40, 3)).astype(np.float32)
+    xyz = torch.from_numpy(pts[None])
+    start = torch.tensor([17])
+    got = p2.farthest_point_sample(xyz.to(cuda_device), 400, start=start).cpu()
+    assert torch.equal(got, oref.farthest_point_sample(xyz, 400, start))
 
 
 def test_farthest_point_sample_default_start_follows_torch_seed(cuda_device):
