@@ -183,7 +183,7 @@ __device__ __forceinline__ void fps_find(int gw, int wl, unsigned bv, const unsi
 // NT threads, thread t owns points t, t+NT, ...; PPT even.
 template <int NT, int PPT>
 __global__ __launch_bounds__(NT) void fps_kernel(const float* __restrict__ xyz, const long long* __restrict__ start, int N, int npoint,
-                                                 long long* __restrict__ out) {
+                                                 long long* __restrict__ out, float* __restrict__ out_xyz) {
   static_assert(PPT % 2 == 0 && NT % 64 == 0 && NT <= 1024, "geometry");
   constexpr int H = PPT / 2;
   constexpr int GS = PPT < 8 ? PPT : 8, NG = PPT / GS;
@@ -208,7 +208,10 @@ __global__ __launch_bounds__(NT) void fps_kernel(const float* __restrict__ xyz, 
   int farthest = (int)start[b];
   float cx = xb[farthest * 3 + 0], cy = xb[farthest * 3 + 1], cz = xb[farthest * 3 + 2];
   for (int it = 0; it < npoint; ++it) {
-    if (tid == 0) out[(size_t)b * npoint + it] = farthest;
+    if (tid == 0) {
+      out[(size_t)b * npoint + it] = farthest;
+      if (out_xyz) { float* o = out_xyz + ((size_t)b * npoint + it) * 3; o[0] = cx; o[1] = cy; o[2] = cz; }   // = index_points(xyz, out), for free
+    }
     const f32x2 c2x = {cx, cx}, c2y = {cy, cy}, c2z = {cz, cz};
     // the thread's slots in groups of GS: only the running MAXIMUM is tracked while the distances are updated (one v_max3_u32 per
     // pair), per group and over all; which slot holds it is looked up afterwards, in the winner's group only
@@ -320,6 +323,12 @@ __device__ __forceinline__ int fps_slot_pos(int wv, int lane, int k) {
   return (((((k / GS) * NW + wv) * GS) + (k % GS)) << 6) + lane;
 }
 
+// bits = 2 * bits + (a == b): one v_cmp + one v_addc per element (the compare's carry shifts itself in), against compare + select + add
+// for "first match and how many" -- both are read off the accumulated bits afterwards, on the scalar side, for the one lane that matters
+__device__ __forceinline__ void push_eq_bit(unsigned& bits, unsigned a, unsigned b) {
+  asm("v_cmp_eq_u32_e32 vcc, %1, %2\n\ts_nop 1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(bits) : "v"(a), "v"(b) : "vcc");   // gfx950: 2 wait states between a VALU write of vcc and a VALU read of it
+}
+
 // inside group gw of the winner lane wl (both wave-uniform; binary search over the groups): its first slot at the wave maximum, how
 // many of its slots hold it, the slot's coordinates
 template <int GLO, int GHI, int GS, int PPT, int H>
@@ -329,15 +338,12 @@ __device__ __forceinline__ void fps_ball_find(int gw, int wl, unsigned wmax, con
     constexpr int G = GLO;
     unsigned bv = wmax;
     asm volatile("" : "+v"(bv));                            // the search stays inside its branch
-    int k = G * GS + GS - 1, cnt = 0;
+    unsigned bits = 0u;                                     // bit GS-1-j: slot j of the group holds the maximum
 #pragma unroll
-    for (int j = GS - 1; j >= 0; --j) {
-      const bool eq = dist[G * GS + j] == bv;
-      k = eq ? G * GS + j : k;
-      cnt += eq ? 1 : 0;
-    }
-    kw = __builtin_amdgcn_readlane(k, wl);
-    cw = __builtin_amdgcn_readlane(cnt, wl);
+    for (int j = 0; j < GS; ++j) push_eq_bit(bits, dist[G * GS + j], bv);
+    const unsigned bw = (unsigned)__builtin_amdgcn_readlane((int)bits, wl);      // != 0: the winner lane holds the maximum in this group
+    kw = G * GS + (GS - 1) - (31 - __builtin_clz(bw));
+    cw = __builtin_popcount(bw);
     fps_pick<G * GS, G * GS + GS, H>(kw, px, py, pz, x, y, z);
   } else {
     constexpr int MID = (GLO + GHI) / 2;
@@ -348,7 +354,7 @@ __device__ __forceinline__ void fps_ball_find(int gw, int wl, unsigned wmax, con
 
 template <int NT, int PPT, int GS>
 __global__ __launch_bounds__(NT) void fps_blob_kernel(const float* __restrict__ xyz, const long long* __restrict__ start, int N, int npoint,
-                                                      long long* __restrict__ out) {
+                                                      long long* __restrict__ out, float* __restrict__ out_xyz) {
   static_assert(NT % 64 == 0 && NT <= 1024 && GS % 2 == 0 && PPT % GS == 0 && (GS & (GS - 1)) == 0, "geometry");
   static_assert(FPS_BINS % NT == 0 && NT * PPT < 0xffff, "one scan chunk per thread; 16-bit point indices with 0xffff = none");
   constexpr int H = PPT / 2, NG = PPT / GS, NW = NT / 64, CAP = NT * PPT, BPT = FPS_BINS / NT;
@@ -362,6 +368,7 @@ __global__ __launch_bounds__(NT) void fps_blob_kernel(const float* __restrict__ 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const float* xb = xyz + (size_t)b * N * 3;
   long long* ob = out + (size_t)b * npoint;
+  float* oxb = out_xyz ? out_xyz + (size_t)b * npoint * 3 : nullptr;
 
   // ---- prologue 1: the cloud's box (the thread's share of the cloud in index order, CH points in flight at a time) ----
   constexpr int CH = PPT / 2;
@@ -498,7 +505,10 @@ __global__ __launch_bounds__(NT) void fps_blob_kernel(const float* __restrict__ 
 
   const int first = (int)start[b];
   float cx = xb[first * 3 + 0], cy = xb[first * 3 + 1], cz = xb[first * 3 + 2];
-  if (tid == 0 && npoint > 0) ob[0] = first;
+  if (tid == 0 && npoint > 0) {
+    ob[0] = first;
+    if (oxb) { oxb[0] = cx; oxb[1] = cy; oxb[2] = cz; }
+  }
   float rad = 1e10f;                   // the largest running distance of the whole cloud (= the new centre's, when it was chosen)
   for (int it = 1; it < npoint; ++it) {
     // ---- which of the wave's blobs can change: distance from the centre to the blob's box, rounded exactly like a point's ----
@@ -532,13 +542,14 @@ __global__ __launch_bounds__(NT) void fps_blob_kernel(const float* __restrict__ 
     const unsigned wmax = wave_max_u32(bv);
     const unsigned long long cand = __ballot(bv == wmax);
     int wl = __builtin_ctzll(cand);
-    int gi = NG - 1, cg = 0;                                 // per lane: the first group at the lane's maximum, and how many are
+    unsigned gbits = 0u;                                     // per lane, bit NG-1-g: group g holds the lane's maximum
 #pragma unroll
-    for (int g = NG - 1; g >= 0; --g) { const bool eq = gmax[g] == bv; gi = eq ? g : gi; cg += eq ? 1 : 0; }
-    const int gw = __builtin_amdgcn_readlane(gi, wl);
+    for (int g = 0; g < NG; ++g) push_eq_bit(gbits, gmax[g], bv);
+    const unsigned gbw = (unsigned)__builtin_amdgcn_readlane((int)gbits, wl);     // the winner lane's: != 0
+    const int gw = (NG - 1) - (31 - __builtin_clz(gbw));     // its first group at the maximum
     int kw, cw; float bx, by, bz;
     fps_ball_find<0, NG, GS, PPT, H>(gw, wl, wmax, dist, px, py, pz, kw, cw, bx, by, bz);
-    const int tie = (__builtin_popcountll(cand) - 1) | (__builtin_amdgcn_readlane(cg, wl) - 1) | (cw - 1);
+    const int tie = (__builtin_popcountll(cand) - 1) | (__builtin_popcount(gbw) - 1) | (cw - 1);
     if (tie) {                                               // equal maxima somewhere in the wave: the smallest point index wins
       int bi = 0x7fffffff, bk = 0;
 #pragma unroll
@@ -580,7 +591,10 @@ __global__ __launch_bounds__(NT) void fps_blob_kernel(const float* __restrict__ 
     cy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e[2]), win));
     cz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e[3]), win));
     rad = __uint_as_float(best);
-    if (tid == 0) ob[it] = farthest;                         // a sorted position for now
+    if (tid == 0) {
+      ob[it] = farthest;                                     // a sorted position for now
+      if (oxb) { oxb[it * 3 + 0] = cx; oxb[it * 3 + 1] = cy; oxb[it * 3 + 2] = cz; }   // = index_points(xyz, out), for free
+    }
   }
   __syncthreads();                                           // thread 0's stores are visible to the workgroup
   for (int i = 1 + tid; i < npoint; i += NT) ob[i] = perm[(int)ob[i]];
@@ -588,7 +602,7 @@ __global__ __launch_bounds__(NT) void fps_blob_kernel(const float* __restrict__ 
 
 // generic fallback for clouds larger than the register path: running distances live in a global scratch row.
 __global__ __launch_bounds__(1024) void fps_kernel_global(const float* __restrict__ xyz, const long long* __restrict__ start, int N, int npoint,
-                                                          float* __restrict__ dist_scratch, long long* __restrict__ out) {
+                                                          float* __restrict__ dist_scratch, long long* __restrict__ out, float* __restrict__ out_xyz) {
   __shared__ float red_v[2][16];
   __shared__ int red_i[2][16];
   const int b = blockIdx.x;
@@ -598,8 +612,11 @@ __global__ __launch_bounds__(1024) void fps_kernel_global(const float* __restric
   for (int p = tid; p < N; p += 1024) db[p] = 1e10f;
   int farthest = (int)start[b];
   for (int it = 0; it < npoint; ++it) {
-    if (tid == 0) out[(size_t)b * npoint + it] = farthest;
     const float cx = xb[farthest * 3 + 0], cy = xb[farthest * 3 + 1], cz = xb[farthest * 3 + 2];
+    if (tid == 0) {
+      out[(size_t)b * npoint + it] = farthest;
+      if (out_xyz) { float* o = out_xyz + ((size_t)b * npoint + it) * 3; o[0] = cx; o[1] = cy; o[2] = cz; }
+    }
     float bv = -2.0f; int bi = 0x7fffffff;
     for (int p = tid; p < N; p += 1024) {
       const float dx = xb[p * 3 + 0] - cx, dy = xb[p * 3 + 1] - cy, dz = xb[p * 3 + 2] - cz;
@@ -630,6 +647,7 @@ __global__ __launch_bounds__(1024) void fps_kernel_global(const float* __restric
 // One wavefront per query point.  Points are scanned in index order 64 at a time; the in-radius lanes of a
 // chunk get their output slots from a prefix popcount of the ballot, so the result is exactly "the first
 // nsample indices with d <= r^2, ascending", padded with the first hit (all N when the ball is empty).
+constexpr int BQ_U = 8;
 __global__ __launch_bounds__(256) void ball_query_kernel(const float* __restrict__ xyz, const float* __restrict__ new_xyz, int N, int S,
                                                          float r2, int nsample, long long* __restrict__ out) {
   const int lane = threadIdx.x & 63;
@@ -643,21 +661,29 @@ __global__ __launch_bounds__(256) void ball_query_kernel(const float* __restrict
   long long* o = out + ((size_t)b * S + q) * nsample;
   int count = 0;
   long long first = N;
-  for (int p0 = 0; p0 < N && count < nsample; p0 += 64) {
-    const int p = p0 + lane;
-    bool in = false;
-    if (p < N) {
-      const float x = xb[p * 3 + 0], y = xb[p * 3 + 1], z = xb[p * 3 + 2];
-      const float p2 = (x * x + y * y) + z * z;
-      const float d = sqdist_expanded(qx, qy, qz, q2, x, y, z, p2);
-      in = !(d > r2);                                          // group_idx[sqrdists > radius**2] = N
+  // BQ_U chunks of 64 points per trip, their loads all in flight before the first is looked at (a trip is one L2 round trip whatever its
+  // size, and a typical ball is full after a few hundred points); the chunks are then consumed in index order exactly as one at a time
+  for (int p0 = 0; p0 < N && count < nsample; p0 += 64 * BQ_U) {
+    float x[BQ_U], y[BQ_U], z[BQ_U];
+#pragma unroll
+    for (int u = 0; u < BQ_U; ++u) {
+      const int p = p0 + u * 64 + lane, c = p < N ? p : N - 1;
+      x[u] = xb[c * 3 + 0]; y[u] = xb[c * 3 + 1]; z[u] = xb[c * 3 + 2];
     }
-    const unsigned long long mask = __ballot(in);
-    if (mask == 0ull) continue;
-    if (first == N) first = p0 + __builtin_ctzll(mask);
-    const int pos = count + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
-    if (in && pos < nsample) o[pos] = p;
-    count += __builtin_popcountll(mask);
+#pragma unroll
+    for (int u = 0; u < BQ_U; ++u) {
+      if (count >= nsample) break;
+      const int p = p0 + u * 64 + lane;
+      const float p2 = (x[u] * x[u] + y[u] * y[u]) + z[u] * z[u];
+      const float d = sqdist_expanded(qx, qy, qz, q2, x[u], y[u], z[u], p2);
+      const bool in = p < N && !(d > r2);                      // group_idx[sqrdists > radius**2] = N
+      const unsigned long long mask = __ballot(in);
+      if (mask == 0ull) continue;
+      if (first == N) first = p0 + u * 64 + __builtin_ctzll(mask);
+      const int pos = count + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
+      if (in && pos < nsample) o[pos] = p;
+      count += __builtin_popcountll(mask);
+    }
   }
   if (count > nsample) count = nsample;
   for (int k = count + lane; k < nsample; k += 64) o[k] = first;
@@ -728,8 +754,8 @@ static bool fps_plain() {
   return e && e[0] == 'p';
 }
 
-extern "C" int cg_farthest_point_sample(const float* xyz, const long long* start, int B, int N, int npoint, float* dist_scratch,
-                                        long long* out, void* stream) {
+static int fps_launch(const float* xyz, const long long* start, int B, int N, int npoint, float* dist_scratch, long long* out, float* out_xyz,
+                      void* stream) {
   if (B < 0 || N <= 0 || npoint < 0) return CG_ERR_ARG;
   if ((long)B * npoint == 0) return CG_OK;
   if (!xyz || !start || !out) return CG_ERR_ARG;
@@ -737,21 +763,21 @@ extern "C" int cg_farthest_point_sample(const float* xyz, const long long* start
   dim3 grid((unsigned)B), block(1024);
   if (N > 512 * 48) {
     if (!dist_scratch) return CG_ERR_ARG;   // (B,N) floats needed for clouds beyond the register paths
-    hipLaunchKernelGGL(fps_kernel_global, grid, block, 0, s, xyz, start, N, npoint, dist_scratch, out);
+    hipLaunchKernelGGL(fps_kernel_global, grid, block, 0, s, xyz, start, N, npoint, dist_scratch, out, out_xyz);
   }
   // <= 2,048 points: 512 threads x 4 points (0.60 us per round at N = 2,048 against 0.64 for 1,024 x 2 and 0.67 for 256 x 8: the round
   // is all exchange there, and eight wave records are cheaper to reduce than sixteen)
-  else if (N <= 512 * 4) hipLaunchKernelGGL((fps_kernel<512, 4>), grid, dim3(512), 0, s, xyz, start, N, npoint, out);
+  else if (N <= 512 * 4) hipLaunchKernelGGL((fps_kernel<512, 4>), grid, dim3(512), 0, s, xyz, start, N, npoint, out, out_xyz);
   else if (fps_plain()) {
-    if (N <= 1024 * 8) hipLaunchKernelGGL((fps_kernel<1024, 8>), grid, block, 0, s, xyz, start, N, npoint, out);
-    else if (N <= 512 * 40) hipLaunchKernelGGL((fps_kernel<512, 40>), grid, dim3(512), 0, s, xyz, start, N, npoint, out);
-    else hipLaunchKernelGGL((fps_kernel<512, 48>), grid, dim3(512), 0, s, xyz, start, N, npoint, out);
+    if (N <= 1024 * 8) hipLaunchKernelGGL((fps_kernel<1024, 8>), grid, block, 0, s, xyz, start, N, npoint, out, out_xyz);
+    else if (N <= 512 * 40) hipLaunchKernelGGL((fps_kernel<512, 40>), grid, dim3(512), 0, s, xyz, start, N, npoint, out, out_xyz);
+    else hipLaunchKernelGGL((fps_kernel<512, 48>), grid, dim3(512), 0, s, xyz, start, N, npoint, out, out_xyz);
   }
   // 2,049 .. 24,576 points: 512 threads (two waves per SIMD) x 8 .. 48 points, skipping the blobs a round cannot change; 256-point
   // blobs up to 8,192 points, 512-point blobs above.  us per round, uniform volume / surface cloud, against fps_kernel (which updates
   // every point every round; profiles/r4_fps_blob.json): 8,192 points 0.83 / 0.79 against 0.95; 12,288: 0.94 / 0.90 against 1.45;
   // 20,000: 1.05 / 1.00 against 1.45; 24,576: 1.10 / 1.05 against 1.62.
-#define CG_FPS_BLOB(PPT, GS) hipLaunchKernelGGL((fps_blob_kernel<512, PPT, GS>), grid, dim3(512), 0, s, xyz, start, N, npoint, out)
+#define CG_FPS_BLOB(PPT, GS) hipLaunchKernelGGL((fps_blob_kernel<512, PPT, GS>), grid, dim3(512), 0, s, xyz, start, N, npoint, out, out_xyz)
   else if (N <= 512 * 8) CG_FPS_BLOB(8, 4);
   else if (N <= 512 * 16) CG_FPS_BLOB(16, 4);
   else if (N <= 512 * 24) CG_FPS_BLOB(24, 8);
@@ -760,6 +786,17 @@ extern "C" int cg_farthest_point_sample(const float* xyz, const long long* start
   else CG_FPS_BLOB(48, 8);
 #undef CG_FPS_BLOB
   return cg_hip_status(hipGetLastError());
+}
+
+extern "C" int cg_farthest_point_sample(const float* xyz, const long long* start, int B, int N, int npoint, float* dist_scratch,
+                                        long long* out, void* stream) {
+  return fps_launch(xyz, start, B, N, npoint, dist_scratch, out, nullptr, stream);
+}
+
+extern "C" int cg_farthest_point_sample_xyz(const float* xyz, const long long* start, int B, int N, int npoint, float* dist_scratch,
+                                            long long* out, float* out_xyz, void* stream) {
+  if ((long)B * npoint > 0 && !out_xyz) return CG_ERR_ARG;
+  return fps_launch(xyz, start, B, N, npoint, dist_scratch, out, out_xyz, stream);
 }
 
 extern "C" int cg_query_ball_point(const float* xyz, const float* new_xyz, int B, int N, int S, float radius_sq, int nsample,

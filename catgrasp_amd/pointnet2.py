@@ -254,8 +254,7 @@ class PointNetSetAbstraction(nn.Module):
                           for i in range(len(self.mlp_convs))]
                 return _prim.SetAbstractionWeights(layers, self.in_channel, dev)
             W = _cached_weights(self, xyz.device, prep)
-            fps_idx = farthest_point_sample(xyz, self.npoint, start)
-            new_xyz = index_points(xyz, fps_idx)
+            _, new_xyz = farthest_point_sample(xyz, self.npoint, start, return_xyz=True)      # = index_points(xyz, fps_idx), same launch
             idx = query_ball_point(self.radius, self.nsample, xyz, new_xyz)
             return new_xyz, _prim.group_mlp_max(xyz, points, new_xyz, idx, W).permute(0, 2, 1)
         new_xyz, new_points = sample_and_group(self.npoint, self.radius, self.nsample, xyz, points, start=start)

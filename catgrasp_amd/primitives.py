@@ -49,10 +49,11 @@ def index_points(points, idx):
     return out
 
 
-def farthest_point_sample(xyz, npoint, start=None):
+def farthest_point_sample(xyz, npoint, start=None, return_xyz=False):
     """xyz (B,N,3) -> centroids (B,npoint) int64 (pointnet2.py:54-75).  `start` defaults to the reference's
     draw, `torch.randint(0, N, (B,), dtype=torch.long)` on the CPU generator (:66), so seeding torch
-    reproduces the reference's samples exactly."""
+    reproduces the reference's samples exactly.  return_xyz=True also returns the sampled points,
+    (B,npoint,3) == index_points(xyz, centroids), written by the same launch."""
     require_cuda(xyz)
     xyz = _f32(xyz)
     B, N, C = xyz.shape
@@ -65,6 +66,11 @@ def farthest_point_sample(xyz, npoint, start=None):
         raise ValueError('start must hold one valid point index per cloud')
     out = torch.empty((B, npoint), dtype=torch.int64, device=xyz.device)
     scratch = torch.empty((B, N), dtype=torch.float32, device=xyz.device) if N > 24576 else None
+    if return_xyz:
+        new_xyz = torch.empty((B, npoint, 3), dtype=torch.float32, device=xyz.device)
+        check(L.lib().cg_farthest_point_sample_xyz(_p(xyz), _p(start), _c_int(B), _c_int(N), _c_int(npoint), _p(scratch), _p(out), _p(new_xyz),
+                                                   _stream()), 'cg_farthest_point_sample_xyz')
+        return out, new_xyz
     check(L.lib().cg_farthest_point_sample(_p(xyz), _p(start), _c_int(B), _c_int(N), _c_int(npoint), _p(scratch), _p(out), _stream()),
           'cg_farthest_point_sample')
     return out
@@ -92,8 +98,7 @@ def sample_and_group(npoint, radius, nsample, xyz, points, returnfps=False, star
     xyz = _f32(xyz)
     B, N, C = xyz.shape
     S = npoint
-    fps_idx = farthest_point_sample(xyz, npoint, start)
-    new_xyz = index_points(xyz, fps_idx)
+    fps_idx, new_xyz = farthest_point_sample(xyz, npoint, start, return_xyz=True)      # new_xyz = index_points(xyz, fps_idx)
     idx = query_ball_point(radius, nsample, xyz, new_xyz)
     K = idx.shape[2]
     D = 0

@@ -322,6 +322,12 @@ int cg_index_points(const float* points, const long long* idx, int B, int N, int
 int cg_farthest_point_sample(const float* xyz, const long long* start, int B, int N, int npoint, float* dist_scratch,
                              long long* out, void* stream);
 
+/* The same sampling, which also writes the sampled points themselves: out_xyz (B,npoint,3) = index_points(xyz, out), the
+ * `new_xyz` of sample_and_group (pointnet2.py:110-112) -- the kernel holds each new centre's coordinates anyway, so the
+ * set-abstraction layer needs no gather launch behind it.  Same samples as cg_farthest_point_sample. */
+int cg_farthest_point_sample_xyz(const float* xyz, const long long* start, int B, int N, int npoint, float* dist_scratch,
+                                 long long* out, float* out_xyz, void* stream);
+
 /* query_ball_point (pointnet2.py:78-98): first `nsample` indices (ascending) with d^2 <= radius_sq, padded
  * with the first hit; an empty ball yields N in every slot, as the reference does.  out (B,S,nsample). */
 int cg_query_ball_point(const float* xyz, const float* new_xyz, int B, int N, int S, float radius_sq, int nsample,

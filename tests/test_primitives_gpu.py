@@ -104,6 +104,18 @@ def test_farthest_point_sample_skips_nothing_it_should_not(cuda_device, fps_kern
     assert torch.equal(got, oref.farthest_point_sample(xyz, 400, start))
 
 
+@pytest.mark.parametrize('B,N,npoint', [(2, 900, 50), (1, 5000, 64), (2, 20000, 64), (1, 30000, 20)])
+def test_farthest_point_sample_also_returns_the_sampled_points(cuda_device, fps_kernel, B, N, npoint):
+    """cg_farthest_point_sample_xyz: the same samples, plus new_xyz == index_points(xyz, fps_idx) bit for bit (pointnet2.py:110-112), from
+    every kernel geometry."""
+    from catgrasp_amd import pointnet2 as p2
+    xyz = _cloud(B, N, 31 + N).to(cuda_device)
+    start = torch.from_numpy(np.random.default_rng(6).integers(0, N, B))
+    idx, new_xyz = p2.farthest_point_sample(xyz, npoint, start=start, return_xyz=True)
+    assert torch.equal(idx, p2.farthest_point_sample(xyz, npoint, start=start))
+    assert new_xyz.shape == (B, npoint, 3) and torch.equal(new_xyz, p2.index_points(xyz, idx))
+
+
 def test_farthest_point_sample_default_start_follows_torch_seed(cuda_device):
     """pointnet2.py:66 draws the start on the CPU generator: same torch seed -> same samples as the reference."""
     from catgrasp_amd import pointnet2 as p2
