@@ -52,6 +52,13 @@ __device__ __forceinline__ unsigned row_max_u32(unsigned v) {
                "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf" : "+v"(v));
   return v;
 }
+// the same over the 8 lanes of every half row
+__device__ __forceinline__ unsigned half_row_max_u32(unsigned v) {
+  asm volatile("s_nop 1\n\tv_max_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+               "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+               "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf" : "+v"(v));
+  return v;
+}
 __device__ __forceinline__ int row_min_i32(int v) {
   v = dpp_min_i32<0xB1, 0xf>(v); v = dpp_min_i32<0x4E, 0xf>(v); v = dpp_min_i32<0x141, 0xf>(v);
   return dpp_min_i32<0x140, 0xf>(v);
@@ -241,7 +248,8 @@ __device__ __forceinline__ int fps_cell(float x, float y, float z, const float (
 // sorted position of slot k of (wavefront wv, lane): blob (k / GS) * NW + wv, then slot-major inside the blob
 template <int NW, int GS>
 __device__ __forceinline__ int fps_slot_pos(int wv, int lane, int k) {
-  return (((((k / GS) * NW + wv) * GS) + (k % GS)) << 6) + lane;
+  const unsigned g = (unsigned)k / GS, j = (unsigned)k % GS;
+  return (int)(((((g * NW + wv) * GS) + j) << 6) + lane);
 }
 
 // bits = 2 * bits + (a == b): one v_cmp + one v_addc per element (the compare's carry shifts itself in), against compare + select + add
@@ -457,7 +465,7 @@ __global__ __launch_bounds__(NT) void fps_blob_kernel(const float* __restrict__ 
     const float qx = fmaxf(fmaxf(blo[0] - cx, cx - bhi[0]), 0.f), qy = fmaxf(fmaxf(blo[1] - cy, cy - bhi[1]), 0.f),
                 qz = fmaxf(fmaxf(blo[2] - cz, cz - bhi[2]), 0.f);
     const float lb = (qx * qx + qy * qy) + qz * qz;
-    const unsigned need = (unsigned)(__ballot(lane < NG && lb < rad));
+    const unsigned need = (unsigned)__builtin_amdgcn_fcmpf(lb, rad, 4 /* ordered < */) & ((1u << NG) - 1u);   // lanes >= NG hold no box
     const f32x2 c2x = {cx, cx}, c2y = {cy, cy}, c2z = {cz, cz};
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
@@ -523,19 +531,20 @@ __global__ __launch_bounds__(NT) void fps_blob_kernel(const float* __restrict__ 
     const f32x4 e = red_v[buf][lane & 15];
     const int ei = red_i[buf][lane & 15];
     const unsigned ev = __float_as_uint(e[0]);
-    const unsigned best = row_max_u32(ev);
-    unsigned c16 = (unsigned)__ballot(ev == best) & 0xffffu;
+    constexpr unsigned RECS = NW <= 8 ? 0xffu : 0xffffu;     // lanes 0..NW-1 (rounded up) of the wave look at the records
+    const unsigned best = NW <= 8 ? half_row_max_u32(ev) : row_max_u32(ev);
+    unsigned c16 = (unsigned)__ballot(ev == best) & RECS;
     if (__builtin_popcount(c16) != 1) {
       const int oi = (unsigned)ei < (unsigned)CAP ? (int)perm[ei] : 0x7fffffff;
       const int mi = row_min_i32(ev == best ? oi : 0x7fffffff);
-      c16 = (unsigned)__ballot(ev == best && oi == mi) & 0xffffu;
+      c16 = (unsigned)__ballot(ev == best && oi == mi) & RECS;
     }
     const int win = __builtin_ctz(c16);
     const int farthest = __builtin_amdgcn_readlane(ei, win);
     cx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e[1]), win));
     cy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e[2]), win));
     cz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e[3]), win));
-    rad = __uint_as_float(best);
+    rad = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)ev, win));     // wave-uniform (`best` is only valid in the lanes that look at records)
     if (tid == 0) {
       ob[it] = farthest;                                     // a sorted position for now
       if (oxb) { oxb[it * 3 + 0] = cx; oxb[it * 3 + 1] = cy; oxb[it * 3 + 2] = cz; }   // = index_points(xyz, out), for free
