@@ -226,10 +226,11 @@ __global__ __launch_bounds__(NT) void fps_kernel(const float* __restrict__ xyz, 
 //    any tie -- two lanes, two groups or two slots at the maximum -- takes a wave-uniform slow path that looks the indices up in `perm`;
 //  * the exchange between wavefronts is the one of fps_kernel, carrying sorted positions; the samples are translated through `perm` when
 //    the rounds are over.
-// Measured and rejected (profiles/r4_fps_blob.json holds the kept ones): the blob's own running maximum as the bound instead of the
-// cloud's (a wave reduction per updated group: 2 % fewer updates, 1.06 us per round against 1.05; with 256-point blobs 1.16 against
-// 1.07); 256-point blobs above 8,192 points (more skipped, more bookkeeping: 1.07 against 1.05); keeping a wavefront's previous winner
-// when it updated nothing (1.08 against 1.06: the branch costs more than the search it saves).
+// Measured and rejected (profiles/r4_fps_blob.json holds the kept ones; DESIGN.md 4.6 has the sequence): the blob's own running maximum
+// as the bound instead of the cloud's (a wave reduction per updated group: 2 % fewer updates, 1.06 us per round against 1.05; with
+// 256-point blobs 1.16 against 1.07); 256-point blobs above 8,192 points (more skipped, more bookkeeping: 0.97 against 0.94); keeping a
+// wavefront's previous winner when it updated nothing (1.08 against 1.06: the branch costs more than the search it saves); a binary
+// branch pick of the winner's coordinates (1.03 against 0.96 for the register-indexed read).
 constexpr int FPS_CELL_BITS = 4, FPS_BINS = 1 << (3 * FPS_CELL_BITS);
 
 __device__ __forceinline__ int fps_cell(float x, float y, float z, const float (&lo)[3], const float (&inv)[3]) {
@@ -627,8 +628,8 @@ static int fps_launch(const float* xyz, const long long* start, int B, int N, in
   }
   // 2,049 .. 24,576 points: 512 threads (two waves per SIMD) x 8 .. 48 points, skipping the blobs a round cannot change; 256-point
   // blobs up to 8,192 points, 512-point blobs above.  us per round, uniform volume / surface cloud, against fps_kernel (which updates
-  // every point every round; profiles/r4_fps_blob.json): 8,192 points 0.83 / 0.79 against 0.95; 12,288: 0.94 / 0.90 against 1.45;
-  // 20,000: 1.05 / 1.00 against 1.45; 24,576: 1.10 / 1.05 against 1.62.
+  // every point every round; profiles/r4_fps_blob.json): 8,192 points 0.77 / 0.71 against 0.97; 12,288: 0.84 / 0.82 against 1.44;
+  // 20,000: 0.94 / 0.89 against 1.44; 24,576: 0.99 / 0.93 against 1.63.
 #define CG_FPS_BLOB(PPT, GS) hipLaunchKernelGGL((fps_blob_kernel<512, PPT, GS>), grid, dim3(512), 0, s, xyz, start, N, npoint, out, out_xyz)
   else if (N <= 512 * 8) CG_FPS_BLOB(8, 4);
   else if (N <= 512 * 16) CG_FPS_BLOB(16, 4);

@@ -622,7 +622,7 @@ def test_hot_kernels_stay_out_of_scratch():
     kr = importlib.util.module_from_spec(spec); spec.loader.exec_module(kr)
     if not all(os.path.exists(os.path.join(kr.LLVM, t)) for t in ('llvm-objcopy', 'clang-offload-bundler', 'llvm-readelf')) or shutil.which('c++filt') is None:
         pytest.skip('ROCm llvm binutils / c++filt not found')
-    hot = {'pointmlp.o': ('pointmlp_max_kernel<',), 'setabstraction.o': ('sa_reg_kernel<',), 'primitives.o': ('fps_kernel<', 'square_distance', 'ball_query', 'group_points'),
+    hot = {'pointmlp.o': ('pointmlp_max_kernel<',), 'setabstraction.o': ('sa_reg_kernel<',), 'primitives.o': ('square_distance', 'ball_query', 'group_points'), 'fps.o': ('fps_kernel<', 'fps_blob_kernel<'),
            'gemm.o': ('gemm_bias_act_kernel',), 'collision.o': ('filter_grasp_pose_kernel',), 'misc.o': ('build_grasp_input', 'softmax_pg', 'nunocs_decode'),
            'pointmlp_split.o': ('pointmlp_max_split_kernel<0, 8, true, false>', 'pointmlp_max_split_kernel<2, 8, false, false>')}
     seen = 0
@@ -636,7 +636,9 @@ def test_hot_kernels_stay_out_of_scratch():
             if any(name.startswith(p) for p in prefixes):
                 seen += 1
                 assert r['private_segment_fixed_size'] == 0 and r['vgpr_spill_count'] == 0, r
-    assert seen >= 100          # 3 + 117 set-abstraction signatures + 4 FPS geometries + ...
+    assert seen >= 100          # 3 + 117 set-abstraction signatures + 10 FPS geometries + ...
+    fps = [r['kernel'] for r in kr.resources(os.path.join(root, 'catgrasp_amd', 'csrc', 'fps.o'))]
+    assert sum('fps_blob_kernel<' in n for n in fps) == 6 and sum('fps_kernel<' in n for n in fps) == 4
     # the collision kernels additionally keep every scalar register: their wave-uniform state (posed matrices, grid geometry, output
     # pointers) is laid out so that nothing is spilled to VGPR lanes (round 3: 364 spilled SGPRs in filter_grasp_pose_kernel)
     rows = kr.resources(os.path.join(root, 'catgrasp_amd', 'csrc', 'collision.o'))
