@@ -61,9 +61,10 @@ def farthest_point_sample(xyz, npoint, start=None, return_xyz=False):
         raise NotImplementedError('farthest_point_sample HIP kernel is built for 3-D points')
     if start is None:
         start = torch.randint(0, N, (B,), dtype=torch.long)
-    start = torch.as_tensor(start).long().to(xyz.device).contiguous()
-    if start.numel() != B or (B > 0 and (int(start.min()) < 0 or int(start.max()) >= N)):
+    start = torch.as_tensor(start).long()
+    if start.numel() != B or (B > 0 and bool(((start < 0) | (start >= N)).any())):      # one read-back when `start` lives on the device, none otherwise
         raise ValueError('start must hold one valid point index per cloud')
+    start = start.to(xyz.device).contiguous()
     out = torch.empty((B, npoint), dtype=torch.int64, device=xyz.device)
     scratch = torch.empty((B, N), dtype=torch.float32, device=xyz.device) if N > 24576 else None
     if return_xyz:

@@ -73,12 +73,12 @@ row('square_distance_kernel', timed(lambda: primitives.square_distance(new, pts)
 idx = torch.randint(0, N, (1, S, K), device=dev, generator=g)
 row('index_points (group) kernel', timed(lambda: primitives.index_points(feat, idx)), S * K * (8 + 24), '8 B index + 24 B row written per neighbour (gathers are L2 hits)')
 t_fps = timed(lambda: primitives.farthest_point_sample(pts, S, start=torch.zeros(1, dtype=torch.long, device=dev)), iters=5, warm=1)
-row('farthest_point_sample_kernel', t_fps, N * 12 + S * 8, 'N x 12 B read once + S x 8 B out', bound='VALU of one CU (sequential over npoint)',
+row('fps_blob_kernel (farthest_point_sample)', t_fps, N * 24 + S * 8, 'N x 12 B read twice (box, cells) + gathered once + S x 8 B out', bound='latency chain of one CU (sequential over npoint)',
     extra={'rounds_per_s': round(S / t_fps), 'us_per_round': round(t_fps / S * 1e6, 3),
-           'note': 'one 512-thread workgroup, 40 points per thread in VGPRs, 5.5 VALU per point per round; reference CPU: 0.24 s'})
+           'note': 'one 512-thread workgroup, 40 points per thread in VGPRs in spatial order; a round updates only the 512-point blobs within the sampling radius of the new centre (~21 % here), 5.5 VALU per updated point; reference CPU: 0.24 s'})
 pts8 = (torch.rand(8, N, 3, device=dev, generator=g) * 0.1).contiguous()
 t_fps8 = timed(lambda: primitives.farthest_point_sample(pts8, S, start=torch.zeros(8, dtype=torch.long, device=dev)), iters=5, warm=1)
-row('farthest_point_sample_kernel (the 8 clouds of C3 in one launch)', t_fps8, 8 * (N * 12 + S * 8), 'as above x 8 clouds, one workgroup each', bound='VALU of one CU per cloud',
+row('fps_blob_kernel (the 8 clouds of C3 in one launch)', t_fps8, 8 * (N * 24 + S * 8), 'as above x 8 clouds, one workgroup each', bound='latency chain of one CU per cloud',
     extra={'us_per_round_all_clouds': round(t_fps8 / S * 1e6, 3)})
 t_bq = timed(lambda: primitives.query_ball_point(0.02, K, pts, new), iters=10)
 row('query_ball_point_kernel', t_bq, (N + S) * 12 + S * K * 8, '(N+S) x 12 B read + S x nsample x 8 B written (HBM level)', bound='L2 scan',
