@@ -279,9 +279,9 @@ __device__ __forceinline__ void fps_group_pick(int g, int j, const V* PX, const 
 
 // inside group gw of the winner lane wl (both wave-uniform; binary search over the groups): its first slot at the wave maximum, how
 // many of its slots hold it, the slot's coordinates
-template <int GLO, int GHI, int GS, int PPT, typename V>
+template <int GLO, int GHI, int GS, int PPT, int NW, typename V>
 __device__ __forceinline__ void fps_ball_find(int gw, int wl, unsigned wmax, const unsigned (&dist)[PPT], const V* PX, const V* PY, const V* PZ,
-                                              int& kw, int& cw, float& x, float& y, float& z) {
+                                              int& pw, int& cw, float& x, float& y, float& z) {
   if constexpr (GHI - GLO == 1) {
     constexpr int G = GLO;
     unsigned bv = wmax;
@@ -291,14 +291,14 @@ __device__ __forceinline__ void fps_ball_find(int gw, int wl, unsigned wmax, con
     for (int j = 0; j < GS; ++j) push_eq_bit(bits, dist[G * GS + j], bv);
     const unsigned bw = (unsigned)__builtin_amdgcn_readlane((int)bits, wl);      // != 0: the winner lane holds the maximum in this group
     const int jw = (GS - 1) - (31 - __builtin_clz(bw));
-    kw = G * GS + jw;
+    pw = (G * NW * GS + jw) << 6;                           // fps_slot_pos of slot G * GS + jw, without the wave's and the lane's share
     cw = __builtin_popcount(bw);
     x = PX[G][jw]; y = PY[G][jw]; z = PZ[G][jw];
     asm volatile("" : "+v"(x), "+v"(y), "+v"(z));
   } else {
     constexpr int MID = (GLO + GHI) / 2;
-    if (gw < MID) fps_ball_find<GLO, MID, GS, PPT, V>(gw, wl, wmax, dist, PX, PY, PZ, kw, cw, x, y, z);
-    else fps_ball_find<MID, GHI, GS, PPT, V>(gw, wl, wmax, dist, PX, PY, PZ, kw, cw, x, y, z);
+    if (gw < MID) fps_ball_find<GLO, MID, GS, PPT, NW, V>(gw, wl, wmax, dist, PX, PY, PZ, pw, cw, x, y, z);
+    else fps_ball_find<MID, GHI, GS, PPT, NW, V>(gw, wl, wmax, dist, PX, PY, PZ, pw, cw, x, y, z);
   }
 }
 
@@ -463,8 +463,9 @@ __global__ __launch_bounds__(NT) void fps_blob_kernel(const float* __restrict__ 
   float rad = 1e10f;                   // the largest running distance of the whole cloud (= the new centre's, when it was chosen)
   for (int it = 1; it < npoint; ++it) {
     // ---- which of the wave's blobs can change: distance from the centre to the blob's box, rounded exactly like a point's ----
-    const float qx = fmaxf(fmaxf(blo[0] - cx, cx - bhi[0]), 0.f), qy = fmaxf(fmaxf(blo[1] - cy, cy - bhi[1]), 0.f),
-                qz = fmaxf(fmaxf(blo[2] - cz, cz - bhi[2]), 0.f);
+    const f32x2 cxy = {cx, cy};
+    const f32x2 lo2 = f32x2{blo[0], blo[1]} - cxy, hi2 = cxy - f32x2{bhi[0], bhi[1]};      // x and y in one packed subtraction each
+    const float qx = fmaxf(fmaxf(lo2[0], hi2[0]), 0.f), qy = fmaxf(fmaxf(lo2[1], hi2[1]), 0.f), qz = fmaxf(fmaxf(blo[2] - cz, cz - bhi[2]), 0.f);
     const float lb = (qx * qx + qy * qy) + qz * qz;
     const unsigned need = (unsigned)__builtin_amdgcn_fcmpf(lb, rad, 4 /* ordered < */) & ((1u << NG) - 1u);   // lanes >= NG hold no box
     const f32x2 c2x = {cx, cx}, c2y = {cy, cy}, c2z = {cz, cz};
@@ -501,10 +502,10 @@ __global__ __launch_bounds__(NT) void fps_blob_kernel(const float* __restrict__ 
     for (int g = 0; g < NG; ++g) push_eq_bit(gbits, gmax[g], bv);
     const unsigned gbw = (unsigned)__builtin_amdgcn_readlane((int)gbits, wl);     // the winner lane's: != 0
     const int gw = (NG - 1) - (31 - __builtin_clz(gbw));     // its first group at the maximum
-    int kw, cw; float bx, by, bz;
-    fps_ball_find<0, NG, GS, PPT, V>(gw, wl, wmax, dist, PX, PY, PZ, kw, cw, bx, by, bz);
-    const int tie = (__builtin_popcountll(cand) - 1) | (__builtin_popcount(gbw) - 1) | (cw - 1);
-    if (tie) {                                               // equal maxima somewhere in the wave: the smallest point index wins
+    int pw, cw; float bx, by, bz;
+    fps_ball_find<0, NG, GS, PPT, NW, V>(gw, wl, wmax, dist, PX, PY, PZ, pw, cw, bx, by, bz);
+    int iw = pw + ((wv * GS) << 6) + wl;                     // the winner's sorted position (fps_slot_pos)
+    if (__builtin_popcountll(cand) + __builtin_popcount(gbw) + cw != 3) {   // more than one lane, group or slot at the maximum                                               // equal maxima somewhere in the wave: the smallest point index wins
       int bi = 0x7fffffff, bk = 0;
 #pragma unroll
       for (int g = 0; g < NG; ++g) {
@@ -521,10 +522,10 @@ __global__ __launch_bounds__(NT) void fps_blob_kernel(const float* __restrict__ 
       }
       const int mi = wave_min_i32(bi);
       wl = __builtin_ctzll(__ballot(bi == mi));
-      kw = __builtin_amdgcn_readlane(bk, wl);
-      fps_group_pick<0, NG, V>(kw / GS, kw % GS, PX, PY, PZ, bx, by, bz);
+      const unsigned kw = (unsigned)__builtin_amdgcn_readlane(bk, wl);
+      fps_group_pick<0, NG, V>((int)(kw / GS), (int)(kw % GS), PX, PY, PZ, bx, by, bz);
+      iw = fps_slot_pos<NW, GS>(wv, wl, (int)kw);
     }
-    const int iw = fps_slot_pos<NW, GS>(wv, wl, kw);
     const int buf = it & 1;
     if (lane == wl) { red_v[buf][wv] = f32x4{__uint_as_float(wmax), bx, by, bz}; red_i[buf][wv] = iw; }
     __syncthreads();
