@@ -629,8 +629,8 @@ static int fps_launch(const float* xyz, const long long* start, int B, int N, in
   }
   // 2,049 .. 24,576 points: 512 threads (two waves per SIMD) x 8 .. 48 points, skipping the blobs a round cannot change; 256-point
   // blobs up to 8,192 points, 512-point blobs above.  us per round, uniform volume / surface cloud, against fps_kernel (which updates
-  // every point every round; profiles/r4_fps_blob.json): 8,192 points 0.77 / 0.71 against 0.97; 12,288: 0.84 / 0.82 against 1.44;
-  // 20,000: 0.94 / 0.89 against 1.44; 24,576: 0.99 / 0.93 against 1.63.
+  // every point every round; profiles/r4_fps_blob.json): 8,192 points 0.74 / 0.68 against 0.96; 12,288: 0.82 / 0.79 against 1.43;
+  // 20,000: 0.92 / 0.87 against 1.44; 24,576: 0.98 / 0.92 against 1.62.
 #define CG_FPS_BLOB(PPT, GS) hipLaunchKernelGGL((fps_blob_kernel<512, PPT, GS>), grid, dim3(512), 0, s, xyz, start, N, npoint, out, out_xyz)
   else if (N <= 512 * 8) CG_FPS_BLOB(8, 4);
   else if (N <= 512 * 16) CG_FPS_BLOB(16, 4);
