@@ -522,9 +522,9 @@ __global__ __launch_bounds__(NT) void fps_blob_kernel(const float* __restrict__ 
       }
       const int mi = wave_min_i32(bi);
       wl = __builtin_ctzll(__ballot(bi == mi));
-      const unsigned kw = (unsigned)__builtin_amdgcn_readlane(bk, wl);
-      fps_group_pick<0, NG, V>((int)(kw / GS), (int)(kw % GS), PX, PY, PZ, bx, by, bz);
-      iw = fps_slot_pos<NW, GS>(wv, wl, (int)kw);
+      const int kw = __builtin_amdgcn_readlane(bk, wl);        // (signed on purpose: with an unsigned slot number LLVM turns the pick below into one
+      fps_group_pick<0, NG, V>(kw / GS, kw % GS, PX, PY, PZ, bx, by, bz);   //  dynamically indexed array and puts the coordinates into scratch)
+      iw = fps_slot_pos<NW, GS>(wv, wl, kw);
     }
     const int buf = it & 1;
     if (lane == wl) { red_v[buf][wv] = f32x4{__uint_as_float(wmax), bx, by, bz}; red_i[buf][wv] = iw; }
@@ -629,8 +629,8 @@ static int fps_launch(const float* xyz, const long long* start, int B, int N, in
   }
   // 2,049 .. 24,576 points: 512 threads (two waves per SIMD) x 8 .. 48 points, skipping the blobs a round cannot change; 256-point
   // blobs up to 8,192 points, 512-point blobs above.  us per round, uniform volume / surface cloud, against fps_kernel (which updates
-  // every point every round; profiles/r4_fps_blob.json): 8,192 points 0.74 / 0.68 against 0.96; 12,288: 0.82 / 0.79 against 1.43;
-  // 20,000: 0.92 / 0.87 against 1.44; 24,576: 0.98 / 0.92 against 1.62.
+  // every point every round; profiles/r4_fps_blob.json): 8,192 points 0.73 / 0.68 against 0.96; 12,288: 0.82 / 0.80 against 1.43;
+  // 20,000: 0.91 / 0.86 against 1.44; 24,576: 0.97 / 0.91 against 1.62.
 #define CG_FPS_BLOB(PPT, GS) hipLaunchKernelGGL((fps_blob_kernel<512, PPT, GS>), grid, dim3(512), 0, s, xyz, start, N, npoint, out, out_xyz)
   else if (N <= 512 * 8) CG_FPS_BLOB(8, 4);
   else if (N <= 512 * 16) CG_FPS_BLOB(16, 4);
