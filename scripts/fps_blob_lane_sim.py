@@ -1,8 +1,10 @@
 #!/usr/bin/env python
-"""dev (host only, numpy): fps_blob_kernel of primitives.hip emulated lane by lane -- the sorted-position layout, the per-lane group
-maxima, the wave-uniform blob maxima, the tie detection (two groups / two lanes / two slots at the maximum), the slow path through
-`perm`, the wave records and the second-stage tie break -- against the plain loop of pointnet2.py:54-75.  The scatter order inside a
-cell is randomised (the device's atomics give an arbitrary one).  usage: fps_blob_lane_sim.py [GS]"""
+"""Host only, numpy: fps_blob_kernel of csrc/fps.hip emulated lane by lane -- the sorted-position layout, the per-lane group maxima, the
+box test (radius=True: against the cloud's largest running distance, what the kernel ships; radius=False: against each blob's own
+maximum, the first design), the tie detection (two lanes / two groups / two slots at the maximum), the slow path through `perm`, the
+wave records and the second-stage tie break -- against the plain loop of pointnet2.py:54-75.  The scatter order inside a cell is
+randomised (the device's atomics give an arbitrary one).  tests/test_fps_blob_model_cpu.py runs it against the oracle.
+usage: fps_blob_lane_sim.py [GS] [radius]"""
 import sys
 
 import numpy as np
