@@ -307,7 +307,7 @@ __global__ __launch_bounds__(NT) void fps_blob_kernel(const float* __restrict__ 
                                                       long long* __restrict__ out, float* __restrict__ out_xyz) {
   static_assert(NT % 64 == 0 && NT <= 1024 && GS % 2 == 0 && PPT % GS == 0 && (GS & (GS - 1)) == 0, "geometry");
   static_assert(FPS_BINS % NT == 0 && NT * PPT < 0xffff, "one scan chunk per thread; 16-bit point indices with 0xffff = none");
-  constexpr int H = PPT / 2, NG = PPT / GS, NW = NT / 64, CAP = NT * PPT, BPT = FPS_BINS / NT;
+  constexpr int H = PPT / 2, NG = PPT / GS, NW = NT / 64, CAP = NT * PPT, BPT = FPS_BINS / NT;   // H: slot pairs per thread
   static_assert(NG <= 64, "one lane per group for the skip test");
   __shared__ __attribute__((aligned(16))) unsigned short perm[CAP];   // sorted position -> point index (0xffff: padding)
   __shared__ __attribute__((aligned(16))) int scr[FPS_BINS];   // prologue: box partials, then the cell histogram; rounds: the wave records
@@ -475,8 +475,7 @@ __global__ __launch_bounds__(NT) void fps_blob_kernel(const float* __restrict__ 
         unsigned m = 0u;
 #pragma unroll
         for (int h = g * (GS / 2); h < (g + 1) * (GS / 2); ++h) {
-          constexpr int J0 = 0;
-          const int j = 2 * (h - g * (GS / 2)) + J0;
+          const int j = 2 * (h - g * (GS / 2));               // the pair's first slot inside the group
           const f32x2 ax = {PX[g][j], PX[g][j + 1]}, ay = {PY[g][j], PY[g][j + 1]}, az = {PZ[g][j], PZ[g][j + 1]};
           const f32x2 dx = ax - c2x, dy = ay - c2y, dz = az - c2z;
           const f32x2 d = (dx * dx + dy * dy) + dz * dz;      // torch.sum((xyz - centroid) ** 2, -1), two points per instruction
