@@ -13,6 +13,7 @@ import torch
 from catgrasp_amd import synth
 from oracle import pointnet_ref as oref
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))      # tests/fps_clouds.py
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'pointnet2_golden.npz')
 
 
@@ -68,6 +69,20 @@ def test_primitives_match_reference_golden(gold):
     ax, ap = oref.sample_and_group_all(xyz, feats)
     assert np.array_equal(ax.numpy(), gold['sga_new_xyz'])
     assert abs(float(ap.numpy().astype(np.float64).sum()) - float(gold['sga_new_points_sum'][0])) < 1e-9
+
+
+def test_farthest_point_sample_matches_reference_golden_at_working_sizes():
+    """tests/golden/fps_large_golden.npz: the real reference's samples on 3,000 .. 24,000-point clouds (filled volume, surface,
+    duplicated points, lattice) -- the sizes and the tie situations the blob-skipping HIP kernel is built for."""
+    import fps_clouds
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'fps_large_golden.npz'))
+    for kind, n, seed in fps_clouds.CASES:
+        xyz = torch.from_numpy(fps_clouds.cloud(kind, n, seed)[None])
+        torch.manual_seed(seed)
+        start = torch.randint(0, n, (1,), dtype=torch.long)        # pointnet2.py:66
+        assert np.array_equal(start.numpy(), gold[f'{kind}_{n}_start'])
+        got = oref.farthest_point_sample(xyz, fps_clouds.NPOINT, start).numpy()
+        assert np.array_equal(got, gold[f'{kind}_{n}_fps']), (kind, n)
 
 
 @pytest.mark.skipif(not os.path.exists('/root/reference/pointnet2.py'), reason='reference checkout only exists in the build container')

@@ -116,6 +116,23 @@ def test_farthest_point_sample_also_returns_the_sampled_points(cuda_device, fps_
     assert new_xyz.shape == (B, npoint, 3) and torch.equal(new_xyz, p2.index_points(xyz, idx))
 
 
+def test_farthest_point_sample_matches_the_reference_at_working_sizes(cuda_device, fps_kernel):
+    """tests/golden/fps_large_golden.npz holds the REAL reference's samples (pointnet2.py:54-75, imported by
+    tests/golden/make_golden_fps_large.py) for 3,000 .. 24,000-point clouds -- filled volume, surface, duplicated points, lattice:
+    both kernels against the reference itself, at the sizes and in the tie situations they are built for."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import fps_clouds
+    from catgrasp_amd import pointnet2 as p2
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'fps_large_golden.npz'))
+    for kind, n, seed in fps_clouds.CASES:
+        xyz = torch.from_numpy(fps_clouds.cloud(kind, n, seed)[None]).to(cuda_device)
+        torch.manual_seed(seed)
+        got = p2.farthest_point_sample(xyz, fps_clouds.NPOINT).cpu().numpy()          # the start is drawn like pointnet2.py:66 does
+        assert np.array_equal(got, gold[f'{kind}_{n}_fps']), (kind, n)
+
+
 def test_farthest_point_sample_default_start_follows_torch_seed(cuda_device):
     """pointnet2.py:66 draws the start on the CPU generator: same torch seed -> same samples as the reference."""
     from catgrasp_amd import pointnet2 as p2
