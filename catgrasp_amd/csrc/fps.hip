@@ -618,8 +618,8 @@ static int fps_launch(const float* xyz, const long long* start, int B, int N, in
     if (!dist_scratch) return CG_ERR_ARG;   // (B,N) floats needed for clouds beyond the register paths
     hipLaunchKernelGGL(fps_kernel_global, grid, block, 0, s, xyz, start, N, npoint, dist_scratch, out, out_xyz);
   }
-  // <= 2,048 points: 512 threads x 4 points (0.60 us per round at N = 2,048 against 0.64 for 1,024 x 2 and 0.67 for 256 x 8: the round
-  // is all exchange there, and eight wave records are cheaper to reduce than sixteen)
+  // <= 2,048 points: 512 threads x 4 points, every point every round (0.54 us per round at N = 2,048; the blob-skipping kernel with one
+  // 256-point blob per wavefront: 0.56, and its prologue is not amortised over few rounds -- 0.76 against 0.56 at 1,024 -> 512)
   else if (N <= 512 * 4) hipLaunchKernelGGL((fps_kernel<512, 4>), grid, dim3(512), 0, s, xyz, start, N, npoint, out, out_xyz);
   else if (fps_plain()) {
     if (N <= 1024 * 8) hipLaunchKernelGGL((fps_kernel<1024, 8>), grid, block, 0, s, xyz, start, N, npoint, out, out_xyz);

@@ -42,7 +42,7 @@ def timed(fn, reps=5):
 res = {'parity': [], 'time': []}
 rng = np.random.default_rng(7)
 bad = 0
-for N, S in ((20000, 1024), (2049, 200), (3000, 200), (4096, 300), (4097, 300), (8192, 300), (8193, 300), (12000, 300), (12288, 300), (12289, 300), (16384, 300), (16385, 300), (20480, 300), (20481, 300), (22000, 300), (24576, 300)):
+for N, S in ((20000, 1024), (600, 200), (1500, 200), (2048, 200), (2049, 200), (3000, 200), (4096, 300), (4097, 300), (8192, 300), (8193, 300), (12000, 300), (12288, 300), (12289, 300), (16384, 300), (16385, 300), (20480, 300), (20481, 300), (22000, 300), (24576, 300)):
     for name, xyz in clouds(N, rng):
         pts = torch.from_numpy(np.stack([xyz, xyz[rng.permutation(N)]])).to(dev)
         start = torch.tensor([int(rng.integers(0, N)), N - 1], device=dev)
@@ -68,7 +68,7 @@ for xyz in (np.full((9000, 3), np.float32(0.25)), np.concatenate([np.full((8999,
         row[v] = bool(np.array_equal(fps(pts, 20, start, v).cpu().numpy(), ref)); bad += not row[v]
     res['parity'].append(row); print(row, flush=True)
 g = torch.Generator(device=dev); g.manual_seed(0)
-for N, S in ((20000, 1024), (2049, 1024), (4096, 1024), (8192, 1024), (12288, 1024), (16384, 1024), (24576, 1024)):
+for N, S in ((20000, 1024), (1024, 512), (2048, 1024), (2049, 1024), (4096, 1024), (8192, 1024), (12288, 1024), (16384, 1024), (24576, 1024)):
     sets = {'uniform cube': (torch.rand(8, N, 3, device=dev, generator=g) * 0.1).contiguous()}
     surf = [c for n, c in clouds(N, np.random.default_rng(3)) if n == 'surface'][0]
     sets['surface'] = torch.from_numpy(np.stack([surf[np.random.default_rng(i).permutation(N)] for i in range(8)])).to(dev)
