@@ -1,0 +1,387 @@
+// PointNet++ set-abstraction layers PAST the first one: wide inputs (3 + D up to ~590 channels), wide layers (hidden <= 512, last any
+// multiple of 32), any neighbourhood size, and the group-all layer's input.
+// (BASELINE.json north_star: "the PointNet++ set-abstraction encoder ... grouped per-neighbourhood MLP reductions ... LDS-staged
+// neighbourhoods ... MFMA only for the dense per-point MLP GEMMs"; the primitives it stacks are pointnet2.py:101-149.)
+//
+// Replaces the op sequence that consumes sample_and_group's output (pointnet2.py:101-129)
+//   new_points (B,S,K,3+D) = cat(xyz[idx] - new_xyz, points[idx])     -> permute -> [Conv2d(1x1) -> BatchNorm2d -> ReLU] x L -> max over K
+// for layers the register-resident kernel of setabstraction.hip cannot hold (SA2 of an SSG stack: 3 + 128 inputs, 128-128-256, K = 64;
+// the MSG scales: 3 + 320 inputs, K = 128, a 96-wide layer).
+//
+// sa_tile_kernel: one workgroup (4 wavefronts) carries a tile of 64 grouped rows through every layer inside ONE LDS strip
+// (64 x (widest stored activation + 4) floats: 36 KB for SA2 -> several workgroups per CU):
+//   * gather: the tile's 64 (neighbourhood, neighbour) rows -- indices, then 16-byte feature loads, rows coalesced; the channel order
+//     inside the strip is [features | centred xyz | zero pad to 8] so that the feature copies are aligned 16-byte LDS stores (the host
+//     permutes the first layer's weight columns the same way, catgrasp_amd/primitives.py);
+//   * a layer: rows are the MFMA M dimension (A operand, ds_read_b128 from the strip), output channels the N dimension (B operand =
+//     fragment-packed weights streamed from L2, one k-step ahead, each fragment feeding both 32-row halves).  A wave owns the channel
+//     blocks {w, w+4, ...} and keeps ALL its accumulators until every wave has finished reading the strip, so the layer's output
+//     overwrites its own input (two workgroup barriers per layer, no second buffer); bias = the accumulators' initial value;
+//   * the last layer goes from the accumulators straight into the max over the neighbourhood: a per-lane reduction over accumulator
+//     registers + one lane^32 exchange (K <= 32 packs 2 / 4 / 8 neighbourhoods into a tile; K > 64 takes several row tiles with a
+//     running max in LDS); its bias + ReLU commute with the max and are applied once per output.
+// v_mfma_f32_32x32x2_f32 throughout: exact float32 products and accumulation, like the reference's float32 convolution.
+// Algorithmic work per neighbourhood: 2 K sum_l cin_l cout_l flop; HBM bytes: K (8 B index + (3 + D) 4 B gathered) + 12 B + C_L 4 B.
+#include "cg_common.hpp"
+#include "../../include/catgrasp_amd.h"
+
+namespace {
+
+constexpr int ST_MAX_LAYERS = 4;
+constexpr int TR = 64;                      // rows per tile
+
+struct STArgs {
+  const float* xyz; const float* points; const float* new_xyz; const long long* idx;
+  int B, N, S, K, D;
+  int nlayers; int cin[ST_MAX_LAYERS]; int cout[ST_MAX_LAYERS];
+  const float* w[ST_MAX_LAYERS]; const float* b[ST_MAX_LAYERS];
+  float* out; long out_bs, out_ss, out_cs;          // out[b * out_bs + s * out_ss + c * out_cs]
+  int* err_flag;
+  int CS;                                           // strip row stride (floats)
+  int KP, RT;                                       // rows of a tile per neighbourhood (8 / 16 / 32 / 64); row tiles per neighbourhood (KP = 64)
+};
+
+// The MFMA stream of one wave for one layer: NBW channel blocks x NH row halves, B fragments one k-step ahead in a double buffer.
+// arow: this lane's A-fragment row of the first half (strip + (rowbase + l31) * CS + lhi * 4); the second half is 32 rows further.
+// wp: packed weights + lane; fragment of (block nb, k-step ks) = wp[(nb * nks + ks) * 64].
+template <int NBW, int NH>
+__device__ __forceinline__ void st_mma(const float* arow, int CS, const f32x4* wp, int nks, const int (&blk)[NBW], f32x16 (&acc)[NBW][NH]) {
+  f32x4 av[2][NH], bv[2][NBW];
+  auto load = [&](int ks, int slot) {
+#pragma unroll
+    for (int h = 0; h < NH; ++h) av[slot][h] = *(const f32x4*)(arow + h * 32 * CS + ks * 8);
+#pragma unroll
+    for (int i = 0; i < NBW; ++i) bv[slot][i] = wp[(blk[i] * nks + ks) * 64];
+  };
+  auto mma = [&](int slot) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < NBW; ++i)
+#pragma unroll
+        for (int h = 0; h < NH; ++h) acc[i][h] = mfma32(av[slot][h][j], bv[slot][i][j], acc[i][h]);
+  };
+  auto pin = [&](int slot) {               // a use that keeps the prefetch in THIS iteration (LLVM otherwise sinks it in front of its MFMAs)
+#pragma unroll
+    for (int h = 0; h < NH; ++h) asm volatile("" : "+v"(av[slot][h]));
+#pragma unroll
+    for (int i = 0; i < NBW; ++i) asm volatile("" : "+v"(bv[slot][i]));
+  };
+  load(0, 0);
+  for (int ks = 0; ks < nks; ks += 2) {
+    load(ks + 1 < nks ? ks + 1 : ks, 1);     // past the end: a repeated, unused load (a conditional one would put a phi on the registers)
+    __builtin_amdgcn_sched_barrier(0);
+    mma(0);
+    __builtin_amdgcn_sched_barrier(0);
+    pin(1);
+    if (ks + 1 >= nks) break;
+    load(ks + 2 < nks ? ks + 2 : ks + 1, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(1);
+    __builtin_amdgcn_sched_barrier(0);
+    pin(0);
+  }
+}
+
+// Hidden layer for one wave: NBW blocks {nb0, nb0 + nbs, ...} x NH halves (NH = 2: both halves; NH = 1: the half at rowbase).
+// Every wave of the workgroup runs exactly two barriers per hidden layer, whatever its share (st_hidden_idle for a wave without one).
+template <int NBW, int NH>
+__device__ __forceinline__ void st_hidden(float* strip, int CS, const float* w, const float* bias, int nks, int nb0, int nbs, int rowbase, int lane) {
+  const int l31 = lane & 31, lhi = lane >> 5;
+  int blk[NBW];
+  f32x16 acc[NBW][NH];
+#pragma unroll
+  for (int i = 0; i < NBW; ++i) {
+    blk[i] = nb0 + i * nbs;
+    const float bq = bias[blk[i] * 32 + l31];
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][h][r] = bq;
+  }
+  st_mma<NBW, NH>(strip + (rowbase + l31) * CS + lhi * 4, CS, (const f32x4*)w + lane, nks, blk, acc);
+  __syncthreads();                         // every wave has read its last fragment of the strip: the layer may overwrite its input
+  // one opaque per-lane base + wave-uniform row offsets: left to itself LLVM hoists all 16 x NBW x NH store addresses of every layer
+  // shape out of the tile loop and keeps them in (spilled) registers
+  int base = (rowbase + 4 * lhi) * CS + l31;
+  asm volatile("" : "+v"(base));
+#pragma unroll
+  for (int i = 0; i < NBW; ++i)
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        strip[base + ((r & 3) + 8 * (r >> 2) + 32 * h) * CS + blk[i] * 32] = fmaxf(acc[i][h][r], 0.f);
+  __syncthreads();
+}
+__device__ __forceinline__ void st_hidden_idle() { __syncthreads(); __syncthreads(); }
+
+// max over the accumulator registers [r0, r0 + n) of a lane
+template <int R0, int NR>
+__device__ __forceinline__ float st_max_regs(const f32x16& c) {
+  float m = c[R0];
+#pragma unroll
+  for (int r = 1; r < NR; ++r) m = fmaxf(m, c[R0 + r]);
+  return m;
+}
+
+// Last layer for one wave, NBW blocks (both halves) per pass: accumulators -> neighbourhood maxima -> out (+ bias, ReLU) or the running
+// maxima in LDS (several row tiles per neighbourhood).  KP = rows per neighbourhood in the tile.
+template <int NBW, int KP>
+__device__ __forceinline__ void st_last(const STArgs& a, const float* strip, const float* w, const float* bias, int nks, int nb0, int lane,
+                                        int kt, float* rmax, const long* goff) {
+  const int l31 = lane & 31, lhi = lane >> 5;
+  int blk[NBW];
+  f32x16 acc[NBW][2];
+#pragma unroll
+  for (int i = 0; i < NBW; ++i) {
+    blk[i] = nb0 + i * 4;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) acc[i][h] = f32x16{0};
+  }
+  st_mma<NBW, 2>(strip + l31 * a.CS + lhi * 4, a.CS, (const f32x4*)w + lane, nks, blk, acc);
+  // goff[j]: offset of the tile's j-th neighbourhood inside `out`, or -1 for the padding of the last tile
+  auto store = [&](int j, int ch, float m) {
+    const long o = goff[j];
+    if (o >= 0) a.out[o + (long)ch * a.out_cs] = fmaxf(m + bias[ch], 0.f);
+  };
+#pragma unroll
+  for (int i = 0; i < NBW; ++i) {
+    const int ch = blk[i] * 32 + l31;
+    if constexpr (KP == 64) {
+      float m = fmaxf(max16(acc[i][0]), max16(acc[i][1]));
+      m = fmaxf(m, __shfl_xor(m, 32));
+      if (lane < 32) {
+        if (a.RT == 1) store(0, ch, m);
+        else {
+          if (kt > 0) m = fmaxf(m, rmax[ch]);
+          if (kt == a.RT - 1) store(0, ch, m); else rmax[ch] = m;
+        }
+      }
+    } else {
+      constexpr int NPH = 32 / KP;         // neighbourhoods per 32-row half; registers [p * 16 / NPH, ...) hold the rows of neighbourhood p
+      constexpr int RP = 16 / NPH;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        float m[NPH];
+        if constexpr (NPH == 1) m[0] = max16(acc[i][h]);
+        if constexpr (NPH == 2) { m[0] = st_max_regs<0, RP>(acc[i][h]); m[1] = st_max_regs<RP, RP>(acc[i][h]); }
+        if constexpr (NPH == 4) {
+          m[0] = st_max_regs<0, RP>(acc[i][h]); m[1] = st_max_regs<RP, RP>(acc[i][h]);
+          m[2] = st_max_regs<2 * RP, RP>(acc[i][h]); m[3] = st_max_regs<3 * RP, RP>(acc[i][h]);
+        }
+#pragma unroll
+        for (int p = 0; p < NPH; ++p) {
+          const float v = fmaxf(m[p], __shfl_xor(m[p], 32));
+          if (lane < 32) store(h * NPH + p, ch, v);
+        }
+      }
+    }
+  }
+}
+
+// KP: rows of a tile per neighbourhood.  WIDE: hidden layers up to 512 channels (4 blocks x 2 halves of accumulators per wave) -- the
+// narrow instance (<= 256) needs half the registers and so holds twice the wavefronts.
+template <int KP, bool WIDE>
+__global__ __launch_bounds__(256, WIDE ? 1 : 2) void sa_tile_kernel(STArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int CS = a.CS;
+  const int c_last = a.cout[a.nlayers - 1];
+  float* strip = smem;
+  float* rmax = strip + TR * CS;
+  long* goff = (long*)(rmax + c_last);          // (TR * CS + c_last) * 4 is a multiple of 16
+  int* pbase = (int*)(goff + 8);                // row -> b * N + point index
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  constexpr int NPT = TR / KP;
+  const int G = a.B * a.S;                      // < 2^31 / 8 (checked by the launcher); so is B * N < 2^31
+  const int nslots = KP == 64 ? G : (G + NPT - 1) / NPT;
+  const int RT = KP == 64 ? a.RT : 1;
+  const int D = a.D, cin0 = a.cin[0];
+
+  auto row_id = [&](int slot, int kt, int r, int& g_out) -> long long {
+    int g, k;
+    if (KP == 64) { g = slot; k = kt * 64 + r; } else { g = slot * NPT + r / KP; k = r % KP; }
+    if (g >= G) g = G - 1;                     // tail slot: a repeated neighbourhood whose result is not stored
+    if (k >= a.K) k = 0;                       // short neighbourhood: neighbour 0 again (the max is idempotent)
+    g_out = g;
+    return a.idx ? a.idx[(long)g * a.K + k] : (long long)k;      // no index list: the group-all layer, row k = point k
+  };
+
+  int slot = blockIdx.x, kt = 0;
+  if (slot >= nslots) return;
+  long long id_next = 0; int g_next = 0;
+  if (tid < TR) id_next = row_id(slot, 0, tid, g_next);
+  for (;;) {
+    __syncthreads();                           // the previous tile's last layer has read the strip (and goff)
+    int g_row = 0, p_row = 0;
+    if (tid < TR) {
+      long long id = id_next;
+      if (id < 0 || id >= a.N) { if (a.err_flag) *a.err_flag = 1; id = 0; }      // index_points raises on such an index
+      g_row = g_next;
+      p_row = (g_row / a.S) * a.N + (int)id;
+      pbase[tid] = p_row;
+    }
+    if (tid >= 64 && tid < 64 + NPT) {          // where the tile's neighbourhoods go in `out`
+      const int g = (KP == 64 ? slot : slot * NPT) + (tid - 64);
+      const int b = g / a.S;
+      goff[tid - 64] = g < G ? (long)b * a.out_bs + (long)(g - b * a.S) * a.out_ss : -1;
+    }
+    __syncthreads();
+    int nslot = slot, nkt = kt + 1;
+    if (nkt >= RT) { nkt = 0; nslot = slot + (int)gridDim.x; }
+    const bool more = nslot < nslots;
+    if (tid < TR && more) id_next = row_id(nslot, nkt, tid, g_next);             // in flight under this tile's gather and layers
+    // ---- gather: features (the strip's first D channels), then centred xyz, then the zero pad
+    if (D > 0) {
+      if ((D & 3) == 0 && ((uintptr_t)a.points & 15) == 0) {
+        const int nq = D >> 2;
+        int row = tid / nq, q = tid - row * nq;
+        const int drow = 256 / nq, dq = 256 - drow * nq;
+        while (row < TR) {
+          const f32x4 v = *(const f32x4*)(a.points + (size_t)pbase[row] * D + 4 * q);
+          *(f32x4*)(strip + row * CS + 4 * q) = v;
+          row += drow; q += dq;
+          if (q >= nq) { q -= nq; ++row; }
+        }
+      } else {
+        for (int i = tid; i < TR * D; i += 256) {
+          const int row = i / D, c = i - row * D;
+          strip[row * CS + c] = a.points[(size_t)pbase[row] * D + c];
+        }
+      }
+    }
+    if (tid < TR) {
+      const float* px = a.xyz + (size_t)p_row * 3;
+      float cx = 0.f, cy = 0.f, cz = 0.f;
+      if (a.new_xyz) { const float* pc = a.new_xyz + (size_t)g_row * 3; cx = pc[0]; cy = pc[1]; cz = pc[2]; }
+      float* dst = strip + tid * CS + D;
+      dst[0] = px[0] - cx; dst[1] = px[1] - cy; dst[2] = px[2] - cz;
+      for (int c = D + 3; c < cin0; ++c) strip[tid * CS + c] = 0.f;
+    }
+    __syncthreads();
+    // ---- the layers
+    for (int l = 0; l < a.nlayers; ++l) {
+      const int nks = a.cin[l] >> 3, nb = a.cout[l] >> 5;
+      if (l + 1 < a.nlayers) {
+        if (nb >= 4) {                          // a wave: blocks {wv, wv + 4, ...}, both 32-row halves (one weight fragment feeds both)
+          const int cnt = nb > wv ? (nb - wv + 3) >> 2 : 0;
+          switch (cnt) {
+            case 1: st_hidden<1, 2>(strip, CS, a.w[l], a.b[l], nks, wv, 4, 0, lane); break;
+            case 2: st_hidden<2, 2>(strip, CS, a.w[l], a.b[l], nks, wv, 4, 0, lane); break;
+            case 3: if constexpr (WIDE) { st_hidden<3, 2>(strip, CS, a.w[l], a.b[l], nks, wv, 4, 0, lane); break; }
+            case 4: if constexpr (WIDE) { st_hidden<4, 2>(strip, CS, a.w[l], a.b[l], nks, wv, 4, 0, lane); break; }
+            default: st_hidden_idle(); break;
+          }
+        } else {                                // 32 / 64 / 96 channels: a wave takes ONE half and the blocks {wv >> 1, (wv >> 1) + 2}
+          const int p = wv >> 1, cnt = nb > p ? (nb - p + 1) >> 1 : 0;
+          switch (cnt) {
+            case 1: st_hidden<1, 1>(strip, CS, a.w[l], a.b[l], nks, p, 2, 32 * (wv & 1), lane); break;
+            case 2: st_hidden<2, 1>(strip, CS, a.w[l], a.b[l], nks, p, 2, 32 * (wv & 1), lane); break;
+            default: st_hidden_idle(); break;
+          }
+        }
+      } else {
+        const int cnt = nb > wv ? (nb - wv + 3) >> 2 : 0;
+        for (int i0 = 0; i0 < cnt; i0 += 2) {
+          if (cnt - i0 >= 2) st_last<2, KP>(a, strip, a.w[l], a.b[l], nks, wv + 4 * i0, lane, kt, rmax, goff);
+          else st_last<1, KP>(a, strip, a.w[l], a.b[l], nks, wv + 4 * i0, lane, kt, rmax, goff);
+        }
+      }
+    }
+    if (!more) break;
+    slot = nslot; kt = nkt;
+  }
+}
+
+// rows of [features | xyz | zero pad]: the input matrix of the group-all layer's GEMM chain (sample_and_group_all, pointnet2.py:132-149:
+// grouped_xyz is xyz itself, not centred)
+__global__ void sa_concat_kernel(const float* xyz, const float* points, long rows, int D, int ld, float* out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * ld) return;
+  const long r = i / ld; const int c = (int)(i - r * ld);
+  float v = 0.f;
+  if (c < D) v = points[r * D + c];
+  else if (c < D + 3) v = xyz[r * 3 + (c - D)];
+  out[i] = v;
+}
+
+template <int KP, bool WIDE>
+int launch_st(const STArgs& a, size_t lds, long nslots, int dev, hipStream_t s) {
+  auto kern = sa_tile_kernel<KP, WIDE>;
+  static bool attr_set[CG_MAX_DEVICES] = {};
+  if (!attr_set[dev]) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_set[dev] = true;
+  }
+  const int n_cu = cg_device_cu_count(dev);
+  if (n_cu <= 0) return CG_ERR_UNSUPPORTED;
+  int per_cu = (int)((160 * 1024) / lds);
+  const int reg_cap = WIDE ? 1 : 2;              // workgroups of 4 waves a CU's registers hold (448 / 228 registers per lane)
+  if (per_cu > reg_cap) per_cu = reg_cap;
+  if (per_cu < 1) per_cu = 1;
+  long grid = nslots < (long)n_cu * per_cu ? nslots : (long)n_cu * per_cu;        // persistent: a workgroup walks slots blockIdx, + grid, ...
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, s, a);
+  return cg_hip_status(hipGetLastError());
+}
+
+template <bool WIDE>
+int launch_st_kp(const STArgs& a, size_t lds, long nslots, int dev, hipStream_t s) {
+  switch (a.KP) {
+    case 8: return launch_st<8, WIDE>(a, lds, nslots, dev, s);
+    case 16: return launch_st<16, WIDE>(a, lds, nslots, dev, s);
+    case 32: return launch_st<32, WIDE>(a, lds, nslots, dev, s);
+  }
+  return launch_st<64, WIDE>(a, lds, nslots, dev, s);
+}
+
+}  // namespace
+
+extern "C" int cg_sa_tile_mlp_max(const float* xyz, const float* points, const float* new_xyz, const long long* idx, int B, int N, int S,
+                                  int K, int D, int n_layers, const int* h_cin, const int* h_cout, const float* const* h_w_packed,
+                                  const float* const* h_bias, float* out, long out_bs, long out_ss, long out_cs, int* err_flag,
+                                  void* stream) {
+  if (B < 0 || N <= 0 || S < 0 || K <= 0 || D < 0 || n_layers < 1 || n_layers > ST_MAX_LAYERS) return CG_ERR_ARG;
+  if (!h_cin || !h_cout || !h_w_packed || !h_bias) return CG_ERR_ARG;
+  if ((long)B * S == 0) return CG_OK;
+  if (!xyz || !out || (D > 0 && !points)) return CG_ERR_ARG;
+  if (!idx && (S != 1 || K != N)) return CG_ERR_ARG;             // no index list: the group-all layer (one group of all N points)
+  if ((long)B * S >= 0x7fffffffL / 8 || (long)B * N >= 0x7fffffffL) return CG_ERR_UNSUPPORTED;
+  STArgs a{};
+  a.xyz = xyz; a.points = D > 0 ? points : nullptr; a.new_xyz = new_xyz; a.idx = idx;
+  a.B = B; a.N = N; a.S = S; a.K = K; a.D = D; a.nlayers = n_layers;
+  a.out = out; a.out_bs = out_bs; a.out_ss = out_ss; a.out_cs = out_cs; a.err_flag = err_flag;
+  int cstore = 0, hidden_max = 0;
+  for (int l = 0; l < n_layers; ++l) {
+    if (!h_w_packed[l] || !h_bias[l]) return CG_ERR_ARG;
+    const int want = l == 0 ? ((3 + D + 7) & ~7) : h_cout[l - 1];       // layer 0: [features | xyz] zero padded to a multiple of 8 by the host
+    if (h_cin[l] != want) return CG_ERR_ARG;
+    if (h_cout[l] <= 0 || (h_cout[l] % 32) != 0) return CG_ERR_UNSUPPORTED;
+    if (((uintptr_t)h_w_packed[l] & 15) != 0) return CG_ERR_ARG;
+    a.cin[l] = h_cin[l]; a.cout[l] = h_cout[l]; a.w[l] = h_w_packed[l]; a.b[l] = h_bias[l];
+    if (h_cin[l] > cstore) cstore = h_cin[l];
+    if (l + 1 < n_layers && h_cout[l] > hidden_max) hidden_max = h_cout[l];
+  }
+  if (hidden_max > 512) return CG_ERR_UNSUPPORTED;               // a hidden layer's accumulators must fit one wave's registers (4 blocks x 2 halves)
+  a.CS = cstore + 4;
+  a.KP = K <= 8 ? 8 : K <= 16 ? 16 : K <= 32 ? 32 : 64;
+  a.RT = a.KP == 64 ? (K + 63) / 64 : 1;
+  const size_t lds = ((size_t)TR * a.CS + a.cout[n_layers - 1]) * 4 + 8 * sizeof(long) + TR * sizeof(int);
+  if (lds > 158 * 1024) return CG_ERR_UNSUPPORTED;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= CG_MAX_DEVICES) return CG_ERR_UNSUPPORTED;
+  const long G = (long)B * S;
+  const int npt = TR / a.KP;
+  const long nslots = a.KP == 64 ? G : (G + npt - 1) / npt;
+  if (hidden_max > 256) return launch_st_kp<true>(a, lds, nslots, dev, (hipStream_t)stream);
+  return launch_st_kp<false>(a, lds, nslots, dev, (hipStream_t)stream);
+}
+
+extern "C" int cg_sa_concat_input(const float* xyz, const float* points, long rows, int D, int ld, float* out, void* stream) {
+  if (rows < 0 || D < 0 || ld < D + 3) return CG_ERR_ARG;
+  if (rows == 0) return CG_OK;
+  if (!xyz || !out || (D > 0 && !points)) return CG_ERR_ARG;
+  const long n = rows * ld;
+  hipLaunchKernelGGL(sa_concat_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, xyz, points, rows, D, ld, out);
+  return cg_hip_status(hipGetLastError());
+}

@@ -46,7 +46,8 @@ struct SAArgs {
   int w_off[SA_MAX_LAYERS];       // float offset of the layer's packed weights inside the LDS weight region, or -1: read from L2
   int b_off[SA_MAX_LAYERS];       // float offset of the layer's bias (always staged)
   int wb_floats;                  // size of the LDS weight + bias region
-  float* out; int* err_flag;
+  float* out; long out_bs, out_ss, out_cs;       // out[b * out_bs + s * out_ss + c * out_cs]
+  int* err_flag;
 };
 
 __device__ __forceinline__ void wave_sync() {
@@ -242,7 +243,7 @@ __global__ __launch_bounds__(512) void sa_group_mlp_max_kernel(SAArgs a, int CS,
           const int b = g / a.S, s = g - b * a.S;
 #pragma unroll
           for (int q = 0; q < MAXNB; ++q)
-            if (q * 32 < c_last) a.out[((size_t)b * c_last + q * 32 + lane) * a.S + s] = run[q][p];
+            if (q * 32 < c_last) a.out[b * a.out_bs + s * a.out_ss + (q * 32 + lane) * a.out_cs] = run[q][p];
         }
       }
     }
@@ -554,7 +555,7 @@ __global__ __launch_bounds__(NT) void sa_reg_kernel(SAArgs a) {
           const int b = g / a.S, s = g - b * a.S;
 #pragma unroll
           for (int q = 0; q < NL; ++q)                     // bias + ReLU after the max: both commute with it (see the header)
-            a.out[((size_t)b * c_last + q * 32 + lane) * a.S + s] = fmaxf(run[q][p] + bl[q * 32 + lane], 0.f);
+            a.out[b * a.out_bs + s * a.out_ss + (q * 32 + lane) * a.out_cs] = fmaxf(run[q][p] + bl[q * 32 + lane], 0.f);
         }
       }
     }
@@ -697,9 +698,10 @@ int launch_sa_pack(SAArgs& a, int cs, hipStream_t s, int dev) {
 
 }  // namespace
 
-extern "C" int cg_sa_group_mlp_max(const float* xyz, const float* points, const float* new_xyz, const long long* idx, int B, int N, int S,
-                                   int K, int D, int n_layers, const int* h_cin, const int* h_cout, const float* const* h_w_packed,
-                                   const float* const* h_bias, float* out, int* err_flag, void* stream) {
+extern "C" int cg_sa_group_mlp_max_strided(const float* xyz, const float* points, const float* new_xyz, const long long* idx, int B, int N,
+                                           int S, int K, int D, int n_layers, const int* h_cin, const int* h_cout,
+                                           const float* const* h_w_packed, const float* const* h_bias, float* out, long out_bs, long out_ss,
+                                           long out_cs, int* err_flag, void* stream) {
   if (B < 0 || N <= 0 || S < 0 || K <= 0 || D < 0 || n_layers < 1 || n_layers > SA_MAX_LAYERS) return CG_ERR_ARG;
   if (!h_cin || !h_cout || !h_w_packed || !h_bias) return CG_ERR_ARG;
   if ((long)B * S == 0) return CG_OK;
@@ -708,6 +710,7 @@ extern "C" int cg_sa_group_mlp_max(const float* xyz, const float* points, const 
   SAArgs a{};
   a.xyz = xyz; a.points = D > 0 ? points : nullptr; a.new_xyz = new_xyz; a.idx = idx;
   a.B = B; a.N = N; a.S = S; a.K = K; a.D = D; a.nlayers = n_layers; a.out = out; a.err_flag = err_flag;
+  a.out_bs = out_bs; a.out_ss = out_ss; a.out_cs = out_cs;
   int cmax = 0, cstore = C0;
   for (int l = 0; l < n_layers; ++l) {
     if (!h_w_packed[l] || !h_bias[l]) return CG_ERR_ARG;
@@ -727,4 +730,14 @@ extern "C" int cg_sa_group_mlp_max(const float* xyz, const float* points, const 
   }
   if (cmax <= 128) return launch_sa_pack<4>(a, cstore + 4, (hipStream_t)stream, dev);
   return launch_sa_pack<8>(a, cstore + 4, (hipStream_t)stream, dev);
+}
+
+// (B, C_last, S) output: the layout of torch.max(new_points, 2)[0]
+extern "C" int cg_sa_group_mlp_max(const float* xyz, const float* points, const float* new_xyz, const long long* idx, int B, int N, int S,
+                                   int K, int D, int n_layers, const int* h_cin, const int* h_cout, const float* const* h_w_packed,
+                                   const float* const* h_bias, float* out, int* err_flag, void* stream) {
+  if (n_layers < 1 || n_layers > SA_MAX_LAYERS || !h_cout) return CG_ERR_ARG;
+  const long c_last = h_cout[n_layers - 1];
+  return cg_sa_group_mlp_max_strided(xyz, points, new_xyz, idx, B, N, S, K, D, n_layers, h_cin, h_cout, h_w_packed, h_bias, out, c_last * S, 1, S,
+                                     err_flag, stream);
 }

@@ -24,7 +24,8 @@ from . import engine, folding
 from . import primitives as _prim
 
 __all__ = ['square_distance', 'index_points', 'farthest_point_sample', 'query_ball_point', 'sample_and_group',
-           'sample_and_group_all', 'STN3d', 'STNkd', 'PointNetEncoder', 'PointNetCls', 'PointNetSeg', 'PointNetSetAbstraction']
+           'sample_and_group_all', 'STN3d', 'STNkd', 'PointNetEncoder', 'PointNetCls', 'PointNetSeg', 'PointNetSetAbstraction', 'PointNetSetAbstractionMsg',
+           'PointNet2Encoder']
 
 # PointNet++ primitives (pointnet2.py:14-149): HIP implementations with the reference's tensor signatures
 square_distance = _prim.square_distance
@@ -228,37 +229,208 @@ class PointNetSeg(_HipCached):
         return self.conv4(h).permute(0, 2, 1), trans_feat
 
 
+def _sa_layers_from_state(sd, prefix, n):
+    g = lambda k: sd[k].detach().cpu().double().numpy()
+    return [(g(f'{prefix}convs.{i}.weight'), g(f'{prefix}convs.{i}.bias'),
+             tuple(g(f'{prefix}bns.{i}.{k}') for k in ('weight', 'bias', 'running_mean', 'running_var'))) for i in range(n)]
+
+
+def _mlp_torch(h, convs, bns):
+    for conv, bn in zip(convs, bns):
+        h = F.relu(bn(conv(h)))
+    return h
+
+
 class PointNetSetAbstraction(nn.Module):
     """The set-abstraction layer the reference's primitives were written for (pointnet2.py:14-149 define sample_and_group and
     friends, but the reference never assembles them into a layer -- SURVEY.md §0 F1; BASELINE.json's north_star names it):
-        new_xyz, new_points = sample_and_group(npoint, radius, nsample, xyz, points)
+        new_xyz, new_points = sample_and_group(npoint, radius, nsample, xyz, points)      [group_all: sample_and_group_all(xyz, points)]
         new_points -> (B, 3+D, K, S) -> [Conv2d(1x1) -> BatchNorm2d -> ReLU] per mlp width -> max over the K neighbours
-    forward(xyz (B,N,3), points (B,N,D) | None) -> (new_xyz (B,S,3), new_points (B,S,C_last)).
-    Eval-mode inference on a HIP tensor: FPS + ball query + ONE fused group->MLP->max kernel (primitives.group_mlp_max), the
-    grouped tensor never exists; training / grad-enabled calls use the torch ops on the grouped tensor."""
+    forward(xyz (B,N,3), points (B,N,D) | None) -> (new_xyz (B,S,3), new_points (B,S,C_last)); in_channel = 3 + D.
+    Eval-mode inference on a HIP tensor: FPS + ball query + ONE fused group->MLP->max kernel (primitives.group_mlp_max: the
+    register-resident kernel for a first layer, the LDS-tile kernel for 3 + D > 16 inputs or wider layers), the grouped tensor never
+    exists; group_all: primitives.group_all_mlp_max.  Training / grad-enabled calls use the torch ops on the grouped tensor."""
 
-    def __init__(self, npoint, radius, nsample, in_channel, mlp):
+    def __init__(self, npoint, radius, nsample, in_channel, mlp, group_all=False):
         super().__init__()
-        self.npoint, self.radius, self.nsample, self.in_channel = npoint, radius, nsample, in_channel
+        self.npoint, self.radius, self.nsample, self.in_channel, self.group_all = npoint, radius, nsample, in_channel, group_all
         self.mlp_convs = nn.ModuleList(); self.mlp_bns = nn.ModuleList()
         last = in_channel
         for c in mlp:
             self.mlp_convs.append(nn.Conv2d(last, c, 1)); self.mlp_bns.append(nn.BatchNorm2d(c))
             last = c
 
-    def forward(self, xyz, points, start=None):
+    def _weights(self, device):
+        n = len(self.mlp_convs)
+        kind = 'tile' if self.group_all else None
+        return _cached_weights(self, device, lambda sd, dev: _prim.SetAbstractionWeights(_sa_layers_from_state(sd, 'mlp_', n), self.in_channel,
+                                                                                          dev, kind=kind))
+
+    def forward(self, xyz, points, start=None, _err=None):
+        """_err: a list the caller collects the index-error flags in (one read-back for a whole stack instead of one per layer)."""
         if _use_hip(self, xyz):
-            def prep(sd, dev):
-                layers = [(sd[f'mlp_convs.{i}.weight'].detach().cpu().double().numpy(), sd[f'mlp_convs.{i}.bias'].detach().cpu().double().numpy(),
-                           tuple(sd[f'mlp_bns.{i}.{k}'].detach().cpu().double().numpy() for k in ('weight', 'bias', 'running_mean', 'running_var')))
-                          for i in range(len(self.mlp_convs))]
-                return _prim.SetAbstractionWeights(layers, self.in_channel, dev)
-            W = _cached_weights(self, xyz.device, prep)
+            W = self._weights(xyz.device)
+            if self.group_all:
+                B = xyz.shape[0]
+                return torch.zeros((B, 1, 3), dtype=torch.float32, device=xyz.device), _prim.group_all_mlp_max(xyz, points, W).view(B, 1, -1)
             _, new_xyz = farthest_point_sample(xyz, self.npoint, start, return_xyz=True)      # = index_points(xyz, fps_idx), same launch
             idx = query_ball_point(self.radius, self.nsample, xyz, new_xyz)
-            return new_xyz, _prim.group_mlp_max(xyz, points, new_xyz, idx, W).permute(0, 2, 1)
-        new_xyz, new_points = sample_and_group(self.npoint, self.radius, self.nsample, xyz, points, start=start)
-        h = new_points.permute(0, 3, 2, 1)                      # (B, 3+D, K, S)
-        for conv, bn in zip(self.mlp_convs, self.mlp_bns):
-            h = F.relu(bn(conv(h)))
+            if _err is not None:
+                out, e = _prim.group_mlp_max(xyz, points, new_xyz, idx, W, check_indices=False, channels_last=True)
+                _err.append(e)
+                return new_xyz, out
+            return new_xyz, _prim.group_mlp_max(xyz, points, new_xyz, idx, W, channels_last=True)
+        if self.group_all:
+            new_xyz, new_points = sample_and_group_all(xyz, points)
+        else:       # indices from the HIP kernels (or torch ops on a CPU tensor); the gathers are differentiable torch indexing
+            fps_idx = farthest_point_sample(xyz, self.npoint, start) if xyz.is_cuda else _torch_fps(xyz, self.npoint, start)
+            new_xyz = _torch_index(xyz, fps_idx)
+            idx = query_ball_point(self.radius, self.nsample, xyz, new_xyz) if xyz.is_cuda else _torch_ball(self.radius, self.nsample, xyz, new_xyz)
+            new_points = _torch_index(xyz, idx) - new_xyz.unsqueeze(2)
+            if points is not None:
+                new_points = torch.cat([new_points, _torch_index(points, idx)], dim=-1)
+        h = _mlp_torch(new_points.permute(0, 3, 2, 1), self.mlp_convs, self.mlp_bns)          # (B, 3+D, K, S) -> (B, C, K, S)
         return new_xyz, torch.max(h, 2)[0].permute(0, 2, 1)
+
+
+class PointNetSetAbstractionMsg(nn.Module):
+    """Multi-scale grouping: ONE farthest-point sample, then per scale i  query_ball_point(radius_list[i], nsample_list[i]) -> group ->
+    shared MLP mlp_list[i] -> max, the scales' outputs concatenated along the channels (the multi-scale layer the primitives of
+    pointnet2.py:54-129 build; north_star: "set-abstraction encoder").  in_channel = D, the feature channels WITHOUT the 3 coordinates
+    (the convention of the usual PointNet++ code for this layer).  forward(xyz (B,N,3), points (B,N,D) | None) ->
+    (new_xyz (B,S,3), new_points (B,S,sum_i mlp_list[i][-1])).  HIP path: every scale's fused kernel writes its channel slice of the
+    output directly (strided store); nothing is concatenated."""
+
+    def __init__(self, npoint, radius_list, nsample_list, in_channel, mlp_list):
+        super().__init__()
+        assert len(radius_list) == len(nsample_list) == len(mlp_list)
+        self.npoint, self.radius_list, self.nsample_list, self.in_channel = npoint, list(radius_list), list(nsample_list), in_channel
+        self.conv_blocks = nn.ModuleList(); self.bn_blocks = nn.ModuleList()
+        for mlp in mlp_list:
+            convs, bns = nn.ModuleList(), nn.ModuleList()
+            last = in_channel + 3
+            for c in mlp:
+                convs.append(nn.Conv2d(last, c, 1)); bns.append(nn.BatchNorm2d(c))
+                last = c
+            self.conv_blocks.append(convs); self.bn_blocks.append(bns)
+        self.out_channel = sum(m[-1] for m in mlp_list)
+
+    def forward(self, xyz, points, start=None, _err=None):
+        if _use_hip(self, xyz):
+            def prep(sd, dev):
+                out = []
+                for i, convs in enumerate(self.conv_blocks):
+                    g = lambda k: sd[k].detach().cpu().double().numpy()
+                    layers = [(g(f'conv_blocks.{i}.{j}.weight'), g(f'conv_blocks.{i}.{j}.bias'),
+                               tuple(g(f'bn_blocks.{i}.{j}.{k}') for k in ('weight', 'bias', 'running_mean', 'running_var'))) for j in range(len(convs))]
+                    out.append(_prim.SetAbstractionWeights(layers, self.in_channel + 3, dev))
+                return out
+            Ws = _cached_weights(self, xyz.device, prep)
+            B = xyz.shape[0]
+            _, new_xyz = farthest_point_sample(xyz, self.npoint, start, return_xyz=True)
+            out = torch.empty((B, self.npoint, self.out_channel), dtype=torch.float32, device=xyz.device)
+            errs = [] if _err is None else _err
+            c0 = 0
+            for W, radius, K in zip(Ws, self.radius_list, self.nsample_list):
+                idx = query_ball_point(radius, K, xyz, new_xyz)
+                _, e = _prim.group_mlp_max(xyz, points, new_xyz, idx, W, check_indices=False, channels_last=True, out=out[:, :, c0:c0 + W.cout[-1]])
+                errs.append(e)
+                c0 += W.cout[-1]
+            if _err is None:
+                _prim._raise_if(torch.stack(errs).max(), 'PointNetSetAbstractionMsg (a query ball was empty or an index is out of range)')
+            return new_xyz, out
+        fps_idx = farthest_point_sample(xyz, self.npoint, start) if xyz.is_cuda else _torch_fps(xyz, self.npoint, start)
+        new_xyz = _torch_index(xyz, fps_idx)
+        outs = []
+        for convs, bns, radius, K in zip(self.conv_blocks, self.bn_blocks, self.radius_list, self.nsample_list):
+            idx = query_ball_point(radius, K, xyz, new_xyz) if xyz.is_cuda else _torch_ball(radius, K, xyz, new_xyz)
+            grouped = _torch_index(xyz, idx) - new_xyz.unsqueeze(2)
+            if points is not None:
+                grouped = torch.cat([grouped, _torch_index(points, idx)], dim=-1)
+            outs.append(torch.max(_mlp_torch(grouped.permute(0, 3, 2, 1), convs, bns), 2)[0])
+        return new_xyz, torch.cat(outs, dim=1).permute(0, 2, 1)
+
+
+def _torch_index(points, idx):
+    """index_points (pointnet2.py:35-51) in differentiable torch ops (training path of the multi-scale layer)."""
+    B = points.shape[0]
+    view = [B] + [1] * (idx.dim() - 1)
+    b = torch.arange(B, device=points.device).view(view).expand_as(idx)
+    return points[b, idx]
+
+
+def _torch_fps(xyz, npoint, start):
+    """farthest_point_sample (pointnet2.py:54-75) in torch ops: CPU tensors in training mode only."""
+    B, N, _ = xyz.shape
+    cent = torch.zeros(B, npoint, dtype=torch.long, device=xyz.device)
+    dist = torch.full((B, N), 1e10, device=xyz.device)
+    far = torch.randint(0, N, (B,), dtype=torch.long) if start is None else torch.as_tensor(start).long()
+    far = far.to(xyz.device)
+    bi = torch.arange(B, device=xyz.device)
+    for i in range(npoint):
+        cent[:, i] = far
+        d = ((xyz - xyz[bi, far].view(B, 1, 3)) ** 2).sum(-1)
+        dist = torch.minimum(dist, d)
+        far = dist.max(-1)[1]
+    return cent
+
+
+def _torch_ball(radius, nsample, xyz, new_xyz):
+    """query_ball_point (pointnet2.py:78-98) in torch ops: CPU tensors in training mode only."""
+    B, N, _ = xyz.shape
+    S = new_xyz.shape[1]
+    d = -2 * new_xyz @ xyz.transpose(1, 2) + (new_xyz ** 2).sum(-1, keepdim=True) + (xyz ** 2).sum(-1).unsqueeze(1)
+    idx = torch.arange(N, device=xyz.device).view(1, 1, N).repeat(B, S, 1)
+    idx[d > radius ** 2] = N
+    idx = idx.sort(dim=-1)[0][:, :, :nsample]
+    first = idx[:, :, :1].expand_as(idx)
+    return torch.where(idx == N, first, idx)
+
+
+class PointNet2Encoder(nn.Module):
+    """The PointNet++ set-abstraction ENCODER BASELINE.json's north_star names, assembled from the reference's primitives
+    (pointnet2.py:54-149): three set-abstraction levels ending in one group over everything that is left.
+        single-scale (default):  SA(512, r 0.2, K 32, [64, 64, 128]) -> SA(128, r 0.4, K 64, [128, 128, 256]) -> SA(all, [256, 512, 1024])
+        multi-scale (msg=True):  SA(512, r [0.1, 0.2, 0.4], K [16, 32, 128], [[32, 32, 64], [64, 64, 128], [64, 96, 128]])
+                              -> SA(128, r [0.2, 0.4, 0.8], K [32, 64, 128], [[64, 64, 128], [128, 128, 256], [128, 128, 256]]) -> SA(all, [256, 512, 1024])
+    forward(x (B,N,channel) -- coordinates first, like PointNetCls.forward's x; channel = 3 + features)
+        -> (global feature (B,1024), [(l1_xyz, l1_points), (l2_xyz, l2_points)])
+    `start`: per-level FPS start indices [(B,), (B,)] (default: the reference's torch.randint draw per level, pointnet2.py:66).
+    Eval mode on a HIP tensor: per level one FPS launch, one ball query and one fused group->MLP->max kernel per scale, the levels'
+    outputs written as the (B,S,C) rows the next level gathers from; the index-error flags of all levels are read back once."""
+
+    def __init__(self, channel=6, msg=False, npoints=(512, 128), radii=None, nsamples=None, mlps=None):
+        super().__init__()
+        D = channel - 3
+        self.channel, self.msg = channel, msg
+        if not msg:
+            radii = radii or (0.2, 0.4); nsamples = nsamples or (32, 64)
+            mlps = mlps or ((64, 64, 128), (128, 128, 256), (256, 512, 1024))
+            self.sa1 = PointNetSetAbstraction(npoints[0], radii[0], nsamples[0], 3 + D, list(mlps[0]))
+            self.sa2 = PointNetSetAbstraction(npoints[1], radii[1], nsamples[1], 3 + mlps[0][-1], list(mlps[1]))
+            c2 = mlps[1][-1]
+        else:
+            radii = radii or ((0.1, 0.2, 0.4), (0.2, 0.4, 0.8)); nsamples = nsamples or ((16, 32, 128), (32, 64, 128))
+            mlps = mlps or (((32, 32, 64), (64, 64, 128), (64, 96, 128)), ((64, 64, 128), (128, 128, 256), (128, 128, 256)), (256, 512, 1024))
+            self.sa1 = PointNetSetAbstractionMsg(npoints[0], radii[0], nsamples[0], D, [list(m) for m in mlps[0]])
+            self.sa2 = PointNetSetAbstractionMsg(npoints[1], radii[1], nsamples[1], self.sa1.out_channel, [list(m) for m in mlps[1]])
+            c2 = self.sa2.out_channel
+        self.sa3 = PointNetSetAbstraction(None, None, None, 3 + c2, list(mlps[2]), group_all=True)
+        self.out_channel = mlps[2][-1]
+
+    def forward(self, x, start=None):
+        B, N, C = x.shape
+        if C != self.channel:
+            raise ValueError(f'expected {self.channel} input channels, got {C}')
+        xyz = x[:, :, :3].contiguous()
+        feats = x[:, :, 3:].contiguous() if C > 3 else None
+        s1, s2 = (None, None) if start is None else start
+        hip = _use_hip(self, x)
+        errs = [] if hip else None
+        kw = {'_err': errs} if hip else {}
+        l1_xyz, l1_points = self.sa1(xyz, feats, start=s1, **kw)
+        l2_xyz, l2_points = self.sa2(l1_xyz, l1_points, start=s2, **kw)
+        _, l3_points = self.sa3(l2_xyz, l2_points)
+        if hip and errs:
+            _prim._raise_if(torch.stack(errs).max(), 'PointNet2Encoder (a query ball was empty or an index is out of range)')
+        return l3_points.reshape(B, -1), [(l1_xyz, l1_points), (l2_xyz, l2_points)]

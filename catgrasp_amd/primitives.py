@@ -128,38 +128,62 @@ def sample_and_group_all(xyz, points):
 
 
 class SetAbstractionWeights:
-    """Folded (eval BatchNorm) + MFMA-packed weights of a shared per-neighbour MLP [Conv2d(1x1) -> BatchNorm2d -> ReLU] x L."""
+    """Folded (eval BatchNorm) + MFMA-packed weights of a shared per-neighbour MLP [Conv2d(1x1) -> BatchNorm2d -> ReLU] x L.
+    kind 'reg'  : the register-resident / strip kernels of csrc/setabstraction.hip (3 + D <= 16 inputs, widths <= 256: the FIRST layer
+                  of a PointNet++ stack); layer 0's columns are [xyz | features | zero pad to 16].
+    kind 'tile' : csrc/sa_tile.hip (the layers past the first: wide inputs, hidden widths <= 512, last width any multiple of 32) and the
+                  group-all layer's GEMM chain; layer 0's columns are [features | xyz | zero pad to a multiple of 8]."""
 
-    def __init__(self, layers, in_channel, device):
+    TILE_MAX_CIN = 592          # 64 rows x (cin + 4) floats of LDS strip
+
+    def __init__(self, layers, in_channel, device, kind=None):
         """layers: [(conv weight (Cout,Cin[,1,1]), conv bias (Cout), (bn weight, bn bias, running_mean, running_var) or None), ...]"""
         import numpy as np
         from . import folding
         if not 1 <= len(layers) <= 4:
             raise ValueError('1..4 layers')
-        if in_channel > 16:
-            raise NotImplementedError('fused set abstraction: 3 + D <= 16 input channels')
+        if in_channel < 3:
+            raise ValueError('in_channel counts the 3 coordinates: >= 3')
+        widths = [int(np.shape(w)[0]) for w, _, _ in layers]
+        if any(c % 32 or c <= 0 for c in widths):
+            raise NotImplementedError('fused set abstraction: layer widths must be multiples of 32')
+        if kind is None:
+            kind = 'reg' if in_channel <= 16 and max(widths) <= 256 else 'tile'
+        if kind == 'reg' and (in_channel > 16 or max(widths) > 256):
+            raise ValueError("kind 'reg' holds 3 + D <= 16 inputs and widths <= 256")
+        self.kind = kind
         self.cin, self.cout, self.w, self.b = [], [], [], []
         prev = in_channel
         for li, (w, b, bn) in enumerate(layers):
             w = np.asarray(w, dtype=np.float64).reshape(np.shape(w)[0], -1)
             if w.shape[1] != prev:
                 raise ValueError(f'layer {li}: expected {prev} input channels, got {w.shape[1]}')
-            if w.shape[0] % 32 or w.shape[0] > 256:
-                raise NotImplementedError('fused set abstraction: layer widths must be multiples of 32, <= 256')
             wf, bf = folding.fold_bn(w, b, bn)
             if li == 0:
-                wf = np.concatenate([wf, np.zeros((wf.shape[0], 16 - prev))], axis=1)
+                if kind == 'reg':
+                    wf = np.concatenate([wf, np.zeros((wf.shape[0], 16 - prev))], axis=1)
+                else:
+                    pad = (-prev) % 8
+                    wf = np.concatenate([wf[:, 3:], wf[:, :3], np.zeros((wf.shape[0], pad))], axis=1)
             self.cin.append(wf.shape[1]); self.cout.append(wf.shape[0])
             self.w.append(torch.from_numpy(folding.pack_b(wf)).to(device))
             self.b.append(torch.from_numpy(bf.astype(np.float32)).to(device))
             prev = w.shape[0]
         self.in_channel = in_channel
+        self.hidden_max = max(widths[:-1]) if len(widths) > 1 else 0
+
+    def _c_arrays(self):
+        L_ = len(self.w)
+        return (L_, (ctypes.c_int * L_)(*self.cin), (ctypes.c_int * L_)(*self.cout),
+                (ctypes.c_void_p * L_)(*[t.data_ptr() for t in self.w]), (ctypes.c_void_p * L_)(*[t.data_ptr() for t in self.b]))
 
 
-def group_mlp_max(xyz, points, new_xyz, idx, W, check_indices=True):
-    """The consumer of sample_and_group fused into one kernel (cg_sa_group_mlp_max): neighbourhoods idx (B,S,K) of xyz/points
-    around new_xyz -> centred coordinates ++ features -> shared MLP W (SetAbstractionWeights) -> max over the K neighbours.
-    -> (B, C_out, S) float32, the layout torch.max(new_points, 2)[0] has in a PointNet++ set-abstraction layer.
+def group_mlp_max(xyz, points, new_xyz, idx, W, check_indices=True, channels_last=False, out=None):
+    """The consumer of sample_and_group fused into one kernel (cg_sa_group_mlp_max_strided / cg_sa_tile_mlp_max by W.kind): neighbourhoods
+    idx (B,S,K) of xyz/points around new_xyz -> centred coordinates ++ features -> shared MLP W (SetAbstractionWeights) -> max over the K
+    neighbours.  -> (B, C_out, S) float32, the layout torch.max(new_points, 2)[0] has in a PointNet++ set-abstraction layer, or with
+    channels_last=True (B, S, C_out): the rows the next layer gathers from.  out: optional view to write into (any strides -- one scale's
+    channel slice of a multi-scale layer's output).
     check_indices=False skips the read-back of the index-error flag (one host synchronisation per call) and returns (out, err_flag tensor):
     for callers that batch the check, and for timing the kernel alone."""
     require_cuda(xyz, new_xyz, idx)
@@ -172,14 +196,64 @@ def group_mlp_max(xyz, points, new_xyz, idx, W, check_indices=True):
         points = _f32(points); D = points.shape[2]
     if 3 + D != W.in_channel:
         raise ValueError(f'weights expect {W.in_channel} input channels, got 3 + {D}')
-    out = torch.empty((B, W.cout[-1], S), dtype=torch.float32, device=xyz.device)
+    C = W.cout[-1]
+    if out is None:
+        out = torch.empty((B, S, C) if channels_last else (B, C, S), dtype=torch.float32, device=xyz.device)
+    elif tuple(out.shape) != ((B, S, C) if channels_last else (B, C, S)) or out.dtype != torch.float32 or not out.is_cuda:
+        raise ValueError('out: wrong shape / dtype / device')
+    sb, s1, s2 = out.stride() if B * S else (0, 0, 0)
+    ss, cs = (s1, s2) if channels_last else (s2, s1)
     err = torch.zeros((1,), dtype=torch.int32, device=xyz.device)
-    L_ = len(W.w)
-    cin = (ctypes.c_int * L_)(*W.cin); cout = (ctypes.c_int * L_)(*W.cout)
-    wp = (ctypes.c_void_p * L_)(*[t.data_ptr() for t in W.w]); bp = (ctypes.c_void_p * L_)(*[t.data_ptr() for t in W.b])
-    check(L.lib().cg_sa_group_mlp_max(_p(xyz), _p(points), _p(new_xyz), _p(idx), _c_int(B), _c_int(N), _c_int(S), _c_int(K), _c_int(D),
-                                      _c_int(L_), cin, cout, wp, bp, _p(out), _p(err), _stream()), 'cg_sa_group_mlp_max')
+    L_, cin, cout, wp, bp = W._c_arrays()
+    if W.kind == 'reg':
+        check(L.lib().cg_sa_group_mlp_max_strided(_p(xyz), _p(points), _p(new_xyz), _p(idx), _c_int(B), _c_int(N), _c_int(S), _c_int(K), _c_int(D),
+                                                  _c_int(L_), cin, cout, wp, bp, _p(out), _c_long(sb), _c_long(ss), _c_long(cs), _p(err),
+                                                  _stream()), 'cg_sa_group_mlp_max_strided')
+    else:
+        if W.cin[0] > W.TILE_MAX_CIN or W.hidden_max > 512:
+            raise NotImplementedError('fused set abstraction (tile kernel): 3 + D <= 592 inputs, hidden widths <= 512')
+        check(L.lib().cg_sa_tile_mlp_max(_p(xyz), _p(points), _p(new_xyz), _p(idx), _c_int(B), _c_int(N), _c_int(S), _c_int(K), _c_int(D),
+                                         _c_int(L_), cin, cout, wp, bp, _p(out), _c_long(sb), _c_long(ss), _c_long(cs), _p(err), _stream()),
+              'cg_sa_tile_mlp_max')
     if not check_indices:
         return out, err
     _raise_if(err, 'group_mlp_max (a query ball was empty or an index is out of range)')
     return out
+
+
+GROUP_ALL_FUSED_MIN_TILES = 512      # from this many 64-row tiles on the group-all layer runs in the fused tile kernel
+
+
+def group_all_mlp_max(xyz, points, W, fused=None):
+    """The group-all layer (sample_and_group_all, pointnet2.py:132-149, + the shared MLP + max over ALL points): xyz (B,N,3), points
+    (B,N,D) | None -> (B, C_out).  One group per cloud means B * ceil(N / 64) row tiles: a handful for a PointNet++ head (N = 128), so by
+    default the layers run as row-batched GEMMs over all B * N rows (cg_sa_concat_input -> cg_gemm_bias_act per layer -> cg_group_max:
+    the 32 x 32 output tiles of every layer spread over the chip; the activations, B * N x <= 1024 floats, are the only intermediates);
+    with many tiles (or fused=True) the fused tile kernel takes the layer whole (cg_sa_tile_mlp_max, idx == NULL)."""
+    from . import ops
+    require_cuda(xyz)
+    xyz = _f32(xyz)
+    B, N, _ = xyz.shape
+    D = 0
+    if points is not None:
+        points = _f32(points); D = points.shape[2]
+    if W.kind != 'tile' or 3 + D != W.in_channel:
+        raise ValueError("group_all_mlp_max needs kind='tile' weights for 3 + D input channels")
+    C = W.cout[-1]
+    can_fuse = W.cin[0] <= W.TILE_MAX_CIN and W.hidden_max <= 512
+    if fused is None:
+        fused = can_fuse and B * ((N + 63) // 64) >= GROUP_ALL_FUSED_MIN_TILES
+    if fused:
+        if not can_fuse:
+            raise NotImplementedError('fused group-all layer: 3 + D <= 592 inputs, hidden widths <= 512')
+        out = torch.empty((B, C), dtype=torch.float32, device=xyz.device)
+        L_, cin, cout, wp, bp = W._c_arrays()
+        check(L.lib().cg_sa_tile_mlp_max(_p(xyz), _p(points), _p(None), _p(None), _c_int(B), _c_int(N), _c_int(1), _c_int(N), _c_int(D),
+                                         _c_int(L_), cin, cout, wp, bp, _p(out), _c_long(C), _c_long(0), _c_long(1), _p(None), _stream()),
+              'cg_sa_tile_mlp_max')
+        return out
+    h = torch.empty((B * N, W.cin[0]), dtype=torch.float32, device=xyz.device)
+    check(L.lib().cg_sa_concat_input(_p(xyz), _p(points), _c_long(B * N), _c_int(D), _c_int(W.cin[0]), _p(h), _stream()), 'cg_sa_concat_input')
+    for wp, b, co in zip(W.w, W.b, W.cout):
+        h = ops.gemm_bias_act(h, wp, co, bias=b, relu=True)
+    return ops.group_max(h, B)

@@ -492,6 +492,30 @@ int cg_pg_cc_propagate(const int* semantic_label, const int* ball_query_idxs, in
 int cg_sa_group_mlp_max(const float* xyz, const float* points, const float* new_xyz, const long long* idx, int B, int N, int S, int K,
                         int D, int n_layers, const int* h_cin, const int* h_cout, const float* const* h_w_packed,
                         const float* const* h_bias, float* out, int* err_flag, void* stream);
+/* The same with the output addressed by strides, out[b * out_bs + s * out_ss + c * out_cs]: (B,S,C) rows for the next layer to gather
+ * from (out_bs = S C, out_ss = C, out_cs = 1), or a channel slice of a multi-scale layer's concatenated output. */
+int cg_sa_group_mlp_max_strided(const float* xyz, const float* points, const float* new_xyz, const long long* idx, int B, int N, int S,
+                                int K, int D, int n_layers, const int* h_cin, const int* h_cout, const float* const* h_w_packed,
+                                const float* const* h_bias, float* out, long out_bs, long out_ss, long out_cs, int* err_flag,
+                                void* stream);
+
+/* The same fused layer for the layers PAST the first one of a PointNet++ stack (csrc/sa_tile.hip): any 3 + D with
+ * roundup8(3 + D) <= ~590, hidden widths <= 512, last width any multiple of 32, any K, and -- idx == NULL, new_xyz == NULL, S == 1,
+ * K == N -- the single group of sample_and_group_all (pointnet2.py:132-149: every point, not centred).  A 64-row tile per
+ * workgroup, activations in one LDS strip, weights streamed from L2.  Differences from cg_sa_group_mlp_max in the arguments:
+ * layer 0's packed weights take their input columns in the order [D features | xyz | zero pad] with cin[0] = roundup8(3 + D)
+ * (the kernel stores the gathered features with aligned 16-byte LDS writes), and the output is addressed by strides --
+ * out[b * out_bs + s * out_ss + c * out_cs] -- so that a caller writes (B,C,S) like torch.max(new_points, 2)[0] (out_bs = C S,
+ * out_ss = 1, out_cs = S), the (B,S,C) rows the next layer gathers from (out_bs = S C, out_ss = C, out_cs = 1), or one scale's
+ * channel slice of a multi-scale layer's concatenated output. */
+int cg_sa_tile_mlp_max(const float* xyz, const float* points, const float* new_xyz, const long long* idx, int B, int N, int S, int K,
+                       int D, int n_layers, const int* h_cin, const int* h_cout, const float* const* h_w_packed,
+                       const float* const* h_bias, float* out, long out_bs, long out_ss, long out_cs, int* err_flag, void* stream);
+
+/* Input matrix of the group-all layer when it runs as a GEMM chain (few rows: cg_gemm_bias_act per layer + cg_group_max): rows of
+ * [D features | xyz | zero pad to ld], the column order of cg_sa_tile_mlp_max's layer 0.  xyz (rows,3), points (rows,D) or NULL
+ * -> out (rows, ld), ld >= D + 3.  (sample_and_group_all's cat([grouped_xyz, points]), pointnet2.py:145-148.) */
+int cg_sa_concat_input(const float* xyz, const float* points, long rows, int D, int ld, float* out, void* stream);
 
 /* get_ik_within_limits(...).size() > 0 (my_cpp/common.cpp:9-72, called at :230-236 of filterGraspPose): closed-form IK of the
  * KUKA LBR iiwa14 with the redundancy joint (index 2) at 0 -- what the reference's generated IKFast file solves -- one thread

@@ -1,0 +1,31 @@
+#!/bin/bash
+# The GPU-box jobs of the build rounds, one parameterised script:  gpurun --timeout T -- 'bash scripts/gpu_job.sh <job> [args]'
+# Everything is written under gpurun_out/<job>/ ; summaries to be judged are copied to profiles/ afterwards.
+export TMPDIR=/tmp
+JOB=${1:-suite}; shift
+O=gpurun_out/$JOB; rm -rf $O; mkdir -p $O
+stats() {   # stats <name> <cmd...>: rocprofv3 kernel statistics of a command -> $O/<name>_kernel_stats.csv
+  local name=$1; shift
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/_st -- "$@" > $O/${name}_trace.log 2>&1
+  find $O/_st -name '*kernel_stats.csv' -exec cp {} $O/${name}_kernel_stats.csv \; ; rm -rf $O/_st
+}
+case $JOB in
+  suite)      # the whole GPU suite + smoke
+    timeout 2400 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; tail -5 $O/pytest.log
+    timeout 120 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -1 $O/smoke.log ;;
+  tests)      # selected test files / -k expressions:  tests <pytest args>
+    timeout 1500 python -m pytest "$@" -m gpu -x -q > $O/pytest.log 2>&1; tail -15 $O/pytest.log ;;
+  encoder)    # the PointNet++ encoder: tests, stage table, kernel statistics
+    timeout 900 python -m pytest tests/test_pointnet2_encoder_gpu.py tests/test_primitives_gpu.py -m gpu -x -q > $O/pytest.log 2>&1; tail -15 $O/pytest.log
+    timeout 300 python scripts/pp_encoder_profile.py $O/pp_encoder.json > $O/pp_encoder.txt 2>&1; tail -4 $O/pp_encoder.txt
+    timeout 300 python scripts/pp_encoder_profile.py $O/pp_encoder_msg.json --msg > $O/pp_encoder_msg.txt 2>&1; tail -3 $O/pp_encoder_msg.txt
+    stats pp_encoder python scripts/pp_encoder_profile.py --trace
+    stats pp_encoder_msg python scripts/pp_encoder_profile.py --trace --msg
+    head -12 $O/pp_encoder_kernel_stats.csv | cut -c1-160 ;;
+  bench)      # the default bench line + its kernel statistics
+    ( time timeout 900 python bench.py "$@" ) > $O/bench.json 2> $O/bench.err; tail -c 300 $O/bench.err; head -c 600 $O/bench.json
+    stats bench python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-api --no-pmc-traffic --no-rccl-selftest --no-projection ;;
+  py)         # any script:  py scripts/x.py args...
+    timeout 1200 python "$@" > $O/out.txt 2>&1; tail -40 $O/out.txt ;;
+  *) echo "unknown job $JOB"; exit 2 ;;
+esac

@@ -1,0 +1,82 @@
+"""The differentiable torch path of the set-abstraction modules (training / grad-enabled calls; SURVEY §8 B2: the reference's trainers
+must keep working) against the oracle stack, on CPU: same indices as the restated reference primitives, same features."""
+import torch
+
+from oracle import pointnet_ref as oref
+from oracle import setabstraction_ref as sref
+
+
+def test_torch_primitives_follow_the_reference():
+    from catgrasp_amd import pointnet2 as p2
+    torch.manual_seed(3)
+    xyz = torch.rand(2, 400, 3)
+    start = torch.tensor([5, 399])
+    fps = p2._torch_fps(xyz, 40, start)
+    assert torch.equal(fps, oref.farthest_point_sample(xyz, 40, start))
+    new_xyz = oref.index_points(xyz, fps)
+    assert torch.equal(p2._torch_index(xyz, fps), new_xyz)
+    for r, k in ((0.15, 16), (0.05, 8), (5.0, 64)):
+        assert torch.equal(p2._torch_ball(r, k, xyz, new_xyz), oref.query_ball_point(r, k, xyz, new_xyz))
+
+
+def _bn(module, seed):
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for m in module.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.1, generator=g); m.running_var.uniform_(0.5, 1.5, generator=g)
+                m.weight.uniform_(0.5, 1.5, generator=g); m.bias.normal_(0, 0.1, generator=g)
+
+
+def test_encoder_torch_path_equals_the_oracle_stack_and_is_differentiable():
+    from catgrasp_amd import pointnet2 as p2
+    torch.manual_seed(1)
+    B, N = 2, 300
+    x = torch.rand(B, N, 6)
+    enc = p2.PointNet2Encoder(channel=6, npoints=(48, 12), radii=(0.3, 0.6), nsamples=(8, 16), mlps=((32, 32, 64), (64, 64, 128), (128, 256)))
+    _bn(enc, 4); enc.eval()
+    sd = enc.state_dict()
+    assert len(sd) == 8 * 7            # 8 conv + bn pairs x (w, b, bn w, bn b, mean, var, num_batches_tracked)
+    start = (torch.tensor([0, 7]), torch.tensor([3, 47]))
+    xg = x.clone().requires_grad_(True)
+    g, ((x1, p1), (x2, p2_)) = enc(xg, start=start)                 # eval-mode BatchNorm, grad enabled -> torch ops
+    xyz, feats = x[:, :, :3].contiguous(), x[:, :, 3:].contiguous()
+    nx1, r1, _, _ = sref.sa_forward(xyz, feats, 48, 0.3, 8, sref.layers_of(sd, 'sa1.', 3), start[0])
+    nx2, r2, _, _ = sref.sa_forward(nx1, r1, 12, 0.6, 16, sref.layers_of(sd, 'sa2.', 3), start[1])
+    r3 = sref.sa_all_forward(nx2, r2, sref.layers_of(sd, 'sa3.', 2))
+    assert torch.equal(x1, nx1) and torch.equal(x2, nx2)
+    assert (p1 - r1).abs().max().item() <= 1e-5 and (p2_ - r2).abs().max().item() <= 1e-5 and (g - r3).abs().max().item() <= 1e-5
+    g.sum().backward()
+    assert xg.grad is not None and float(xg.grad.abs().sum()) > 0 and float(enc.sa1.mlp_convs[0].weight.grad.abs().sum()) > 0
+    # multi-scale stack: shapes and the oracle
+    enc = p2.PointNet2Encoder(channel=6, msg=True, npoints=(32, 8), radii=((0.2, 0.4), (0.4, 0.8)), nsamples=((4, 8), (8, 16)),
+                              mlps=(((32, 32), (32, 64)), ((64, 64), (64, 96)), (128, 256)))
+    _bn(enc, 6); enc.eval()
+    sd = enc.state_dict()
+    start = (torch.tensor([1, 2]), torch.tensor([3, 4]))
+    with torch.enable_grad():
+        g, ((x1, p1), (x2, p2_)) = enc(x, start=start)
+    ml = lambda prefix, n: [sref.layers_of(sd, prefix, 2, conv=f'conv_blocks.{i}', bn=f'bn_blocks.{i}') for i in range(n)]
+    nx1, r1, _, _ = sref.sa_msg_forward(xyz, feats, 32, (0.2, 0.4), (4, 8), ml('sa1.', 2), start[0])
+    nx2, r2, _, _ = sref.sa_msg_forward(nx1, r1, 8, (0.4, 0.8), (8, 16), ml('sa2.', 2), start[1])
+    r3 = sref.sa_all_forward(nx2, r2, sref.layers_of(sd, 'sa3.', 2))
+    assert p1.shape == (B, 32, 96) and p2_.shape == (B, 8, 160)
+    assert (p1 - r1).abs().max().item() <= 1e-5 and (p2_ - r2).abs().max().item() <= 1e-5 and (g - r3).abs().max().item() <= 1e-5
+
+
+def test_set_abstraction_weights_layouts():
+    """Host packing of the two kernel families: column order and padding of layer 0."""
+    import numpy as np
+    from catgrasp_amd import folding
+    from catgrasp_amd.primitives import SetAbstractionWeights
+    rng = np.random.default_rng(0)
+    w0 = rng.normal(size=(64, 9)); b0 = rng.normal(size=64)
+    reg = SetAbstractionWeights([(w0, b0, None)], 9, 'cpu')
+    assert reg.kind == 'reg' and reg.cin == [16]
+    assert np.array_equal(reg.w[0].numpy(), folding.pack_b(np.concatenate([w0, np.zeros((64, 7))], 1)))
+    tile = SetAbstractionWeights([(w0, b0, None)], 9, 'cpu', kind='tile')
+    assert tile.kind == 'tile' and tile.cin == [16]
+    assert np.array_equal(tile.w[0].numpy(), folding.pack_b(np.concatenate([w0[:, 3:], w0[:, :3], np.zeros((64, 7))], 1)))
+    w1 = rng.normal(size=(128, 131))
+    t2 = SetAbstractionWeights([(w1, rng.normal(size=128), None), (rng.normal(size=(256, 128)), rng.normal(size=256), None)], 131, 'cpu')
+    assert t2.kind == 'tile' and t2.cin == [136, 128] and t2.cout == [128, 256] and t2.hidden_max == 128

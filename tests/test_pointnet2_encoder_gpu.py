@@ -1,0 +1,233 @@
+"""Row X1: the PointNet++ set-abstraction ENCODER past its first layer -- the LDS-tile fused layer (csrc/sa_tile.hip:
+wide inputs, wide layers, any K), the group-all layer (GEMM chain and fused), the multi-scale layer and the 3-level stack -- against
+the oracle: the restated primitives of pointnet2.py:54-149 (pinned to the imported reference) + torch float32 Conv2d / BN / ReLU / max."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import pointnet_ref as oref
+from oracle import setabstraction_ref as sref
+
+pytestmark = pytest.mark.gpu
+
+
+def _randomize_bn(module, seed):
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for m in module.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.1, generator=g); m.running_var.uniform_(0.5, 1.5, generator=g)
+                m.weight.uniform_(0.5, 1.5, generator=g); m.bias.normal_(0, 0.1, generator=g)
+
+
+def _relerr(a, b):
+    return (a - b).abs().max().item() / max(1.0, b.abs().max().item())
+
+
+# D (features), K, mlp, kind.  SA2 of the SSG stack; the MSG scales (3 + 320 inputs, K = 128 = two row tiles, a 96-wide layer); a hidden
+# layer of 512 (the WIDE instance); 8 / 4 / 2 neighbourhoods per tile; D not a multiple of 4 (scalar gather); no features at all; one layer;
+# a width that leaves waves without a block; first-layer shapes forced onto the tile kernel
+@pytest.mark.parametrize('D,K,mlp,kind', [(128, 64, [128, 128, 256], None), (320, 128, [128, 128, 256], None), (64, 16, [64, 96, 128], None),
+                                          (32, 32, [256, 512, 1024], None), (20, 8, [64, 64], None), (13, 24, [128, 128, 512], None),
+                                          (0, 32, [64, 64, 128], 'tile'), (6, 100, [32], 'tile'), (128, 5, [160, 288], None),
+                                          (61, 33, [32, 64, 96, 128], None), (3, 16, [128, 128, 256], 'tile'), (512, 48, [384, 256], None)])
+def test_tile_set_abstraction_matches_grouping_plus_torch_ops(cuda_device, D, K, mlp, kind):
+    from catgrasp_amd import pointnet2 as p2
+    from catgrasp_amd import primitives as prim
+    torch.manual_seed(11)
+    B, N, S, r = 3, 700, 70, 0.12
+    xyz = torch.rand(B, N, 3) * 0.5
+    pts = torch.randn(B, N, D) * 0.5 if D else None
+    sa = p2.PointNetSetAbstraction(S, r, K, 3 + D, mlp)
+    _randomize_bn(sa, 5)
+    sa.eval()
+    start = torch.tensor([3, 300, 699])
+    fps = oref.farthest_point_sample(xyz, S, start)
+    new_xyz = oref.index_points(xyz, fps)
+    idx = p2.query_ball_point(r, K, xyz.cuda(), new_xyz.cuda()).cpu()
+    assert (idx != oref.query_ball_point(r, K, xyz, new_xyz)).float().mean().item() < 1e-3
+    layers = sref.layers_of(sa.state_dict(), '', len(mlp))
+    _, ref, _, _ = sref.sa_forward(xyz, pts, S, r, K, layers, start, idx=idx)
+    W = prim.SetAbstractionWeights([(w.double().numpy(), b.double().numpy(), tuple(t.double().numpy() for t in (g, be, mu, var)))
+                                    for w, b, g, be, mu, var in layers], 3 + D, cuda_device, kind=kind)
+    assert W.kind == 'tile'
+    got_cs = prim.group_mlp_max(xyz.cuda(), pts.cuda() if D else None, new_xyz.cuda(), idx.cuda(), W)                       # (B, C, S)
+    got_cl = prim.group_mlp_max(xyz.cuda(), pts.cuda() if D else None, new_xyz.cuda(), idx.cuda(), W, channels_last=True)   # (B, S, C)
+    assert got_cs.shape == (B, mlp[-1], S) and got_cl.shape == (B, S, mlp[-1])
+    assert torch.equal(got_cs.permute(0, 2, 1), got_cl)
+    assert _relerr(got_cl.cpu(), ref) <= 1e-5
+    # a channel slice of a wider output (the multi-scale layer's concatenation): neighbours untouched
+    wide = torch.full((B, S, mlp[-1] + 64), -7.0, device=cuda_device)
+    prim.group_mlp_max(xyz.cuda(), pts.cuda() if D else None, new_xyz.cuda(), idx.cuda(), W, channels_last=True, out=wide[:, :, 32:32 + mlp[-1]])
+    assert torch.equal(wide[:, :, 32:32 + mlp[-1]], got_cl) and bool((wide[:, :, :32] == -7).all()) and bool((wide[:, :, 32 + mlp[-1]:] == -7).all())
+    # an out-of-range index is reported like index_points does
+    bad = idx.clone(); bad[1, 5, 0] = N
+    with pytest.raises(IndexError):
+        prim.group_mlp_max(xyz.cuda(), pts.cuda() if D else None, new_xyz.cuda(), bad.cuda(), W)
+    if kind is None:
+        # through the module (FPS + ball query + the fused kernel), eval and grad-enabled
+        sa.cuda()
+        with torch.no_grad():
+            nx, np_ = sa(xyz.cuda(), pts.cuda() if D else None, start=start)
+        assert torch.equal(nx.cpu(), new_xyz) and _relerr(np_.cpu(), ref) <= 1e-5
+        with torch.enable_grad():
+            _, np2 = sa(xyz.cuda(), pts.cuda() if D else None, start=start)
+        assert _relerr(np2.detach().cpu(), ref) <= 1e-4
+
+
+def test_first_layer_reg_kernel_strided_output(cuda_device):
+    """The register-resident first-layer kernel writing (B,S,C) rows / a channel slice (cg_sa_group_mlp_max_strided)."""
+    from catgrasp_amd import pointnet2 as p2
+    from catgrasp_amd import primitives as prim
+    torch.manual_seed(2)
+    B, N, S, K, D = 2, 900, 50, 32, 3
+    xyz = torch.rand(B, N, 3) * 0.4; pts = torch.randn(B, N, D)
+    sa = p2.PointNetSetAbstraction(S, 0.1, K, 3 + D, [64, 64, 128]); _randomize_bn(sa, 1); sa.eval()
+    start = torch.tensor([0, 1])
+    layers = sref.layers_of(sa.state_dict(), '', 3)
+    new_xyz = oref.index_points(xyz, oref.farthest_point_sample(xyz, S, start))
+    idx = p2.query_ball_point(0.1, K, xyz.cuda(), new_xyz.cuda())
+    _, ref, _, _ = sref.sa_forward(xyz, pts, S, 0.1, K, layers, start, idx=idx.cpu())
+    W = sa.cuda()._weights(cuda_device)
+    assert W.kind == 'reg'
+    a = prim.group_mlp_max(xyz.cuda(), pts.cuda(), new_xyz.cuda(), idx, W)
+    b = prim.group_mlp_max(xyz.cuda(), pts.cuda(), new_xyz.cuda(), idx, W, channels_last=True)
+    assert torch.equal(a.permute(0, 2, 1), b) and _relerr(b.cpu(), ref) <= 1e-5
+
+
+@pytest.mark.parametrize('B,N,D,mlp', [(1, 128, 256, [256, 512, 1024]), (8, 128, 256, [256, 512, 1024]), (3, 200, 640, [256, 512, 1024]),
+                                        (2, 77, 5, [64, 128]), (2, 1000, 0, [64, 128, 1024]), (1, 130, 61, [32])])
+def test_group_all_layer_gemm_chain_and_fused(cuda_device, B, N, D, mlp):
+    """sample_and_group_all (pointnet2.py:132-149) + shared MLP + max over all points: both execution plans against the torch ops."""
+    from catgrasp_amd import pointnet2 as p2
+    from catgrasp_amd import primitives as prim
+    torch.manual_seed(4)
+    xyz = torch.rand(B, N, 3) - 0.5
+    pts = torch.randn(B, N, D) * 0.5 if D else None
+    sa = p2.PointNetSetAbstraction(None, None, None, 3 + D, mlp, group_all=True); _randomize_bn(sa, 9); sa.eval()
+    layers = sref.layers_of(sa.state_dict(), '', len(mlp))
+    ref = sref.sa_all_forward(xyz, pts, layers)
+    sa.cuda()
+    W = sa._weights(cuda_device)
+    chain = prim.group_all_mlp_max(xyz.cuda(), pts.cuda() if D else None, W, fused=False)
+    assert chain.shape == (B, mlp[-1]) and _relerr(chain.cpu(), ref) <= 1e-5
+    if W.cin[0] <= W.TILE_MAX_CIN:
+        fused = prim.group_all_mlp_max(xyz.cuda(), pts.cuda() if D else None, W, fused=True)
+        assert _relerr(fused.cpu(), ref) <= 1e-5
+    with torch.no_grad():
+        nx, out = sa(xyz.cuda(), pts.cuda() if D else None)
+    assert nx.shape == (B, 1, 3) and not bool(nx.any()) and out.shape == (B, 1, mlp[-1]) and _relerr(out[:, 0].cpu(), ref) <= 1e-5
+
+
+def _scene_cloud(B, N, seed):
+    """20k-point 'clutter': points on a handful of small boxes / cylinders inside the unit ball, with unit normals as features."""
+    rng = np.random.default_rng(seed)
+    out = np.zeros((B, N, 6), np.float32)
+    for b in range(B):
+        k = 8
+        centres = rng.uniform(-0.55, 0.55, size=(k, 3))
+        which = rng.integers(0, k, size=N)
+        local = rng.normal(size=(N, 3)); local /= np.linalg.norm(local, axis=1, keepdims=True)
+        radius = rng.uniform(0.08, 0.25, size=k)[which]
+        out[b, :, :3] = centres[which] + local * radius[:, None] * rng.uniform(0.9, 1.0, size=(N, 1))
+        out[b, :, 3:] = local
+    return torch.from_numpy(out)
+
+
+@pytest.mark.parametrize('B', [1, 8])
+def test_pointnet2_encoder_ssg_20k_points(cuda_device, B):
+    """The 3-level single-scale stack (512 / 0.2 / 32 -> 128 / 0.4 / 64 -> all) on 20,000-point clouds: every level against the oracle
+    (sample indices exact; neighbour lists equal outside the rounding band; features within 1e-4)."""
+    from catgrasp_amd import pointnet2 as p2
+    N = 20000
+    x = _scene_cloud(B, N, 31 + B)
+    enc = p2.PointNet2Encoder(channel=6); _randomize_bn(enc, 3); enc.eval()
+    sd = enc.state_dict()
+    torch.manual_seed(5)
+    start = (torch.randint(0, N, (B,)), torch.randint(0, 512, (B,)))
+    enc.cuda()
+    xd = x.to(cuda_device)
+    with torch.no_grad():
+        g, ((l1_xyz, l1_pts), (l2_xyz, l2_pts)) = enc(xd, start=start)
+    xyz, feats = x[:, :, :3].contiguous(), x[:, :, 3:].contiguous()
+    # level 1
+    fps1 = oref.farthest_point_sample(xyz, 512, start[0])
+    nx1 = oref.index_points(xyz, fps1)
+    assert torch.equal(l1_xyz.cpu(), nx1)
+    idx1 = p2.query_ball_point(0.2, 32, xd[:, :, :3].contiguous(), l1_xyz).cpu()
+    if B == 1:
+        assert (idx1 != oref.query_ball_point(0.2, 32, xyz, nx1)).float().mean().item() < 1e-3
+    _, r1, _, _ = sref.sa_forward(xyz, feats, 512, 0.2, 32, sref.layers_of(sd, 'sa1.', 3), start[0], idx=idx1)
+    assert _relerr(l1_pts.cpu(), r1) <= 1e-4
+    # level 2 (on the ORACLE's level-1 output: errors may accumulate through the stack, the bar stays 1e-4)
+    fps2 = oref.farthest_point_sample(nx1, 128, start[1])
+    nx2 = oref.index_points(nx1, fps2)
+    assert torch.equal(l2_xyz.cpu(), nx2)
+    idx2 = p2.query_ball_point(0.4, 64, l1_xyz, l2_xyz).cpu()
+    assert (idx2 != oref.query_ball_point(0.4, 64, nx1, nx2)).float().mean().item() < 1e-3
+    _, r2, _, _ = sref.sa_forward(nx1, r1, 128, 0.4, 64, sref.layers_of(sd, 'sa2.', 3), start[1], idx=idx2)
+    assert _relerr(l2_pts.cpu(), r2) <= 1e-4
+    # level 3
+    r3 = sref.sa_all_forward(nx2, r2, sref.layers_of(sd, 'sa3.', 3))
+    assert g.shape == (B, 1024) and _relerr(g.cpu(), r3) <= 1e-4
+    # float64 evaluation of the same stack: the kernels are as close to it as the float32 oracle is
+    _, t1, _, _ = sref.sa_forward(xyz.double(), feats.double(), 512, 0.2, 32, sref.layers_of(sd, 'sa1.', 3), start[0], idx=idx1, dtype=torch.float64)
+    _, t2, _, _ = sref.sa_forward(nx1.double(), t1, 128, 0.4, 64, sref.layers_of(sd, 'sa2.', 3), start[1], idx=idx2, dtype=torch.float64)
+    t3 = sref.sa_all_forward(nx2.double(), t2, sref.layers_of(sd, 'sa3.', 3), dtype=torch.float64)
+    assert _relerr(g.cpu().double(), t3) <= max(2 * _relerr(r3.double(), t3), 2e-6)
+
+
+def test_pointnet2_encoder_msg(cuda_device):
+    """The multi-scale stack (3 radii per level, 3 + 320 / 3 + 640 inputs further up) on a 20,000-point cloud."""
+    from catgrasp_amd import pointnet2 as p2
+    B, N = 2, 20000
+    x = _scene_cloud(B, N, 77)
+    enc = p2.PointNet2Encoder(channel=6, msg=True); _randomize_bn(enc, 8); enc.eval()
+    sd = enc.state_dict()
+    start = (torch.tensor([17, 19999]), torch.tensor([0, 511]))
+    enc.cuda()
+    xd = x.to(cuda_device)
+    with torch.no_grad():
+        g, ((l1_xyz, l1_pts), (l2_xyz, l2_pts)) = enc(xd, start=start)
+    xyz, feats = x[:, :, :3].contiguous(), x[:, :, 3:].contiguous()
+
+    def msg_layers(prefix, n_scales):
+        return [sref.layers_of(sd, prefix, 3, conv=f'conv_blocks.{i}', bn=f'bn_blocks.{i}') for i in range(n_scales)]
+    radii1, ks1 = (0.1, 0.2, 0.4), (16, 32, 128)
+    nx1 = oref.index_points(xyz, oref.farthest_point_sample(xyz, 512, start[0]))
+    assert torch.equal(l1_xyz.cpu(), nx1)
+    idx1 = [p2.query_ball_point(r, k, xd[:, :, :3].contiguous(), l1_xyz).cpu() for r, k in zip(radii1, ks1)]
+    _, r1, _, _ = sref.sa_msg_forward(xyz, feats, 512, radii1, ks1, msg_layers('sa1.', 3), start[0], idx_list=idx1)
+    assert l1_pts.shape == (B, 512, 320) and _relerr(l1_pts.cpu(), r1) <= 1e-4
+    radii2, ks2 = (0.2, 0.4, 0.8), (32, 64, 128)
+    nx2 = oref.index_points(nx1, oref.farthest_point_sample(nx1, 128, start[1]))
+    assert torch.equal(l2_xyz.cpu(), nx2)
+    idx2 = [p2.query_ball_point(r, k, l1_xyz, l2_xyz).cpu() for r, k in zip(radii2, ks2)]
+    for i2, r, k in zip(idx2, radii2, ks2):
+        assert (i2 != oref.query_ball_point(r, k, nx1, nx2)).float().mean().item() < 1e-3
+    _, r2, _, _ = sref.sa_msg_forward(nx1, r1, 128, radii2, ks2, msg_layers('sa2.', 3), start[1], idx_list=idx2)
+    assert l2_pts.shape == (B, 128, 640) and _relerr(l2_pts.cpu(), r2) <= 1e-4
+    r3 = sref.sa_all_forward(nx2, r2, sref.layers_of(sd, 'sa3.', 3))
+    assert _relerr(g.cpu(), r3) <= 1e-4
+
+
+def test_encoder_state_dict_train_eval_roundtrip(cuda_device):
+    """Weights changed after a forward are picked up (cache keyed on tensor versions); train-mode output == eval-mode HIP output when the
+    BatchNorm statistics are frozen equal (momentum 0), i.e. the torch path and the kernels compute the same function."""
+    from catgrasp_amd import pointnet2 as p2
+    torch.manual_seed(0)
+    enc = p2.PointNet2Encoder(channel=3, npoints=(64, 16), radii=(0.3, 0.6), nsamples=(8, 16)).cuda(); _randomize_bn(enc, 2)
+    x = torch.rand(2, 500, 3, device=cuda_device)
+    start = (torch.tensor([1, 2]), torch.tensor([3, 4]))
+    enc.eval()
+    with torch.no_grad():
+        g0, _ = enc(x, start=start)
+    with torch.enable_grad():
+        g1, _ = enc(x, start=start)              # eval-mode BN, torch ops
+    assert _relerr(g0.cpu(), g1.detach().cpu()) <= 1e-4
+    with torch.no_grad():
+        enc.sa3.mlp_convs[2].bias.add_(1.0)
+        g2, _ = enc(x, start=start)
+    assert (g2 - g0).abs().max().item() > 0.1
+    with pytest.raises(RuntimeError), torch.no_grad():
+        enc(x.cpu(), start=start)                # eval mode, no grad, CPU tensor: there is no CPU inference path
