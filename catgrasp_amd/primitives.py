@@ -221,15 +221,14 @@ def group_mlp_max(xyz, points, new_xyz, idx, W, check_indices=True, channels_las
     return out
 
 
-GROUP_ALL_FUSED_MIN_TILES = 512      # from this many 64-row tiles on the group-all layer runs in the fused tile kernel
-
-
-def group_all_mlp_max(xyz, points, W, fused=None):
+def group_all_mlp_max(xyz, points, W, fused=False):
     """The group-all layer (sample_and_group_all, pointnet2.py:132-149, + the shared MLP + max over ALL points): xyz (B,N,3), points
-    (B,N,D) | None -> (B, C_out).  One group per cloud means B * ceil(N / 64) row tiles: a handful for a PointNet++ head (N = 128), so by
-    default the layers run as row-batched GEMMs over all B * N rows (cg_sa_concat_input -> cg_gemm_bias_act per layer -> cg_group_max:
-    the 32 x 32 output tiles of every layer spread over the chip; the activations, B * N x <= 1024 floats, are the only intermediates);
-    with many tiles (or fused=True) the fused tile kernel takes the layer whole (cg_sa_tile_mlp_max, idx == NULL)."""
+    (B,N,D) | None -> (B, C_out).  One group per cloud means B * ceil(N / 64) row tiles: a handful for a PointNet++ head (N = 128), so
+    the layers run as row-batched GEMMs over all B * N rows (cg_sa_concat_input -> cg_gemm_bias_act per layer -> cg_group_max: the
+    32 x 32 output tiles of every layer spread over the chip; the activations, B * N x <= 1024 floats, are the only intermediates).
+    fused=True: the fused tile kernel takes the layer whole (cg_sa_tile_mlp_max, idx == NULL) -- measured 6..9 x slower at 1..16 clouds
+    of 128 points (profiles/r5_pp_encoder_first.json: two 64-row tiles per cloud carry 0.72 MMAC per row on one CU each), kept for the
+    parity tests of the kernel's index-free mode."""
     from . import ops
     require_cuda(xyz)
     xyz = _f32(xyz)
@@ -241,8 +240,6 @@ def group_all_mlp_max(xyz, points, W, fused=None):
         raise ValueError("group_all_mlp_max needs kind='tile' weights for 3 + D input channels")
     C = W.cout[-1]
     can_fuse = W.cin[0] <= W.TILE_MAX_CIN and W.hidden_max <= 512
-    if fused is None:
-        fused = can_fuse and B * ((N + 63) // 64) >= GROUP_ALL_FUSED_MIN_TILES
     if fused:
         if not can_fuse:
             raise NotImplementedError('fused group-all layer: 3 + D <= 592 inputs, hidden widths <= 512')

@@ -216,7 +216,7 @@ def test_encoder_state_dict_train_eval_roundtrip(cuda_device):
     BatchNorm statistics are frozen equal (momentum 0), i.e. the torch path and the kernels compute the same function."""
     from catgrasp_amd import pointnet2 as p2
     torch.manual_seed(0)
-    enc = p2.PointNet2Encoder(channel=3, npoints=(64, 16), radii=(0.3, 0.6), nsamples=(8, 16)).cuda(); _randomize_bn(enc, 2)
+    enc = p2.PointNet2Encoder(channel=3, npoints=(64, 16), radii=(0.3, 0.6), nsamples=(8, 16)); _randomize_bn(enc, 2); enc.cuda()
     x = torch.rand(2, 500, 3, device=cuda_device)
     start = (torch.tensor([1, 2]), torch.tensor([3, 4]))
     enc.eval()
