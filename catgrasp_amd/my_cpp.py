@@ -130,10 +130,12 @@ def voxel_blocks(keys):
 
 class CollisionManager:
     """my_cpp.CollisionManager (collision_manager.h:55-69).  Objects are triangle meshes and voxelised point clouds (octomap leaves at
-    the registered resolution), each posed by setTransform.  isAnyCollision tests every {mesh, cloud} pair -- the only kind the
-    reference registers together (common.cpp:176-182) -- with the mesh expressed in the cloud's frame, inv(cloud pose) . mesh pose (the
-    reference never moves its octrees; a posed cloud is the same leaf boxes seen from another frame).  mesh/mesh and cloud/cloud
-    pairs raise NotImplementedError instead of answering something else (contract table)."""
+    the registered resolution), each posed by setTransform.  isAnyCollision tests EVERY pair of registered objects like the reference's
+    double loop (collision_manager.cpp:93-111):
+      {mesh, cloud}  -- the pair the grasp filter forms (common.cpp:176-182): the mesh expressed in the cloud's frame, inv(cloud pose) .
+                        mesh pose (the reference never moves its octrees; a posed cloud is the same leaf boxes seen from another frame);
+      {mesh, mesh}   -- triangle against triangle, both posed (cg_mesh_mesh_collide);
+      {cloud, cloud} -- leaf cube against leaf cube, B's cubes carried into A's frame (cg_voxels_voxels_collide)."""
 
     def __init__(self):
         self._obs = []
@@ -153,26 +155,41 @@ class CollisionManager:
     def setTransform(self, pose, ob_id):
         pose = _mat4(pose, 'pose')
         ob = self._obs[ob_id]
-        if ob['kind'] == 'cloud' and abs(float(np.linalg.det(pose[:3, :3].astype(np.float64))) - 1.0) > 1e-3:
-            raise ValueError('a registered point cloud can only be posed rigidly (its leaf boxes are re-expressed, not re-sampled)')
+        if ob['kind'] == 'cloud':
+            R = pose[:3, :3].astype(np.float64)
+            if not (np.allclose(R.T @ R, np.eye(3), atol=1e-4) and np.linalg.det(R) > 0):
+                raise ValueError('a registered point cloud can only be posed rigidly (its leaf boxes are re-expressed, not re-sampled): '
+                                 'the rotation block must be orthonormal with determinant +1')
         ob['pose'] = pose
+
+    def _dev_pose(self, m):
+        return torch.from_numpy(np.ascontiguousarray(m, dtype=np.float32).reshape(1, 16)).to(self._dev)
+
+    def _pair_collides(self, a, b):
+        out = torch.zeros((1,), dtype=torch.uint8, device=self._dev)
+        if a['kind'] == 'mesh' and b['kind'] == 'mesh':
+            check(L.lib().cg_mesh_mesh_collide(_p(a['V']), _p(a['F']), _c_int(a['F'].shape[0]), _p(b['V']), _p(b['F']), _c_int(b['F'].shape[0]),
+                                               _p(self._dev_pose(a['pose'])), _p(self._dev_pose(b['pose'])), _p(out), _stream()),
+                  'cg_mesh_mesh_collide')
+        elif a['kind'] == 'cloud' and b['kind'] == 'cloud':
+            rel = (np.linalg.inv(a['pose'].astype(np.float64)) @ b['pose'].astype(np.float64)).astype(np.float32)
+            check(L.lib().cg_voxels_voxels_collide(_p(a['keys']), _c_int(a['keys'].shape[0]), ctypes.c_float(a['res']), _p(b['keys']),
+                                                   _c_int(b['keys'].shape[0]), ctypes.c_float(b['res']), _p(self._dev_pose(rel)), _p(out),
+                                                   _stream()), 'cg_voxels_voxels_collide')
+        else:
+            mesh, cloud = (a, b) if a['kind'] == 'mesh' else (b, a)
+            rel = mesh['pose']
+            if not np.array_equal(cloud['pose'], np.eye(4, dtype=np.float32)):        # the mesh as seen from the cloud's frame
+                rel = (np.linalg.inv(cloud['pose'].astype(np.float64)) @ mesh['pose'].astype(np.float64)).astype(np.float32)
+            check(L.lib().cg_mesh_voxels_collide(_p(mesh['V']), _p(mesh['F']), _c_int(mesh['F'].shape[0]), _p(self._dev_pose(rel)), _c_long(1),
+                                                 _p(cloud['keys']), _c_int(cloud['keys'].shape[0]), ctypes.c_float(cloud['res']),
+                                                 _p(out), _stream()), 'cg_mesh_voxels_collide')
+        return bool(out.item())
 
     def isAnyCollision(self):
         for i in range(len(self._obs)):
             for j in range(i + 1, len(self._obs)):
-                a, b = self._obs[i], self._obs[j]
-                if a['kind'] == b['kind']:
-                    raise NotImplementedError(f"{a['kind']}/{b['kind']} pairs are not supported")
-                mesh, cloud = (a, b) if a['kind'] == 'mesh' else (b, a)
-                rel = mesh['pose']
-                if not np.array_equal(cloud['pose'], np.eye(4, dtype=np.float32)):        # the mesh as seen from the cloud's frame
-                    rel = (np.linalg.inv(cloud['pose'].astype(np.float64)) @ mesh['pose'].astype(np.float64)).astype(np.float32)
-                pose = torch.from_numpy(np.ascontiguousarray(rel).reshape(1, 16)).to(self._dev)
-                out = torch.zeros((1,), dtype=torch.uint8, device=self._dev)
-                check(L.lib().cg_mesh_voxels_collide(_p(mesh['V']), _p(mesh['F']), _c_int(mesh['F'].shape[0]), _p(pose), _c_long(1),
-                                                     _p(cloud['keys']), _c_int(cloud['keys'].shape[0]), ctypes.c_float(cloud['res']),
-                                                     _p(out), _stream()), 'cg_mesh_voxels_collide')
-                if bool(out.item()):
+                if self._pair_collides(self._obs[i], self._obs[j]):
                     return True
         return False
 

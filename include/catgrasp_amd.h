@@ -174,6 +174,19 @@ int cg_unpack_voxel_keys(const long long* packed, long n, short* keys4, void* st
 int cg_mesh_voxels_collide(const float* vertices, const int* faces, int n_faces, const float* poses, long n_poses,
                            const short* keys, int n_keys, float resolution, unsigned char* out, void* stream);
 
+/* The other pairs of CollisionManager::isAnyCollision (my_cpp/collision_manager.cpp:93-111 loops over EVERY pair of registered
+ * objects; the grasp filter itself only forms {mesh, cloud}).  Both write *out = 1 iff the pair collides, 0 otherwise.
+ *  cg_mesh_mesh_collide     : two triangle meshes (vertices (nv,3) f32, faces (nf,3) i32), each under its own pose (device, 16 floats
+ *                             row-major 4x4: setTransform): some closed triangle of A meets some closed triangle of B
+ *                             (FCL: BVHModel<OBBRSSf> against BVHModel<OBBRSSf>, collision_manager.cpp:41-45).
+ *  cg_voxels_voxels_collide : two voxelised clouds (keys (n,4) int16 as cg_unpack_voxel_keys writes them, each with its own
+ *                             resolution); b_in_a (device, 16 floats) = inv(pose A) . pose B, rigid: some leaf cube of A meets some
+ *                             leaf cube of B (fcl::OcTree against fcl::OcTree, collision_manager.cpp:63-70). */
+int cg_mesh_mesh_collide(const float* vertices_a, const int* faces_a, int n_faces_a, const float* vertices_b, const int* faces_b,
+                         int n_faces_b, const float* pose_a, const float* pose_b, unsigned char* out, void* stream);
+int cg_voxels_voxels_collide(const short* keys_a, int n_keys_a, float resolution_a, const short* keys_b, int n_keys_b,
+                             float resolution_b, const float* b_in_a, unsigned char* out, void* stream);
+
 /* Optional broad phase for a gripper mesh: a uniform grid in the MESH frame (host descriptor, device arrays).
  * Cell (i,j,k) -> index (i*dims[1] + j)*dims[2] + k; tri_ids[cell_start[c] .. cell_start[c+1]) lists every triangle whose
  * bounding box inflated by 2*(resolution*sqrt(3)/2) + slack overlaps the cell.  Valid for point clouds registered at

@@ -47,6 +47,31 @@ def mesh_voxels_collide(V, F, pose, keys, resolution):
                                              ctypes.c_int(len(keys)), ctypes.c_float(resolution)))
 
 
+def mesh_mesh_collide(VA, FA, pose_a, VB, FB, pose_b):
+    """isAnyCollision for two posed meshes (collision_manager.cpp:93-111): float64 segment-through-triangle tests."""
+    VA = _f(VA); VB = _f(VB); FA = np.ascontiguousarray(FA, dtype=np.int32); FB = np.ascontiguousarray(FB, dtype=np.int32)
+    pa = _f(np.asarray(pose_a).reshape(16)); pb = _f(np.asarray(pose_b).reshape(16))
+    return bool(lib().cr_mesh_mesh_collide(_fp(VA), _fp(FA), ctypes.c_int(len(FA)), _fp(VB), _fp(FB), ctypes.c_int(len(FB)), _fp(pa), _fp(pb)))
+
+
+def tri_tri_overlap(P, Q):
+    P = _f(np.asarray(P).reshape(9)); Q = _f(np.asarray(Q).reshape(9))
+    return bool(lib().cr_tri_tri_overlap64(_fp(P), _fp(Q)))
+
+
+def box_box_overlap(ca, ha, cb, hb, R):
+    ca = _f(ca); cb = _f(cb); R = _f(np.asarray(R).reshape(9))
+    return bool(lib().cr_box_box_overlap64(_fp(ca), ctypes.c_float(ha), _fp(cb), ctypes.c_float(hb), _fp(R)))
+
+
+def voxels_voxels_collide(keys_a, res_a, keys_b, res_b, b_in_a):
+    """isAnyCollision for two voxelised clouds; b_in_a = inv(pose A) . pose B (4x4)."""
+    ka = np.ascontiguousarray(keys_a, dtype=np.int32); kb = np.ascontiguousarray(keys_b, dtype=np.int32)
+    rel = _f(np.asarray(b_in_a).reshape(16))
+    return bool(lib().cr_voxels_voxels_collide(_fp(ka), ctypes.c_int(len(ka)), ctypes.c_float(res_a), _fp(kb), ctypes.c_int(len(kb)),
+                                               ctypes.c_float(res_b), _fp(rel)))
+
+
 def tri_box_overlap(c, h, a, b, d):
     c, a, b, d = _f(c), _f(a), _f(b), _f(d)
     return bool(lib().cr_tri_box_overlap(_fp(c), ctypes.c_float(h), _fp(a), _fp(b), _fp(d)))

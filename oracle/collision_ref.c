@@ -458,6 +458,160 @@ void cr_filter_grasp_pose(const float* grasp_poses, int n_pose, const float* sym
   }
 }
 
+/* ---------------- isAnyCollision for mesh/mesh and cloud/cloud pairs (collision_manager.cpp:93-111 tests EVERY pair) ----------------
+ * PARITY UNPINNED like the rest of this file.  Predicates: "some closed triangle of A meets some closed triangle of B" (FCL's
+ * BVH-vs-BVH leaf test) and "some occupied leaf cube of A meets some occupied leaf cube of B" (octree-vs-octree, box-box narrow
+ * phase).  Decided here WITHOUT separating axes, in float64 -- segment-through-triangle tests, polygon clipping -- so that the HIP
+ * kernels' float32 separating-axis tests (csrc/collision_pairs.hip) are compared with a different procedure. */
+
+static void d_sub(const double* a, const double* b, double* o) { o[0] = a[0] - b[0]; o[1] = a[1] - b[1]; o[2] = a[2] - b[2]; }
+static void d_cross(const double* a, const double* b, double* o) {
+  o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0];
+}
+static double d_dot(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+
+/* 2-D closed convex polygons (np, nq <= 3 points; a segment is a 2-gon, a point a 1-gon) by their edge normals */
+static int overlap2d(const double (*P)[2], int np, const double (*Q)[2], int nq) {
+  for (int pass = 0; pass < 2; ++pass) {
+    const double (*A)[2] = pass ? Q : P; const int na = pass ? nq : np;
+    for (int i = 0; i < na; ++i) {
+      const double ex = A[(i + 1) % na][0] - A[i][0], ey = A[(i + 1) % na][1] - A[i][1];
+      const double nx = -ey, ny = ex;
+      if (nx == 0 && ny == 0) continue;
+      double pmin = INFINITY, pmax = -INFINITY, qmin = INFINITY, qmax = -INFINITY;
+      for (int k = 0; k < np; ++k) { const double d = nx * P[k][0] + ny * P[k][1]; pmin = fmin(pmin, d); pmax = fmax(pmax, d); }
+      for (int k = 0; k < nq; ++k) { const double d = nx * Q[k][0] + ny * Q[k][1]; qmin = fmin(qmin, d); qmax = fmax(qmax, d); }
+      if (pmax < qmin || qmax < pmin) return 0;
+    }
+  }
+  return 1;
+}
+
+/* closed segment a-b against closed triangle v[3] (normal n, not zero) */
+static int seg_tri64(const double* a, const double* b, const double (*v)[3], const double* n) {
+  double ra[3], rb[3];
+  d_sub(a, v[0], ra); d_sub(b, v[0], rb);
+  const double da = d_dot(n, ra), db = d_dot(n, rb);
+  if ((da > 0 && db > 0) || (da < 0 && db < 0)) return 0;
+  /* drop the coordinate along which n is largest */
+  int ax = 0;
+  if (fabs(n[1]) > fabs(n[ax])) ax = 1;
+  if (fabs(n[2]) > fabs(n[ax])) ax = 2;
+  const int u = (ax + 1) % 3, w = (ax + 2) % 3;
+  double T[3][2] = {{v[0][u], v[0][w]}, {v[1][u], v[1][w]}, {v[2][u], v[2][w]}};
+  if (da == 0 && db == 0) {                      /* the segment lies in the triangle's plane */
+    double S[2][2] = {{a[u], a[w]}, {b[u], b[w]}};
+    return overlap2d(S, 2, T, 3);
+  }
+  const double t = da / (da - db);
+  double X[1][2] = {{a[u] + t * (b[u] - a[u]), a[w] + t * (b[w] - a[w])}};
+  return overlap2d(X, 1, T, 3);
+}
+
+int cr_tri_tri_overlap64(const float* Pf, const float* Qf) {
+  double P[3][3], Q[3][3];
+  for (int i = 0; i < 3; ++i) for (int k = 0; k < 3; ++k) { P[i][k] = (double)Pf[3 * i + k] - (double)Pf[k]; Q[i][k] = (double)Qf[3 * i + k] - (double)Pf[k]; }
+  double e0[3], e1[3], np_[3], nq[3];
+  d_sub(P[1], P[0], e0); d_sub(P[2], P[0], e1); d_cross(e0, e1, np_);
+  d_sub(Q[1], Q[0], e0); d_sub(Q[2], Q[0], e1); d_cross(e0, e1, nq);
+  const int pdeg = np_[0] == 0 && np_[1] == 0 && np_[2] == 0, qdeg = nq[0] == 0 && nq[1] == 0 && nq[2] == 0;
+  if (pdeg || qdeg) {                           /* a degenerate triangle is its three edges (segments) against the other one */
+    if (pdeg && qdeg) return 0;                 /* segment vs segment: not a case the tests form; FCL's answer is unpinned too */
+    const double (*S)[3] = pdeg ? P : Q; const double (*Tt)[3] = pdeg ? Q : P; const double* n = pdeg ? nq : np_;
+    for (int i = 0; i < 3; ++i) if (seg_tri64(S[i], S[(i + 1) % 3], Tt, n)) return 1;
+    return 0;
+  }
+  for (int i = 0; i < 3; ++i) {
+    if (seg_tri64(P[i], P[(i + 1) % 3], Q, nq)) return 1;
+    if (seg_tri64(Q[i], Q[(i + 1) % 3], P, np_)) return 1;
+  }
+  return 0;
+}
+
+int cr_mesh_mesh_collide(const float* VA, const int* FA, int nfa, const float* VB, const int* FB, int nfb, const float* poseA, const float* poseB) {
+  if (nfa == 0 || nfb == 0) return 0;
+  float* ta = (float*)malloc(sizeof(float) * 9 * (size_t)nfa);
+  float* tb = (float*)malloc(sizeof(float) * 9 * (size_t)nfb);
+  for (int f = 0; f < nfa; ++f) for (int k = 0; k < 3; ++k) pose_vertex(poseA, VA + 3 * FA[f * 3 + k], ta + f * 9 + k * 3);
+  for (int f = 0; f < nfb; ++f) for (int k = 0; k < 3; ++k) pose_vertex(poseB, VB + 3 * FB[f * 3 + k], tb + f * 9 + k * 3);
+  int hit = 0;
+#pragma omp parallel for schedule(dynamic, 8) shared(hit)
+  for (int i = 0; i < nfa; ++i) {
+    if (hit) continue;
+    const float* p = ta + i * 9;
+    float lo[3], hi[3];
+    for (int a = 0; a < 3; ++a) { lo[a] = min3f(p[a], p[3 + a], p[6 + a]); hi[a] = max3f(p[a], p[3 + a], p[6 + a]); }
+    for (int j = 0; j < nfb && !hit; ++j) {
+      const float* q = tb + j * 9;
+      int out = 0;
+      for (int a = 0; a < 3; ++a)
+        if (lo[a] > max3f(q[a], q[3 + a], q[6 + a]) || hi[a] < min3f(q[a], q[3 + a], q[6 + a])) out = 1;
+      if (out) continue;
+      if (cr_tri_tri_overlap64(p, q)) {
+#pragma omp atomic write
+        hit = 1;
+      }
+    }
+  }
+  free(ta); free(tb);
+  return hit;
+}
+
+/* cube A (centre ca, half edge ha, axis-aligned) vs cube B (centre cb, half edge hb, axes = columns of R): some face of B (two
+ * triangles) survives clipping against A, or A's centre lies inside B */
+int cr_box_box_overlap64(const float* ca, float ha, const float* cb, float hb, const float* R) {
+  const float h3[3] = {ha, ha, ha};
+  float corner[8][3];
+  for (int m = 0; m < 8; ++m)
+    for (int r = 0; r < 3; ++r) {
+      double x = cb[r];
+      for (int c = 0; c < 3; ++c) x += (double)R[3 * r + c] * ((m >> c) & 1 ? (double)hb : -(double)hb);
+      corner[m][r] = (float)x;                   /* rounded once: the clipping below works on these corners */
+    }
+  static const int quad[6][4] = {{0, 1, 3, 2}, {4, 5, 7, 6}, {0, 1, 5, 4}, {2, 3, 7, 6}, {0, 2, 6, 4}, {1, 3, 7, 5}};
+  for (int f = 0; f < 6; ++f) {
+    if (cr_tri_box_clip64(ca, h3, corner[quad[f][0]], corner[quad[f][1]], corner[quad[f][2]])) return 1;
+    if (cr_tri_box_clip64(ca, h3, corner[quad[f][0]], corner[quad[f][2]], corner[quad[f][3]])) return 1;
+  }
+  for (int c = 0; c < 3; ++c) {                  /* A's centre in B's coordinates */
+    double x = 0;
+    for (int r = 0; r < 3; ++r) x += (double)R[3 * r + c] * ((double)ca[r] - (double)cb[r]);
+    if (fabs(x) > (double)hb) return 0;
+  }
+  return 1;
+}
+
+/* keys (n,3) int32 (key - 32768); rel: B's frame -> A's frame (4x4 row-major) */
+int cr_voxels_voxels_collide(const int* keysA, int na, float resA, const int* keysB, int nb, float resB, const float* rel) {
+  if (na == 0 || nb == 0) return 0;
+  const float ha = 0.5f * resA, hb = 0.5f * resB;
+  const float R[9] = {rel[0], rel[1], rel[2], rel[4], rel[5], rel[6], rel[8], rel[9], rel[10]};
+  const float reach = 1.7320508f * (ha + hb) * 1.0001f;
+  float* cbs = (float*)malloc(sizeof(float) * 3 * (size_t)nb);
+  for (int j = 0; j < nb; ++j) {
+    float cb[3];
+    for (int a = 0; a < 3; ++a) cb[a] = ((float)keysB[3 * j + a] + 0.5f) * resB;
+    pose_vertex(rel, cb, cbs + 3 * j);
+  }
+  int hit = 0;
+#pragma omp parallel for schedule(dynamic, 16) shared(hit)
+  for (int i = 0; i < na; ++i) {
+    if (hit) continue;
+    float ca[3];
+    for (int a = 0; a < 3; ++a) ca[a] = ((float)keysA[3 * i + a] + 0.5f) * resA;
+    for (int j = 0; j < nb && !hit; ++j) {
+      const float* cb = cbs + 3 * j;
+      if (fabsf(cb[0] - ca[0]) > reach || fabsf(cb[1] - ca[1]) > reach || fabsf(cb[2] - ca[2]) > reach) continue;
+      if (cr_box_box_overlap64(ca, ha, cb, hb, R)) {
+#pragma omp atomic write
+        hit = 1;
+      }
+    }
+  }
+  free(cbs);
+  return hit;
+}
+
 int cr_num_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

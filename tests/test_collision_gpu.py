@@ -184,10 +184,97 @@ def test_collision_manager_api(cuda_device):
     assert 0 < n_hit < len(P)                                                          # ... so the verdicts are those of the unposed scene
     with pytest.raises(ValueError):                     # a cloud can be moved, not scaled
         cm.setTransform(np.diag([2.0, 2.0, 2.0, 1.0]).astype(np.float32), cid)
-    cm2 = my_cpp.CollisionManager()
-    cm2.registerMesh(g['vertices'], g['faces']); cm2.registerMesh(g['vertices'], g['faces'])
-    with pytest.raises(NotImplementedError):            # documented contract limit: mesh / mesh and cloud / cloud pairs
-        cm2.isAnyCollision()
+    with pytest.raises(ValueError):                     # ... nor sheared: a unit-determinant matrix that is not a rotation
+        S = np.eye(4, dtype=np.float32); S[0, 1] = 0.5
+        cm.setTransform(S, cid)
+
+
+def _soup(rng, n, extent, size):
+    """n random triangles of edge ~size scattered in a cube of side `extent`."""
+    c = rng.uniform(-extent / 2, extent / 2, size=(n, 1, 3))
+    V = (c + rng.normal(0, size, size=(n, 3, 3))).reshape(-1, 3).astype(np.float32)
+    return V, np.arange(3 * n, dtype=np.int32).reshape(n, 3)
+
+
+def _rigid(rng, t_scale):
+    T = np.eye(4); T[:3, :3] = synth.random_rotation(rng); T[:3, 3] = rng.normal(0, t_scale, 3)
+    return T.astype(np.float32)
+
+
+def test_collision_manager_tests_every_pair_mesh_mesh_and_cloud_cloud(cuda_device):
+    """collision_manager.cpp:93-111 loops over EVERY pair of registered objects: mesh / mesh (triangle against triangle) and cloud /
+    cloud (leaf cube against leaf cube, each set in its own pose) against the oracle's float64 segment-through-triangle / clipping
+    predicates, on configurations from clearly apart to deeply interpenetrating; then the managers' any-pair logic."""
+    from catgrasp_amd import my_cpp
+    rng = np.random.default_rng(17)
+    # ---- mesh / mesh
+    VA, FA = _soup(rng, 300, 0.05, 0.004)
+    VB, FB = _soup(rng, 500, 0.05, 0.004)
+    n_hit = 0
+    for k in range(40):
+        cm = my_cpp.CollisionManager()
+        a = cm.registerMesh(VA, FA); b = cm.registerMesh(VB, FB)
+        Ta = _rigid(rng, 0.01)
+        Tb = _rigid(rng, 0.01); Tb[0, 3] += np.float32(0.003 * k)      # slides B away from A
+        cm.setTransform(Ta, a); cm.setTransform(Tb, b)
+        got = cm.isAnyCollision()
+        assert got == co.mesh_mesh_collide(VA, FA, Ta, VB, FB, Tb), k
+        n_hit += int(got)
+    assert 0 < n_hit < 40
+    # the gripper meshes of the path against each other (closed surfaces, thousands of triangles when subdivided)
+    g = synth.make_gripper()
+    for shift, expect in ((0.0, True), (0.5, False)):
+        cm = my_cpp.CollisionManager()
+        a = cm.registerMesh(g['vertices'], g['faces']); b = cm.registerMesh(g['enclosed_vertices'], g['enclosed_faces'])
+        T = np.eye(4, dtype=np.float32); T[0, 3] = shift
+        cm.setTransform(T, b)
+        assert cm.isAnyCollision() == expect == co.mesh_mesh_collide(g['vertices'], g['faces'], np.eye(4), g['enclosed_vertices'], g['enclosed_faces'], T)
+    # coplanar pairs: overlapping, and apart inside the same plane (the six in-plane axes decide)
+    tri = np.array([[0, 0, 0], [0.01, 0, 0], [0, 0.01, 0]], np.float32); F1 = np.array([[0, 1, 2]], np.int32)
+    for dx, expect in ((0.004, True), (0.02, False)):
+        cm = my_cpp.CollisionManager()
+        cm.registerMesh(tri, F1); cm.registerMesh(tri + np.float32([dx, 0.001, 0]), F1)
+        assert cm.isAnyCollision() == expect == co.mesh_mesh_collide(tri, F1, np.eye(4), tri + np.float32([dx, 0.001, 0]), F1, np.eye(4))
+    # a small triangle strictly inside a big one's plane region but lifted off it: parallel planes
+    cm = my_cpp.CollisionManager(); cm.registerMesh(tri, F1); cm.registerMesh(tri * 0.2 + np.float32([0.002, 0.002, 0.0005]), F1)
+    assert cm.isAnyCollision() is False
+    # ---- cloud / cloud
+    objs, _, bg = _scene(3, n_obj=2, pts=1200)
+    pa, pb = objs[0]['xyz'].astype(np.float32), objs[1]['xyz'].astype(np.float32)
+    ka, kb = co.voxelize(pa, 0.0005), co.voxelize(pb, 0.001)
+    n_hit = 0
+    ca, cb = pa.mean(0), pb.mean(0)
+    for k in range(30):
+        cm = my_cpp.CollisionManager()
+        a = cm.registerPointCloud(pa, 0.0005); b = cm.registerPointCloud(pb, 0.001)
+        Ta = np.eye(4, dtype=np.float32)
+        Tb = _rigid(rng, 0.0); Tb[:3, 3] = (ca - Tb[:3, :3] @ cb + rng.normal(0, 0.0004 * k, 3)).astype(np.float32)    # B's cloud dropped onto A's, then apart
+        if k % 3 == 0:
+            Ta = _rigid(rng, 0.01); Tb = (Ta.astype(np.float64) @ Tb.astype(np.float64)).astype(np.float32)
+        cm.setTransform(Ta, a); cm.setTransform(Tb, b)
+        rel = (np.linalg.inv(Ta.astype(np.float64)) @ Tb.astype(np.float64)).astype(np.float32)
+        got = cm.isAnyCollision()
+        assert got == co.voxels_voxels_collide(ka, 0.0005, kb, 0.001, rel), k
+        n_hit += int(got)
+    assert 0 < n_hit < 30
+    # the same cloud twice, unposed: every cube meets itself
+    cm = my_cpp.CollisionManager(); cm.registerPointCloud(pa, 0.0005); cm.registerPointCloud(pa, 0.0005)
+    assert cm.isAnyCollision() is True
+    # ---- three objects: the loop reports a hit in ANY pair (collision_manager.cpp:95-108)
+    far = np.eye(4, dtype=np.float32); far[:3, 3] = [5, 5, 5]
+    cm = my_cpp.CollisionManager()
+    m0 = cm.registerMesh(VA, FA); m1 = cm.registerMesh(VB, FB); c0 = cm.registerPointCloud(pa, 0.0005)
+    cm.setTransform(far, m1); far2 = far.copy(); far2[:3, 3] = [-5, 5, 5]; cm.setTransform(far2, m0)
+    assert cm.isAnyCollision() is False                       # all three apart
+    cm.setTransform(np.eye(4, dtype=np.float32), m1)
+    Tm = np.eye(4, dtype=np.float32); Tm[:3, 3] = ca          # mesh 1 onto the cloud
+    cm.setTransform(Tm, m1)
+    assert cm.isAnyCollision() == co.mesh_voxels_collide(VB, FB, Tm, ka, 0.0005)
+    cm.setTransform(far, m1); cm.setTransform(far, m0)        # the two meshes onto each other, far from the cloud
+    assert cm.isAnyCollision() is True
+    # empty objects never collide
+    cm = my_cpp.CollisionManager(); cm.registerMesh(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.int32)); cm.registerMesh(VA, FA)
+    assert cm.isAnyCollision() is False
 
 
 def test_tri_box_predicate_random_and_grazing(cuda_device):

@@ -295,3 +295,84 @@ def test_general_half_extent_sat_equals_the_cube_sat():
         b = l.cr_tri_box_overlap_h3(P(c[i]), P(h3), P(tri[i, 0]), P(tri[i, 1]), P(tri[i, 2]))
         agree += int(a == b)
     assert agree == n
+
+
+def _sat17(P, Q):
+    """closed triangle / closed triangle by 17 separating axes in float64 (numpy): an independent check of the oracle's
+    segment-through-triangle formulation (and the arithmetic plan of the HIP kernel, csrc/collision_pairs.hip)."""
+    P = np.asarray(P, np.float64).reshape(3, 3); Q = np.asarray(Q, np.float64).reshape(3, 3)
+    Q = Q - P[0]; P = P - P[0]
+    ep = [P[(i + 1) % 3] - P[i] for i in range(3)]; eq = [Q[(i + 1) % 3] - Q[i] for i in range(3)]
+    npn, nqn = np.cross(ep[0], ep[1]), np.cross(eq[0], eq[1])
+    axes = [npn, nqn] + [np.cross(a, b) for a in ep for b in eq] + [np.cross(npn, a) for a in ep] + [np.cross(nqn, b) for b in eq]
+    for L in axes:
+        a, b = P @ L, Q @ L
+        if a.max() < b.min() or b.max() < a.min():
+            return False
+    return True
+
+
+def test_tri_tri_oracle_known_answers_and_agreement_with_separating_axes():
+    t = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)
+    assert co.tri_tri_overlap(t, t)                                                             # itself
+    assert co.tri_tri_overlap(t, [[0.2, 0.2, -1], [0.2, 0.2, 1], [2, 2, 0.5]])                  # an edge pierces the interior
+    assert not co.tri_tri_overlap(t, [[0.2, 0.2, 0.1], [0.3, 0.2, 1], [2, 2, 0.5]])             # above the plane
+    assert not co.tri_tri_overlap(t, [[2, 2, -1], [2, 2, 1], [3, 3, 0]])                        # crosses the plane outside the triangle
+    assert co.tri_tri_overlap(t, t + np.float32([0.25, 0.25, 0]))                               # coplanar, overlapping
+    assert not co.tri_tri_overlap(t, t + np.float32([3, 0, 0]))                                 # coplanar, apart
+    assert co.tri_tri_overlap(t, t * 0.2 + np.float32([0.1, 0.1, 0]))                           # coplanar, contained
+    assert co.tri_tri_overlap(t, [[1, 0, 0], [2, 0, 1], [2, 1, -1]])                            # touching in one vertex (closed sets)
+    assert not co.tri_tri_overlap(t, t * 0.2 + np.float32([0.1, 0.1, 0.01]))                    # parallel planes
+    rng = np.random.default_rng(5)
+    n_hit = 0
+    for _ in range(6000):
+        P = rng.normal(0, 1, (3, 3)).astype(np.float32); Q = (rng.normal(0, 1, (3, 3)) + rng.normal(0, 0.8, 3)).astype(np.float32)
+        got = co.tri_tri_overlap(P, Q)
+        assert got == _sat17(P, Q)
+        n_hit += int(got)
+    assert 500 < n_hit < 5000
+
+
+def test_box_box_oracle_known_answers_and_agreement_with_separating_axes():
+    I = np.eye(3, dtype=np.float32)
+    assert co.box_box_overlap([0, 0, 0], 1.0, [1.5, 0, 0], 1.0, I) and not co.box_box_overlap([0, 0, 0], 1.0, [2.5, 0, 0], 1.0, I)
+    assert co.box_box_overlap([0, 0, 0], 1.0, [0.1, 0, 0], 0.2, I) and co.box_box_overlap([0, 0, 0], 0.2, [0.1, 0, 0], 1.0, I)     # containment, both ways
+    c, s_ = np.cos(np.pi / 4), np.sin(np.pi / 4)
+    Rz = np.array([[c, -s_, 0], [s_, c, 0], [0, 0, 1]], np.float32)
+    assert co.box_box_overlap([0, 0, 0], 1.0, [2.3, 0, 0], 1.0, Rz) and not co.box_box_overlap([0, 0, 0], 1.0, [2.5, 0, 0], 1.0, Rz)  # a corner reaches 1.414
+    assert not co.box_box_overlap([0, 0, 0], 1.0, [2.2, 2.2, 0], 1.0, Rz)                       # only an edge-edge axis separates... (face normals do too here)
+
+    def sat15(ca, ha, cb, hb, R):
+        ca, cb, R = np.asarray(ca, np.float64), np.asarray(cb, np.float64), np.asarray(R, np.float64).reshape(3, 3)
+        t = cb - ca
+        axes = [np.eye(3)[i] for i in range(3)] + [R[:, j] for j in range(3)] + [np.cross(np.eye(3)[i], R[:, j]) for i in range(3) for j in range(3)]
+        for L in axes:
+            ra = ha * np.abs(L).sum()
+            rb = hb * sum(abs(L @ R[:, j]) for j in range(3))
+            if abs(t @ L) > ra + rb:
+                return False
+        return True
+    rng = np.random.default_rng(8)
+    n_hit = 0
+    for _ in range(4000):
+        R = synth.random_rotation(rng).astype(np.float32)
+        cb = rng.normal(0, 1.3, 3).astype(np.float32)
+        hb = float(np.float32(rng.uniform(0.3, 1.2)))
+        got = co.box_box_overlap([0, 0, 0], 1.0, cb, hb, R)
+        assert got == sat15([0, 0, 0], 1.0, cb, hb, R)
+        n_hit += int(got)
+    assert 800 < n_hit < 3500
+
+
+def test_mesh_mesh_and_voxels_voxels_oracle_basic():
+    g = synth.make_gripper()
+    assert co.mesh_mesh_collide(g['vertices'], g['faces'], np.eye(4), g['enclosed_vertices'], g['enclosed_faces'], np.eye(4))
+    T = np.eye(4); T[0, 3] = 1.0
+    assert not co.mesh_mesh_collide(g['vertices'], g['faces'], np.eye(4), g['enclosed_vertices'], g['enclosed_faces'], T)
+    pts = np.random.default_rng(0).uniform(0, 0.01, (300, 3)).astype(np.float32)
+    k = co.voxelize(pts, 0.0005)
+    assert co.voxels_voxels_collide(k, 0.0005, k, 0.0005, np.eye(4))
+    assert not co.voxels_voxels_collide(k, 0.0005, k, 0.0005, T)
+    # the same key set at another resolution is another place: (key + 0.5) res
+    assert co.voxels_voxels_collide(k, 0.0005, co.voxelize(pts, 0.001), 0.001, np.eye(4))
+
