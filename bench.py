@@ -192,29 +192,43 @@ def pick_cycle_block(batch, gp, npred, device, n_canonical=2000):
     canon_pts, canon_nrm = synth.nut_surface(3000, rng)
     fast = NunocsPredicter('nut', cfg=DEFAULT_NUNOCS_CFG, state_dict=npred.model.state_dict(), device=device, ransac_sampling='fast')
 
-    def cycle(nun, rng_mode):
-        timings, total, surv = {}, 0, 0
+    job = []
+    for k, ob in enumerate(objs):
+        grasps = np.linalg.inv(batch.nocs_pose[k]) @ synth.make_candidates(ob, n_canonical, np.random.default_rng(100 + k), g['hand_depth'], g['init_bite'])
+        job.append({'ob_pts': ob['xyz'], 'ob_normals': ob['normal'], 'symmetry_tfs': sym, 'nocs_pose_override': batch.nocs_pose[k],
+                    'canonical': {'cloud': canon_pts, 'normals': canon_nrm, 'affordance': np.linspace(0, 1, 3000), 'grasps': grasps}})
+
+    def cycle(nun, rng_mode, draw_ahead):
+        per_ob = []
         np.random.seed(0)
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        for k, ob in enumerate(objs):
-            grasps = np.linalg.inv(batch.nocs_pose[k]) @ synth.make_candidates(ob, n_canonical, np.random.default_rng(100 + k), g['hand_depth'], g['init_bite'])
-            canonical = {'cloud': canon_pts, 'normals': canon_nrm, 'affordance': np.linspace(0, 1, 3000), 'grasps': grasps}
-            out = pipeline.evaluate_object(ob['xyz'], ob['normal'], scene_pts, K, g, gp, nun, canonical=canonical, symmetry_tfs=sym,
-                                           timings=timings, rng=rng_mode, nocs_pose_override=batch.nocs_pose[k])
-            total += out['n_evaluated']; surv += len(out['poses'])
+        outs = pipeline.evaluate_objects(job, scene_pts, K, g, gp, nun, draw_ahead=draw_ahead, timings=per_ob, rng=rng_mode)
         torch.cuda.synchronize(); wall = time.perf_counter() - t0
-        return wall, total, surv, timings
+        timings = {}
+        for tm in per_ob:
+            for k_, v in tm.items():
+                timings[k_] = timings.get(k_, 0.0) + v
+        import hashlib
+        h = hashlib.sha256()
+        for o in outs:
+            h.update(np.ascontiguousarray(o['poses']).tobytes()); h.update(np.ascontiguousarray(o['p_T_G']).tobytes())
+        h.update(np.random.get_state()[1].tobytes()); h.update(str(np.random.get_state()[2]).encode())
+        return wall, sum(o['n_evaluated'] for o in outs), sum(len(o['poses']) for o in outs), timings, h.hexdigest()[:16]
     res = {'objects': len(objs), 'precision': engine.current_precision()}
-    for name, nun, rng_mode in (('default', npred, 'numpy'), ('fast_draws', fast, 'device')):
-        cycle(nun, rng_mode)                                # warm-up: caches, allocator, worker thread
-        wall, total, surv, tm = cycle(nun, rng_mode)
-        res[name] = {'settings': {'default': "ransac_sampling='reference', rng='numpy' (bit-identical to a seeded reference run)",
+    for name, nun, rng_mode, ahead in (('default', npred, 'numpy', True), ('default_serial', npred, 'numpy', False), ('fast_draws', fast, 'device', False)):
+        cycle(nun, rng_mode, ahead)                         # warm-up: caches, allocator, worker threads
+        wall, total, surv, tm, digest = cycle(nun, rng_mode, ahead)
+        res[name] = {'settings': {'default': "pipeline.evaluate_objects: ransac_sampling='reference', rng='numpy' (bit-identical to a seeded reference run), "
+                                             "the next object's hypothesis draws made ahead on a second thread while the device scores the current one",
+                                  'default_serial': 'the same, object after object (draw_ahead=False): the round-4 figure',
                                   'fast_draws': "ransac_sampling='fast', rng='device' (same distributions, not numpy's stream)"}[name],
                      'wall_s_per_cycle': round(wall, 4), 'wall_ms_per_object': round(wall / len(objs) * 1e3, 2),
-                     'evaluations': total, 'survivors_scored': surv,
+                     'evaluations': total, 'survivors_scored': surv, 'results_and_generator_state_sha256_16': digest,
                      'ms_per_object_by_stage': {k: round(v / len(objs) * 1e3, 3) for k, v in tm.items()}}
+    res['draw_ahead_equals_serial'] = res['default']['results_and_generator_state_sha256_16'] == res['default_serial']['results_and_generator_state_sha256_16']
     res['note'] = ("stages: occupancy (background ray cast), nunocs+ransac (= 'nunocs net + decode' + 'ransac id draw (exposed)' + 'ransac kernels + "
-                   "selection'; 'ransac id draw' is the duration of the stream replay itself on the worker thread, which starts before the network is queued), "
+                   "selection'; 'ransac id draw' is the duration of the stream replay itself -- on the stream worker under the network in the serial loop, "
+                   "on the draw-ahead thread under the PREVIOUS object's scoring pass in the default), "
                    'candidate generation (cone sampler), filterGraspPose (cone poses + canonical grasps x 12 symmetries, nudging on), affordance, grasp-Q scoring')
     return res
 

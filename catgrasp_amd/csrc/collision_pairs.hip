@@ -81,8 +81,8 @@ __global__ __launch_bounds__(256) void mesh_mesh_collide_kernel(const float* VA,
   bool hit = false;
   const int c0 = blockIdx.y * chunks_per_block;
   for (int c = c0; c < c0 + chunks_per_block && c * PB_CHUNK < nfb; ++c) {
-    if (*(volatile unsigned char*)out) break;                      // some workgroup already found a pair (wave-uniform enough: a flag)
-    __syncthreads();
+    if (__syncthreads_or(threadIdx.x == 0 && *(volatile unsigned char*)out)) break;      // some workgroup already found a pair (the
+                                                                                        // barrier also orders the LDS reuse below)
     const int tbi = c * PB_CHUNK + threadIdx.x;
     if (threadIdx.x < PB_CHUNK && tbi < nfb) {
       float Q[9];
@@ -162,8 +162,7 @@ __global__ __launch_bounds__(256) void cloud_cloud_collide_kernel(const short* k
   bool hit = false;
   const int c0 = blockIdx.y * chunks_per_block;
   for (int c = c0; c < c0 + chunks_per_block && c * PB_CHUNK < nb; ++c) {
-    if (*(volatile unsigned char*)out) break;
-    __syncthreads();
+    if (__syncthreads_or(threadIdx.x == 0 && *(volatile unsigned char*)out)) break;
     const int ib = c * PB_CHUNK + threadIdx.x;
     if (threadIdx.x < PB_CHUNK && ib < nb) {
       float cb[3], o[3];

@@ -167,21 +167,23 @@ class CollisionManager:
 
     def _pair_collides(self, a, b):
         out = torch.zeros((1,), dtype=torch.uint8, device=self._dev)
+        # the pose tensors stay referenced until the launch is queued: a temporary's block would be handed to the next allocation
         if a['kind'] == 'mesh' and b['kind'] == 'mesh':
+            pa, pb = self._dev_pose(a['pose']), self._dev_pose(b['pose'])
             check(L.lib().cg_mesh_mesh_collide(_p(a['V']), _p(a['F']), _c_int(a['F'].shape[0]), _p(b['V']), _p(b['F']), _c_int(b['F'].shape[0]),
-                                               _p(self._dev_pose(a['pose'])), _p(self._dev_pose(b['pose'])), _p(out), _stream()),
-                  'cg_mesh_mesh_collide')
+                                               _p(pa), _p(pb), _p(out), _stream()), 'cg_mesh_mesh_collide')
         elif a['kind'] == 'cloud' and b['kind'] == 'cloud':
-            rel = (np.linalg.inv(a['pose'].astype(np.float64)) @ b['pose'].astype(np.float64)).astype(np.float32)
+            rel = self._dev_pose((np.linalg.inv(a['pose'].astype(np.float64)) @ b['pose'].astype(np.float64)).astype(np.float32))
             check(L.lib().cg_voxels_voxels_collide(_p(a['keys']), _c_int(a['keys'].shape[0]), ctypes.c_float(a['res']), _p(b['keys']),
-                                                   _c_int(b['keys'].shape[0]), ctypes.c_float(b['res']), _p(self._dev_pose(rel)), _p(out),
-                                                   _stream()), 'cg_voxels_voxels_collide')
+                                                   _c_int(b['keys'].shape[0]), ctypes.c_float(b['res']), _p(rel), _p(out), _stream()),
+                  'cg_voxels_voxels_collide')
         else:
             mesh, cloud = (a, b) if a['kind'] == 'mesh' else (b, a)
             rel = mesh['pose']
             if not np.array_equal(cloud['pose'], np.eye(4, dtype=np.float32)):        # the mesh as seen from the cloud's frame
                 rel = (np.linalg.inv(cloud['pose'].astype(np.float64)) @ mesh['pose'].astype(np.float64)).astype(np.float32)
-            check(L.lib().cg_mesh_voxels_collide(_p(mesh['V']), _p(mesh['F']), _c_int(mesh['F'].shape[0]), _p(self._dev_pose(rel)), _c_long(1),
+            rel = self._dev_pose(rel)
+            check(L.lib().cg_mesh_voxels_collide(_p(mesh['V']), _p(mesh['F']), _c_int(mesh['F'].shape[0]), _p(rel), _c_long(1),
                                                  _p(cloud['keys']), _c_int(cloud['keys'].shape[0]), ctypes.c_float(cloud['res']),
                                                  _p(out), _stream()), 'cg_mesh_voxels_collide')
         return bool(out.item())

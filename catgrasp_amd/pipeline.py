@@ -49,7 +49,7 @@ def canonical_fields(canonical):
 
 def evaluate_object(ob_pts, ob_normals, scene_pts, K, gripper, grasp_predicter, nunocs_predicter, canonical=None, symmetry_tfs=None,
                     n_surface_samples=50, sphere_pts=None, approach_step=0.004, resolution=0.0005, cam_in_world=None, timings=None, ik=None,
-                    rng=None, nocs_pose_override=None):
+                    rng=None, nocs_pose_override=None, nunocs_predrawn=None, on_scoring_draws=None):
     """Returns dict(poses (n,4,4) f32, p_G, p_T_given_G, p_T_G, order) for the surviving candidates, best first.
     `gripper`: dict with vertices/faces/enclosed_vertices/enclosed_faces/gripper_in_grasp/hand_depth/init_bite/diameter and
     finger_vertices (list of 2 arrays), grip_dirs.  `canonical`: optional dict(cloud, normals, affordance, grasps (m,4,4))
@@ -60,7 +60,9 @@ def evaluate_object(ob_pts, ob_normals, scene_pts, K, gripper, grasp_predicter, 
     `rng`: the per-candidate resampling draw of the grasp-Q stage -- 'numpy' (numpy's global stream, as predict_batch's default),
     'device' (counter-based device draw); default: the predicter's own setting.  `nocs_pose_override`: use this 4x4 for the canonical
     branch instead of the RANSAC result (NunocsPredicter.predict still runs and is timed): random-init weights cannot recover a pose.
-    `timings` additionally receives the split of the NUNOCS stage that NunocsPredicter.predict records (net / id draw / RANSAC)."""
+    `timings` additionally receives the split of the NUNOCS stage that NunocsPredicter.predict records (net / id draw / RANSAC).
+    `nunocs_predrawn` / `on_scoring_draws`: the two ends of evaluate_objects' draw-ahead (NunocsPredicter.draw_ahead's result for this
+    object; a callback(state, n_valid, n_pts, n_rows) fired when this object's scoring pass starts drawing from numpy's stream)."""
     dev = grasp_predicter.device
     t = time.perf_counter
     canonical = canonical_fields(canonical)
@@ -80,7 +82,11 @@ def evaluate_object(ob_pts, ob_normals, scene_pts, K, gripper, grasp_predicter, 
     # --- NUNOCS + 9-D pose ---
     t0 = t()
     data = {'cloud_xyz': ob_pts, 'cloud_normal': ob_normals}
-    nocs_cloud, nocs_pose = nunocs_predicter.predict(data)
+    if nunocs_predrawn is not None:
+        nunocs_predrawn = nunocs_predrawn.result() if hasattr(nunocs_predrawn, 'result') else nunocs_predrawn
+        nocs_cloud, nocs_pose = nunocs_predicter.predict(data, predrawn=nunocs_predrawn)
+    else:
+        nocs_cloud, nocs_pose = nunocs_predicter.predict(data)
     lap('nunocs+ransac', t0)
     if timings is not None:
         for k, v in getattr(nunocs_predicter, 'timings', {}).items():
@@ -138,6 +144,8 @@ def evaluate_object(ob_pts, ob_normals, scene_pts, K, gripper, grasp_predicter, 
     cloud = transforms.DeviceCloud(ob_pts, ob_normals, dev)
     rng = rng or getattr(grasp_predicter, 'rng', 'device')
     if rng == 'numpy':         # the reference's stream (dataset_grasp.py:72-73), replayed one chunk ahead of the device
+        if on_scoring_draws is not None:     # numpy's generator stands at the first of this pass's n resampling draws
+            on_scoring_draws(np.random.get_state(), cloud.n, grasp_predicter.cfg['n_pts'], n)
         ids = grasp_predicter._numpy_id_chunks(cloud.n, grasp_predicter.cfg['n_pts'], n)
     else:
         ids = transforms.draw_ids_device(cloud.n, grasp_predicter.cfg['n_pts'], n, dev)
@@ -155,3 +163,46 @@ def evaluate_object(ob_pts, ob_normals, scene_pts, K, gripper, grasp_predicter, 
     order = order[valid[order]]
     out.update(poses=surv_np[order].astype(np.float32), p_G=p_g[order], p_T_given_G=p_t_g[order], p_T_G=p_tg[order])
     return out
+
+
+def evaluate_objects(objects, scene_pts, K, gripper, grasp_predicter, nunocs_predicter, draw_ahead=True, timings=None, **kw):
+    """evaluate_object over the segmented objects of a scene, in order (the loop of compute_candidate_grasp,
+    run_grasp_simulation.py:188-329) -- same results, same numpy generator state afterwards as calling evaluate_object per object.
+
+    objects: [dict(ob_pts, ob_normals [, canonical, symmetry_tfs, nocs_pose_override])].  draw_ahead: with the reference's streams
+    (rng='numpy', ransac_sampling='reference') the 2 x 10,000 hypothesis samples of object k+1's NunocsPredicter.predict are ~80 ms
+    of sequential host work (numpy's Fisher-Yates rejection walk) that the serial loop exposes after the NUNOCS network of every
+    object.  Their position in numpy's stream is known as soon as object k's survivor count is -- the scoring pass of object k draws
+    exactly one resampling row per survivor in between -- so they are drawn on a second thread while the device scores object k:
+    that thread first advances a copy of the generator over object k's resampling rows (transforms.advance_choice_rows: the rows
+    themselves are produced a chunk ahead of the device by the stream worker, as before), then replays object k+1's draws from
+    there.  NunocsPredicter.predict takes them only if numpy's generator really stands where they started (it does, unless a
+    caller's own code drew in between: then they are dropped and drawn afresh).  timings: optional list, one dict per object."""
+    from . import predicter as pred_mod
+    rng = kw.get('rng') or getattr(grasp_predicter, 'rng', 'device')
+    ahead = draw_ahead and rng == 'numpy' and getattr(nunocs_predicter, '_predraw', False)
+    results, pending = [], [None]
+    for k, ob in enumerate(objects):
+        nxt = objects[k + 1] if k + 1 < len(objects) else None
+        hook = None
+        if ahead and nxt is not None:
+            n_valid_next = int(transforms.valid_mask(np.asarray(nxt['ob_pts'], dtype=np.float64)).sum())
+
+            def hook(state, n_valid, n_pts, n_rows, _nv=n_valid_next):
+                pending[0] = nunocs_predicter.draw_ahead(_nv, lambda: transforms.advance_choice_rows(state, n_valid, n_pts, n_rows),
+                                                         pred_mod.draw_ahead_worker())
+        predrawn, pending[0] = pending[0], None
+        tm = {} if timings is not None else None
+        try:
+            results.append(evaluate_object(ob['ob_pts'], ob['ob_normals'], scene_pts, K, gripper, grasp_predicter, nunocs_predicter,
+                                           canonical=ob.get('canonical'), symmetry_tfs=ob.get('symmetry_tfs'),
+                                           nocs_pose_override=ob.get('nocs_pose_override'), timings=tm, nunocs_predrawn=predrawn,
+                                           on_scoring_draws=hook, **kw))
+        except BaseException:
+            if pending[0] is not None:
+                pending[0].exception()          # let the draw-ahead thread finish before the error travels on
+            raise
+        if timings is not None:
+            timings.append(tm)
+    return results
+

@@ -84,6 +84,18 @@ def _draw_worker():
     return _WORKER[0]
 
 
+_AHEAD = []
+
+
+def draw_ahead_worker():
+    """A second thread for draws made AHEAD of numpy's global stream (pipeline.evaluate_objects: the next object's NUNOCS-stage draws
+    while the stream worker above is still handing the current object's resampling rows to the device)."""
+    if not _AHEAD:
+        from concurrent.futures import ThreadPoolExecutor
+        _AHEAD.append(ThreadPoolExecutor(max_workers=1, thread_name_prefix='catgrasp-numpy-ahead'))
+    return _AHEAD[0]
+
+
 def _event():
     ev = torch.cuda.Event(); ev.record()
     return ev
@@ -460,14 +472,45 @@ class NunocsPredicter:
                 raise FloatingPointError('NUNOCS confidences are not finite (non-finite weights or activations beyond float32)')
             return coords[0].cpu().numpy(), conf_h, self.data_transformed
 
-    def predict(self, data, ids=None):
+    RANSAC_THRESHOLDS, RANSAC_MAX_ITER = (0.003, 0.005), 10000             # predicter.py:167,170
+
+    def draw_ahead(self, n_valid, state, pool):
+        """The numpy-stream draws of ONE predict() call, made ahead of time from an explicit generator state on `pool`'s thread (a
+        callable may be given for `state`: it is evaluated on that thread first -- e.g. transforms.advance_choice_rows over the
+        scoring draws still in flight): the resampling row of the NUNOCS transform (dataset_nunocs.py:45-52) and the
+        2 x 10,000 hypothesis samples (predicter.py:167-170 -> aligning.py:89-93).  -> a future of dict(start_state, ids, heads,
+        end_state, seconds) for predict(..., predrawn=...); None when this predicter does not draw from numpy's stream that way."""
+        n_pts = self.cfg['n_pts']
+        if not self._predraw or n_pts < 4:
+            return None
+
+        def run():
+            import time
+            t0 = time.perf_counter()
+            st0 = state() if callable(state) else state
+            rows = transforms.NumpyChoiceStream(n_valid, n_pts, state=st0)
+            ids = rows.draw(1)
+            heads = transforms.NumpyHeadsDraw(n_pts, 4, len(self.RANSAC_THRESHOLDS) * self.RANSAC_MAX_ITER, state=rows.state())
+            h = heads.result(set_state=False)
+            return {'start_state': st0, 'n_valid': int(n_valid), 'ids': ids, 'heads': h, 'end_state': heads.state(), 'seconds': time.perf_counter() - t0}
+        return pool.submit(run)
+
+    def predict(self, data, ids=None, predrawn=None):
         """predicter.py:135-203: (nocs_cloud, 4x4 nocs_pose) or (None, None).  The 9-D RANSAC alignment
-        (predicter.py:159-203 -> aligning.estimate9DTransform) runs on the device by default (`align_fn`)."""
-        thresholds, max_iter = [0.003, 0.005], 10000                       # predicter.py:167,170
+        (predicter.py:159-203 -> aligning.estimate9DTransform) runs on the device by default (`align_fn`).
+        predrawn: the result of draw_ahead() for THIS call; used iff numpy's generator stands exactly where the draws started (and the
+        cloud has the size they were made for) -- the call then returns the same values and leaves the same generator state as
+        without it -- and silently ignored otherwise."""
+        thresholds, max_iter = list(self.RANSAC_THRESHOLDS), self.RANSAC_MAX_ITER
         draw = []
+        if predrawn is not None and (ids is not None or not transforms.same_state(np.random.get_state(), predrawn['start_state'])
+                                     or predrawn['n_valid'] != int(transforms.valid_mask(np.asarray(data['cloud_xyz'], dtype=np.float64)).sum())):
+            predrawn = None
+        if predrawn is not None:
+            ids = predrawn['ids']
 
         def start_hypothesis_draw(n):
-            if self._predraw and n >= 4:
+            if predrawn is None and self._predraw and n >= 4:
                 draw.append(transforms.NumpyHeadsDraw(n, 4, len(thresholds) * max_iter, pool=_draw_worker()))
         import time
         t0 = time.perf_counter()
@@ -482,6 +525,9 @@ class NunocsPredicter:
             self._after_draw = None
         t1 = time.perf_counter()
         hyp = draw[0].result() if draw else None
+        if predrawn is not None:
+            hyp = predrawn['heads']
+            np.random.set_state(predrawn['end_state'])      # where the reference's own draws would have left the generator
         t2 = time.perf_counter()
         ori = dt['cloud_xyz_original']
         best_ratio, best_transform = 0, None
@@ -501,6 +547,8 @@ class NunocsPredicter:
         self.timings = {'nunocs net + decode': t1 - t0, 'ransac id draw (exposed)': t2 - t1, 'ransac kernels + selection': time.perf_counter() - t2}
         if draw:
             self.timings['ransac id draw'] = draw[0].seconds
+        if predrawn is not None:
+            self.timings['ransac id draw'] = predrawn['seconds']          # spent earlier, on the draw-ahead thread
         if best_transform is None:
             return None, None
         self.best_ratio = best_ratio

@@ -20,18 +20,24 @@ class NumpyChoiceStream:
     Mersenne-Twister state back into numpy on close().  The C call holds no GIL, so a worker thread can draw the next chunk while
     the device scores the current one."""
 
-    def __init__(self, n_valid, n_pts):
+    def __init__(self, n_valid, n_pts, state=None):
+        """state: an explicit generator state (get_state() layout) to replay from instead of numpy's current one -- drawing AHEAD of
+        the point the global generator has reached (pipeline.evaluate_objects); close() then is the caller's decision."""
         import ctypes
         from . import _lib as L
         self._ct, self._fn = ctypes, L.lib().cg_host_numpy_choice_rows
         self.n_valid, self.n_pts = int(n_valid), int(n_pts)
-        st = np.random.get_state()
+        st = np.random.get_state() if state is None else state
         if st[0] != 'MT19937':
             raise RuntimeError(f'numpy global generator is {st[0]}, expected the legacy MT19937')
         self._rest = (st[3], st[4])
         self._key = np.ascontiguousarray(st[1], dtype=np.uint32).copy()
         self._pos = ctypes.c_int(int(st[2]))
         self._scratch = np.empty((max(self.n_valid, 1),), dtype=np.int32)
+
+    def state(self):
+        """The generator state this replay has reached (get_state() layout, own copy of the key)."""
+        return ('MT19937', self._key.copy(), int(self._pos.value)) + self._rest
 
     def draw(self, count, out=None):
         ct = self._ct
@@ -89,12 +95,12 @@ class NumpyHeadsDraw:
 
     HEAD_MAX, N_MAX = 16, 65536
 
-    def __init__(self, n, k, count, pool=None, isa=0):
+    def __init__(self, n, k, count, pool=None, isa=0, state=None):
         import ctypes
         from . import _lib as L
         if not (2 <= n <= self.N_MAX and 1 <= k <= min(n, self.HEAD_MAX)):
             raise ValueError(f'NumpyHeadsDraw: n={n}, k={k} outside 2 <= n <= {self.N_MAX}, 1 <= k <= min(n, {self.HEAD_MAX})')
-        st = np.random.get_state()
+        st = np.random.get_state() if state is None else state          # explicit state: a draw ahead of the global generator
         if st[0] != 'MT19937':
             raise RuntimeError(f'numpy global generator is {st[0]}, expected the legacy MT19937')
         self._rest = (st[3], st[4])
@@ -117,14 +123,42 @@ class NumpyHeadsDraw:
         self._future = pool.submit(run) if pool is not None else None
         self._run = run
 
-    def result(self):
+    def result(self, set_state=True):
         out = self._future.result() if self._future is not None else self._run()
-        np.random.set_state(('MT19937', self._key, int(self._pos.value)) + self._rest)
+        if set_state:
+            np.random.set_state(('MT19937', self._key, int(self._pos.value)) + self._rest)
         return out
+
+    def state(self):
+        """The generator state after the draw (valid once result() returned)."""
+        return ('MT19937', self._key.copy(), int(self._pos.value)) + self._rest
 
     def cancel(self):
         if self._future is not None:
             self._future.exception()
+
+
+def same_state(a, b):
+    """Two generator states (get_state() layout) denote the same point of the stream."""
+    return a[0] == b[0] and int(a[2]) == int(b[2]) and int(a[3]) == int(b[3]) and float(a[4]) == float(b[4]) and np.array_equal(a[1], b[1])
+
+
+def advance_choice_rows(state, n_valid, n_pts, count, piece=1024):
+    """The generator state after `count` further draws of np.random.choice(np.arange(n_valid), n_pts, replace=n_valid<n_pts) from
+    `state`, without keeping the rows: where the stream WILL stand once a scoring pass has drawn its resampling indices."""
+    st = NumpyChoiceStream(n_valid, n_pts, state=state)
+    if st.on_device_chain:
+        buf = np.empty((min(piece, max(count, 1)), st.partner_stride), dtype=np.uint16)
+        draw = st.draw_partners
+    else:
+        buf = np.empty((min(piece, max(count, 1)), n_pts), dtype=np.int32)
+        draw = st.draw
+    done = 0
+    while done < count:
+        c = min(len(buf), count - done)
+        draw(c, out=buf[:c])
+        done += c
+    return st.state()
 
 
 def draw_choice_heads(n, k, count):

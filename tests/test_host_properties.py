@@ -102,3 +102,28 @@ def test_numpy_choice_heads_at_arbitrary_sizes_and_positions(n, k, seed, burn, c
     np.random.seed(seed); np.random.randint(0, 7, burn)
     got = transforms.NumpyHeadsDraw(n, k, count, isa=isa).result()
     assert np.array_equal(got, want) and np.array_equal(np.random.randint(0, 2 ** 31, 3), after_want)
+
+
+def test_explicit_state_replays_draw_ahead_of_the_global_generator():
+    """transforms.NumpyChoiceStream / NumpyHeadsDraw from an explicit generator state, advance_choice_rows: what
+    pipeline.evaluate_objects uses to make the next object's draws before numpy's global generator has got there."""
+    import numpy as np
+    from catgrasp_amd import transforms as T
+    for n_valid, n_pts, rows in ((2500, 2048, 37), (900, 2048, 5), (2048, 2048, 3), (70000, 2048, 2)):
+        np.random.seed(n_valid)
+        s0 = np.random.get_state()
+        ref = [np.random.choice(np.arange(n_valid), n_pts, replace=n_valid < n_pts) for _ in range(rows)]
+        s1 = np.random.get_state()
+        nocs = np.random.choice(np.arange(3000), 8192, replace=True)
+        heads = np.array([np.random.choice(8192, size=4, replace=False) for _ in range(60)])
+        s2 = np.random.get_state()
+        np.random.set_state(s0)                                   # the global generator has NOT advanced yet
+        a = T.advance_choice_rows(s0, n_valid, n_pts, rows, piece=4)
+        assert T.same_state(a, s1) and not T.same_state(a, s0)
+        st = T.NumpyChoiceStream(3000, 8192, state=a)
+        assert np.array_equal(st.draw(1)[0], nocs)
+        hd = T.NumpyHeadsDraw(8192, 4, 60, state=st.state())
+        assert np.array_equal(hd.result(set_state=False), heads) and T.same_state(hd.state(), s2)
+        assert T.same_state(np.random.get_state(), s0)            # nothing touched numpy itself
+        got = T.draw_ids_reference(n_valid, n_pts, rows)          # the real draws, later: same rows, and the stream arrives where predicted
+        assert np.array_equal(got, np.array(ref)) and T.same_state(np.random.get_state(), s1)

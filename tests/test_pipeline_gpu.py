@@ -60,3 +60,69 @@ def test_evaluate_object_end_to_end(cuda_device):
     assert 0 < len(out_ik['poses']) and out_ik['n_evaluated'] == out['n_evaluated']
     ee = cam_in_world[None] @ out_ik['poses'].astype(np.float64) @ ee_in_grasp[None]
     assert iiwa_ik.ik_within_limits(ee.astype(np.float32).astype(np.float64), upper, lower).mean() > 0.999
+
+
+def test_evaluate_objects_draw_ahead_equals_the_serial_loop(cuda_device):
+    """the next object's NUNOCS-stage draws are made ahead of numpy's global stream while the device scores the current
+    object (pipeline.evaluate_objects, run_grasp_simulation.py:188-329 order preserved) -- poses, scores, the NUNOCS transforms and the
+    generator state afterwards are those of the serial per-object loop; a foreign draw in between makes the predicter drop the
+    pre-drawn values instead of using stale ones."""
+    from catgrasp_amd import pipeline, transforms
+    from catgrasp_amd.predicter import DEFAULT_GRASP_CFG, DEFAULT_NUNOCS_CFG, GraspPredicter, NunocsPredicter
+    objs = synth.make_scene(4, 2300, seed=5)
+    g = synth.make_gripper()
+    g['finger_vertices'] = [g['vertices'][8:16], g['vertices'][16:24]]
+    g['grip_dirs'] = [[0, -1, 0], [0, 1, 0]]
+    gp = GraspPredicter('nut', cfg=DEFAULT_GRASP_CFG, state_dict=synth.make_state_dict('cls', 6, 10, seed=0), device=cuda_device)
+    npred = NunocsPredicter('nut', cfg=DEFAULT_NUNOCS_CFG, state_dict=synth.make_state_dict('seg', 6, 300, seed=1), device=cuda_device)
+    assert npred._predraw
+    scene_pts = np.concatenate([o['xyz'] for o in objs])
+    K = np.array([[600, 0, 320], [0, 600, 240], [0, 0, 1.0]])
+    rng = np.random.default_rng(0)
+    canon_pts, canon_nrm = synth.nut_surface(2000, rng)
+    job = [{'ob_pts': o['xyz'], 'ob_normals': o['normal'], 'symmetry_tfs': [np.eye(4)], 'nocs_pose_override': o['pose'],
+            'canonical': {'cloud': canon_pts, 'normals': canon_nrm, 'affordance': rng.uniform(0, 1, 2000),
+                          'grasps': np.linalg.inv(o['pose']) @ synth.make_candidates(o, 40, np.random.default_rng(k))}} for k, o in enumerate(objs)]
+    kw = dict(n_surface_samples=10, rng='numpy')
+
+    def run(**extra):
+        np.random.seed(3)
+        used = []
+        orig = npred.predict
+
+        def spy(data, ids=None, predrawn=None):
+            r = orig(data, ids, predrawn)
+            used.append(predrawn is not None and 'ransac id draw (exposed)' in npred.timings and npred.timings['ransac id draw (exposed)'] < 5e-3)
+            return r
+        npred.predict = spy
+        try:
+            outs = pipeline.evaluate_objects(job, scene_pts, K, g, gp, npred, **kw, **extra)
+        finally:
+            del npred.predict
+        return outs, np.random.get_state(), used
+    serial, st_serial, _ = run(draw_ahead=False)
+    ahead, st_ahead, used = run(draw_ahead=True)
+    assert transforms.same_state(st_serial, st_ahead)
+    assert used[0] is False and all(used[1:])                   # objects 1.. took their pre-drawn hypothesis samples without waiting
+    for a, b in zip(serial, ahead):
+        assert a['n_evaluated'] == b['n_evaluated'] and len(a['poses']) > 0
+        assert np.array_equal(a['poses'], b['poses']) and np.array_equal(a['p_G'], b['p_G']) and np.array_equal(a['p_T_G'], b['p_T_G'])
+        assert (a['nocs_pose'] is None) == (b['nocs_pose'] is None) and (a['nocs_pose'] is None or np.array_equal(a['nocs_pose'], b['nocs_pose']))
+    # the per-object calls of the reference loop give the same again
+    np.random.seed(3)
+    for ob, want in zip(job, serial):
+        one = pipeline.evaluate_object(ob['ob_pts'], ob['ob_normals'], scene_pts, K, g, gp, npred, canonical=ob['canonical'], symmetry_tfs=ob['symmetry_tfs'],
+                                       nocs_pose_override=ob['nocs_pose_override'], **kw)
+        assert np.array_equal(one['poses'], want['poses']) and np.array_equal(one['p_T_G'], want['p_T_G'])
+    assert transforms.same_state(np.random.get_state(), st_serial)
+    # pre-drawn values made for another stream position are not used
+    np.random.seed(3)
+    fut = npred.draw_ahead(int(transforms.valid_mask(objs[0]['xyz']).sum()), np.random.get_state(), __import__('catgrasp_amd.predicter', fromlist=['x']).draw_ahead_worker())
+    np.random.rand()                                            # somebody else draws in between
+    st = np.random.get_state()
+    a_cloud, a_pose = npred.predict({'cloud_xyz': objs[0]['xyz'], 'cloud_normal': objs[0]['normal']}, predrawn=fut.result())
+    st_after = np.random.get_state()
+    np.random.set_state(st)
+    b_cloud, b_pose = npred.predict({'cloud_xyz': objs[0]['xyz'], 'cloud_normal': objs[0]['normal']})
+    assert transforms.same_state(st_after, np.random.get_state())
+    assert (a_pose is None) == (b_pose is None) and (a_pose is None or np.array_equal(a_pose, b_pose))
