@@ -117,6 +117,17 @@ def make_occupancy_grid(pts, resolution):
     return out[:n]
 
 
+def cast_ray(pts, resolution, direction, max_range):
+    """octomap castRay restatement from the origin over the occupied leaves of pts -> (hit, leaf centre (3,) f32)."""
+    pts = _f(np.asarray(pts).reshape(-1, 3)); d = _f(direction); end = np.zeros(3, dtype=np.float32)
+    hit = lib().cr_cast_ray(_fp(pts), ctypes.c_int(len(pts)), ctypes.c_float(resolution), _fp(d), ctypes.c_float(max_range), _fp(end))
+    return bool(hit), end
+
+
+def set_occupancy_variant(tie=0, range_last=0, fcoord=0, fdir=0, strict=0):
+    lib().cr_set_occupancy_variant(*[ctypes.c_int(int(v)) for v in (tie, range_last, fcoord, fdir, strict)])
+
+
 _IK_SO = os.path.join(_DIR, '_ref', 'libikfast_ref.so')
 
 

@@ -653,16 +653,36 @@ static int keyset_has(const keyset_t* s, uint64_t k) {
 
 /* castRay from the origin (0,0,0) along `dirf` (float, already normalised by the caller, normalised again here
  * like octomap does).  Returns 1 and the hit leaf centre (float) on a hit. */
+/* Points where octomap implementations / readings of castRay can differ (the library is absent: PARITY UNPINNED); selectable for the
+ * sensitivity study oracle/occupancy_sensitivity.py.  All 0 = the parity oracle (and csrc/occupancy.hip).
+ *   tie        0: the dimension with the smallest tMax, ties broken as `<` does (x before y before z only on strict order);  1: `<=`
+ *   range_last 0: the maxRange test on the new leaf's centre comes BEFORE its occupancy test;  1: after (an occupied leaf just beyond
+ *                 maxRange is still reported)
+ *   fcoord     0: leaf centre = (float)(((double)key - 32768 + 0.5) * res);  1: float arithmetic throughout, ((float)(key - 32768) + 0.5f) * (float)res
+ *   fdir       0: direction normalised by a double square root of the float dot product (octomath::Vector3::normalized as restated);
+ *                 1: float square root
+ *   strict     0: lattice point kept iff dist <= dist_query;  1: iff dist < dist_query  (common.cpp:399 reads `<=`; the variant
+ *                 measures how many points sit exactly on the boundary) */
+static struct { int tie, range_last, fcoord, fdir, strict; } g_occ_variant = {0, 0, 0, 0, 0};
+void cr_set_occupancy_variant(int tie, int range_last, int fcoord, int fdir, int strict) {
+  g_occ_variant.tie = tie; g_occ_variant.range_last = range_last; g_occ_variant.fcoord = fcoord; g_occ_variant.fdir = fdir; g_occ_variant.strict = strict;
+}
+static float occ_leaf_coord(int key, double resolution) {
+  if (g_occ_variant.fcoord) return ((float)(key - TREE_MAX_VAL) + 0.5f) * (float)resolution;
+  return (float)(((double)key - TREE_MAX_VAL + 0.5) * resolution);
+}
+
 static int cast_ray_origin(const keyset_t* occ, const float dirf[3], double resolution, double max_range, float end[3]) {
   int key[3] = {TREE_MAX_VAL, TREE_MAX_VAL, TREE_MAX_VAL};                 /* coordToKey(0) = floor(0) + 32768 */
   if (keyset_has(occ, pack_key(key[0], key[1], key[2]))) {
-    for (int i = 0; i < 3; ++i) end[i] = (float)(((double)key[i] - TREE_MAX_VAL + 0.5) * resolution);
+    for (int i = 0; i < 3; ++i) end[i] = occ_leaf_coord(key[i], resolution);
     return 1;
   }
   /* octomath::Vector3::normalized(): len = sqrt(x*x+y*y+z*z) (float products, double sqrt), components / (float)len */
   float d[3];
   {
-    const double len = sqrt((double)(dirf[0] * dirf[0] + dirf[1] * dirf[1] + dirf[2] * dirf[2]));
+    const float dot = dirf[0] * dirf[0] + dirf[1] * dirf[1] + dirf[2] * dirf[2];
+    const double len = g_occ_variant.fdir ? (double)sqrtf(dot) : sqrt((double)dot);
     for (int i = 0; i < 3; ++i) d[i] = (len > 0) ? dirf[i] / (float)len : dirf[i];
   }
   int step[3]; double tmax[3], tdelta[3];
@@ -679,18 +699,36 @@ static int cast_ray_origin(const keyset_t* occ, const float dirf[3], double reso
   const double max_range_sq = max_range * max_range;
   for (;;) {
     int dim;
-    if (tmax[0] < tmax[1]) dim = (tmax[0] < tmax[2]) ? 0 : 2; else dim = (tmax[1] < tmax[2]) ? 1 : 2;
+    if (g_occ_variant.tie) { if (tmax[0] <= tmax[1]) dim = (tmax[0] <= tmax[2]) ? 0 : 2; else dim = (tmax[1] <= tmax[2]) ? 1 : 2; }
+    else { if (tmax[0] < tmax[1]) dim = (tmax[0] < tmax[2]) ? 0 : 2; else dim = (tmax[1] < tmax[2]) ? 1 : 2; }
     if ((step[dim] < 0 && key[dim] == 0) || (step[dim] > 0 && key[dim] == 2 * TREE_MAX_VAL - 1)) return 0;
     key[dim] += step[dim];
     tmax[dim] += tdelta[dim];
-    for (int i = 0; i < 3; ++i) end[i] = (float)(((double)key[i] - TREE_MAX_VAL + 0.5) * resolution);
+    for (int i = 0; i < 3; ++i) end[i] = occ_leaf_coord(key[i], resolution);
+    int beyond = 0;
     if (max_range > 0.0) {
       double dsq = 0.0;
       for (int i = 0; i < 3; ++i) dsq += ((double)end[i] - 0.0) * ((double)end[i] - 0.0);
-      if (dsq > max_range_sq) return 0;
+      beyond = dsq > max_range_sq;
     }
+    if (beyond && !g_occ_variant.range_last) return 0;
     if (keyset_has(occ, pack_key(key[0], key[1], key[2]))) return 1;
+    if (beyond) return 0;
   }
+}
+
+/* one castRay from the origin over the occupied leaves of `pts` (tests of the variants above): 1 + the hit leaf centre, or 0 */
+int cr_cast_ray(const float* pts, int P, float resolution, const float* dir, float max_range, float* end) {
+  keyset_t occ; keyset_init(&occ, (size_t)(P > 0 ? P : 1));
+  const double res_factor = 1.0 / (double)resolution;
+  for (int i = 0; i < P; ++i) {
+    int k[3], ok = 1;
+    for (int a = 0; a < 3; ++a) ok &= coord_to_key(pts[i * 3 + a], res_factor, &k[a]);
+    if (ok) keyset_insert(&occ, pack_key(k[0], k[1], k[2]));
+  }
+  const int hit = cast_ray_origin(&occ, dir, (double)resolution, (double)max_range, end);
+  free(occ.slots);
+  return hit;
 }
 
 /* Returns the number of occupied lattice points written to out (capacity cap points, (x,y,z) float each);
@@ -737,7 +775,7 @@ long cr_make_occupancy_grid(const float* pts, int P, float resolution, float* ou
           if (!cast_ray_origin(&occ, dir, res_d, (double)max_range, end)) continue;
           const float dist_query = sqrtf(x * x + y * y + z * z);
           const float dist = (float)sqrt((double)(end[0] * end[0] + end[1] * end[1] + end[2] * end[2]));
-          if (dist <= dist_query) {
+          if (g_occ_variant.strict ? dist < dist_query : dist <= dist_query) {
             if (pass == 1 && offs[xi] + c < cap) { float* o = out + (offs[xi] + c) * 3; o[0] = x; o[1] = y; o[2] = z; }
             ++c;
           }

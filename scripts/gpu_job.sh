@@ -25,6 +25,10 @@ case $JOB in
   bench)      # the default bench line + its kernel statistics
     ( time timeout 900 python bench.py "$@" ) > $O/bench.json 2> $O/bench.err; tail -c 300 $O/bench.err; head -c 600 $O/bench.json
     stats bench python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-api --no-pmc-traffic --no-rccl-selftest --no-projection ;;
+  pick)       # the pick cycle block of the bench alone (api.pick_cycle) + the tests of the pipeline
+    timeout 600 python -m pytest tests/test_pipeline_gpu.py tests/test_collision_gpu.py tests/test_dataparallel_gpu.py tests/test_pointnet2_encoder_gpu.py -m gpu -x -q > $O/pytest.log 2>&1; tail -8 $O/pytest.log
+    timeout 600 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pmc-traffic --no-rccl-selftest --no-projection --secondary "" > $O/bench.json 2> $O/bench.err; tail -c 300 $O/bench.err
+    python -c "import json;d=json.load(open('$O/bench.json'));print(json.dumps(d['api']['pick_cycle'],indent=1))" | head -80 ;;
   py)         # any script:  py scripts/x.py args...
     timeout 1200 python "$@" > $O/out.txt 2>&1; tail -40 $O/out.txt ;;
   *) echo "unknown job $JOB"; exit 2 ;;

@@ -53,3 +53,38 @@ def test_ray_cast_on_synthetic_walls_and_single_points():
     occ, ok = oe.decide(pts, 0.002, q, max_range)
     mutant = np.sqrt((q.astype(np.float64) ** 2).sum(1)) >= np.sqrt(((oe.occupied_leaves(pts, 0.002) + 0.5) ** 2).sum(1)).min() * 0.002
     assert (ok & (mutant != occ)).sum() > 100
+
+
+def test_cast_ray_variants_of_the_sensitivity_study_are_live():
+    """oracle/occupancy_sensitivity.py reports 0 flipped lattice points on the C3 background clouds for every alternative reading of
+    octomap::castRay; this shows that each switch does change the walk where its case arises (so 0 is a measurement, not a dead flag)."""
+    from oracle import collision_oracle as co
+    res = 0.001
+    try:
+        # a tie of tMax on the diagonal: `<` steps y first, `<=` steps x first -> different leaves are visited on the way
+        d = np.float32([1, 1, 0]) / np.float32(np.sqrt(2.0))
+        only_x = np.float32([[0.0015, 0.0005, 0.0005]])             # leaf (1, 0, 0)
+        co.set_occupancy_variant()
+        hit0, _ = co.cast_ray(only_x, res, d, 1.0)
+        co.set_occupancy_variant(tie=1)
+        hit1, end1 = co.cast_ray(only_x, res, d, 1.0)
+        assert (hit0, hit1) == (False, True) and np.allclose(end1, [0.0015, 0.0005, 0.0005])
+        # an occupied leaf whose centre lies just beyond maxRange
+        far = np.float32([[0.0105, 0.0005, 0.0005]])                # leaf (10, 0, 0), centre at 10.5 mm
+        co.set_occupancy_variant()
+        assert co.cast_ray(far, res, np.float32([1, 0, 0]), 0.0104)[0] is False
+        co.set_occupancy_variant(range_last=1)
+        assert co.cast_ray(far, res, np.float32([1, 0, 0]), 0.0104)[0] is True
+        # leaf centres in float arithmetic: NOT a degree of freedom -- (k + 0.5) and res are floats, their double product is exact, so
+        # rounding it once IS the float product
+        diff = 0
+        for k in range(1, 400):
+            p = np.float32([[(k + 0.5) * res, 0.0005, 0.0005]])
+            co.set_occupancy_variant()
+            _, a = co.cast_ray(p, res, np.float32([1, 0, 0]), 10.0)
+            co.set_occupancy_variant(fcoord=1)
+            _, b = co.cast_ray(p, res, np.float32([1, 0, 0]), 10.0)
+            diff += int(a[0] != b[0])
+        assert diff == 0
+    finally:
+        co.set_occupancy_variant()
