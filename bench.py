@@ -134,9 +134,10 @@ GRIPPER_SUBDIVISIONS = 4                                # the step's gripper mes
 PEAK_L2_GBS = 34500.0                                   # MI355X_MICROARCH.md: L2 4 MiB per XCD, ~34.5 TB/s aggregate
 
 
-def filter_roofline_block(batch, device, reps=5):
+def filter_roofline_block(batch, device, reps=5, issue=None):
     """roofline_filter: the collision filter of the step, object 0's two segments (canonical grasps x symmetries with nudging; cone poses),
     alone on the stream: HIP-event time of the three launches of a call (pose composition, grid kernel, exhaustive finisher) against the
+    chip's vector-instruction issue rate (`issue` = pmc_filter_issue's counters of the same two calls), with, beside it, the
     CACHE-LEVEL bytes the grid kernel itself counts (cg_filter_grasp_pose_accel work_stats: 8 B per voxel key read, 8 B per grid cell
     looked up, 48 B of triangle + 4 B of list entry per (voxel, triangle) pair tested) plus the algorithmic HBM bytes (64 B pose in,
     66 B out per evaluation).  HBM-wise the kernel is trivial; the voxel keys, cell table and triangles are L2 / L1 resident."""
@@ -161,16 +162,26 @@ def filter_roofline_block(batch, device, reps=5):
         tot_ms += e0.elapsed_time(e1) / reps; E_tot += E; w_tot += w
         tot_bytes += int(8 * w[0] + 8 * w[1] + 52 * w[2] + 130 * E)
     gbs = tot_bytes / (tot_ms * 1e-3) / 1e9
-    return {'bound': 'l2', 'kernel': 'compose_grasp_pose_kernel + filter_grasp_pose_kernel<true> (+ the exhaustive finisher, which finds nothing to do)',
-            'achieved': round(gbs, 1), 'peak': PEAK_L2_GBS, 'unit': 'GB/s', 'frac': round(gbs / PEAK_L2_GBS, 4),
-            'traffic': None, 'cache_level_bytes': tot_bytes, 'evaluations': E_tot, 'ms': round(tot_ms, 4),
-            'evaluations_per_s': round(E_tot / (tot_ms * 1e-3), 1),
-            'voxel_keys_read': int(w_tot[0]), 'grid_cells_looked_up': int(w_tot[1]), 'pairs_tested': int(w_tot[2]),
-            'gripper_triangles': [int(len(g['faces'])), int(len(g['enclosed_faces']))],
-            'hbm_algorithmic_bytes': 130 * E_tot,
-            'note': 'cache-level figure (what the lanes load from L1 / L2), not HBM; `traffic` (HBM by PMC) and the issue-side counters of the same call '
-                    'shapes are in profiles/r4_pmc_*_filter.csv: the kernel is bound by vector-instruction issue (broad-phase arithmetic per voxel, '
-                    'the 13-axis SAT per pair), not by bytes'}
+    cache = {'cache_level_bytes': tot_bytes, 'cache_level_GBps': round(gbs, 1), 'frac_of_l2_peak': round(gbs / PEAK_L2_GBS, 4), 'l2_peak_GBps': PEAK_L2_GBS,
+             'voxel_keys_read': int(w_tot[0]), 'grid_cells_looked_up': int(w_tot[1]), 'pairs_tested': int(w_tot[2]),
+             'note': 'what the lanes load from L1 / L2 (counted by the kernel itself), not HBM: 8 B per voxel key, 8 B per grid cell, 52 B per pair'}
+    out = {'bound': 'valu-issue', 'kernel': 'compose_grasp_pose_kernel + filter_grasp_pose_kernel<true> (+ the exhaustive finisher, which finds nothing to do)',
+           'achieved': None, 'peak': round(PEAK_VALU_WAVE_INSTS_PER_S / 1e9, 1), 'unit': 'G wave-instructions/s', 'frac': None, 'traffic': None,
+           'evaluations': E_tot, 'ms': round(tot_ms, 4), 'evaluations_per_s': round(E_tot / (tot_ms * 1e-3), 1),
+           'gripper_triangles': [int(len(g['faces'])), int(len(g['enclosed_faces']))], 'hbm_algorithmic_bytes': 130 * E_tot, 'cache_level': cache,
+           'note': 'the kernel is bound by vector-instruction issue (broad-phase arithmetic per voxel, the 13-axis separating-axis test per pair), '
+                   'neither by HBM (130 B per evaluation) nor by cache bytes: `achieved` = wavefront-level VALU instructions of the grid kernel '
+                   '(SQ_INSTS_VALU, PMC child pass of this run) / the HIP-event time of the calls; peak = one wave64 instruction per CU per clock '
+                   '(256 CUs x 2.4 GHz); wait_share = SQ_WAIT_ANY / SQ_WAVE_CYCLES'}
+    if issue is not None and issue[0] is not None:
+        c = issue[0]
+        ach = c['valu_wave_insts'] / (tot_ms * 1e-3)
+        out.update(achieved=round(ach / 1e9, 1), frac=round(ach / PEAK_VALU_WAVE_INSTS_PER_S, 4), valu_wave_insts=int(c['valu_wave_insts']),
+                   valu_wave_insts_per_evaluation=round(c['valu_wave_insts'] / max(E_tot, 1), 1), wait_share=round(c['wait_any'] / c['wave_cycles'], 4),
+                   counters_source=issue[1])
+    elif issue is not None:
+        out['counters_source'] = f'not measured in this run ({issue[1]}); profiles/r4_pmc_sq_filter.csv holds the round-4 counters'
+    return out
 
 
 def pick_cycle_block(batch, gp, npred, device, n_canonical=2000):
@@ -347,6 +358,52 @@ def cpu_baseline(batch, sd_cls, sd_seg, n_score=100, n_coll=4096):
             'thread_scan_ms_per_candidate': scan}
 
 
+PEAK_VALU_WAVE_INSTS_PER_S = 256 * 2.4e9                # one wave64 vector instruction per CU and clock (4 SIMD16 x 4 cycles), 256 CUs, 2.4 GHz
+
+
+def pmc_filter_issue(args):
+    """The issue-side counters of the filter's grid kernel for THIS run's scene: one child run of this script (--pmc-filter-child: object
+    0's two filter calls, 1 warm-up + 3 timed) under `rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY` (counters only).
+    -> ({'valu_wave_insts', 'wave_cycles', 'wait_any'} per pair of calls, source text) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    from collections import defaultdict
+    exe = shutil.which('rocprofv3') or '/opt/rocm/bin/rocprofv3'
+    if not os.path.exists(exe):
+        return None, 'rocprofv3 not found'
+    tmp = tempfile.mkdtemp(prefix='cg_pmcf_', dir='/tmp')
+    counters = ('SQ_INSTS_VALU', 'SQ_WAVE_CYCLES', 'SQ_WAIT_ANY')
+    try:
+        cmd = [exe, '--pmc', *counters, '--kernel-include-regex', 'filter_grasp_pose_kernel', '--output-format', 'csv', '-d', tmp, '--',
+               sys.executable, os.path.abspath(__file__), '--pmc-filter-child', '--gpus', '1', '--workload', args.workload, '--candidates',
+               str(args.candidates), '--candidates-total', str(args.candidates_total)]
+        r = subprocess.run(cmd, cwd='/tmp', env=dict(os.environ, TMPDIR='/tmp'), capture_output=True, text=True, timeout=300)
+        if r.returncode != 0:
+            return None, f'rocprofv3 exited with {r.returncode}: {r.stderr[-300:]}'
+        child = [ln for ln in r.stdout.splitlines() if ln.startswith('{"pmc_filter_child"')]
+        if not child:
+            return None, 'the counter pass printed no child record'
+        rounds = json.loads(child[-1])['rounds']
+        tot = defaultdict(float)
+        for path in glob.glob(os.path.join(tmp, '**', '*counter_collection.csv'), recursive=True):
+            with open(path) as f:
+                for row in csv.DictReader(f):
+                    name = row.get('Kernel_Name') or row.get('kernel_name') or ''
+                    if 'filter_grasp_pose_kernel<true>' in name.replace('(anonymous namespace)::', '') or 'filter_grasp_pose_kernelILb1' in name:
+                        tot[row.get('Counter_Name') or row.get('counter_name')] += float(row.get('Counter_Value') or row.get('counter_value'))
+        if not all(tot.get(c) for c in counters):
+            return None, f'counters missing in the rocprofv3 output: {dict(tot)}'
+        return ({'valu_wave_insts': tot['SQ_INSTS_VALU'] / rounds, 'wave_cycles': tot['SQ_WAVE_CYCLES'] / rounds, 'wait_any': tot['SQ_WAIT_ANY'] / rounds},
+                f'rocprofv3 --pmc {" ".join(counters)} over {rounds} rounds of the two filter calls of object 0 (child pass of this command)')
+    except Exception as e:
+        return None, f'{type(e).__name__}: {e}'
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def pmc_traffic(args, precision):
     """roofline.traffic measured for THIS run's workload instead of quoted from profiles/ (opt-in: --pmc-traffic, N = 1): two child
     runs of this script under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes, counters only -- no tracing
@@ -475,9 +532,11 @@ def main():
                     help='measure roofline.traffic for this run with two rocprofv3 --pmc child passes (N = 1 only; adds ~1 min).  Default: on '
                          'when rocprofv3 is present')
     ap.add_argument('--no-pmc-traffic', dest='pmc_traffic', action='store_false', help='quote the constant from profiles/ instead')
+    ap.add_argument('--pmc-traffic-all', action='store_true', help='measure the traffic of every secondary precision too (two child passes each)')
     ap.add_argument('--no-projection', action='store_true', help='skip the projected_scaling block (N = 1: slice timings of the 2 / 4 / 8-rank shards)')
     ap.add_argument('--no-rccl-selftest', action='store_true', help='skip the one-rank RCCL all-gather check after the timed region (N = 1)')
     ap.add_argument('--pmc-child', action='store_true', help=argparse.SUPPRESS)      # the child run of --pmc-traffic: workload only
+    ap.add_argument('--pmc-filter-child', action='store_true', help=argparse.SUPPRESS)   # the child run of pmc_filter_issue: object 0's filter calls
     args = ap.parse_args()
     if args.scaling == 'weak' and args.workload != 'C3':
         ap.error(f'--workload {args.workload} is a strong-scaling workload')
@@ -542,6 +601,24 @@ def main():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
+
+    if args.pmc_filter_child:   # counter pass of pmc_filter_issue: the two filter calls of object 0, 1 warm-up + 3 rounds
+        from catgrasp_amd import my_cpp
+        I4 = np.eye(4, dtype=np.float32)
+        g = batch.gripper
+        segs0 = [s_ for s_ in batch.segs if s_.obj == 0 and s_.replica == 0]
+
+        def one_round():
+            for seg in segs0:
+                P = batch.segment_poses(seg)
+                sym, nocs = (batch.syms[batch.cats[0]], batch.nocs_pose[0]) if seg.kind == 'nocs' else (batch.eye, I4)
+                my_cpp.filter_on_device(batch.scenes[0], P, sym, nocs, I4, I4, I4, g['gripper_in_grasp'], True, False, seg.adjust, keep_rejected_pose=True)
+        rounds = 4
+        for _ in range(rounds):
+            one_round()
+        torch.cuda.synchronize()
+        emit({'pmc_filter_child': True, 'rounds': rounds})
+        return
 
     if args.pmc_child:          # counter pass of --pmc-traffic: run the step, report how many candidates the encoder-pass kernel scored
         engine.set_precision(args.precision)
@@ -670,11 +747,20 @@ def main():
         selftest = rccl_selftest(batch, n_total, ref_out, device)
 
     if rank == 0 and world == 1 and args.pmc_traffic:
-        per, why = pmc_traffic(args, args.precision)
-        if per is not None:
-            measured_traffic[args.precision] = (per, why + '; algorithmic bytes are 69,632 B/candidate')
-        else:
-            print(f'bench.py: --pmc-traffic failed ({why}); quoting the constant from profiles/', file=sys.stderr)
+        # the primary arithmetic and, when it is among the secondaries, bf16x3 (the C5 arithmetic); --pmc-traffic-all: every secondary
+        wanted = [args.precision] + [x['precision'] for x in secondary if 'precision' in x and 'roofline' in x
+                                     and (args.pmc_traffic_all or x['precision'] == 'bf16x3')]
+        for prec in wanted:
+            per, why = pmc_traffic(args, prec)
+            if per is not None:
+                measured_traffic[prec] = (per, why + '; algorithmic bytes are 69,632 B/candidate')
+            else:
+                print(f'bench.py: --pmc-traffic failed for {prec} ({why}); quoting the constant from profiles/', file=sys.stderr)
+        for x in secondary:                     # the secondaries' roofline blocks were built before their traffic was measured
+            if x.get('precision') in measured_traffic and 'roofline' in x:
+                per, source = measured_traffic[x['precision']]
+                x['roofline']['traffic'] = int(per * x['roofline']['candidates_per_launch'])
+                x['roofline']['traffic_source'] = source
     if rank == 0:
         from catgrasp_amd.workload import SYMMETRY_COUNT
         sym_txt = ' / '.join(str(SYMMETRY_COUNT[c]) for c in cats)
@@ -720,7 +806,7 @@ def main():
             line['roofline_hbm'] = prim['bgi']
         if world == 1:
             try:
-                line['roofline_filter'] = filter_roofline_block(batch, device)
+                line['roofline_filter'] = filter_roofline_block(batch, device, issue=pmc_filter_issue(args) if args.pmc_traffic else (None, '--no-pmc-traffic'))
             except Exception as e:          # an extra: never let it take the bench line down
                 line['roofline_filter'] = {'error': f'{type(e).__name__}: {e}'[:300]}
         if secondary:

@@ -45,3 +45,27 @@ def test_bench_line_of_an_8_rank_job_equals_the_1_rank_job(cuda_device):
     assert len(eight['per_rank_ms']['ranks']) == 8 and eight['config']['candidates_per_gpu'] == 750
     assert eight['records_sha256'] == one['records_sha256']              # 8 shards + one all_gather == the unsharded batch, bit for bit
     assert eight['config']['reject_code_histogram_0keep_1dir_2ik_3open_4enclosed'] == one['config']['reject_code_histogram_0keep_1dir_2ik_3open_4enclosed']
+
+
+@pytest.mark.parametrize('workload', ['C4', 'C5'])
+def test_8_rank_job_of_the_8_gpu_configurations_equals_the_1_rank_job(cuda_device, workload):
+    """the layouts the C3 test never takes -- C4 (configs[3]: 40k-point scene, 16 objects, hnm / screw symmetry counts) and
+    C5 (configs[4]: mixed bin, 24 objects, three categories with their own predicters, bf16x3) -- as 8-rank jobs launched like the
+    driver launches them, all ranks on this one device under gloo: the line carries the contract's fields and the gathered records
+    are those of the 1-rank job."""
+    env = dict(os.environ, CATGRASP_BENCH_BACKEND='gloo', CATGRASP_BENCH_DEVICE='0', HSA_ENABLE_IPC_MODE_LEGACY='0', OMP_NUM_THREADS='4')
+    common = ['--workload', workload, '--candidates-total', '4800', '--steps', '1', '--warmup', '1', '--secondary', '', '--no-cpu-baseline', '--no-api',
+              '--no-pmc-traffic', '--no-rccl-selftest', '--no-projection']
+    one = _run([sys.executable, 'bench.py', '--gpus', '1'] + common, env)
+    eight = _run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '8', '--master-addr', '127.0.0.1',
+                  '--master-port', str(_free_port()), 'bench.py', '--gpus', '8'] + common, env)
+    for line, n in ((one, 1), (eight, 8)):
+        for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype',
+                    'data', 'config', 'roofline', 'per_rank_ms', 'records_sha256'):
+            assert key in line, key
+        assert line['n_gpus'] == n and line['scaling'] == 'strong' and line['config']['candidates_total'] == 4800 and line['value'] > 0
+        assert line['config']['workload'].startswith(workload)
+    assert len(eight['per_rank_ms']['ranks']) == 8 and eight['config']['candidates_per_gpu'] == 600
+    assert eight['records_sha256'] == one['records_sha256']
+    if workload == 'C5':
+        assert 'bf16' in one['dtype'] and set(one['config']['symmetries']) == {'nut', 'hnm', 'screw'}
