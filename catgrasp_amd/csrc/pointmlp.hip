@@ -13,6 +13,7 @@
 // points are the MFMA M dimension (A operand, ds_read_b128 from LDS), channels the N dimension
 // (B operand, pre-packed weight fragments streamed from L2 with global_load_dwordx4), so the
 // max over points is a per-lane reduction over the 16 accumulator registers + one lane^32 swap.
+#include <stdlib.h>
 #include "cg_common.hpp"
 #include "../../include/catgrasp_amd.h"
 #include "l3_f32_asm.inc"
@@ -43,7 +44,13 @@ struct Args {
 constexpr int WM_FLOATS = 2 * 8 * 64 * 4;          // the 64 -> 64 layer's B fragments [nb 2][ks 8][lane 64][4]: 16 KB
 constexpr int LDS_FLOATS = TP * S128 + TP * S64 + TP * XS + 1024 + WM_FLOATS;
 
-template <int MID>
+// CS: workgroups that share one (sample, tile slice) and divide the 1024 output channels of the 128 -> 1024 layer between them (each
+// repeats the cheap front layers).  CS = 1 is the throughput kernel; CS = 2 / 4 / 8 serve calls of a few poses (predicter.py:67-94 scores
+// a few hundred per object, a live caller one at a time): one pose is 32 tiles, i.e. 32 workgroups that each stream the whole 0.5 MB
+// weight image through one MFMA chain per wave (38 us per pass) -- split 8 ways it is 256 workgroups with one 32-channel block per wave.
+// Per output element the sequence of MFMAs is the one the CS = 1 stream issues (k ascending from a zero accumulator), so a
+// candidate's bits do not depend on how many candidates it was scored with.
+template <int MID, int CS>
 __global__ __launch_bounds__(256) void pointmlp_max_kernel(Args a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* h2 = smem;                 // also hosts hA (first TP*S64 floats) while h2 is not live
@@ -57,10 +64,12 @@ __global__ __launch_bounds__(256) void pointmlp_max_kernel(Args a) {
   const int lane = tid & 63;
   const int w = tid >> 6;
   int b, split, nsp;
-  if ((int)blockIdx.x < a.n_main * a.nsplit) {
-    nsp = a.nsplit; b = blockIdx.x / nsp; split = blockIdx.x - b * nsp;
+  const int bid = CS == 1 ? (int)blockIdx.x : (int)blockIdx.x / CS;
+  const int cs = CS == 1 ? 0 : (int)blockIdx.x % CS;           // this workgroup's share of the last layer's channels
+  if (bid < a.n_main * a.nsplit) {
+    nsp = a.nsplit; b = bid / nsp; split = bid - b * nsp;
   } else {
-    const int r = blockIdx.x - a.n_main * a.nsplit;
+    const int r = bid - a.n_main * a.nsplit;
     nsp = a.tail_split; b = a.n_main + r / nsp; split = r - (r / nsp) * nsp;
   }
   const int ntiles = (a.N + TP - 1) / TP;
@@ -167,7 +176,7 @@ __global__ __launch_bounds__(256) void pointmlp_max_kernel(Args a) {
         float v = c[r] + bias;
         if (MID == 1) v = fmaxf(v, 0.f);
         hB[row * S64 + col] = v;
-        if (MID == 2 && a.pointfeat) {
+        if (MID == 2 && a.pointfeat && cs == 0) {
           const int p = tile * TP + row;
           if (p < a.N) a.pointfeat[((size_t)b * a.N + p) * 64 + col] = v;
         }
@@ -203,7 +212,29 @@ __global__ __launch_bounds__(256) void pointmlp_max_kernel(Args a) {
     // ---- L3: 128 -> 1024 + running max over points.  wave w owns channel blocks [8w, 8w+8), two at a time x both row tiles.
     // The 1024-MFMA stream of the tile is hand-scheduled assembly (gen_l3_f32_asm.py -> l3_f32_asm.inc): operands prefetched one
     // whole k-step ahead into a double buffer in accumulation registers; it returns the per-lane maxima of the 8 blocks.
-    {
+    if constexpr (CS > 1) {
+      constexpr int NBW = 8 / CS;                          // 32-channel blocks per wave
+      const float* ar0 = h2 + l31 * S128 + lhi * 4;
+      const float* ar1 = ar0 + 32 * S128;
+#pragma unroll
+      for (int p = 0; p < NBW; ++p) {
+        const int nb = cs * (32 / CS) + w * NBW + p;
+        f32x4 bv[16];                                      // the block's 16 weight fragments: all requested before the first product
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) bv[ks] = ((const f32x4*)a.w3)[(size_t)(nb * 16 + ks) * 64 + lane];
+        f32x16 c0 = {0}, c1 = {0};
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+          const f32x4 a0 = *(const f32x4*)(ar0 + ks * 8);
+          const f32x4 a1 = *(const f32x4*)(ar1 + ks * 8);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { c0 = mfma32(a0[j], bv[ks][j], c0); c1 = mfma32(a1[j], bv[ks][j], c1); }
+        }
+        float m = fmaxf(max16(c0), max16(c1));
+        m = fmaxf(m, __shfl_xor(m, 32));
+        if (lane < 32) rmax[nb * 32 + lane] = fmaxf(rmax[nb * 32 + lane], m);
+      }
+    } else {
       const unsigned ar = (unsigned)(uintptr_t)(h2 + l31 * S128 + lhi * 4);      // generic -> LDS byte address = low 32 bits
       const unsigned voff = (unsigned)((w * 8 * 16) * 64 + lane) * 16u;          // this wave's first weight fragment
       float m00, m01, m10, m11, m20, m21, m30, m31, t0, t1;
@@ -230,6 +261,7 @@ __global__ __launch_bounds__(256) void pointmlp_max_kernel(Args a) {
   __syncthreads();
   if (t_end > t_begin) {
     for (int ch = tid; ch < 1024; ch += 256) {
+      if (CS > 1 && ch / (1024 / CS) != cs) continue;
       float v = rmax[ch] + a.b3[ch];
       if (a.relu3) v = fmaxf(v, 0.f);
       if (nsp == 1) a.out[(size_t)b * 1024 + ch] = v;
@@ -278,16 +310,24 @@ extern "C" int cg_pointmlp_max(const float* x, int B, int N, const float* t3, co
   const size_t lds = LDS_FLOATS * sizeof(float);          // 73,728 B: above the 64 KB default limit -> per-device function attribute
   int dev_l = 0;
   if (hipGetDevice(&dev_l) != hipSuccess || dev_l < 0 || dev_l >= CG_MAX_DEVICES) return CG_ERR_UNSUPPORTED;
-  static bool attr_set[3][CG_MAX_DEVICES] = {};
-  const void* kerns[3] = {(const void*)pointmlp_max_kernel<0>, (const void*)pointmlp_max_kernel<1>, (const void*)pointmlp_max_kernel<2>};
-  if (!attr_set[mid_mode][dev_l]) {
-    hipError_t e = hipFuncSetAttribute(kerns[mid_mode], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  // few workgroups (a call of a few poses): divide the last layer's channels over 2 / 4 / 8 workgroups per (sample, slice)
+  const long wgs = (long)n_main * nsplit + (long)(B - n_main) * tail_split;
+  int csi = tail_split > 1 ? 0 : wgs <= 64 ? 3 : wgs <= 128 ? 2 : wgs <= 256 ? 1 : 0;
+  static const char* cs_env = getenv("CATGRASP_AMD_POINTMLP_CSPLIT");     // dev knob: 1 / 2 / 4 / 8
+  if (cs_env) { const int v = atoi(cs_env); csi = tail_split > 1 ? 0 : v == 8 ? 3 : v == 4 ? 2 : v == 2 ? 1 : 0; }
+  static bool attr_set[3][4][CG_MAX_DEVICES] = {};
+  typedef void (*kern_t)(Args);
+  static const kern_t kerns[3][4] = {
+      {pointmlp_max_kernel<0, 1>, pointmlp_max_kernel<0, 2>, pointmlp_max_kernel<0, 4>, pointmlp_max_kernel<0, 8>},
+      {pointmlp_max_kernel<1, 1>, pointmlp_max_kernel<1, 2>, pointmlp_max_kernel<1, 4>, pointmlp_max_kernel<1, 8>},
+      {pointmlp_max_kernel<2, 1>, pointmlp_max_kernel<2, 2>, pointmlp_max_kernel<2, 4>, pointmlp_max_kernel<2, 8>}};
+  const kern_t kern = kerns[mid_mode][csi];
+  if (!attr_set[mid_mode][csi][dev_l]) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    attr_set[mid_mode][dev_l] = true;
+    attr_set[mid_mode][csi][dev_l] = true;
   }
-  dim3 grid((unsigned)(n_main * nsplit + (B - n_main) * tail_split)), block(256);
-  if (mid_mode == 0) hipLaunchKernelGGL(pointmlp_max_kernel<0>, grid, block, lds, s, a);
-  else if (mid_mode == 1) hipLaunchKernelGGL(pointmlp_max_kernel<1>, grid, block, lds, s, a);
-  else hipLaunchKernelGGL(pointmlp_max_kernel<2>, grid, block, lds, s, a);
+  dim3 grid((unsigned)(wgs << csi)), block(256);
+  hipLaunchKernelGGL(kern, grid, block, lds, s, a);
   return cg_hip_status(hipGetLastError());
 }
