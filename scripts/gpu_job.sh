@@ -29,6 +29,12 @@ case $JOB in
     timeout 600 python -m pytest tests/test_pipeline_gpu.py tests/test_collision_gpu.py tests/test_dataparallel_gpu.py tests/test_pointnet2_encoder_gpu.py -m gpu -x -q > $O/pytest.log 2>&1; tail -8 $O/pytest.log
     timeout 600 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pmc-traffic --no-rccl-selftest --no-projection --secondary "" > $O/bench.json 2> $O/bench.err; tail -c 300 $O/bench.err
     python -c "import json;d=json.load(open('$O/bench.json'));print(json.dumps(d['api']['pick_cycle'],indent=1))" | head -80 ;;
+  small)      # small-call latency with / without the channel split + the tests that pin its bits + the multi-rank dev runs
+    timeout 900 python -m pytest tests/test_pointnet_gpu.py tests/test_pointnet_blocks_gpu.py tests/test_predicter_gpu.py -m gpu -x -q > $O/pytest.log 2>&1; tail -5 $O/pytest.log
+    timeout 300 python scripts/time_predict_small.py > $O/predict_small.txt 2>&1; tail -1 $O/predict_small.txt > $O/predict_small.json
+    CATGRASP_AMD_POINTMLP_CSPLIT=1 timeout 300 python scripts/time_predict_small.py > $O/predict_small_nosplit.txt 2>&1
+    grep candidates $O/predict_small.txt | head -12; echo ---; grep candidates $O/predict_small_nosplit.txt | head -12
+    timeout 900 python -m pytest tests/test_bench_multirank_gpu.py -m gpu -x -q > $O/pytest_multirank.log 2>&1; tail -5 $O/pytest_multirank.log ;;
   py)         # any script:  py scripts/x.py args...
     timeout 1200 python "$@" > $O/out.txt 2>&1; tail -40 $O/out.txt ;;
   *) echo "unknown job $JOB"; exit 2 ;;

@@ -104,14 +104,14 @@ def test_dense_layer_bits_do_not_depend_on_the_kernel_or_the_batch(cuda_device):
 def test_a_pose_scored_alone_has_the_bits_it_has_inside_a_large_batch(cuda_device, N):
     """calls of a few poses divide the 1024 output channels of the 128 -> 1024 layer over 2 / 4 / 8 workgroups per point
     tile (pointmlp_max_kernel<MID, CS>), large batches do not; per output element the sequence of matrix FMAs is the same, so logits,
-    feature transform and the NUNOCS head's input are bit-identical whatever the batch a cloud is scored in (1, 3, 9, 20 clouds cover
-    CS = 8, 4, 2 and 1 at 2,048 points)."""
+    feature transform and the NUNOCS head's input are bit-identical whatever the batch a cloud is scored in (1, 3, 5, 20 clouds cover
+    CS = 8, 4, 2 and 1 at 2,048 points; 1 ... 200 clouds at 64 points)."""
     from catgrasp_amd import engine, folding
     sd = synth.make_state_dict('cls', 6, 10, seed=4)
     W = folding.prepare_cls(sd, cuda_device)
     x = _inputs(600, N, 9).to(cuda_device)
     big_logits, big_tf = engine.cls_forward(W, x)
-    for B in (1, 3, 9, 20):
+    for B in (1, 3, 5, 20, 100, 200):
         logits, tf = engine.cls_forward(W, x[:B].contiguous())
         assert torch.equal(logits, big_logits[:B]) and torch.equal(tf, big_tf[:B]), B
     sds = synth.make_state_dict('seg', 6, 30, seed=5)
