@@ -11,7 +11,7 @@ HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-Wall', '-Wno-unused-function']
 # Per-file extras.  The fused MLP kernels reduce MFMA accumulators with fmaxf; under IEEE NaN rules the backend quiets every
 # operand first (v_max x, x), tripling the VALU work of the max epilogue.  Their inputs are finite, so NaNs need no honouring.
-EXTRA_FLAGS = {'pointmlp.hip': ['-fno-honor-nans'], 'pointmlp_split.hip': ['-fno-honor-nans'],
+EXTRA_FLAGS = {'pointmlp.hip': ['-fno-honor-nans'], 'pointmlp_split.hip': ['-fno-honor-nans'], 'sa_tile.hip': ['-fno-honor-nans'],
                # farthest point sampling reads the winner's coordinates out of register vectors with a wave-uniform index; without this
                # LLVM expands an 8-element dynamic extract into a compare + select chain (SIISelLowering: shouldExpandVectorDynExt)
                'fps.hip': ['-mllvm', '-amdgpu-use-divergent-register-indexing']}

@@ -465,7 +465,7 @@ __device__ __forceinline__ T karg_load(const __attribute__((address_space(4))) c
 template <bool GRID>
 __global__ __launch_bounds__(64 * WAVES, 4) void filter_grasp_pose_kernel(FilterArgs a) {
   const __attribute__((address_space(4))) char* kargs = (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
-  __shared__ char lds_raw[WAVES * (GRID ? sizeof(PairList) : sizeof(float) * TRI_CHUNK * TRI_FLOATS)];
+  __shared__ __attribute__((aligned(16))) char lds_raw[WAVES * (GRID ? sizeof(PairList) : sizeof(float) * TRI_CHUNK * TRI_FLOATS)];   // cast to PairList (alignas 16)
   __shared__ float gig_lds[16];                // gripper_in_grasp: read back (broadcast) where a pose is composed, costs no register between
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);

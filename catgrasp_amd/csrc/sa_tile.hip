@@ -22,6 +22,7 @@
 //     running max in LDS); its bias + ReLU commute with the max and are applied once per output.
 // v_mfma_f32_32x32x2_f32 throughout: exact float32 products and accumulation, like the reference's float32 convolution.
 // Algorithmic work per neighbourhood: 2 K sum_l cin_l cout_l flop; HBM bytes: K (8 B index + (3 + D) 4 B gathered) + 12 B + C_L 4 B.
+#include <stdlib.h>
 #include "cg_common.hpp"
 #include "../../include/catgrasp_amd.h"
 
@@ -41,13 +42,24 @@ struct STArgs {
   int KP, RT;                                       // rows of a tile per neighbourhood (8 / 16 / 32 / 64); row tiles per neighbourhood (KP = 64)
 };
 
-// The MFMA stream of one wave for one layer: NBW channel blocks x NH row halves, B fragments one k-step ahead in a double buffer.
+// The MFMA stream of one wave for one layer: NBW channel blocks x NH row halves.  Operand fragments travel DEPTH k-steps ahead of
+// their products through a ring of DEPTH + 1 register slots: a k-step of a narrow share (one block: 8 MFMAs = 512 cycles) is shorter
+// than an L2 round trip, so one k-step of lead leaves the matrix pipe waiting (measured: 0.60 of the f32 peak at 16 clouds with
+// DEPTH = 1); wide shares (>= 4 block-halves per wave) keep DEPTH = 1, their k-steps are long enough and their accumulators need the
+// registers.
 // arow: this lane's A-fragment row of the first half (strip + (rowbase + l31) * CS + lhi * 4); the second half is 32 rows further.
 // wp: packed weights + lane; fragment of (block nb, k-step ks) = wp[(nb * nks + ks) * 64].
 template <int NBW, int NH>
 __device__ __forceinline__ void st_mma(const float* arow, int CS, const f32x4* wp, int nks, const int (&blk)[NBW], f32x16 (&acc)[NBW][NH]) {
-  f32x4 av[2][NH], bv[2][NBW];
-  auto load = [&](int ks, int slot) {
+#ifndef ST_DEPTH_NARROW
+#define ST_DEPTH_NARROW 3
+#endif
+  constexpr int DEPTH = NBW * NH <= 2 ? ST_DEPTH_NARROW : 1;
+  constexpr int SLOTS = DEPTH + 1;
+  f32x4 av[SLOTS][NH], bv[SLOTS][NBW];
+  const int last = nks - 1;
+  auto load = [&](int ks, int slot) {       // past the end: a repeated, unused load (a conditional one would put a phi on the registers)
+    ks = ks < last ? ks : last;
 #pragma unroll
     for (int h = 0; h < NH; ++h) av[slot][h] = *(const f32x4*)(arow + h * 32 * CS + ks * 8);
 #pragma unroll
@@ -61,25 +73,24 @@ __device__ __forceinline__ void st_mma(const float* arow, int CS, const f32x4* w
 #pragma unroll
         for (int h = 0; h < NH; ++h) acc[i][h] = mfma32(av[slot][h][j], bv[slot][i][j], acc[i][h]);
   };
-  auto pin = [&](int slot) {               // a use that keeps the prefetch in THIS iteration (LLVM otherwise sinks it in front of its MFMAs)
-#pragma unroll
+  auto pin = [&](int slot) {               // a use that keeps the NEXT k-step's operands in this iteration (LLVM otherwise sinks their loads
+#pragma unroll                              // in front of their MFMAs); they were requested DEPTH k-steps ago
     for (int h = 0; h < NH; ++h) asm volatile("" : "+v"(av[slot][h]));
 #pragma unroll
     for (int i = 0; i < NBW; ++i) asm volatile("" : "+v"(bv[slot][i]));
   };
-  load(0, 0);
-  for (int ks = 0; ks < nks; ks += 2) {
-    load(ks + 1 < nks ? ks + 1 : ks, 1);     // past the end: a repeated, unused load (a conditional one would put a phi on the registers)
-    __builtin_amdgcn_sched_barrier(0);
-    mma(0);
-    __builtin_amdgcn_sched_barrier(0);
-    pin(1);
-    if (ks + 1 >= nks) break;
-    load(ks + 2 < nks ? ks + 2 : ks + 1, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    mma(1);
-    __builtin_amdgcn_sched_barrier(0);
-    pin(0);
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) load(d, d);
+  for (int ks0 = 0; ks0 < nks; ks0 += SLOTS) {
+#pragma unroll
+    for (int u = 0; u < SLOTS; ++u) {
+      if (u > 0 && ks0 + u >= nks) break;
+      load(ks0 + u + DEPTH, (u + DEPTH) % SLOTS);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(u);
+      __builtin_amdgcn_sched_barrier(0);
+      pin((u + 1) % SLOTS);
+    }
   }
 }
 
@@ -183,7 +194,7 @@ __device__ __forceinline__ void st_last(const STArgs& a, const float* strip, con
 // KP: rows of a tile per neighbourhood.  WIDE: hidden layers up to 512 channels (4 blocks x 2 halves of accumulators per wave) -- the
 // narrow instance (<= 256) needs half the registers and so holds twice the wavefronts.
 template <int KP, bool WIDE>
-__global__ __launch_bounds__(256, WIDE ? 1 : 2) void sa_tile_kernel(STArgs a) {
+__global__ __launch_bounds__(256, WIDE ? 1 : 3) void sa_tile_kernel(STArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int CS = a.CS;
   const int c_last = a.cout[a.nlayers - 1];
@@ -317,8 +328,10 @@ int launch_st(const STArgs& a, size_t lds, long nslots, int dev, hipStream_t s) 
   const int n_cu = cg_device_cu_count(dev);
   if (n_cu <= 0) return CG_ERR_UNSUPPORTED;
   int per_cu = (int)((160 * 1024) / lds);
-  const int reg_cap = WIDE ? 1 : 2;              // workgroups of 4 waves a CU's registers hold (448 / 228 registers per lane)
+  const int reg_cap = WIDE ? 1 : 3;              // workgroups of 4 waves a CU's registers hold (304 / 155 registers per lane)
   if (per_cu > reg_cap) per_cu = reg_cap;
+  static const char* pc_env = getenv("CATGRASP_AMD_SAT_PER_CU");        // dev knob: resident workgroups per CU
+  if (pc_env && atoi(pc_env) > 0 && atoi(pc_env) < per_cu) per_cu = atoi(pc_env);
   if (per_cu < 1) per_cu = 1;
   long grid = nslots < (long)n_cu * per_cu ? nslots : (long)n_cu * per_cu;        // persistent: a workgroup walks slots blockIdx, + grid, ...
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, s, a);

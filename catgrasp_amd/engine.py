@@ -281,13 +281,16 @@ def encoder_module_forward(W, x, global_feat, status=None):
 FUSED_LAUNCH_MAX_B = 1024      # batches up to this size issue the exact-f32 PointNetCls forward as ONE C call (cg_pointnet_cls_forward)
 
 
-class _ClsWeightsC(__import__('ctypes').Structure):
+import ctypes as _ctypes
+
+
+class _ClsWeightsC(_ctypes.Structure):
     """cg_cls_weights (include/catgrasp_amd.h): device pointers to the folded, packed f32 weights, field order as declared there."""
     _NAMES = ('stn.w1', 'stn.b1', 'stn.w2', 'stn.b2', 'stn.w3', 'stn.b3', 'stn.fc1', 'stn.fc1b', 'stn.fc2', 'stn.fc2b', 'stn.fc3', 'stn.fc3b',
               'enc.w1', 'enc.b1', 'fstn.wm', 'fstn.bm', 'fstn.w2', 'fstn.b2', 'fstn.w3', 'fstn.b3',
               'fstn.fc1', 'fstn.fc1b', 'fstn.fc2', 'fstn.fc2b', 'fstn.fc3', 'fstn.fc3b', 'enc.w2', 'enc.b2', 'enc.w3', 'enc.b3',
               'head.fc1', 'head.fc1b', 'head.fc2', 'head.fc2b', 'head.fc3', 'head.fc3b')
-    _fields_ = [(n.replace('.', '_'), __import__('ctypes').c_void_p) for n in _NAMES] + [('n_out', __import__('ctypes').c_int)]
+    _fields_ = [(n.replace('.', '_'), _ctypes.c_void_p) for n in _NAMES] + [('n_out', _ctypes.c_int)]
 
 
 def _cls_forward_one_call(W, x):
@@ -299,17 +302,20 @@ def _cls_forward_one_call(W, x):
     ops.require_cuda(x); ops.f32c(x)
     B, N, D = x.shape
     assert D == 6
-    cw = getattr(W, '_cls_c', None)
-    if cw is None:
+    ptrs = tuple(W[n].data_ptr() for n in _ClsWeightsC._NAMES)
+    cached = getattr(W, '_cls_c', None)
+    if cached is None or cached[0] != ptrs:       # keyed on the tensors' addresses: a re-folded / reloaded weight is picked up
         cw = _ClsWeightsC()
-        for n in _ClsWeightsC._NAMES:
+        for n, ptr in zip(_ClsWeightsC._NAMES, ptrs):
             t = W[n]
             assert t.dtype == torch.float32 and t.is_cuda, n
-            setattr(cw, n.replace('.', '_'), t.data_ptr())
+            setattr(cw, n.replace('.', '_'), ptr)
         cw.n_out = int(W.n_out)
-        W._cls_c = cw
+        W._cls_c = cached = (ptrs, cw)
+    cw = cached[1]
     lib = L.lib()
-    lib.cg_pointnet_cls_workspace_floats.restype = ctypes.c_size_t
+    if lib.cg_pointnet_cls_workspace_floats.restype is not ctypes.c_size_t:
+        lib.cg_pointnet_cls_workspace_floats.restype = ctypes.c_size_t
     ws = torch.empty((lib.cg_pointnet_cls_workspace_floats(ctypes.c_int(B)),), dtype=torch.float32, device=x.device)
     logits = torch.empty((B, W.n_out), dtype=torch.float32, device=x.device)
     tf = ctypes.c_void_p(0)

@@ -147,6 +147,7 @@ class DeviceWeights:
 
     def put(self, name, arr):
         self.t[name] = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32)).to(self.device)
+        self.__dict__.pop('_cls_c', None)      # engine._cls_forward_one_call caches raw device pointers of these tensors
 
     def put_split(self, name, w):
         """Split images of a (N,K) weight matrix (int16 storage of the 16-bit patterns): `name` ('....s') holds the bf16 pieces,

@@ -330,10 +330,14 @@ class GraspPredicter:
                 with _gc_paused():
                     return self._predict_chunks(cloud, grasp_poses, ids_d, G)
             except BaseException:
-                if hasattr(ids_d, 'close'):
-                    ids_d.close(); ids_d.close = lambda: None
-                if rng_state is not None:        # the worker had drawn ahead of the failing chunk: a failed call consumes nothing
-                    np.random.set_state(rng_state)
+                try:
+                    if hasattr(ids_d, 'close'):
+                        ids_d.close(); ids_d.close = lambda: None
+                except BaseException:            # a draw still in flight on the worker failed too: the caller gets the FIRST error
+                    ids_d.close = lambda: None
+                finally:
+                    if rng_state is not None:    # the worker had drawn ahead of the failing chunk: a failed call consumes nothing
+                        np.random.set_state(rng_state)     # (the reference's loop would have consumed its draws: INTEGRATION.md)
                 raise
             finally:
                 if hasattr(ids_d, 'close'):
