@@ -23,7 +23,29 @@ struct GemmArgs {
   const float* row_bias; int rows_per_group; int ld_rb;  // optional per-group bias (groups = row / rows_per_group)
   int relu; int eye_k;                    // eye_k>0: add identity of a flattened k x k matrix
   float* y; int ldy;
+  int gmax_rows;                          // > 0: instead of storing Y, fold relu(Y) into y[row / gmax_rows][col] with an atomic max (y pre-zeroed)
 };
+
+// Epilogue of the group-all layer's last GEMM (sample_and_group_all + shared MLP + max over all points, pointnet2.py:132-149): the 32 x 32
+// accumulator tile `c` (rows row_base ..., column col) is not stored; relu(c + bias) >= 0 is folded into y[group][col] with an integer
+// atomic max on the float bits (y pre-zeroed: the order of non-negative floats is the order of their bit patterns).  A tile inside one
+// group reduces in registers first (one atomic per column); a tile across a group boundary falls back to one atomic per element.
+__device__ __forceinline__ void gemm_fold_groupmax(const GemmArgs& a, const f32x16& c, int row_base, int col, float bias, int lane) {
+  const int last = min(row_base + 31, a.M - 1);
+  if (row_base >= a.M) return;
+  const int g0 = row_base / a.gmax_rows;
+  if (last / a.gmax_rows == g0 && row_base + 31 < a.M) {
+    float m = max16(c);
+    m = fmaxf(m, __shfl_xor(m, 32));
+    if (lane < 32) atomicMax((int*)(a.y + (size_t)g0 * a.ldy + col), __float_as_int(fmaxf(m + bias, 0.f)));
+    return;
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = row_base + acc_row(r, lane);
+    if (row < a.M) atomicMax((int*)(a.y + (size_t)(row / a.gmax_rows) * a.ldy + col), __float_as_int(fmaxf(c[r] + bias, 0.f)));
+  }
+}
 
 __global__ __launch_bounds__(256) void gemm_bias_act_kernel(GemmArgs a) {
   __shared__ __attribute__((aligned(16))) float xs[BM * SA];
@@ -69,6 +91,7 @@ __global__ __launch_bounds__(256) void gemm_bias_act_kernel(GemmArgs a) {
   if (col >= a.N) return;
   float bias = a.bias ? a.bias[col] : 0.f;
   if (a.eye_k > 0 && (col % (a.eye_k + 1)) == 0) bias += 1.f;   // flattened identity: col = i*k + i
+  if (a.gmax_rows > 0) { gemm_fold_groupmax(a, c0, row0, col, bias, lane); gemm_fold_groupmax(a, c1, row0 + 32, col, bias, lane); return; }
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
 #pragma unroll
@@ -142,6 +165,7 @@ __global__ __launch_bounds__(256) void gemm_bias_act_small_kernel(GemmArgs a) {
   if (col >= a.N) return;
   float bias = a.bias ? a.bias[col] : 0.f;
   if (a.eye_k > 0 && (col % (a.eye_k + 1)) == 0) bias += 1.f;
+  if (a.gmax_rows > 0) { gemm_fold_groupmax(a, c, tm * 32, col, bias, lane); return; }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int row = tm * 32 + acc_row(r, lane);
@@ -156,7 +180,20 @@ __global__ __launch_bounds__(256) void gemm_bias_act_small_kernel(GemmArgs a) {
 
 constexpr long SMALL_TILES = 2048;  // 32 x 32 output tiles up to which the wavefront-per-tile kernel is used (measured: profiles/r4_gemm_small.txt)
 
+int launch_gemm(GemmArgs& a, void* stream) {
+  static const long small_tiles = getenv("CATGRASP_AMD_GEMM_SMALL_TILES") ? atol(getenv("CATGRASP_AMD_GEMM_SMALL_TILES")) : SMALL_TILES;   // dev knob
+  const long tiles = (long)((a.M + 31) / 32) * a.nblocks;
+  if (tiles <= small_tiles) {
+    hipLaunchKernelGGL(gemm_bias_act_small_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
+    return cg_hip_status(hipGetLastError());
+  }
+  dim3 grid((unsigned)((a.M + BM - 1) / BM), (unsigned)((a.nblocks + 3) / 4)), block(256);
+  hipLaunchKernelGGL(gemm_bias_act_kernel, grid, block, 0, (hipStream_t)stream, a);
+  return cg_hip_status(hipGetLastError());
+}
+
 }  // namespace
+
 
 extern "C" int cg_gemm_bias_act(const float* x, int M, int K, int ldx, const float* w_packed, int N,
                                 const float* bias, const float* row_bias, int rows_per_group, int ld_rb,
@@ -166,14 +203,20 @@ extern "C" int cg_gemm_bias_act(const float* x, int M, int K, int ldx, const flo
   if (((uintptr_t)x & 15) != 0) return CG_ERR_ARG;
   if (row_bias && (rows_per_group <= 0 || ld_rb < N)) return CG_ERR_ARG;
   if (M == 0) return CG_OK;
-  GemmArgs a{x, M, K, ldx, w_packed, N, (N + 31) / 32, bias, row_bias, rows_per_group, ld_rb, relu, eye_k, y, ldy};
-  static const long small_tiles = getenv("CATGRASP_AMD_GEMM_SMALL_TILES") ? atol(getenv("CATGRASP_AMD_GEMM_SMALL_TILES")) : SMALL_TILES;   // dev knob
-  const long tiles = (long)((M + 31) / 32) * a.nblocks;
-  if (tiles <= small_tiles) {
-    hipLaunchKernelGGL(gemm_bias_act_small_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
-    return cg_hip_status(hipGetLastError());
-  }
-  dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((a.nblocks + 3) / 4)), block(256);
-  hipLaunchKernelGGL(gemm_bias_act_kernel, grid, block, 0, (hipStream_t)stream, a);
-  return cg_hip_status(hipGetLastError());
+  GemmArgs a{x, M, K, ldx, w_packed, N, (N + 31) / 32, bias, row_bias, rows_per_group, ld_rb, relu, eye_k, y, ldy, 0};
+  return launch_gemm(a, stream);
+}
+
+// out[g][n] = max over the rows_per_group rows of group g of relu(X . W^T + bias): the last layer of the group-all set-abstraction level
+// with its max over the points folded into the epilogue (the (M, N) activation is never written).  out (M / rows_per_group, N).
+extern "C" int cg_gemm_bias_relu_groupmax(const float* x, int M, int K, int ldx, const float* w_packed, int N, const float* bias,
+                                          int rows_per_group, float* out, void* stream) {
+  if (!x || !w_packed || !out) return CG_ERR_ARG;
+  if (M < 0 || N <= 0 || K <= 0 || (K % 8) != 0 || (ldx % 4) != 0 || ldx < K || rows_per_group <= 0 || (M % rows_per_group) != 0) return CG_ERR_ARG;
+  if (((uintptr_t)x & 15) != 0) return CG_ERR_ARG;
+  if (M == 0) return CG_OK;
+  hipError_t e = hipMemsetAsync(out, 0, (size_t)(M / rows_per_group) * N * sizeof(float), (hipStream_t)stream);
+  if (e != hipSuccess) return (int)e;
+  GemmArgs a{x, M, K, ldx, w_packed, N, (N + 31) / 32, bias, nullptr, 1, 0, 1, 0, out, N, rows_per_group};
+  return launch_gemm(a, stream);
 }

@@ -40,6 +40,8 @@ struct STArgs {
   int* err_flag;
   int CS;                                           // strip row stride (floats)
   int KP, RT;                                       // rows of a tile per neighbourhood (8 / 16 / 32 / 64); row tiles per neighbourhood (KP = 64)
+  int prio_div;                                     // > 0: wave priority = (blockIdx.x / prio_div) & 3 (see the kernel)
+  int append_n;                                     // > 0: channels [C_last, C_last + append_n) of every output row = new_xyz (3) ++ zeros
 };
 
 // The MFMA stream of one wave for one layer: NBW channel blocks x NH row halves.  Operand fragments travel DEPTH k-steps ahead of
@@ -220,6 +222,18 @@ __global__ __launch_bounds__(256, WIDE ? 1 : 3) void sa_tile_kernel(STArgs a) {
 
   int slot = blockIdx.x, kt = 0;
   if (slot >= nslots) return;
+  // The workgroups resident on one CU run the same phases for the same time: under fair issue they stay in lockstep -- all in their
+  // matrix phase together, all in their gather / store phases together -- and the matrix pipe idles through the latter.  Unequal wave
+  // priorities break the tie: the k-th workgroup of a CU (dispatch order: blockIdx / #CUs) gets priority k, finishes its matrix phase
+  // first and gathers while the others multiply.
+  if (a.prio_div > 0) {
+    switch ((blockIdx.x / a.prio_div) & 3) {
+      case 1: __builtin_amdgcn_s_setprio(1); break;
+      case 2: __builtin_amdgcn_s_setprio(2); break;
+      case 3: __builtin_amdgcn_s_setprio(3); break;
+      default: break;
+    }
+  }
   long long id_next = 0; int g_next = 0;
   if (tid < TR) id_next = row_id(slot, 0, tid, g_next);
   for (;;) {
@@ -235,24 +249,46 @@ __global__ __launch_bounds__(256, WIDE ? 1 : 3) void sa_tile_kernel(STArgs a) {
     if (tid >= 64 && tid < 64 + NPT) {          // where the tile's neighbourhoods go in `out`
       const int g = (KP == 64 ? slot : slot * NPT) + (tid - 64);
       const int b = g / a.S;
-      goff[tid - 64] = g < G ? (long)b * a.out_bs + (long)(g - b * a.S) * a.out_ss : -1;
+      const long o = g < G ? (long)b * a.out_bs + (long)(g - b * a.S) * a.out_ss : -1;
+      goff[tid - 64] = o;
+      if (a.append_n > 0 && o >= 0 && kt == 0) {      // the row the NEXT level's group-all GEMM reads: [features | xyz | zero pad]
+        const float* pc = a.new_xyz + (size_t)g * 3;
+        for (int e = 0; e < a.append_n; ++e) a.out[o + (long)(c_last + e) * a.out_cs] = e < 3 ? pc[e] : 0.f;
+      }
     }
     __syncthreads();
     int nslot = slot, nkt = kt + 1;
     if (nkt >= RT) { nkt = 0; nslot = slot + (int)gridDim.x; }
     const bool more = nslot < nslots;
     if (tid < TR && more) id_next = row_id(nslot, nkt, tid, g_next);             // in flight under this tile's gather and layers
-    // ---- gather: features (the strip's first D channels), then centred xyz, then the zero pad
+    // ---- gather: features (the strip's first D channels), then centred xyz, then the zero pad.  The coordinate loads go out first and
+    // are consumed last: they ride along with the feature loads instead of adding a round trip of their own
+    float px0 = 0.f, px1 = 0.f, px2 = 0.f, cx = 0.f, cy = 0.f, cz = 0.f;
+    if (tid < TR) {
+      const float* px = a.xyz + (size_t)p_row * 3;
+      px0 = px[0]; px1 = px[1]; px2 = px[2];
+      if (a.new_xyz) { const float* pc = a.new_xyz + (size_t)g_row * 3; cx = pc[0]; cy = pc[1]; cz = pc[2]; }
+    }
     if (D > 0) {
       if ((D & 3) == 0 && ((uintptr_t)a.points & 15) == 0) {
-        const int nq = D >> 2;
-        int row = tid / nq, q = tid - row * nq;
-        const int drow = 256 / nq, dq = 256 - drow * nq;
-        while (row < TR) {
-          const f32x4 v = *(const f32x4*)(a.points + (size_t)pbase[row] * D + 4 * q);
-          *(f32x4*)(strip + row * CS + 4 * q) = v;
-          row += drow; q += dq;
-          if (q >= nq) { q -= nq; ++row; }
+        // 16-byte pieces, GU of them in flight per thread: written as load-then-store per piece the compiler waits out one L2 round
+        // trip per piece (8 in a row for D = 128: ~6 us of a 14 us tile)
+        constexpr int GU = 8;
+        const int nq = D >> 2, total = TR * nq;
+        for (int base = tid; base < total; base += 256 * GU) {
+          f32x4 v[GU];
+          int off[GU];
+#pragma unroll
+          for (int u = 0; u < GU; ++u) {
+            const int i = base + u * 256;
+            const int ic = i < total ? i : total - 1;
+            const int row = ic / nq, q = ic - row * nq;
+            off[u] = i < total ? row * CS + 4 * q : -1;
+            v[u] = *(const f32x4*)(a.points + (size_t)pbase[row] * D + 4 * q);
+          }
+#pragma unroll
+          for (int u = 0; u < GU; ++u)
+            if (off[u] >= 0) *(f32x4*)(strip + off[u]) = v[u];
         }
       } else {
         for (int i = tid; i < TR * D; i += 256) {
@@ -262,11 +298,8 @@ __global__ __launch_bounds__(256, WIDE ? 1 : 3) void sa_tile_kernel(STArgs a) {
       }
     }
     if (tid < TR) {
-      const float* px = a.xyz + (size_t)p_row * 3;
-      float cx = 0.f, cy = 0.f, cz = 0.f;
-      if (a.new_xyz) { const float* pc = a.new_xyz + (size_t)g_row * 3; cx = pc[0]; cy = pc[1]; cz = pc[2]; }
       float* dst = strip + tid * CS + D;
-      dst[0] = px[0] - cx; dst[1] = px[1] - cy; dst[2] = px[2] - cz;
+      dst[0] = px0 - cx; dst[1] = px1 - cy; dst[2] = px2 - cz;
       for (int c = D + 3; c < cin0; ++c) strip[tid * CS + c] = 0.f;
     }
     __syncthreads();
@@ -334,7 +367,10 @@ int launch_st(const STArgs& a, size_t lds, long nslots, int dev, hipStream_t s) 
   if (pc_env && atoi(pc_env) > 0 && atoi(pc_env) < per_cu) per_cu = atoi(pc_env);
   if (per_cu < 1) per_cu = 1;
   long grid = nslots < (long)n_cu * per_cu ? nslots : (long)n_cu * per_cu;        // persistent: a workgroup walks slots blockIdx, + grid, ...
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, s, a);
+  STArgs b = a;
+  static const char* pr_env = getenv("CATGRASP_AMD_SAT_PRIO");           // dev knob: 0 = equal priorities
+  b.prio_div = (pr_env && atoi(pr_env) == 0) ? 0 : n_cu;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, s, b);
   return cg_hip_status(hipGetLastError());
 }
 
@@ -352,18 +388,19 @@ int launch_st_kp(const STArgs& a, size_t lds, long nslots, int dev, hipStream_t 
 
 extern "C" int cg_sa_tile_mlp_max(const float* xyz, const float* points, const float* new_xyz, const long long* idx, int B, int N, int S,
                                   int K, int D, int n_layers, const int* h_cin, const int* h_cout, const float* const* h_w_packed,
-                                  const float* const* h_bias, float* out, long out_bs, long out_ss, long out_cs, int* err_flag,
-                                  void* stream) {
+                                  const float* const* h_bias, float* out, long out_bs, long out_ss, long out_cs, int append_xyz,
+                                  int* err_flag, void* stream) {
   if (B < 0 || N <= 0 || S < 0 || K <= 0 || D < 0 || n_layers < 1 || n_layers > ST_MAX_LAYERS) return CG_ERR_ARG;
   if (!h_cin || !h_cout || !h_w_packed || !h_bias) return CG_ERR_ARG;
   if ((long)B * S == 0) return CG_OK;
   if (!xyz || !out || (D > 0 && !points)) return CG_ERR_ARG;
   if (!idx && (S != 1 || K != N)) return CG_ERR_ARG;             // no index list: the group-all layer (one group of all N points)
+  if (append_xyz != 0 && (append_xyz < 3 || append_xyz > 16 || !new_xyz)) return CG_ERR_ARG;
   if ((long)B * S >= 0x7fffffffL / 8 || (long)B * N >= 0x7fffffffL) return CG_ERR_UNSUPPORTED;
   STArgs a{};
   a.xyz = xyz; a.points = D > 0 ? points : nullptr; a.new_xyz = new_xyz; a.idx = idx;
   a.B = B; a.N = N; a.S = S; a.K = K; a.D = D; a.nlayers = n_layers;
-  a.out = out; a.out_bs = out_bs; a.out_ss = out_ss; a.out_cs = out_cs; a.err_flag = err_flag;
+  a.out = out; a.out_bs = out_bs; a.out_ss = out_ss; a.out_cs = out_cs; a.err_flag = err_flag; a.append_n = append_xyz;
   int cstore = 0, hidden_max = 0;
   for (int l = 0; l < n_layers; ++l) {
     if (!h_w_packed[l] || !h_bias[l]) return CG_ERR_ARG;

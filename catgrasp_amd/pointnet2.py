@@ -266,20 +266,33 @@ class PointNetSetAbstraction(nn.Module):
         return _cached_weights(self, device, lambda sd, dev: _prim.SetAbstractionWeights(_sa_layers_from_state(sd, 'mlp_', n), self.in_channel,
                                                                                           dev, kind=kind))
 
-    def forward(self, xyz, points, start=None, _err=None):
-        """_err: a list the caller collects the index-error flags in (one read-back for a whole stack instead of one per layer)."""
+    def forward(self, xyz, points, start=None, _err=None, _rows=None):
+        """_err: a list the caller collects the index-error flags in (one read-back for a whole stack instead of one per layer).
+        _rows (stack-internal): for a sampling level, a (B, S, roundup8(C + 3)) buffer to produce the output in -- features in
+        [..., :C] (the returned new_points is that view), the level's new_xyz ++ zeros behind them, i.e. the input rows of a following
+        group-all level; for the group-all level, that buffer."""
         if _use_hip(self, xyz):
             W = self._weights(xyz.device)
             if self.group_all:
                 B = xyz.shape[0]
-                return torch.zeros((B, 1, 3), dtype=torch.float32, device=xyz.device), _prim.group_all_mlp_max(xyz, points, W).view(B, 1, -1)
+                rows = None if _rows is None else _rows.view(-1, _rows.shape[-1])
+                return (torch.zeros((B, 1, 3), dtype=torch.float32, device=xyz.device),
+                        _prim.group_all_mlp_max(xyz, points, W, rows=rows).view(B, 1, -1))
             _, new_xyz = farthest_point_sample(xyz, self.npoint, start, return_xyz=True)      # = index_points(xyz, fps_idx), same launch
             idx = query_ball_point(self.radius, self.nsample, xyz, new_xyz)
+            kw = {}
+            if _rows is not None:
+                C = W.cout[-1]
+                kw = {'out': _rows[:, :, :C]}
+                if W.kind == 'tile':
+                    kw['append_xyz'] = _rows.shape[-1] - C
+                else:                      # a first-layer shape feeding a group-all level directly: the three columns by a copy
+                    _rows[:, :, C:C + 3] = new_xyz; _rows[:, :, C + 3:] = 0
             if _err is not None:
-                out, e = _prim.group_mlp_max(xyz, points, new_xyz, idx, W, check_indices=False, channels_last=True)
+                out, e = _prim.group_mlp_max(xyz, points, new_xyz, idx, W, check_indices=False, channels_last=True, **kw)
                 _err.append(e)
                 return new_xyz, out
-            return new_xyz, _prim.group_mlp_max(xyz, points, new_xyz, idx, W, channels_last=True)
+            return new_xyz, _prim.group_mlp_max(xyz, points, new_xyz, idx, W, channels_last=True, **kw)
         if self.group_all:
             new_xyz, new_points = sample_and_group_all(xyz, points)
         else:       # indices from the HIP kernels (or torch ops on a CPU tensor); the gathers are differentiable torch indexing
@@ -315,7 +328,7 @@ class PointNetSetAbstractionMsg(nn.Module):
             self.conv_blocks.append(convs); self.bn_blocks.append(bns)
         self.out_channel = sum(m[-1] for m in mlp_list)
 
-    def forward(self, xyz, points, start=None, _err=None):
+    def forward(self, xyz, points, start=None, _err=None, _rows=None):
         if _use_hip(self, xyz):
             def prep(sd, dev):
                 out = []
@@ -328,14 +341,19 @@ class PointNetSetAbstractionMsg(nn.Module):
             Ws = _cached_weights(self, xyz.device, prep)
             B = xyz.shape[0]
             _, new_xyz = farthest_point_sample(xyz, self.npoint, start, return_xyz=True)
-            out = torch.empty((B, self.npoint, self.out_channel), dtype=torch.float32, device=xyz.device)
+            buf = _rows if _rows is not None else torch.empty((B, self.npoint, self.out_channel), dtype=torch.float32, device=xyz.device)
+            out = buf[:, :, :self.out_channel]
             errs = [] if _err is None else _err
             c0 = 0
-            for W, radius, K in zip(Ws, self.radius_list, self.nsample_list):
+            for i, (W, radius, K) in enumerate(zip(Ws, self.radius_list, self.nsample_list)):
                 idx = query_ball_point(radius, K, xyz, new_xyz)
-                _, e = _prim.group_mlp_max(xyz, points, new_xyz, idx, W, check_indices=False, channels_last=True, out=out[:, :, c0:c0 + W.cout[-1]])
+                last = i == len(Ws) - 1 and _rows is not None and W.kind == 'tile'      # the last scale's kernel also writes xyz ++ pad
+                _, e = _prim.group_mlp_max(xyz, points, new_xyz, idx, W, check_indices=False, channels_last=True, out=out[:, :, c0:c0 + W.cout[-1]],
+                                           append_xyz=buf.shape[-1] - self.out_channel if last else 0)
                 errs.append(e)
                 c0 += W.cout[-1]
+            if _rows is not None and Ws[-1].kind != 'tile':
+                buf[:, :, self.out_channel:self.out_channel + 3] = new_xyz; buf[:, :, self.out_channel + 3:] = 0
             if _err is None:
                 _prim._raise_if(torch.stack(errs).max(), 'PointNetSetAbstractionMsg (a query ball was empty or an index is out of range)')
             return new_xyz, out
@@ -429,8 +447,13 @@ class PointNet2Encoder(nn.Module):
         errs = [] if hip else None
         kw = {'_err': errs} if hip else {}
         l1_xyz, l1_points = self.sa1(xyz, feats, start=s1, **kw)
+        rows = None
+        if hip:      # level 2 writes [features | xyz | pad] rows: what the group-all level's first GEMM reads (no concatenation pass)
+            c2 = self.sa3.in_channel - 3
+            rows = torch.empty((B, self.sa2.npoint, (c2 + 3 + 7) & ~7), dtype=torch.float32, device=x.device)
+            kw = dict(kw, _rows=rows)
         l2_xyz, l2_points = self.sa2(l1_xyz, l1_points, start=s2, **kw)
-        _, l3_points = self.sa3(l2_xyz, l2_points)
+        _, l3_points = self.sa3(l2_xyz, l2_points, **({'_rows': rows} if rows is not None else {}))
         if hip and errs:
             _prim._raise_if(torch.stack(errs).max(), 'PointNet2Encoder (a query ball was empty or an index is out of range)')
         return l3_points.reshape(B, -1), [(l1_xyz, l1_points), (l2_xyz, l2_points)]

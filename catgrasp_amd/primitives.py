@@ -178,12 +178,14 @@ class SetAbstractionWeights:
                 (ctypes.c_void_p * L_)(*[t.data_ptr() for t in self.w]), (ctypes.c_void_p * L_)(*[t.data_ptr() for t in self.b]))
 
 
-def group_mlp_max(xyz, points, new_xyz, idx, W, check_indices=True, channels_last=False, out=None):
+def group_mlp_max(xyz, points, new_xyz, idx, W, check_indices=True, channels_last=False, out=None, append_xyz=0):
     """The consumer of sample_and_group fused into one kernel (cg_sa_group_mlp_max_strided / cg_sa_tile_mlp_max by W.kind): neighbourhoods
     idx (B,S,K) of xyz/points around new_xyz -> centred coordinates ++ features -> shared MLP W (SetAbstractionWeights) -> max over the K
     neighbours.  -> (B, C_out, S) float32, the layout torch.max(new_points, 2)[0] has in a PointNet++ set-abstraction layer, or with
     channels_last=True (B, S, C_out): the rows the next layer gathers from.  out: optional view to write into (any strides -- one scale's
     channel slice of a multi-scale layer's output).
+    append_xyz = n (tile kernel, channels_last, `out` a view with >= n further channels behind it in memory): channels [C, C + n) of
+    every row also receive new_xyz ++ zeros: the [features | xyz | pad] rows group_all_mlp_max(rows=...) reads.
     check_indices=False skips the read-back of the index-error flag (one host synchronisation per call) and returns (out, err_flag tensor):
     for callers that batch the check, and for timing the kernel alone."""
     require_cuda(xyz, new_xyz, idx)
@@ -205,6 +207,8 @@ def group_mlp_max(xyz, points, new_xyz, idx, W, check_indices=True, channels_las
     ss, cs = (s1, s2) if channels_last else (s2, s1)
     err = torch.zeros((1,), dtype=torch.int32, device=xyz.device)
     L_, cin, cout, wp, bp = W._c_arrays()
+    if append_xyz and (W.kind != 'tile' or not channels_last or cs != 1):
+        raise ValueError("append_xyz needs kind='tile' weights and a channels_last output with unit channel stride")
     if W.kind == 'reg':
         check(L.lib().cg_sa_group_mlp_max_strided(_p(xyz), _p(points), _p(new_xyz), _p(idx), _c_int(B), _c_int(N), _c_int(S), _c_int(K), _c_int(D),
                                                   _c_int(L_), cin, cout, wp, bp, _p(out), _c_long(sb), _c_long(ss), _c_long(cs), _p(err),
@@ -213,19 +217,21 @@ def group_mlp_max(xyz, points, new_xyz, idx, W, check_indices=True, channels_las
         if W.cin[0] > W.TILE_MAX_CIN or W.hidden_max > 512:
             raise NotImplementedError('fused set abstraction (tile kernel): 3 + D <= 592 inputs, hidden widths <= 512')
         check(L.lib().cg_sa_tile_mlp_max(_p(xyz), _p(points), _p(new_xyz), _p(idx), _c_int(B), _c_int(N), _c_int(S), _c_int(K), _c_int(D),
-                                         _c_int(L_), cin, cout, wp, bp, _p(out), _c_long(sb), _c_long(ss), _c_long(cs), _p(err), _stream()),
-              'cg_sa_tile_mlp_max')
+                                         _c_int(L_), cin, cout, wp, bp, _p(out), _c_long(sb), _c_long(ss), _c_long(cs), _c_int(int(append_xyz)), _p(err),
+                                         _stream()), 'cg_sa_tile_mlp_max')
     if not check_indices:
         return out, err
     _raise_if(err, 'group_mlp_max (a query ball was empty or an index is out of range)')
     return out
 
 
-def group_all_mlp_max(xyz, points, W, fused=False):
+def group_all_mlp_max(xyz, points, W, fused=False, rows=None):
     """The group-all layer (sample_and_group_all, pointnet2.py:132-149, + the shared MLP + max over ALL points): xyz (B,N,3), points
     (B,N,D) | None -> (B, C_out).  One group per cloud means B * ceil(N / 64) row tiles: a handful for a PointNet++ head (N = 128), so
-    the layers run as row-batched GEMMs over all B * N rows (cg_sa_concat_input -> cg_gemm_bias_act per layer -> cg_group_max: the
-    32 x 32 output tiles of every layer spread over the chip; the activations, B * N x <= 1024 floats, are the only intermediates).
+    the layers run as row-batched GEMMs over all B * N rows ([cg_sa_concat_input ->] cg_gemm_bias_act per hidden layer ->
+    cg_gemm_bias_relu_groupmax: the 32 x 32 output tiles of every layer spread over the chip, the last layer's max over the points in
+    its epilogue; the hidden activations, B * N x <= 512 floats, are the only intermediates).  rows: the (B * N, cin) input matrix
+    [features | xyz | pad] when the previous level already wrote it (group_mlp_max(append_xyz=...)): no concatenation pass.
     fused=True: the fused tile kernel takes the layer whole (cg_sa_tile_mlp_max, idx == NULL) -- measured 6..9 x slower at 1..16 clouds
     of 128 points (profiles/r5_pp_encoder_first.json: two 64-row tiles per cloud carry 0.72 MMAC per row on one CU each), kept for the
     parity tests of the kernel's index-free mode."""
@@ -235,7 +241,9 @@ def group_all_mlp_max(xyz, points, W, fused=False):
     B, N, _ = xyz.shape
     D = 0
     if points is not None:
-        points = _f32(points); D = points.shape[2]
+        D = points.shape[2]
+        if rows is None or fused:
+            points = _f32(points)
     if W.kind != 'tile' or 3 + D != W.in_channel:
         raise ValueError("group_all_mlp_max needs kind='tile' weights for 3 + D input channels")
     C = W.cout[-1]
@@ -246,11 +254,19 @@ def group_all_mlp_max(xyz, points, W, fused=False):
         out = torch.empty((B, C), dtype=torch.float32, device=xyz.device)
         L_, cin, cout, wp, bp = W._c_arrays()
         check(L.lib().cg_sa_tile_mlp_max(_p(xyz), _p(points), _p(None), _p(None), _c_int(B), _c_int(N), _c_int(1), _c_int(N), _c_int(D),
-                                         _c_int(L_), cin, cout, wp, bp, _p(out), _c_long(C), _c_long(0), _c_long(1), _p(None), _stream()),
+                                         _c_int(L_), cin, cout, wp, bp, _p(out), _c_long(C), _c_long(0), _c_long(1), _c_int(0), _p(None), _stream()),
               'cg_sa_tile_mlp_max')
         return out
-    h = torch.empty((B * N, W.cin[0]), dtype=torch.float32, device=xyz.device)
-    check(L.lib().cg_sa_concat_input(_p(xyz), _p(points), _c_long(B * N), _c_int(D), _c_int(W.cin[0]), _p(h), _stream()), 'cg_sa_concat_input')
-    for wp, b, co in zip(W.w, W.b, W.cout):
+    if rows is not None:       # the previous level already wrote the [features | xyz | pad] rows (group_mlp_max(append_xyz=...))
+        if tuple(rows.shape) != (B * N, W.cin[0]) or not rows.is_contiguous() or rows.dtype != torch.float32:
+            raise ValueError(f'rows must be a contiguous float32 ({B * N}, {W.cin[0]}) tensor')
+        h = rows
+    else:
+        h = torch.empty((B * N, W.cin[0]), dtype=torch.float32, device=xyz.device)
+        check(L.lib().cg_sa_concat_input(_p(xyz), _p(points), _c_long(B * N), _c_int(D), _c_int(W.cin[0]), _p(h), _stream()), 'cg_sa_concat_input')
+    for wp, b, co in zip(W.w[:-1], W.b[:-1], W.cout[:-1]):
         h = ops.gemm_bias_act(h, wp, co, bias=b, relu=True)
-    return ops.group_max(h, B)
+    out = torch.empty((B, C), dtype=torch.float32, device=xyz.device)       # last layer: the max over the N points in the GEMM's epilogue
+    check(L.lib().cg_gemm_bias_relu_groupmax(_p(h), _c_int(B * N), _c_int(h.shape[1]), _c_int(h.shape[1]), _p(W.w[-1]), _c_int(C), _p(W.b[-1]),
+                                             _c_int(N), _p(out), _stream()), 'cg_gemm_bias_relu_groupmax')
+    return out

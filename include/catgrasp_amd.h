@@ -520,15 +520,25 @@ int cg_sa_group_mlp_max_strided(const float* xyz, const float* points, const flo
  * (the kernel stores the gathered features with aligned 16-byte LDS writes), and the output is addressed by strides --
  * out[b * out_bs + s * out_ss + c * out_cs] -- so that a caller writes (B,C,S) like torch.max(new_points, 2)[0] (out_bs = C S,
  * out_ss = 1, out_cs = S), the (B,S,C) rows the next layer gathers from (out_bs = S C, out_ss = C, out_cs = 1), or one scale's
- * channel slice of a multi-scale layer's concatenated output. */
+ * channel slice of a multi-scale layer's concatenated output.  append_xyz = n (3 <= n <= 16, else 0): channels [C, C + n) of every
+ * output row additionally receive new_xyz (3 floats) followed by zeros -- the rows [features | xyz | pad] the next level's group-all
+ * GEMM chain reads, written by the kernel that produced the features (no concatenation pass). */
 int cg_sa_tile_mlp_max(const float* xyz, const float* points, const float* new_xyz, const long long* idx, int B, int N, int S, int K,
                        int D, int n_layers, const int* h_cin, const int* h_cout, const float* const* h_w_packed,
-                       const float* const* h_bias, float* out, long out_bs, long out_ss, long out_cs, int* err_flag, void* stream);
+                       const float* const* h_bias, float* out, long out_bs, long out_ss, long out_cs, int append_xyz, int* err_flag,
+                       void* stream);
 
 /* Input matrix of the group-all layer when it runs as a GEMM chain (few rows: cg_gemm_bias_act per layer + cg_group_max): rows of
  * [D features | xyz | zero pad to ld], the column order of cg_sa_tile_mlp_max's layer 0.  xyz (rows,3), points (rows,D) or NULL
  * -> out (rows, ld), ld >= D + 3.  (sample_and_group_all's cat([grouped_xyz, points]), pointnet2.py:145-148.) */
 int cg_sa_concat_input(const float* xyz, const float* points, long rows, int D, int ld, float* out, void* stream);
+
+/* Last layer of the group-all level with its max over the points in the epilogue: out[g][n] = max over the rows_per_group rows of
+ * group g of relu(X[M,K] . W^T + bias) -- sample_and_group_all + Conv2d/BN/ReLU + torch.max(.., 2) (pointnet2.py:132-149) without
+ * writing the (M, N) activation.  out (M / rows_per_group, N) is zeroed by the call (stream-ordered), then folded into with an
+ * integer atomic max on the non-negative float bits.  Same kernels, operands and argument rules as cg_gemm_bias_act. */
+int cg_gemm_bias_relu_groupmax(const float* x, int M, int K, int ldx, const float* w_packed, int N, const float* bias,
+                               int rows_per_group, float* out, void* stream);
 
 /* get_ik_within_limits(...).size() > 0 (my_cpp/common.cpp:9-72, called at :230-236 of filterGraspPose): closed-form IK of the
  * KUKA LBR iiwa14 with the redundancy joint (index 2) at 0 -- what the reference's generated IKFast file solves -- one thread

@@ -38,6 +38,7 @@ case $JOB in
   satile)     # the LDS-tile set-abstraction kernel alone: shipped build, ablation builds (build_abl/lib_sat_*.so), resident-workgroup knob
     timeout 300 python scripts/sa_tile_time.py $O/sa_tile.json > $O/sa_tile.txt 2>&1; grep ssg_sa2 $O/sa_tile.txt
     for lib in build_abl/lib_sat_*.so; do t=$(basename $lib .so); CATGRASP_AMD_LIB=$PWD/$lib timeout 300 python scripts/sa_tile_time.py $O/sa_tile_$t.json > $O/sa_tile_$t.txt 2>&1; echo $t; grep ssg_sa2 $O/sa_tile_$t.txt; done
+    CATGRASP_AMD_SAT_PRIO=0 timeout 300 python scripts/sa_tile_time.py $O/sa_tile_noprio.json > $O/sa_tile_noprio.txt 2>&1; echo no prio; grep ssg_sa2 $O/sa_tile_noprio.txt
     for pc in 1 2; do CATGRASP_AMD_SAT_PER_CU=$pc timeout 300 python scripts/sa_tile_time.py $O/sa_tile_percu$pc.json > $O/sa_tile_percu$pc.txt 2>&1; echo per_cu $pc; grep ssg_sa2 $O/sa_tile_percu$pc.txt; done
     timeout 600 python -m pytest tests/test_pointnet2_encoder_gpu.py -m gpu -x -q > $O/pytest.log 2>&1; tail -3 $O/pytest.log ;;
   py)         # any script:  py scripts/x.py args...

@@ -231,3 +231,44 @@ def test_encoder_state_dict_train_eval_roundtrip(cuda_device):
     assert (g2 - g0).abs().max().item() > 0.1
     with pytest.raises(RuntimeError), torch.no_grad():
         enc(x.cpu(), start=start)                # eval mode, no grad, CPU tensor: there is no CPU inference path
+
+
+def test_group_all_gemm_epilogue_max_and_appended_rows(cuda_device):
+    """cg_gemm_bias_relu_groupmax (the group-all level's last layer with its max over the points in the GEMM epilogue): groups that are
+    not a multiple of the 32-row tile (per-element atomics across a group boundary), many groups, a width that is not a multiple of 32;
+    and the [features | xyz | pad] rows the tile kernel appends (append_xyz) == what cg_sa_concat_input builds."""
+    import ctypes
+    from catgrasp_amd import _lib as L
+    from catgrasp_amd import folding, ops
+    from catgrasp_amd import pointnet2 as p2
+    from catgrasp_amd import primitives as prim
+    g = torch.Generator().manual_seed(1)
+    for groups, rows, K, N in ((1, 128, 264, 1024), (5, 77, 64, 96), (300, 20, 32, 40), (3, 1000, 128, 512)):
+        x = torch.randn(groups * rows, K, generator=g)
+        w = torch.randn(N, K, generator=g) * 0.2
+        b = torch.randn(N, generator=g)
+        ref = torch.relu(x @ w.t() + b).view(groups, rows, N).max(dim=1)[0]
+        wp = torch.from_numpy(folding.pack_b(w.numpy())).to(cuda_device)
+        xd, bd = x.to(cuda_device), b.to(cuda_device)
+        out = torch.full((groups, N), -5.0, device=cuda_device)
+        L.check(L.lib().cg_gemm_bias_relu_groupmax(L._p(xd), ctypes.c_int(groups * rows), ctypes.c_int(K), ctypes.c_int(K), L._p(wp), ctypes.c_int(N),
+                                                   L._p(bd), ctypes.c_int(rows), L._p(out), L._stream()), 'cg_gemm_bias_relu_groupmax')
+        two_step = ops.group_max(ops.gemm_bias_act(xd, wp, N, bias=bd, relu=True), groups)
+        assert torch.equal(out, two_step)                     # same products, same order; the max is order-free
+        assert (out.cpu() - ref).abs().max().item() <= 1e-4 * max(1.0, ref.abs().max().item())
+    # appended rows
+    torch.manual_seed(3)
+    B, N, S, K, D = 2, 400, 37, 16, 20
+    xyz = torch.rand(B, N, 3, device=cuda_device); pts = torch.randn(B, N, D, device=cuda_device)
+    sa = p2.PointNetSetAbstraction(S, 0.3, K, 3 + D, [64, 160]); _randomize_bn(sa, 4); sa.eval(); sa.to(cuda_device)
+    W = prim.SetAbstractionWeights(p2._sa_layers_from_state(sa.state_dict(), 'mlp_', 2), 3 + D, cuda_device, kind='tile')
+    new_xyz = xyz[:, :S].contiguous()
+    idx = p2.query_ball_point(0.3, K, xyz, new_xyz)
+    plain = prim.group_mlp_max(xyz, pts, new_xyz, idx, W, channels_last=True)
+    rows = torch.full((B, S, 168), 9.0, device=cuda_device)
+    got = prim.group_mlp_max(xyz, pts, new_xyz, idx, W, channels_last=True, out=rows[:, :, :160], append_xyz=8)
+    assert torch.equal(got, plain) and torch.equal(rows[:, :, :160], plain)
+    want = torch.empty((B * S, 168), device=cuda_device)
+    L.check(L.lib().cg_sa_concat_input(L._p(new_xyz), L._p(plain.contiguous()), ctypes.c_long(B * S), ctypes.c_int(160), ctypes.c_int(168), L._p(want),
+                                       L._stream()), 'cg_sa_concat_input')
+    assert torch.equal(rows.view(B * S, 168), want)
