@@ -267,7 +267,7 @@ class PointNetSetAbstraction(nn.Module):
                                                                                           dev, kind=kind))
 
     def forward(self, xyz, points, start=None, _err=None, _rows=None):
-        """_err: a list the caller collects the index-error flags in (one read-back for a whole stack instead of one per layer).
+        """_err: a pre-zeroed (1,) int32 device flag shared by the levels of a stack (one read-back for the stack instead of one per layer).
         _rows (stack-internal): for a sampling level, a (B, S, roundup8(C + 3)) buffer to produce the output in -- features in
         [..., :C] (the returned new_points is that view), the level's new_xyz ++ zeros behind them, i.e. the input rows of a following
         group-all level; for the group-all level, that buffer."""
@@ -289,9 +289,7 @@ class PointNetSetAbstraction(nn.Module):
                 else:                      # a first-layer shape feeding a group-all level directly: the three columns by a copy
                     _rows[:, :, C:C + 3] = new_xyz; _rows[:, :, C + 3:] = 0
             if _err is not None:
-                out, e = _prim.group_mlp_max(xyz, points, new_xyz, idx, W, check_indices=False, channels_last=True, **kw)
-                _err.append(e)
-                return new_xyz, out
+                return new_xyz, _prim.group_mlp_max(xyz, points, new_xyz, idx, W, check_indices=False, channels_last=True, err=_err, **kw)[0]
             return new_xyz, _prim.group_mlp_max(xyz, points, new_xyz, idx, W, channels_last=True, **kw)
         if self.group_all:
             new_xyz, new_points = sample_and_group_all(xyz, points)
@@ -343,19 +341,18 @@ class PointNetSetAbstractionMsg(nn.Module):
             _, new_xyz = farthest_point_sample(xyz, self.npoint, start, return_xyz=True)
             buf = _rows if _rows is not None else torch.empty((B, self.npoint, self.out_channel), dtype=torch.float32, device=xyz.device)
             out = buf[:, :, :self.out_channel]
-            errs = [] if _err is None else _err
+            err = torch.zeros((1,), dtype=torch.int32, device=xyz.device) if _err is None else _err
             c0 = 0
             for i, (W, radius, K) in enumerate(zip(Ws, self.radius_list, self.nsample_list)):
                 idx = query_ball_point(radius, K, xyz, new_xyz)
                 last = i == len(Ws) - 1 and _rows is not None and W.kind == 'tile'      # the last scale's kernel also writes xyz ++ pad
-                _, e = _prim.group_mlp_max(xyz, points, new_xyz, idx, W, check_indices=False, channels_last=True, out=out[:, :, c0:c0 + W.cout[-1]],
-                                           append_xyz=buf.shape[-1] - self.out_channel if last else 0)
-                errs.append(e)
+                _prim.group_mlp_max(xyz, points, new_xyz, idx, W, check_indices=False, channels_last=True, out=out[:, :, c0:c0 + W.cout[-1]],
+                                    append_xyz=buf.shape[-1] - self.out_channel if last else 0, err=err)
                 c0 += W.cout[-1]
             if _rows is not None and Ws[-1].kind != 'tile':
                 buf[:, :, self.out_channel:self.out_channel + 3] = new_xyz; buf[:, :, self.out_channel + 3:] = 0
             if _err is None:
-                _prim._raise_if(torch.stack(errs).max(), 'PointNetSetAbstractionMsg (a query ball was empty or an index is out of range)')
+                _prim._raise_if(err, 'PointNetSetAbstractionMsg (a query ball was empty or an index is out of range)')
             return new_xyz, out
         fps_idx = farthest_point_sample(xyz, self.npoint, start) if xyz.is_cuda else _torch_fps(xyz, self.npoint, start)
         new_xyz = _torch_index(xyz, fps_idx)
@@ -444,8 +441,8 @@ class PointNet2Encoder(nn.Module):
         feats = x[:, :, 3:].contiguous() if C > 3 else None
         s1, s2 = (None, None) if start is None else start
         hip = _use_hip(self, x)
-        errs = [] if hip else None
-        kw = {'_err': errs} if hip else {}
+        err = torch.zeros((1,), dtype=torch.int32, device=x.device) if hip else None
+        kw = {'_err': err} if hip else {}
         l1_xyz, l1_points = self.sa1(xyz, feats, start=s1, **kw)
         rows = None
         if hip:      # level 2 writes [features | xyz | pad] rows: what the group-all level's first GEMM reads (no concatenation pass)
@@ -454,6 +451,6 @@ class PointNet2Encoder(nn.Module):
             kw = dict(kw, _rows=rows)
         l2_xyz, l2_points = self.sa2(l1_xyz, l1_points, start=s2, **kw)
         _, l3_points = self.sa3(l2_xyz, l2_points, **({'_rows': rows} if rows is not None else {}))
-        if hip and errs:
-            _prim._raise_if(torch.stack(errs).max(), 'PointNet2Encoder (a query ball was empty or an index is out of range)')
+        if hip:
+            _prim._raise_if(err, 'PointNet2Encoder (a query ball was empty or an index is out of range)')
         return l3_points.reshape(B, -1), [(l1_xyz, l1_points), (l2_xyz, l2_points)]

@@ -178,7 +178,7 @@ class SetAbstractionWeights:
                 (ctypes.c_void_p * L_)(*[t.data_ptr() for t in self.w]), (ctypes.c_void_p * L_)(*[t.data_ptr() for t in self.b]))
 
 
-def group_mlp_max(xyz, points, new_xyz, idx, W, check_indices=True, channels_last=False, out=None, append_xyz=0):
+def group_mlp_max(xyz, points, new_xyz, idx, W, check_indices=True, channels_last=False, out=None, append_xyz=0, err=None):
     """The consumer of sample_and_group fused into one kernel (cg_sa_group_mlp_max_strided / cg_sa_tile_mlp_max by W.kind): neighbourhoods
     idx (B,S,K) of xyz/points around new_xyz -> centred coordinates ++ features -> shared MLP W (SetAbstractionWeights) -> max over the K
     neighbours.  -> (B, C_out, S) float32, the layout torch.max(new_points, 2)[0] has in a PointNet++ set-abstraction layer, or with
@@ -205,7 +205,8 @@ def group_mlp_max(xyz, points, new_xyz, idx, W, check_indices=True, channels_las
         raise ValueError('out: wrong shape / dtype / device')
     sb, s1, s2 = out.stride() if B * S else (0, 0, 0)
     ss, cs = (s1, s2) if channels_last else (s2, s1)
-    err = torch.zeros((1,), dtype=torch.int32, device=xyz.device)
+    if err is None:            # err: a caller-owned, pre-zeroed (1,) int32 flag shared by several calls (a whole stack reads it back once)
+        err = torch.zeros((1,), dtype=torch.int32, device=xyz.device)
     L_, cin, cout, wp, bp = W._c_arrays()
     if append_xyz and (W.kind != 'tile' or not channels_last or cs != 1):
         raise ValueError("append_xyz needs kind='tile' weights and a channels_last output with unit channel stride")
