@@ -41,6 +41,14 @@ case $JOB in
     CATGRASP_AMD_SAT_PRIO=0 timeout 300 python scripts/sa_tile_time.py $O/sa_tile_noprio.json > $O/sa_tile_noprio.txt 2>&1; echo no prio; grep ssg_sa2 $O/sa_tile_noprio.txt
     for pc in 1 2; do CATGRASP_AMD_SAT_PER_CU=$pc timeout 300 python scripts/sa_tile_time.py $O/sa_tile_percu$pc.json > $O/sa_tile_percu$pc.txt 2>&1; echo per_cu $pc; grep ssg_sa2 $O/sa_tile_percu$pc.txt; done
     timeout 600 python -m pytest tests/test_pointnet2_encoder_gpu.py -m gpu -x -q > $O/pytest.log 2>&1; tail -3 $O/pytest.log ;;
+  filter)     # the collision filter: parity tests, timing of the call shapes, issue-side counters
+    timeout 900 python -m pytest tests/test_collision_gpu.py tests/test_fullsize_properties_gpu.py tests/test_workload_gpu.py -m gpu -x -q -k "not f16 and not bf16" > $O/pytest.log 2>&1; tail -4 $O/pytest.log
+    timeout 200 python scripts/time_filter.py > $O/filter_time.txt 2>&1; tail -12 $O/filter_time.txt
+    SQ="SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU GRBM_GUI_ACTIVE"
+    timeout 300 rocprofv3 --pmc $SQ --kernel-include-regex 'filter_grasp_pose|compose_grasp' --output-format csv -d $O/pmc_sq -- python scripts/pmc_filter.py > $O/pmc_sq_filter.log 2>&1
+    timeout 300 rocprofv3 --kernel-trace --kernel-include-regex 'filter_grasp_pose|compose_grasp' --output-format csv -d $O/ktrace -- python scripts/pmc_filter.py 10 > $O/ktrace_filter.log 2>&1
+    python scripts/pmc_summary.py $O/pmc_sq $O/pmc_sq_filter.csv > /dev/null; python scripts/pmc_summary.py $O/ktrace $O/ktrace_filter.csv "grasp_pose" > /dev/null
+    rm -rf $O/pmc_sq $O/ktrace; grep "true" $O/pmc_sq_filter.csv; cat $O/ktrace_filter.csv ;;
   py)         # any script:  py scripts/x.py args...
     timeout 1200 python "$@" > $O/out.txt 2>&1; tail -40 $O/out.txt ;;
   *) echo "unknown job $JOB"; exit 2 ;;
