@@ -287,7 +287,7 @@ def cpu_baseline(batch, sd_cls, sd_seg, n_score=100, n_coll=4096):
     # (FCL has), so it is timed on the SAME surfaces un-subdivided (36 / 48 triangles: identical verdicts) and with the float32
     # separating-axis narrow phase -- the cheapest form of the predicate, not the oracle's float64 clipping.
     g = _synth.make_gripper()
-    co.lib().cr_set_variant(0, ctypes_float0(), 1)
+    co.lib().cr_set_variant(0, ctypes_float0(), 1)           # restored in the `finally` below
     seg_nocs = next(s for s in batch.segs if s.kind == 'nocs' and s.obj == 0)
     seg_cone = next(s for s in batch.segs if s.kind == 'cone' and s.obj == 0)
     P = batch.host_poses(seg_cone)
@@ -332,7 +332,19 @@ def cpu_baseline(batch, sd_cls, sd_seg, n_score=100, n_coll=4096):
     co.filter_grasp_pose(P[:n_coll // 2], [I4], I4, I4, I4, I4, g['gripper_in_grasp'], 1, 0, 0, g['vertices'], g['faces'],
                          g['enclosed_vertices'], g['enclosed_faces'], ob['xyz'], bg, 0.0005)
     t_coll = (time.perf_counter() - t0) / (n_can * len(sym) + n_coll // 2)
-    co.lib().cr_set_variant(0, ctypes_float0(), 0)
+    # The SAME call on the step's own subdivided meshes (9,216 / 12,288 triangles), a small sample: what the restatement -- which has
+    # no bounding-volume hierarchy where FCL has one -- costs on identical inputs.  Reported beside the figure above, not used in `value`
+    # (it would credit the GPU with FCL's missing BVH).
+    t_coll_same = None
+    try:
+        V, F = _synth.subdivide(g['vertices'], g['faces'], GRIPPER_SUBDIVISIONS); Ve, Fe = _synth.subdivide(g['enclosed_vertices'], g['enclosed_faces'], GRIPPER_SUBDIVISIONS)
+        n_same = 96
+        t0 = time.perf_counter()
+        co.filter_grasp_pose(can[:max(1, n_same // (2 * len(sym)))], sym, batch.nocs_pose[0], I4, I4, I4, g['gripper_in_grasp'], 1, 0, 1, V, F, Ve, Fe, ob['xyz'], bg, 0.0005)
+        co.filter_grasp_pose(P[:n_same // 2], [I4], I4, I4, I4, I4, g['gripper_in_grasp'], 1, 0, 0, V, F, Ve, Fe, ob['xyz'], bg, 0.0005)
+        t_coll_same = (time.perf_counter() - t0) / (max(1, n_same // (2 * len(sym))) * len(sym) + n_same // 2)
+    finally:
+        co.lib().cr_set_variant(0, ctypes_float0(), 0)       # the oracle's default predicate (float64 clipping) for whoever uses it next
     pss = oref.prepared_state_dict(sd_seg)
     t0 = time.perf_counter()
     ids = tref.draw_ids(len(ob['xyz']), 8192)
@@ -347,6 +359,7 @@ def cpu_baseline(batch, sd_cls, sd_seg, n_score=100, n_coll=4096):
             'kind_note': 'port pinned to reference goldens: the F.conv1d / F.batch_norm op sequence of oracle/pointnet_ref.py is checked against outputs of the '
                          'imported /root/reference/pointnet2.py (tests/golden/make_golden*.py); the reference package itself cannot travel to the GPU box',
             'collision_threads': co.num_threads(),
+            'collision_ms_per_evaluation_on_the_steps_subdivided_meshes': None if t_coll_same is None else round(t_coll_same * 1e3, 3),
             'sample': f'{n_score} candidates x (3 warm-ups, median of 5): python transform loop + PointNetCls fp32 in chunks of 200 through '
                       f'F.conv1d/F.batch_norm/F.linear on {nthreads} torch threads (best of the scan); {n_can * len(sym) + n_coll // 2} '
                       f'evaluations collision-filtered by the C/OpenMP restatement on {co.num_threads()} threads (both call shapes, structure build '

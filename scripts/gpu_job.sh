@@ -49,6 +49,20 @@ case $JOB in
     timeout 300 rocprofv3 --kernel-trace --kernel-include-regex 'filter_grasp_pose|compose_grasp' --output-format csv -d $O/ktrace -- python scripts/pmc_filter.py 10 > $O/ktrace_filter.log 2>&1
     python scripts/pmc_summary.py $O/pmc_sq $O/pmc_sq_filter.csv > /dev/null; python scripts/pmc_summary.py $O/ktrace $O/ktrace_filter.csv "grasp_pose" > /dev/null
     rm -rf $O/pmc_sq $O/ktrace; grep "true" $O/pmc_sq_filter.csv; cat $O/ktrace_filter.csv ;;
+  final)      # the measurements of the shipped state: GPU suite, smoke, bench line (+ kernel statistics), helper table, encoder, C4 / C5
+    timeout 2400 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; tail -5 $O/pytest.log
+    timeout 120 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
+    ( time timeout 1200 python bench.py --gpus 1 --steps 20 --warmup 5 ) > $O/bench.json 2> $O/bench.err; tail -c 400 $O/bench.err
+    stats bench python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-api --no-pmc-traffic --no-rccl-selftest --no-projection
+    timeout 300 python scripts/hbm_kernels.py > $O/hbm_kernels.json 2> $O/hbm_kernels.err; tail -2 $O/hbm_kernels.err
+    timeout 300 python scripts/pp_encoder_profile.py $O/pp_encoder.json > $O/pp_encoder.txt 2>&1
+    timeout 300 python scripts/pp_encoder_profile.py $O/pp_encoder_msg.json --msg > $O/pp_encoder_msg.txt 2>&1
+    stats pp_encoder python scripts/pp_encoder_profile.py --trace
+    stats pp_encoder_msg python scripts/pp_encoder_profile.py --trace --msg
+    timeout 300 python scripts/sa_tile_time.py $O/sa_tile.json > $O/sa_tile.txt 2>&1
+    ( time timeout 600 python bench.py --gpus 1 --workload C4 --steps 3 --warmup 1 --secondary "" --no-api --no-cpu-baseline ) > $O/bench_c4_n1.json 2> $O/bench_c4_n1.err
+    ( time timeout 600 python bench.py --gpus 1 --workload C5 --steps 3 --warmup 1 --secondary "f32" --no-api --no-cpu-baseline ) > $O/bench_c5_n1.json 2> $O/bench_c5_n1.err
+    ls -la $O; head -c 600 $O/bench.json ;;
   py)         # any script:  py scripts/x.py args...
     timeout 1200 python "$@" > $O/out.txt 2>&1; tail -40 $O/out.txt ;;
   *) echo "unknown job $JOB"; exit 2 ;;
