@@ -184,6 +184,58 @@ def filter_roofline_block(batch, device, reps=5, issue=None):
     return out
 
 
+def encoder_block(batch, device, clouds=(1, 8)):
+    """The PointNet++ set-abstraction encoder north_star names (catgrasp_amd.pointnet2.PointNet2Encoder: 512 / 0.2 / 32 -> 128 / 0.4 / 64 ->
+    all) on the step's own 20k-point scene cloud, normalised into the unit ball, xyz + normals: ms per forward (HIP events over 10
+    forwards) and the f32 MFMA fraction of the two fused sampling levels from their own event timings.  Random-init weights."""
+    from catgrasp_amd import pointnet2 as p2
+    from catgrasp_amd import primitives as prim
+    pts = np.concatenate([o['xyz'] for o in batch.objs]); nrm = np.concatenate([o['normal'] for o in batch.objs])
+    pts = pts - pts.mean(0); pts = pts / np.linalg.norm(pts, axis=1).max()
+    x1 = torch.from_numpy(np.concatenate([pts, nrm], 1).astype(np.float32)).to(device)
+    torch.manual_seed(0)
+    enc = p2.PointNet2Encoder(channel=6).to(device).eval()
+    was = p2.VALIDATE_INPUTS
+    p2.VALIDATE_INPUTS = False
+    out = {'model': 'PointNet2Encoder(channel=6): SA(512, r 0.2, K 32, [64,64,128]) -> SA(128, r 0.4, K 64, [128,128,256]) -> SA(all, [256,512,1024])',
+           'points': int(len(pts)), 'peak_tflops_f32_mfma': PEAK_F32_MFMA_TFLOPS, 'rows': []}
+
+    def timed(fn, iters=10):
+        for _ in range(2):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters
+    try:
+        with torch.no_grad():
+            for B in clouds:
+                x = x1[None].repeat(B, 1, 1).contiguous()
+                N = x.shape[1]
+                start = (torch.arange(B) * 37 % N, torch.arange(B) * 11 % 512)
+                ms = timed(lambda: enc(x, start=start))
+                xyz, feats = x[:, :, :3].contiguous(), x[:, :, 3:].contiguous()
+                _, l1_xyz = p2.farthest_point_sample(xyz, 512, start[0], return_xyz=True)
+                idx1 = p2.query_ball_point(0.2, 32, xyz, l1_xyz)
+                W1, W2 = enc.sa1._weights(device), enc.sa2._weights(device)
+                l1 = prim.group_mlp_max(xyz, feats, l1_xyz, idx1, W1, channels_last=True)
+                _, l2_xyz = p2.farthest_point_sample(l1_xyz, 128, start[1], return_xyz=True)
+                idx2 = p2.query_ball_point(0.4, 64, l1_xyz, l2_xyz)
+                t1 = timed(lambda: prim.group_mlp_max(xyz, feats, l1_xyz, idx1, W1, check_indices=False, channels_last=True))
+                t2 = timed(lambda: prim.group_mlp_max(l1_xyz, l1, l2_xyz, idx2, W2, check_indices=False, channels_last=True))
+                f1 = B * 512 * 32 * 2 * (9 * 64 + 64 * 64 + 64 * 128); f2 = B * 128 * 64 * 2 * (131 * 128 + 128 * 128 + 128 * 256)
+                out['rows'].append({'clouds': B, 'ms_per_forward': round(ms, 4), 'clouds_per_s': round(B / ms * 1e3, 1),
+                                    'level1_fused_us': round(t1 * 1e3, 2), 'level1_frac_of_peak': round(f1 / (t1 * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                                    'level2_fused_us': round(t2 * 1e3, 2), 'level2_frac_of_peak': round(f2 / (t2 * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)})
+    finally:
+        p2.VALIDATE_INPUTS = was
+    out['note'] = ('a forward at one cloud is dominated by the two farthest-point-sampling chains (one CU per cloud, ~0.9 us per round: 512 + 128 rounds); '
+                   'stage table and rocprofv3 kernel statistics: profiles/r5_pp_encoder*.{json,csv}')
+    return out
+
+
 def pick_cycle_block(batch, gp, npred, device, n_canonical=2000):
     """One pick cycle's per-object work with the package's DEFAULT settings (exact f32, the reference's numpy stream for the resampling
     draw AND for the 2 x 10,000 RANSAC hypothesis draws), as run_grasp_simulation.py:112-183,296-329 issues it: pipeline.evaluate_object
@@ -826,6 +878,10 @@ def main():
             line['secondary'] = secondary
         if api is not None:
             line['api'] = api
+            try:
+                line['pp_encoder'] = encoder_block(batch, device)
+            except Exception as e:          # an extra: never let it take the bench line down
+                line['pp_encoder'] = {'error': f'{type(e).__name__}: {e}'[:300]}
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(batch, sd_cls, sd_seg)
         emit(line)

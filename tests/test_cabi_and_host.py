@@ -90,6 +90,30 @@ def test_argument_errors_are_reported_not_crashed():
     assert lib.cg_sa_group_mlp_max(one, null, one, one, 1, 100, 4, 32, 5, 2, cin, cout, ptrs, ptrs, one, null, null) == -1      # D > 0 without features
     assert lib.cg_sa_group_mlp_max(one, one, one, one, 1, 100, 4, 32, 14, 2, cin, cout, ptrs, ptrs, one, null, null) == -2      # 3 + D > 16
     assert lib.cg_sa_group_mlp_max(one, null, one, one, 0, 100, 4, 32, 0, 2, cin, cout, ptrs, ptrs, one, null, null) == 0
+    assert lib.cg_sa_group_mlp_max_strided(one, null, one, one, 1, 100, 4, 32, 0, 2, cin, cout, ptrs, ptrs, null, L(256), L(1), L(4), null, null) == -1     # no output
+    # the tile kernel of the levels past the first (round 5): layer 0 takes roundup8(3 + D) columns
+    tcin, tcout = (ctypes.c_int * 2)(136, 128), (ctypes.c_int * 2)(128, 256)
+    tcin[0] = 131
+    assert lib.cg_sa_tile_mlp_max(one, one, one, one, 1, 100, 4, 64, 128, 2, tcin, tcout, ptrs, ptrs, one, L(1024), L(256), L(1), 0, null, null) == -1         # cin[0] != roundup8(3 + D)
+    tcin[0] = 136; tcout[0] = 100; tcin[1] = 100
+    assert lib.cg_sa_tile_mlp_max(one, one, one, one, 1, 100, 4, 64, 128, 2, tcin, tcout, ptrs, ptrs, one, L(1024), L(256), L(1), 0, null, null) == -2         # width not a multiple of 32
+    tcout[0] = 1024; tcin[1] = 1024
+    assert lib.cg_sa_tile_mlp_max(one, one, one, one, 1, 100, 4, 64, 128, 2, tcin, tcout, ptrs, ptrs, one, L(1024), L(256), L(1), 0, null, null) == -2         # hidden layer wider than 512
+    tcout[0] = 128; tcin[1] = 128
+    assert lib.cg_sa_tile_mlp_max(one, one, null, null, 1, 100, 4, 64, 128, 2, tcin, tcout, ptrs, ptrs, one, L(1024), L(256), L(1), 0, null, null) == -1       # no index list: S must be 1, K == N
+    assert lib.cg_sa_tile_mlp_max(one, one, null, one, 1, 100, 4, 64, 128, 2, tcin, tcout, ptrs, ptrs, one, L(1024), L(256), L(1), 8, null, null) == -1        # append_xyz needs new_xyz
+    assert lib.cg_sa_tile_mlp_max(one, one, one, one, 0, 100, 4, 64, 128, 2, tcin, tcout, ptrs, ptrs, one, L(1024), L(256), L(1), 0, null, null) == 0
+    assert lib.cg_sa_concat_input(one, null, L(5), 4, 8, one, null) == -1                                          # D > 0 without features
+    assert lib.cg_sa_concat_input(one, one, L(5), 4, 6, one, null) == -1                                           # ld < D + 3
+    assert lib.cg_sa_concat_input(null, null, L(0), 0, 8, null, null) == 0
+    assert lib.cg_gemm_bias_relu_groupmax(one, 128, 264, 264, one, 1024, one, 100, one, null) == -1            # rows not a multiple of the group
+    assert lib.cg_gemm_bias_relu_groupmax(one, 128, 260, 260, one, 1024, one, 128, one, null) == -1               # K not a multiple of 8
+    assert lib.cg_gemm_bias_relu_groupmax(one, 0, 264, 264, one, 1024, one, 128, one, null) == 0
+    F1 = ctypes.c_float
+    assert lib.cg_mesh_mesh_collide(one, one, 5, one, one, 5, null, one, one, null) == -1                          # no pose
+    assert lib.cg_mesh_mesh_collide(one, one, -1, one, one, 5, one, one, one, null) == -1
+    assert lib.cg_voxels_voxels_collide(one, 5, F1(0.0), one, 5, F1(0.001), one, one, null) == -1                  # resolution 0
+    assert lib.cg_voxels_voxels_collide(one, 5, F1(0.001), one, 5, F1(0.001), null, one, null) == -1               # no relative pose
     assert lib.cg_pg_voxel_pack_keys(one, 5, 2, one, null, null) == -1                                            # ncol must be 3 or 4
     assert lib.cg_pg_voxel_fill_maps(one, one, one, one, 5, 1, 4, one, one, null) == -1                           # width < 2
     assert lib.cg_pg_cc_propagate(one, one, 3, one, 5, null, one, null) == -1
