@@ -29,7 +29,6 @@
 namespace {
 
 constexpr int ST_MAX_LAYERS = 4;
-constexpr int TR = 64;                      // rows per tile
 
 struct STArgs {
   const float* xyz; const float* points; const float* new_xyz; const long long* idx;
@@ -138,21 +137,21 @@ __device__ __forceinline__ float st_max_regs(const f32x16& c) {
   return m;
 }
 
-// Last layer for one wave, NBW blocks (both halves) per pass: accumulators -> neighbourhood maxima -> out (+ bias, ReLU) or the running
-// maxima in LDS (several row tiles per neighbourhood).  KP = rows per neighbourhood in the tile.
-template <int NBW, int KP>
+// Last layer for one wave, NBW blocks (all NHT 32-row halves of the tile) per pass: accumulators -> neighbourhood maxima -> out (+ bias,
+// ReLU) or the running maxima in LDS (several row tiles per neighbourhood).  KP = rows per neighbourhood in the tile.
+template <int NBW, int KP, int NHT>
 __device__ __forceinline__ void st_last(const STArgs& a, const float* strip, const float* w, const float* bias, int nks, int nb0, int lane,
                                         int kt, float* rmax, const long* goff) {
   const int l31 = lane & 31, lhi = lane >> 5;
   int blk[NBW];
-  f32x16 acc[NBW][2];
+  f32x16 acc[NBW][NHT];
 #pragma unroll
   for (int i = 0; i < NBW; ++i) {
     blk[i] = nb0 + i * 4;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) acc[i][h] = f32x16{0};
+    for (int h = 0; h < NHT; ++h) acc[i][h] = f32x16{0};
   }
-  st_mma<NBW, 2>(strip + l31 * a.CS + lhi * 4, a.CS, (const f32x4*)w + lane, nks, blk, acc);
+  st_mma<NBW, NHT>(strip + l31 * a.CS + lhi * 4, a.CS, (const f32x4*)w + lane, nks, blk, acc);
   // goff[j]: offset of the tile's j-th neighbourhood inside `out`, or -1 for the padding of the last tile
   auto store = [&](int j, int ch, float m) {
     const long o = goff[j];
@@ -161,23 +160,28 @@ __device__ __forceinline__ void st_last(const STArgs& a, const float* strip, con
 #pragma unroll
   for (int i = 0; i < NBW; ++i) {
     const int ch = blk[i] * 32 + l31;
-    if constexpr (KP == 64) {
-      float m = fmaxf(max16(acc[i][0]), max16(acc[i][1]));
-      m = fmaxf(m, __shfl_xor(m, 32));
-      if (lane < 32) {
-        if (a.RT == 1) store(0, ch, m);
-        else {
-          if (kt > 0) m = fmaxf(m, rmax[ch]);
-          if (kt == a.RT - 1) store(0, ch, m); else rmax[ch] = m;
+    if constexpr (KP >= 32) {
+      constexpr int HPN = KP / 32;         // 32-row halves per neighbourhood; NHT / HPN neighbourhoods in the tile
+#pragma unroll
+      for (int j = 0; j < NHT / HPN; ++j) {
+        float m = max16(acc[i][j * HPN]);
+#pragma unroll
+        for (int h = 1; h < HPN; ++h) m = fmaxf(m, max16(acc[i][j * HPN + h]));
+        m = fmaxf(m, __shfl_xor(m, 32));
+        if (lane < 32) {
+          if (HPN < NHT || a.RT == 1) store(j, ch, m);
+          else {                           // the tile is one neighbourhood's row tile kt of RT: running maximum in LDS
+            if (kt > 0) m = fmaxf(m, rmax[ch]);
+            if (kt == a.RT - 1) store(0, ch, m); else rmax[ch] = m;
+          }
         }
       }
     } else {
       constexpr int NPH = 32 / KP;         // neighbourhoods per 32-row half; registers [p * 16 / NPH, ...) hold the rows of neighbourhood p
       constexpr int RP = 16 / NPH;
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
+      for (int h = 0; h < NHT; ++h) {
         float m[NPH];
-        if constexpr (NPH == 1) m[0] = max16(acc[i][h]);
         if constexpr (NPH == 2) { m[0] = st_max_regs<0, RP>(acc[i][h]); m[1] = st_max_regs<RP, RP>(acc[i][h]); }
         if constexpr (NPH == 4) {
           m[0] = st_max_regs<0, RP>(acc[i][h]); m[1] = st_max_regs<RP, RP>(acc[i][h]);
@@ -194,26 +198,29 @@ __device__ __forceinline__ void st_last(const STArgs& a, const float* strip, con
 }
 
 // KP: rows of a tile per neighbourhood.  WIDE: hidden layers up to 512 channels (4 blocks x 2 halves of accumulators per wave) -- the
-// narrow instance (<= 256) needs half the registers and so holds twice the wavefronts.
-template <int KP, bool WIDE>
-__global__ __launch_bounds__(256, WIDE ? 1 : 3) void sa_tile_kernel(STArgs a) {
+// narrow instance (<= 256) needs half the registers and so holds twice the wavefronts.  TR: rows per tile -- 64, or 128 for launches
+// with enough rows to fill the chip that way: half the barriers, gathers and pipeline fills per matrix FMA, each weight fragment
+// feeding four 32-row halves (narrow instance only: a two-block share is 128 accumulator registers).
+template <int KP, bool WIDE, int TR>
+__global__ __launch_bounds__(256, WIDE ? 1 : (TR == 128 ? 2 : 3)) void sa_tile_kernel(STArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int CS = a.CS;
   const int c_last = a.cout[a.nlayers - 1];
   float* strip = smem;
   float* rmax = strip + TR * CS;
   long* goff = (long*)(rmax + c_last);          // (TR * CS + c_last) * 4 is a multiple of 16
-  int* pbase = (int*)(goff + 8);                // row -> b * N + point index
+  int* pbase = (int*)(goff + 16);               // row -> b * N + point index
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   constexpr int NPT = TR / KP;
   const int G = a.B * a.S;                      // < 2^31 / 8 (checked by the launcher); so is B * N < 2^31
-  const int nslots = KP == 64 ? G : (G + NPT - 1) / NPT;
-  const int RT = KP == 64 ? a.RT : 1;
+  const int nslots = KP == TR ? G : (G + NPT - 1) / NPT;
+  const int RT = KP == TR ? a.RT : 1;
+  constexpr int NHT = TR / 32;
   const int D = a.D, cin0 = a.cin[0];
 
   auto row_id = [&](int slot, int kt, int r, int& g_out) -> long long {
     int g, k;
-    if (KP == 64) { g = slot; k = kt * 64 + r; } else { g = slot * NPT + r / KP; k = r % KP; }
+    if (KP == TR) { g = slot; k = kt * TR + r; } else { g = slot * NPT + r / KP; k = r % KP; }
     if (g >= G) g = G - 1;                     // tail slot: a repeated neighbourhood whose result is not stored
     if (k >= a.K) k = 0;                       // short neighbourhood: neighbour 0 again (the max is idempotent)
     g_out = g;
@@ -246,11 +253,11 @@ __global__ __launch_bounds__(256, WIDE ? 1 : 3) void sa_tile_kernel(STArgs a) {
       p_row = (g_row / a.S) * a.N + (int)id;
       pbase[tid] = p_row;
     }
-    if (tid >= 64 && tid < 64 + NPT) {          // where the tile's neighbourhoods go in `out`
-      const int g = (KP == 64 ? slot : slot * NPT) + (tid - 64);
+    if (tid >= TR && tid < TR + NPT) {          // where the tile's neighbourhoods go in `out`
+      const int g = (KP == TR ? slot : slot * NPT) + (tid - TR);
       const int b = g / a.S;
       const long o = g < G ? (long)b * a.out_bs + (long)(g - b * a.S) * a.out_ss : -1;
-      goff[tid - 64] = o;
+      goff[tid - TR] = o;
       if (a.append_n > 0 && o >= 0 && kt == 0) {      // the row the NEXT level's group-all GEMM reads: [features | xyz | zero pad]
         const float* pc = a.new_xyz + (size_t)g * 3;
         for (int e = 0; e < a.append_n; ++e) a.out[o + (long)(c_last + e) * a.out_cs] = e < 3 ? pc[e] : 0.f;
@@ -307,28 +314,28 @@ __global__ __launch_bounds__(256, WIDE ? 1 : 3) void sa_tile_kernel(STArgs a) {
     for (int l = 0; l < a.nlayers; ++l) {
       const int nks = a.cin[l] >> 3, nb = a.cout[l] >> 5;
       if (l + 1 < a.nlayers) {
-        if (nb >= 4) {                          // a wave: blocks {wv, wv + 4, ...}, both 32-row halves (one weight fragment feeds both)
+        if (nb >= 4) {                          // a wave: blocks {wv, wv + 4, ...}, every 32-row half (one weight fragment feeds them all)
           const int cnt = nb > wv ? (nb - wv + 3) >> 2 : 0;
           switch (cnt) {
-            case 1: st_hidden<1, 2>(strip, CS, a.w[l], a.b[l], nks, wv, 4, 0, lane); break;
-            case 2: st_hidden<2, 2>(strip, CS, a.w[l], a.b[l], nks, wv, 4, 0, lane); break;
-            case 3: if constexpr (WIDE) { st_hidden<3, 2>(strip, CS, a.w[l], a.b[l], nks, wv, 4, 0, lane); break; }
-            case 4: if constexpr (WIDE) { st_hidden<4, 2>(strip, CS, a.w[l], a.b[l], nks, wv, 4, 0, lane); break; }
+            case 1: st_hidden<1, NHT>(strip, CS, a.w[l], a.b[l], nks, wv, 4, 0, lane); break;
+            case 2: st_hidden<2, NHT>(strip, CS, a.w[l], a.b[l], nks, wv, 4, 0, lane); break;
+            case 3: if constexpr (WIDE) { st_hidden<3, NHT>(strip, CS, a.w[l], a.b[l], nks, wv, 4, 0, lane); break; }
+            case 4: if constexpr (WIDE) { st_hidden<4, NHT>(strip, CS, a.w[l], a.b[l], nks, wv, 4, 0, lane); break; }
             default: st_hidden_idle(); break;
           }
-        } else {                                // 32 / 64 / 96 channels: a wave takes ONE half and the blocks {wv >> 1, (wv >> 1) + 2}
+        } else {                                // 32 / 64 / 96 channels: a wave takes ONE half of the rows and the blocks {wv >> 1, (wv >> 1) + 2}
           const int p = wv >> 1, cnt = nb > p ? (nb - p + 1) >> 1 : 0;
           switch (cnt) {
-            case 1: st_hidden<1, 1>(strip, CS, a.w[l], a.b[l], nks, p, 2, 32 * (wv & 1), lane); break;
-            case 2: st_hidden<2, 1>(strip, CS, a.w[l], a.b[l], nks, p, 2, 32 * (wv & 1), lane); break;
+            case 1: st_hidden<1, NHT / 2>(strip, CS, a.w[l], a.b[l], nks, p, 2, (TR / 2) * (wv & 1), lane); break;
+            case 2: st_hidden<2, NHT / 2>(strip, CS, a.w[l], a.b[l], nks, p, 2, (TR / 2) * (wv & 1), lane); break;
             default: st_hidden_idle(); break;
           }
         }
       } else {
         const int cnt = nb > wv ? (nb - wv + 3) >> 2 : 0;
         for (int i0 = 0; i0 < cnt; i0 += 2) {
-          if (cnt - i0 >= 2) st_last<2, KP>(a, strip, a.w[l], a.b[l], nks, wv + 4 * i0, lane, kt, rmax, goff);
-          else st_last<1, KP>(a, strip, a.w[l], a.b[l], nks, wv + 4 * i0, lane, kt, rmax, goff);
+          if (cnt - i0 >= 2) st_last<2, KP, NHT>(a, strip, a.w[l], a.b[l], nks, wv + 4 * i0, lane, kt, rmax, goff);
+          else st_last<1, KP, NHT>(a, strip, a.w[l], a.b[l], nks, wv + 4 * i0, lane, kt, rmax, goff);
         }
       }
     }
@@ -349,9 +356,9 @@ __global__ void sa_concat_kernel(const float* xyz, const float* points, long row
   out[i] = v;
 }
 
-template <int KP, bool WIDE>
+template <int KP, bool WIDE, int TR>
 int launch_st(const STArgs& a, size_t lds, long nslots, int dev, hipStream_t s) {
-  auto kern = sa_tile_kernel<KP, WIDE>;
+  auto kern = sa_tile_kernel<KP, WIDE, TR>;
   static bool attr_set[CG_MAX_DEVICES] = {};
   if (!attr_set[dev]) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -361,15 +368,15 @@ int launch_st(const STArgs& a, size_t lds, long nslots, int dev, hipStream_t s) 
   const int n_cu = cg_device_cu_count(dev);
   if (n_cu <= 0) return CG_ERR_UNSUPPORTED;
   int per_cu = (int)((160 * 1024) / lds);
-  const int reg_cap = WIDE ? 1 : 3;              // workgroups of 4 waves a CU's registers hold (304 / 155 registers per lane)
+  const int reg_cap = WIDE ? 1 : (TR == 128 ? 2 : 3);      // workgroups of 4 waves a CU's registers hold
   if (per_cu > reg_cap) per_cu = reg_cap;
   static const char* pc_env = getenv("CATGRASP_AMD_SAT_PER_CU");        // dev knob: resident workgroups per CU
   if (pc_env && atoi(pc_env) > 0 && atoi(pc_env) < per_cu) per_cu = atoi(pc_env);
   if (per_cu < 1) per_cu = 1;
   long grid = nslots < (long)n_cu * per_cu ? nslots : (long)n_cu * per_cu;        // persistent: a workgroup walks slots blockIdx, + grid, ...
   STArgs b = a;
-  static const char* pr_env = getenv("CATGRASP_AMD_SAT_PRIO");           // dev knob: 0 = equal priorities
-  b.prio_div = (pr_env && atoi(pr_env) == 0) ? 0 : n_cu;
+  static const char* pr_env = getenv("CATGRASP_AMD_SAT_PRIO");           // dev knob: 1 = unequal wave priorities per resident workgroup
+  b.prio_div = (pr_env && atoi(pr_env) == 1) ? n_cu : 0;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, s, b);
   return cg_hip_status(hipGetLastError());
 }
@@ -377,11 +384,20 @@ int launch_st(const STArgs& a, size_t lds, long nslots, int dev, hipStream_t s) 
 template <bool WIDE>
 int launch_st_kp(const STArgs& a, size_t lds, long nslots, int dev, hipStream_t s) {
   switch (a.KP) {
-    case 8: return launch_st<8, WIDE>(a, lds, nslots, dev, s);
-    case 16: return launch_st<16, WIDE>(a, lds, nslots, dev, s);
-    case 32: return launch_st<32, WIDE>(a, lds, nslots, dev, s);
+    case 8: return launch_st<8, WIDE, 64>(a, lds, nslots, dev, s);
+    case 16: return launch_st<16, WIDE, 64>(a, lds, nslots, dev, s);
+    case 32: return launch_st<32, WIDE, 64>(a, lds, nslots, dev, s);
   }
-  return launch_st<64, WIDE>(a, lds, nslots, dev, s);
+  return launch_st<64, WIDE, 64>(a, lds, nslots, dev, s);
+}
+int launch_st_kp128(const STArgs& a, size_t lds, long nslots, int dev, hipStream_t s) {
+  switch (a.KP) {
+    case 8: return launch_st<8, false, 128>(a, lds, nslots, dev, s);
+    case 16: return launch_st<16, false, 128>(a, lds, nslots, dev, s);
+    case 32: return launch_st<32, false, 128>(a, lds, nslots, dev, s);
+    case 64: return launch_st<64, false, 128>(a, lds, nslots, dev, s);
+  }
+  return launch_st<128, false, 128>(a, lds, nslots, dev, s);
 }
 
 }  // namespace
@@ -414,14 +430,29 @@ extern "C" int cg_sa_tile_mlp_max(const float* xyz, const float* points, const f
   }
   if (hidden_max > 512) return CG_ERR_UNSUPPORTED;               // a hidden layer's accumulators must fit one wave's registers (4 blocks x 2 halves)
   a.CS = cstore + 4;
-  a.KP = K <= 8 ? 8 : K <= 16 ? 16 : K <= 32 ? 32 : 64;
-  a.RT = a.KP == 64 ? (K + 63) / 64 : 1;
-  const size_t lds = ((size_t)TR * a.CS + a.cout[n_layers - 1]) * 4 + 8 * sizeof(long) + TR * sizeof(int);
-  if (lds > 158 * 1024) return CG_ERR_UNSUPPORTED;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= CG_MAX_DEVICES) return CG_ERR_UNSUPPORTED;
+  const int n_cu = cg_device_cu_count(dev);
+  if (n_cu <= 0) return CG_ERR_UNSUPPORTED;
   const long G = (long)B * S;
-  const int npt = TR / a.KP;
+  const size_t tail = (size_t)a.cout[n_layers - 1] * 4 + 16 * sizeof(long);
+  // 128-row tiles when the launch still fills the chip with them (>= 4 tiles per CU), the strip leaves room for two workgroups per CU
+  // and no hidden layer needs the wide instance; 64-row tiles otherwise
+  const int kp128 = K <= 8 ? 8 : K <= 16 ? 16 : K <= 32 ? 32 : K <= 64 ? 64 : 128;
+  const long slots128 = kp128 == 128 ? G : (G + 128 / kp128 - 1) / (128 / kp128);
+  const size_t lds128 = (size_t)128 * a.CS * 4 + tail + 128 * sizeof(int);
+  static const char* tr_env = getenv("CATGRASP_AMD_SAT_TILE_ROWS");      // dev knob: 64 / 128
+  bool use128 = hidden_max <= 256 && lds128 <= 80 * 1024 && slots128 * (kp128 == 128 ? (K + 127) / 128 : 1) >= 4L * n_cu;
+  if (tr_env) use128 = atoi(tr_env) == 128 && hidden_max <= 256 && lds128 <= 158 * 1024;
+  if (use128) {
+    a.KP = kp128; a.RT = kp128 == 128 ? (K + 127) / 128 : 1;
+    return launch_st_kp128(a, lds128, slots128, dev, (hipStream_t)stream);
+  }
+  a.KP = K <= 8 ? 8 : K <= 16 ? 16 : K <= 32 ? 32 : 64;
+  a.RT = a.KP == 64 ? (K + 63) / 64 : 1;
+  const size_t lds = (size_t)64 * a.CS * 4 + tail + 64 * sizeof(int);
+  if (lds > 158 * 1024) return CG_ERR_UNSUPPORTED;
+  const int npt = 64 / a.KP;
   const long nslots = a.KP == 64 ? G : (G + npt - 1) / npt;
   if (hidden_max > 256) return launch_st_kp<true>(a, lds, nslots, dev, (hipStream_t)stream);
   return launch_st_kp<false>(a, lds, nslots, dev, (hipStream_t)stream);

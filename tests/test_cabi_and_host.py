@@ -646,7 +646,8 @@ def test_hot_kernels_stay_out_of_scratch():
     kr = importlib.util.module_from_spec(spec); spec.loader.exec_module(kr)
     if not all(os.path.exists(os.path.join(kr.LLVM, t)) for t in ('llvm-objcopy', 'clang-offload-bundler', 'llvm-readelf')) or shutil.which('c++filt') is None:
         pytest.skip('ROCm llvm binutils / c++filt not found')
-    hot = {'pointmlp.o': ('pointmlp_max_kernel<',), 'setabstraction.o': ('sa_reg_kernel<',), 'primitives.o': ('square_distance', 'ball_query', 'group_points'), 'fps.o': ('fps_kernel<', 'fps_blob_kernel<'),
+    hot = {'pointmlp.o': ('pointmlp_max_kernel<',), 'setabstraction.o': ('sa_reg_kernel<',), 'sa_tile.o': ('sa_tile_kernel<64, false, 64>', 'sa_tile_kernel<64, false, 128>', 'sa_tile_kernel<128, false, 128>', 'sa_tile_kernel<64, true, 64>'),
+           'primitives.o': ('square_distance', 'ball_query', 'group_points'), 'fps.o': ('fps_kernel<', 'fps_blob_kernel<'),
            'gemm.o': ('gemm_bias_act_kernel',), 'collision.o': ('filter_grasp_pose_kernel',), 'misc.o': ('build_grasp_input', 'softmax_pg', 'nunocs_decode'),
            'pointmlp_split.o': ('pointmlp_max_split_kernel<0, 8, true, false>', 'pointmlp_max_split_kernel<2, 8, false, false>')}
     seen = 0

@@ -272,3 +272,30 @@ def test_group_all_gemm_epilogue_max_and_appended_rows(cuda_device):
     L.check(L.lib().cg_sa_concat_input(L._p(new_xyz), L._p(plain.contiguous()), ctypes.c_long(B * S), ctypes.c_int(160), ctypes.c_int(168), L._p(want),
                                        L._stream()), 'cg_sa_concat_input')
     assert torch.equal(rows.view(B * S, 168), want)
+
+
+@pytest.mark.parametrize('B,N,S,K,D,mlp', [(20, 300, 128, 64, 16, [64, 96, 128]), (16, 600, 512, 16, 29, [128, 128, 256]), (8, 400, 128, 100, 8, [32, 256]),
+                                             (4, 500, 128, 200, 128, [128, 128, 256]), (16, 256, 1024, 8, 0, [64, 64]), (20, 300, 128, 33, 64, [256, 128, 1024])])
+def test_tile_kernel_with_128_row_tiles(cuda_device, B, N, S, K, D, mlp):
+    """Launches large enough for the 128-row tile instance of sa_tile_kernel (>= 4 tiles per CU; hidden widths <= 256): one, two, eight
+    and sixteen neighbourhoods per tile, two row tiles per neighbourhood (K = 200), a layer narrower than 128 (a wave takes half of the
+    rows), against the torch ops on the gathered tensor (random neighbour lists: the ball query is not under test here)."""
+    from catgrasp_amd import pointnet2 as p2
+    from catgrasp_amd import primitives as prim
+    g = torch.Generator().manual_seed(B * 1000 + K)
+    xyz = torch.rand(B, N, 3, generator=g)
+    pts = torch.randn(B, N, D, generator=g) * 0.5 if D else None
+    new_xyz = xyz[:, torch.randint(0, N, (S,), generator=g)].contiguous()
+    idx = torch.randint(0, N, (B, S, K), generator=g)
+    sa = p2.PointNetSetAbstraction(S, 0.2, K, 3 + D, mlp); _randomize_bn(sa, 6); sa.eval()
+    layers = sref.layers_of(sa.state_dict(), '', len(mlp))
+    grouped = oref.index_points(xyz, idx) - new_xyz.view(B, S, 1, 3)
+    if D:
+        grouped = torch.cat([grouped, oref.index_points(pts, idx)], dim=-1)
+    ref = sref.mlp_max(grouped, layers)
+    W = prim.SetAbstractionWeights([(w.double().numpy(), b.double().numpy(), tuple(t.double().numpy() for t in (ga, be, mu, var)))
+                                    for w, b, ga, be, mu, var in layers], 3 + D, cuda_device, kind='tile')
+    got = prim.group_mlp_max(xyz.cuda(), pts.cuda() if D else None, new_xyz.cuda(), idx.cuda(), W, channels_last=True)
+    assert _relerr(got.cpu(), ref) <= 1e-5
+    got_cs = prim.group_mlp_max(xyz.cuda(), pts.cuda() if D else None, new_xyz.cuda(), idx.cuda(), W)
+    assert torch.equal(got_cs.permute(0, 2, 1), got)
