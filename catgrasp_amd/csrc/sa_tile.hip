@@ -44,16 +44,16 @@ struct STArgs {
 };
 
 // The MFMA stream of one wave for one layer: NBW channel blocks x NH row halves.  Operand fragments travel DEPTH k-steps ahead of
-// their products through a ring of DEPTH + 1 register slots: a k-step of a narrow share (one block: 8 MFMAs = 512 cycles) is shorter
-// than an L2 round trip, so one k-step of lead leaves the matrix pipe waiting (measured: 0.60 of the f32 peak at 16 clouds with
-// DEPTH = 1); wide shares (>= 4 block-halves per wave) keep DEPTH = 1, their k-steps are long enough and their accumulators need the
-// registers.
+// their products through a ring of DEPTH + 1 register slots.  DEPTH = 1 everywhere: a lead of 2 or 3 k-steps for the narrow shares
+// (one block: 8 MFMAs = 512 cycles per k-step, shorter than an L2 round trip) was measured -- once the loop really kept the ring full
+// (see below) -- at 0.706 against 0.736 of the f32 peak (64 clouds): the second and third wavefront of the SIMD already cover the
+// round trip, and the extra slots push the narrow instance over its 168-register budget (4 spilled registers).
 // arow: this lane's A-fragment row of the first half (strip + (rowbase + l31) * CS + lhi * 4); the second half is 32 rows further.
 // wp: packed weights + lane; fragment of (block nb, k-step ks) = wp[(nb * nks + ks) * 64].
 template <int NBW, int NH>
 __device__ __forceinline__ void st_mma(const float* arow, int CS, const f32x4* wp, int nks, const int (&blk)[NBW], f32x16 (&acc)[NBW][NH]) {
 #ifndef ST_DEPTH_NARROW
-#define ST_DEPTH_NARROW 3
+#define ST_DEPTH_NARROW 1
 #endif
   constexpr int DEPTH = NBW * NH <= 2 ? ST_DEPTH_NARROW : 1;
   constexpr int SLOTS = DEPTH + 1;
@@ -82,11 +82,26 @@ __device__ __forceinline__ void st_mma(const float* arow, int CS, const f32x4* w
   };
 #pragma unroll
   for (int d = 0; d < DEPTH; ++d) load(d, d);
-  for (int ks0 = 0; ks0 < nks; ks0 += SLOTS) {
+  // Whole turns of the ring in a loop WITHOUT exits inside its body, the remaining < SLOTS k-steps as straight-line code behind it: with a
+  // `break` in the unrolled body the compiler sees a path back to the loop header on which the newest load is still in flight and
+  // puts `s_waitcnt vmcnt(0)` in front of every turn -- i.e. it drains the ring once per turn (seen in the ISA of the first version).
+  int ks = 0;
+  for (int turn = nks / SLOTS; turn > 0; --turn) {
 #pragma unroll
     for (int u = 0; u < SLOTS; ++u) {
-      if (u > 0 && ks0 + u >= nks) break;
-      load(ks0 + u + DEPTH, (u + DEPTH) % SLOTS);
+      load(ks + u + DEPTH, (u + DEPTH) % SLOTS);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(u);
+      __builtin_amdgcn_sched_barrier(0);
+      pin((u + 1) % SLOTS);
+    }
+    ks += SLOTS;
+  }
+  const int rem = nks - ks;
+#pragma unroll
+  for (int u = 0; u < SLOTS - 1; ++u) {
+    if (u < rem) {
+      load(ks + u + DEPTH, (u + DEPTH) % SLOTS);
       __builtin_amdgcn_sched_barrier(0);
       mma(u);
       __builtin_amdgcn_sched_barrier(0);
@@ -210,6 +225,8 @@ __global__ __launch_bounds__(256, WIDE ? 1 : (TR == 128 ? 2 : 3)) void sa_tile_k
   float* rmax = strip + TR * CS;
   long* goff = (long*)(rmax + c_last);          // (TR * CS + c_last) * 4 is a multiple of 16
   int* pbase = (int*)(goff + 16);               // row -> b * N + point index
+  float* bias_s = (float*)(pbase + TR);         // the biases of every layer, staged once per (persistent) workgroup: a global load at the
+                                                // head of every layer of every tile is an L2 round trip the matrix pipe waits out
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   constexpr int NPT = TR / KP;
   const int G = a.B * a.S;                      // < 2^31 / 8 (checked by the launcher); so is B * N < 2^31
@@ -229,6 +246,15 @@ __global__ __launch_bounds__(256, WIDE ? 1 : (TR == 128 ? 2 : 3)) void sa_tile_k
 
   int slot = blockIdx.x, kt = 0;
   if (slot >= nslots) return;
+  int b_off[ST_MAX_LAYERS];
+  {
+    int o = 0;
+    for (int l = 0; l < a.nlayers; ++l) {
+      b_off[l] = o;
+      for (int i = tid; i < a.cout[l]; i += 256) bias_s[o + i] = a.b[l][i];
+      o += a.cout[l];
+    }
+  }                                             // visible after the first tile's barriers
   // The workgroups resident on one CU run the same phases for the same time: under fair issue they stay in lockstep -- all in their
   // matrix phase together, all in their gather / store phases together -- and the matrix pipe idles through the latter.  Unequal wave
   // priorities break the tie: the k-th workgroup of a CU (dispatch order: blockIdx / #CUs) gets priority k, finishes its matrix phase
@@ -317,25 +343,25 @@ __global__ __launch_bounds__(256, WIDE ? 1 : (TR == 128 ? 2 : 3)) void sa_tile_k
         if (nb >= 4) {                          // a wave: blocks {wv, wv + 4, ...}, every 32-row half (one weight fragment feeds them all)
           const int cnt = nb > wv ? (nb - wv + 3) >> 2 : 0;
           switch (cnt) {
-            case 1: st_hidden<1, NHT>(strip, CS, a.w[l], a.b[l], nks, wv, 4, 0, lane); break;
-            case 2: st_hidden<2, NHT>(strip, CS, a.w[l], a.b[l], nks, wv, 4, 0, lane); break;
-            case 3: if constexpr (WIDE) { st_hidden<3, NHT>(strip, CS, a.w[l], a.b[l], nks, wv, 4, 0, lane); break; }
-            case 4: if constexpr (WIDE) { st_hidden<4, NHT>(strip, CS, a.w[l], a.b[l], nks, wv, 4, 0, lane); break; }
+            case 1: st_hidden<1, NHT>(strip, CS, a.w[l], bias_s + b_off[l], nks, wv, 4, 0, lane); break;
+            case 2: st_hidden<2, NHT>(strip, CS, a.w[l], bias_s + b_off[l], nks, wv, 4, 0, lane); break;
+            case 3: if constexpr (WIDE) { st_hidden<3, NHT>(strip, CS, a.w[l], bias_s + b_off[l], nks, wv, 4, 0, lane); break; }
+            case 4: if constexpr (WIDE) { st_hidden<4, NHT>(strip, CS, a.w[l], bias_s + b_off[l], nks, wv, 4, 0, lane); break; }
             default: st_hidden_idle(); break;
           }
         } else {                                // 32 / 64 / 96 channels: a wave takes ONE half of the rows and the blocks {wv >> 1, (wv >> 1) + 2}
           const int p = wv >> 1, cnt = nb > p ? (nb - p + 1) >> 1 : 0;
           switch (cnt) {
-            case 1: st_hidden<1, NHT / 2>(strip, CS, a.w[l], a.b[l], nks, p, 2, (TR / 2) * (wv & 1), lane); break;
-            case 2: st_hidden<2, NHT / 2>(strip, CS, a.w[l], a.b[l], nks, p, 2, (TR / 2) * (wv & 1), lane); break;
+            case 1: st_hidden<1, NHT / 2>(strip, CS, a.w[l], bias_s + b_off[l], nks, p, 2, (TR / 2) * (wv & 1), lane); break;
+            case 2: st_hidden<2, NHT / 2>(strip, CS, a.w[l], bias_s + b_off[l], nks, p, 2, (TR / 2) * (wv & 1), lane); break;
             default: st_hidden_idle(); break;
           }
         }
       } else {
         const int cnt = nb > wv ? (nb - wv + 3) >> 2 : 0;
         for (int i0 = 0; i0 < cnt; i0 += 2) {
-          if (cnt - i0 >= 2) st_last<2, KP, NHT>(a, strip, a.w[l], a.b[l], nks, wv + 4 * i0, lane, kt, rmax, goff);
-          else st_last<1, KP, NHT>(a, strip, a.w[l], a.b[l], nks, wv + 4 * i0, lane, kt, rmax, goff);
+          if (cnt - i0 >= 2) st_last<2, KP, NHT>(a, strip, a.w[l], bias_s + b_off[l], nks, wv + 4 * i0, lane, kt, rmax, goff);
+          else st_last<1, KP, NHT>(a, strip, a.w[l], bias_s + b_off[l], nks, wv + 4 * i0, lane, kt, rmax, goff);
         }
       }
     }
@@ -435,7 +461,9 @@ extern "C" int cg_sa_tile_mlp_max(const float* xyz, const float* points, const f
   const int n_cu = cg_device_cu_count(dev);
   if (n_cu <= 0) return CG_ERR_UNSUPPORTED;
   const long G = (long)B * S;
-  const size_t tail = (size_t)a.cout[n_layers - 1] * 4 + 16 * sizeof(long);
+  size_t bias_floats = 0;
+  for (int l = 0; l < n_layers; ++l) bias_floats += (size_t)a.cout[l];
+  const size_t tail = (size_t)a.cout[n_layers - 1] * 4 + 16 * sizeof(long) + bias_floats * 4;      // running maxima, output offsets, biases
   // 128-row tiles when the launch still fills the chip with them (>= 4 tiles per CU), the strip leaves room for two workgroups per CU
   // and no hidden layer needs the wide instance; 64-row tiles otherwise
   const int kp128 = K <= 8 ? 8 : K <= 16 ? 16 : K <= 32 ? 32 : K <= 64 ? 64 : 128;

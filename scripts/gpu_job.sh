@@ -35,34 +35,22 @@ case $JOB in
     CATGRASP_AMD_POINTMLP_CSPLIT=1 timeout 300 python scripts/time_predict_small.py > $O/predict_small_nosplit.txt 2>&1
     grep candidates $O/predict_small.txt | head -12; echo ---; grep candidates $O/predict_small_nosplit.txt | head -12
     timeout 900 python -m pytest tests/test_bench_multirank_gpu.py -m gpu -x -q > $O/pytest_multirank.log 2>&1; tail -5 $O/pytest_multirank.log ;;
-  satile)     # the LDS-tile set-abstraction kernel alone: shipped build, ablation builds (build_abl/lib_sat_*.so), resident-workgroup knob
+  satile)     # the LDS-tile set-abstraction kernel alone: shipped build, tile-rows / resident-workgroup knobs, ablation builds (build_abl/lib_sat_*.so)
     timeout 300 python scripts/sa_tile_time.py $O/sa_tile.json > $O/sa_tile.txt 2>&1; grep ssg_sa2 $O/sa_tile.txt
-    for lib in build_abl/lib_sat_*.so; do t=$(basename $lib .so); CATGRASP_AMD_LIB=$PWD/$lib timeout 300 python scripts/sa_tile_time.py $O/sa_tile_$t.json > $O/sa_tile_$t.txt 2>&1; echo $t; grep ssg_sa2 $O/sa_tile_$t.txt; done
-    CATGRASP_AMD_SAT_PRIO=0 timeout 300 python scripts/sa_tile_time.py $O/sa_tile_noprio.json > $O/sa_tile_noprio.txt 2>&1; echo no prio; grep ssg_sa2 $O/sa_tile_noprio.txt
-    for pc in 1 2; do CATGRASP_AMD_SAT_PER_CU=$pc timeout 300 python scripts/sa_tile_time.py $O/sa_tile_percu$pc.json > $O/sa_tile_percu$pc.txt 2>&1; echo per_cu $pc; grep ssg_sa2 $O/sa_tile_percu$pc.txt; done
+    for tr in 64 128; do CATGRASP_AMD_SAT_TILE_ROWS=$tr timeout 300 python scripts/sa_tile_time.py $O/sa_tile_rows$tr.json > $O/sa_tile_rows$tr.txt 2>&1; echo tile rows $tr; grep ssg_sa2 $O/sa_tile_rows$tr.txt; done
+    for lib in build_abl/lib_sat_*.so; do [ -f $lib ] || continue; t=$(basename $lib .so); CATGRASP_AMD_LIB=$PWD/$lib timeout 300 python scripts/sa_tile_time.py $O/sa_tile_$t.json > $O/sa_tile_$t.txt 2>&1; echo $t; grep ssg_sa2 $O/sa_tile_$t.txt; done
+    CATGRASP_AMD_SAT_PER_CU=1 timeout 300 python scripts/sa_tile_time.py $O/sa_tile_percu1.json > $O/sa_tile_percu1.txt 2>&1; echo per_cu 1; grep ssg_sa2 $O/sa_tile_percu1.txt
     timeout 600 python -m pytest tests/test_pointnet2_encoder_gpu.py -m gpu -x -q > $O/pytest.log 2>&1; tail -3 $O/pytest.log ;;
-  filter)     # the collision filter: parity tests, timing of the call shapes, issue-side counters
-    timeout 900 python -m pytest tests/test_collision_gpu.py tests/test_fullsize_properties_gpu.py tests/test_workload_gpu.py -m gpu -x -q -k "not f16 and not bf16" > $O/pytest.log 2>&1; tail -4 $O/pytest.log
-    timeout 200 python scripts/time_filter.py > $O/filter_time.txt 2>&1; tail -12 $O/filter_time.txt
-    SQ="SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU GRBM_GUI_ACTIVE"
-    timeout 300 rocprofv3 --pmc $SQ --kernel-include-regex 'filter_grasp_pose|compose_grasp' --output-format csv -d $O/pmc_sq -- python scripts/pmc_filter.py > $O/pmc_sq_filter.log 2>&1
-    timeout 300 rocprofv3 --kernel-trace --kernel-include-regex 'filter_grasp_pose|compose_grasp' --output-format csv -d $O/ktrace -- python scripts/pmc_filter.py 10 > $O/ktrace_filter.log 2>&1
-    python scripts/pmc_summary.py $O/pmc_sq $O/pmc_sq_filter.csv > /dev/null; python scripts/pmc_summary.py $O/ktrace $O/ktrace_filter.csv "grasp_pose" > /dev/null
-    rm -rf $O/pmc_sq $O/ktrace; grep "true" $O/pmc_sq_filter.csv; cat $O/ktrace_filter.csv ;;
-  final)      # the measurements of the shipped state: GPU suite, smoke, bench line (+ kernel statistics), helper table, encoder, C4 / C5
-    timeout 2400 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; tail -5 $O/pytest.log
-    timeout 120 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
-    ( time timeout 1200 python bench.py --gpus 1 --steps 20 --warmup 5 ) > $O/bench.json 2> $O/bench.err; tail -c 400 $O/bench.err
-    stats bench python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-api --no-pmc-traffic --no-rccl-selftest --no-projection
-    timeout 300 python scripts/hbm_kernels.py > $O/hbm_kernels.json 2> $O/hbm_kernels.err; tail -2 $O/hbm_kernels.err
-    timeout 300 python scripts/pp_encoder_profile.py $O/pp_encoder.json > $O/pp_encoder.txt 2>&1
-    timeout 300 python scripts/pp_encoder_profile.py $O/pp_encoder_msg.json --msg > $O/pp_encoder_msg.txt 2>&1
-    stats pp_encoder python scripts/pp_encoder_profile.py --trace
-    stats pp_encoder_msg python scripts/pp_encoder_profile.py --trace --msg
-    timeout 300 python scripts/sa_tile_time.py $O/sa_tile.json > $O/sa_tile.txt 2>&1
-    ( time timeout 600 python bench.py --gpus 1 --workload C4 --steps 3 --warmup 1 --secondary "" --no-api --no-cpu-baseline ) > $O/bench_c4_n1.json 2> $O/bench_c4_n1.err
-    ( time timeout 600 python bench.py --gpus 1 --workload C5 --steps 3 --warmup 1 --secondary "f32" --no-api --no-cpu-baseline ) > $O/bench_c5_n1.json 2> $O/bench_c5_n1.err
-    ls -la $O; head -c 600 $O/bench.json ;;
+  pmcsat)     # issue-side counters of the tile set-abstraction kernel (64 clouds), 64- and 128-row tiles
+    for tr in 64 128; do
+      C1="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE"
+      C2="SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS"
+      CATGRASP_AMD_SAT_TILE_ROWS=$tr timeout 300 rocprofv3 --pmc $C1 --kernel-include-regex sa_tile --output-format csv -d $O/p1_$tr -- python scripts/pmc_sa_tile.py > $O/p1_$tr.log 2>&1
+      CATGRASP_AMD_SAT_TILE_ROWS=$tr timeout 300 rocprofv3 --pmc $C2 --kernel-include-regex sa_tile --output-format csv -d $O/p2_$tr -- python scripts/pmc_sa_tile.py > $O/p2_$tr.log 2>&1
+      CATGRASP_AMD_SAT_TILE_ROWS=$tr timeout 300 rocprofv3 --kernel-trace --kernel-include-regex sa_tile --output-format csv -d $O/kt_$tr -- python scripts/pmc_sa_tile.py > $O/kt_$tr.log 2>&1
+      python scripts/pmc_summary.py $O/p1_$tr $O/pmc1_rows$tr.csv > /dev/null; python scripts/pmc_summary.py $O/p2_$tr $O/pmc2_rows$tr.csv > /dev/null; python scripts/pmc_summary.py $O/kt_$tr $O/kt_rows$tr.csv > /dev/null
+      rm -rf $O/p1_$tr $O/p2_$tr $O/kt_$tr; cat $O/pmc1_rows$tr.csv $O/pmc2_rows$tr.csv $O/kt_rows$tr.csv; tail -2 $O/p2_$tr.log
+    done ;;
   py)         # any script:  py scripts/x.py args...
     timeout 1200 python "$@" > $O/out.txt 2>&1; tail -40 $O/out.txt ;;
   *) echo "unknown job $JOB"; exit 2 ;;
