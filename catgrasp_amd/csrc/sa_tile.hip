@@ -464,13 +464,13 @@ extern "C" int cg_sa_tile_mlp_max(const float* xyz, const float* points, const f
   size_t bias_floats = 0;
   for (int l = 0; l < n_layers; ++l) bias_floats += (size_t)a.cout[l];
   const size_t tail = (size_t)a.cout[n_layers - 1] * 4 + 16 * sizeof(long) + bias_floats * 4;      // running maxima, output offsets, biases
-  // 128-row tiles when the launch still fills the chip with them (>= 4 tiles per CU), the strip leaves room for two workgroups per CU
-  // and no hidden layer needs the wide instance; 64-row tiles otherwise
+  // 128-row tiles when the launch still fills the chip with them (>= 2 tiles per CU: one round of two resident workgroups), the strip
+  // leaves room for two workgroups per CU and no hidden layer needs the wide instance; 64-row tiles otherwise
   const int kp128 = K <= 8 ? 8 : K <= 16 ? 16 : K <= 32 ? 32 : K <= 64 ? 64 : 128;
   const long slots128 = kp128 == 128 ? G : (G + 128 / kp128 - 1) / (128 / kp128);
   const size_t lds128 = (size_t)128 * a.CS * 4 + tail + 128 * sizeof(int);
   static const char* tr_env = getenv("CATGRASP_AMD_SAT_TILE_ROWS");      // dev knob: 64 / 128
-  bool use128 = hidden_max <= 256 && lds128 <= 80 * 1024 && slots128 * (kp128 == 128 ? (K + 127) / 128 : 1) >= 4L * n_cu;
+  bool use128 = hidden_max <= 256 && lds128 <= 80 * 1024 && slots128 * (kp128 == 128 ? (K + 127) / 128 : 1) >= 2L * n_cu;
   if (tr_env) use128 = atoi(tr_env) == 128 && hidden_max <= 256 && lds128 <= 158 * 1024;
   if (use128) {
     a.KP = kp128; a.RT = kp128 == 128 ? (K + 127) / 128 : 1;

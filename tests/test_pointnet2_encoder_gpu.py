@@ -277,7 +277,7 @@ def test_group_all_gemm_epilogue_max_and_appended_rows(cuda_device):
 @pytest.mark.parametrize('B,N,S,K,D,mlp', [(20, 300, 128, 64, 16, [64, 96, 128]), (16, 600, 512, 16, 29, [128, 128, 256]), (8, 400, 128, 100, 8, [32, 256]),
                                              (4, 500, 128, 200, 128, [128, 128, 256]), (16, 256, 1024, 8, 0, [64, 64]), (20, 300, 128, 33, 64, [256, 128, 1024])])
 def test_tile_kernel_with_128_row_tiles(cuda_device, B, N, S, K, D, mlp):
-    """Launches large enough for the 128-row tile instance of sa_tile_kernel (>= 4 tiles per CU; hidden widths <= 256): one, two, eight
+    """Launches large enough for the 128-row tile instance of sa_tile_kernel (>= 2 tiles per CU; hidden widths <= 256): one, two, eight
     and sixteen neighbourhoods per tile, two row tiles per neighbourhood (K = 200), a layer narrower than 128 (a wave takes half of the
     rows), against the torch ops on the gathered tensor (random neighbour lists: the ball query is not under test here)."""
     from catgrasp_amd import pointnet2 as p2
