@@ -51,6 +51,10 @@ case $JOB in
       python scripts/pmc_summary.py $O/p1_$tr $O/pmc1_rows$tr.csv > /dev/null; python scripts/pmc_summary.py $O/p2_$tr $O/pmc2_rows$tr.csv > /dev/null; python scripts/pmc_summary.py $O/kt_$tr $O/kt_rows$tr.csv > /dev/null
       rm -rf $O/p1_$tr $O/p2_$tr $O/kt_$tr; cat $O/pmc1_rows$tr.csv $O/pmc2_rows$tr.csv $O/kt_rows$tr.csv; tail -2 $O/p2_$tr.log
     done ;;
+  check)      # the driver's round-end sequence on the final tree: GPU suite, smoke, the default bench line
+    timeout 2400 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; tail -5 $O/pytest.log
+    timeout 120 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
+    ( time timeout 900 python bench.py ) > $O/bench_default_flags.json 2> $O/bench.err; tail -c 300 $O/bench.err; head -c 500 $O/bench_default_flags.json ;;
   py)         # any script:  py scripts/x.py args...
     timeout 1200 python "$@" > $O/out.txt 2>&1; tail -40 $O/out.txt ;;
   *) echo "unknown job $JOB"; exit 2 ;;
