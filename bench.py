@@ -134,7 +134,7 @@ GRIPPER_SUBDIVISIONS = 4                                # the step's gripper mes
 PEAK_L2_GBS = 34500.0                                   # MI355X_MICROARCH.md: L2 4 MiB per XCD, ~34.5 TB/s aggregate
 
 
-def filter_roofline_block(batch, device, reps=5, issue=None):
+def filter_roofline_block(batch, device, reps=5, issue=None, repeat=1):
     """roofline_filter: the collision filter of the step, object 0's two segments (canonical grasps x symmetries with nudging; cone poses),
     alone on the stream: HIP-event time of the three launches of a call (pose composition, grid kernel, exhaustive finisher) against the
     chip's vector-instruction issue rate (`issue` = pmc_filter_issue's counters of the same two calls), with, beside it, the
@@ -147,6 +147,8 @@ def filter_roofline_block(batch, device, reps=5, issue=None):
     tot_ms, tot_bytes, E_tot, w_tot = 0.0, 0, 0, np.zeros(3, dtype=np.int64)
     for seg in [s for s in batch.segs if s.obj == 0 and s.replica == 0]:
         P = batch.segment_poses(seg)
+        if repeat > 1:                      # the same poses `repeat` times over: what a launch of that many evaluations costs per evaluation
+            P = P.repeat(repeat, 1).contiguous()
         sym, nocs = (batch.syms[batch.cats[0]], batch.nocs_pose[0]) if seg.kind == 'nocs' else (batch.eye, I4)
         call = lambda ws=None: my_cpp.filter_on_device(batch.scenes[0], P, sym, nocs, I4, I4, I4, g['gripper_in_grasp'], True, False, seg.adjust,
                                                        keep_rejected_pose=True, work_stats=ws)
@@ -426,7 +428,7 @@ def cpu_baseline(batch, sd_cls, sd_seg, n_score=100, n_coll=4096):
 PEAK_VALU_WAVE_INSTS_PER_S = 256 * 2.4e9                # one wave64 vector instruction per CU and clock (4 SIMD16 x 4 cycles), 256 CUs, 2.4 GHz
 
 
-def pmc_filter_issue(args):
+def pmc_filter_issue(args, repeat=1):
     """The issue-side counters of the filter's grid kernel for THIS run's scene: one child run of this script (--pmc-filter-child: object
     0's two filter calls, 1 warm-up + 3 timed) under `rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY` (counters only).
     -> ({'valu_wave_insts', 'wave_cycles', 'wait_any'} per pair of calls, source text) or (None, reason)."""
@@ -443,8 +445,8 @@ def pmc_filter_issue(args):
     counters = ('SQ_INSTS_VALU', 'SQ_WAVE_CYCLES', 'SQ_WAIT_ANY')
     try:
         cmd = [exe, '--pmc', *counters, '--kernel-include-regex', 'filter_grasp_pose_kernel', '--output-format', 'csv', '-d', tmp, '--',
-               sys.executable, os.path.abspath(__file__), '--pmc-filter-child', '--gpus', '1', '--workload', args.workload, '--candidates',
-               str(args.candidates), '--candidates-total', str(args.candidates_total)]
+               sys.executable, os.path.abspath(__file__), '--pmc-filter-child', '--pmc-filter-repeat', str(repeat), '--gpus', '1', '--workload', args.workload,
+               '--candidates', str(args.candidates), '--candidates-total', str(args.candidates_total)]
         r = subprocess.run(cmd, cwd='/tmp', env=dict(os.environ, TMPDIR='/tmp'), capture_output=True, text=True, timeout=300)
         if r.returncode != 0:
             return None, f'rocprofv3 exited with {r.returncode}: {r.stderr[-300:]}'
@@ -602,6 +604,7 @@ def main():
     ap.add_argument('--no-rccl-selftest', action='store_true', help='skip the one-rank RCCL all-gather check after the timed region (N = 1)')
     ap.add_argument('--pmc-child', action='store_true', help=argparse.SUPPRESS)      # the child run of --pmc-traffic: workload only
     ap.add_argument('--pmc-filter-child', action='store_true', help=argparse.SUPPRESS)   # the child run of pmc_filter_issue: object 0's filter calls
+    ap.add_argument('--pmc-filter-repeat', type=int, default=1, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.scaling == 'weak' and args.workload != 'C3':
         ap.error(f'--workload {args.workload} is a strong-scaling workload')
@@ -676,6 +679,8 @@ def main():
         def one_round():
             for seg in segs0:
                 P = batch.segment_poses(seg)
+                if args.pmc_filter_repeat > 1:
+                    P = P.repeat(args.pmc_filter_repeat, 1).contiguous()
                 sym, nocs = (batch.syms[batch.cats[0]], batch.nocs_pose[0]) if seg.kind == 'nocs' else (batch.eye, I4)
                 my_cpp.filter_on_device(batch.scenes[0], P, sym, nocs, I4, I4, I4, g['gripper_in_grasp'], True, False, seg.adjust, keep_rejected_pose=True)
         rounds = 4
@@ -872,6 +877,12 @@ def main():
         if world == 1:
             try:
                 line['roofline_filter'] = filter_roofline_block(batch, device, issue=pmc_filter_issue(args) if args.pmc_traffic else (None, '--no-pmc-traffic'))
+                if args.pmc_traffic and args.workload == 'C3':
+                    # the step's launches are 6,250 evaluations each (three launches of ~0.1 ms: launch- and tail-bound); the same calls with
+                    # 8 x the poses show the kernel's rate when a launch fills the chip
+                    big = filter_roofline_block(batch, device, issue=pmc_filter_issue(args, repeat=8), repeat=8)
+                    line['roofline_filter']['at_8x_the_evaluations_per_launch'] = {k: big.get(k) for k in (
+                        'achieved', 'frac', 'evaluations', 'ms', 'evaluations_per_s', 'valu_wave_insts', 'valu_wave_insts_per_evaluation', 'wait_share')}
             except Exception as e:          # an extra: never let it take the bench line down
                 line['roofline_filter'] = {'error': f'{type(e).__name__}: {e}'[:300]}
         if secondary:

@@ -266,8 +266,9 @@ class PointNetSetAbstraction(nn.Module):
         return _cached_weights(self, device, lambda sd, dev: _prim.SetAbstractionWeights(_sa_layers_from_state(sd, 'mlp_', n), self.in_channel,
                                                                                           dev, kind=kind))
 
-    def forward(self, xyz, points, start=None, _err=None, _rows=None):
-        """_err: a pre-zeroed (1,) int32 device flag shared by the levels of a stack (one read-back for the stack instead of one per layer).
+    def forward(self, xyz, points, start=None, _err=None, _rows=None, _new_xyz=None):
+        """_new_xyz (stack-internal): the level's sampled points when the stack has already run its farthest-point sampling (on a side stream).
+        _err: a pre-zeroed (1,) int32 device flag shared by the levels of a stack (one read-back for the stack instead of one per layer).
         _rows (stack-internal): for a sampling level, a (B, S, roundup8(C + 3)) buffer to produce the output in -- features in
         [..., :C] (the returned new_points is that view), the level's new_xyz ++ zeros behind them, i.e. the input rows of a following
         group-all level; for the group-all level, that buffer."""
@@ -278,7 +279,9 @@ class PointNetSetAbstraction(nn.Module):
                 rows = None if _rows is None else _rows.view(-1, _rows.shape[-1])
                 return (torch.zeros((B, 1, 3), dtype=torch.float32, device=xyz.device),
                         _prim.group_all_mlp_max(xyz, points, W, rows=rows).view(B, 1, -1))
-            _, new_xyz = farthest_point_sample(xyz, self.npoint, start, return_xyz=True)      # = index_points(xyz, fps_idx), same launch
+            new_xyz = _new_xyz
+            if new_xyz is None:
+                _, new_xyz = farthest_point_sample(xyz, self.npoint, start, return_xyz=True)      # = index_points(xyz, fps_idx), same launch
             idx = query_ball_point(self.radius, self.nsample, xyz, new_xyz)
             kw = {}
             if _rows is not None:
@@ -326,7 +329,7 @@ class PointNetSetAbstractionMsg(nn.Module):
             self.conv_blocks.append(convs); self.bn_blocks.append(bns)
         self.out_channel = sum(m[-1] for m in mlp_list)
 
-    def forward(self, xyz, points, start=None, _err=None, _rows=None):
+    def forward(self, xyz, points, start=None, _err=None, _rows=None, _new_xyz=None):
         if _use_hip(self, xyz):
             def prep(sd, dev):
                 out = []
@@ -338,7 +341,9 @@ class PointNetSetAbstractionMsg(nn.Module):
                 return out
             Ws = _cached_weights(self, xyz.device, prep)
             B = xyz.shape[0]
-            _, new_xyz = farthest_point_sample(xyz, self.npoint, start, return_xyz=True)
+            new_xyz = _new_xyz
+            if new_xyz is None:
+                _, new_xyz = farthest_point_sample(xyz, self.npoint, start, return_xyz=True)
             buf = _rows if _rows is not None else torch.empty((B, self.npoint, self.out_channel), dtype=torch.float32, device=xyz.device)
             out = buf[:, :, :self.out_channel]
             err = torch.zeros((1,), dtype=torch.int32, device=xyz.device) if _err is None else _err
@@ -402,6 +407,17 @@ def _torch_ball(radius, nsample, xyz, new_xyz):
     return torch.where(idx == N, first, idx)
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    """One extra HIP stream per device for work a stack overlaps with its main stream (PointNet2Encoder: the next level's sampling)."""
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=key)
+    return _SIDE_STREAMS[key]
+
+
 class PointNet2Encoder(nn.Module):
     """The PointNet++ set-abstraction ENCODER BASELINE.json's north_star names, assembled from the reference's primitives
     (pointnet2.py:54-149): three set-abstraction levels ending in one group over everything that is left.
@@ -443,13 +459,25 @@ class PointNet2Encoder(nn.Module):
         hip = _use_hip(self, x)
         err = torch.zeros((1,), dtype=torch.int32, device=x.device) if hip else None
         kw = {'_err': err} if hip else {}
-        l1_xyz, l1_points = self.sa1(xyz, feats, start=s1, **kw)
         rows = None
-        if hip:      # level 2 writes [features | xyz | pad] rows: what the group-all level's first GEMM reads (no concatenation pass)
+        if hip:
+            # Level 2's sampling chain needs level 1's sampled POINTS only, not its features: it runs on a side stream while level 1's
+            # ball query and fused kernel use the rest of the chip (one CU per cloud is all a sampling chain occupies).
+            _, l1_xyz = farthest_point_sample(xyz, self.sa1.npoint, s1, return_xyz=True)
+            cur, side = torch.cuda.current_stream(x.device), _side_stream(x.device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                _, l2_xyz = farthest_point_sample(l1_xyz, self.sa2.npoint, s2, return_xyz=True)
+            _, l1_points = self.sa1(xyz, feats, _new_xyz=l1_xyz, **kw)
+            cur.wait_stream(side)
+            l2_xyz.record_stream(cur)
+            # level 2 writes [features | xyz | pad] rows: what the group-all level's first GEMM reads (no concatenation pass)
             c2 = self.sa3.in_channel - 3
             rows = torch.empty((B, self.sa2.npoint, (c2 + 3 + 7) & ~7), dtype=torch.float32, device=x.device)
-            kw = dict(kw, _rows=rows)
-        l2_xyz, l2_points = self.sa2(l1_xyz, l1_points, start=s2, **kw)
+            _, l2_points = self.sa2(l1_xyz, l1_points, _new_xyz=l2_xyz, _rows=rows, **kw)
+        else:
+            l1_xyz, l1_points = self.sa1(xyz, feats, start=s1)
+            l2_xyz, l2_points = self.sa2(l1_xyz, l1_points, start=s2)
         _, l3_points = self.sa3(l2_xyz, l2_points, **({'_rows': rows} if rows is not None else {}))
         if hip:
             _prim._raise_if(err, 'PointNet2Encoder (a query ball was empty or an index is out of range)')
