@@ -408,6 +408,7 @@ def _torch_ball(radius, nsample, xyz, new_xyz):
 
 
 _SIDE_STREAMS = {}
+SIDE_STREAM_MIN_CLOUDS = 12     # PointNet2Encoder: batches from this size on overlap level 2's sampling with level 1's grouping
 
 
 def _side_stream(device):
@@ -461,16 +462,22 @@ class PointNet2Encoder(nn.Module):
         kw = {'_err': err} if hip else {}
         rows = None
         if hip:
-            # Level 2's sampling chain needs level 1's sampled POINTS only, not its features: it runs on a side stream while level 1's
-            # ball query and fused kernel use the rest of the chip (one CU per cloud is all a sampling chain occupies).
+            # Level 2's sampling chain needs level 1's sampled POINTS only, not its features: from SIDE_STREAM_MIN_CLOUDS clouds on it runs on
+            # a side stream while level 1's ball query and fused kernel use the rest of the chip (a sampling chain occupies one CU per
+            # cloud).  Measured (profiles/r5_pp_encoder_side_stream.json): 16 clouds 0.973 -> 0.948 ms, 8 clouds unchanged, ONE cloud
+            # 0.771 -> 0.830 ms -- the two cross-stream waits cost more than the 41 us of level-1 work they hide -- hence the threshold.
             _, l1_xyz = farthest_point_sample(xyz, self.sa1.npoint, s1, return_xyz=True)
-            cur, side = torch.cuda.current_stream(x.device), _side_stream(x.device)
-            side.wait_stream(cur)
-            with torch.cuda.stream(side):
+            if B >= SIDE_STREAM_MIN_CLOUDS:
+                cur, side = torch.cuda.current_stream(x.device), _side_stream(x.device)
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    _, l2_xyz = farthest_point_sample(l1_xyz, self.sa2.npoint, s2, return_xyz=True)
+                _, l1_points = self.sa1(xyz, feats, _new_xyz=l1_xyz, **kw)
+                cur.wait_stream(side)
+                l2_xyz.record_stream(cur)
+            else:
+                _, l1_points = self.sa1(xyz, feats, _new_xyz=l1_xyz, **kw)
                 _, l2_xyz = farthest_point_sample(l1_xyz, self.sa2.npoint, s2, return_xyz=True)
-            _, l1_points = self.sa1(xyz, feats, _new_xyz=l1_xyz, **kw)
-            cur.wait_stream(side)
-            l2_xyz.record_stream(cur)
             # level 2 writes [features | xyz | pad] rows: what the group-all level's first GEMM reads (no concatenation pass)
             c2 = self.sa3.in_channel - 3
             rows = torch.empty((B, self.sa2.npoint, (c2 + 3 + 7) & ~7), dtype=torch.float32, device=x.device)
