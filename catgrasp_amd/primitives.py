@@ -148,7 +148,11 @@ class SetAbstractionWeights:
         if any(c % 32 or c <= 0 for c in widths):
             raise NotImplementedError('fused set abstraction: layer widths must be multiples of 32')
         if kind is None:
-            kind = 'reg' if in_channel <= 16 and max(widths) <= 256 else 'tile'
+            # first-level shapes: the register-resident kernel where it applies (<= 3 layers of 32 / 64 / 128 channels: 1.3 x the tile
+            # kernel's rate there); its LDS-strip fallback only for narrow odd nets (<= 64 wide, e.g. four layers); everything else -- a
+            # 256-wide layer, a width of 96, 3 + D > 16 -- the tile kernel (1.3 - 1.9 x the strip kernel: profiles/r5_sa_tile_vs_first_level_kernels.json)
+            fits_reg = len(widths) <= 3 and all(c in (32, 64, 128) for c in widths)
+            kind = 'reg' if in_channel <= 16 and (fits_reg or max(widths) <= 64) else 'tile'
         if kind == 'reg' and (in_channel > 16 or max(widths) > 256):
             raise ValueError("kind 'reg' holds 3 + D <= 16 inputs and widths <= 256")
         self.kind = kind

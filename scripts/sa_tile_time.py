@@ -16,6 +16,10 @@ PEAK = 157.3e12
 dev = torch.device('cuda:0')
 # name, N (points the layer gathers from), S, K, D, mlp
 SHAPES = [('ssg_sa2', 512, 128, 64, 128, [128, 128, 256]),
+          ('ssg_sa1', 20000, 512, 32, 3, [64, 64, 128]),
+          ('msg_sa1_s0', 20000, 512, 16, 3, [32, 32, 64]),
+          ('first_level_256', 20000, 512, 32, 3, [64, 128, 256]),
+          ('first_level_4_layers', 20000, 512, 32, 3, [32, 32, 64, 64]),
           ('msg_sa1_s2', 20000, 512, 128, 3, [64, 96, 128]),
           ('msg_sa2_s0', 512, 128, 32, 320, [64, 64, 128]),
           ('msg_sa2_s1', 512, 128, 64, 320, [128, 128, 256]),
@@ -54,6 +58,10 @@ for name, N, S, K, D, mlp in SHAPES:
         fl *= B * S * K
         rows.append({'shape': name, 'clouds': B, 'S': S, 'K': K, 'cin': 3 + D, 'mlp': mlp, 'us': round(t * 1e6, 2), 'tflops': round(fl / t / 1e12, 2),
                      'frac_of_f32_mfma_peak': round(fl / t / PEAK, 4)})
+        if 3 + D <= 16 and max(mlp) <= 256:      # a first-level shape: the kernels of setabstraction.hip (register-resident, or its LDS-strip fallback) beside it
+            Wr = prim.SetAbstractionWeights(p2._sa_layers_from_state(sa.state_dict(), 'mlp_', len(mlp)), 3 + D, dev, kind='reg')
+            tr = timed(lambda: prim.group_mlp_max(xyz, pts, new_xyz, idx, Wr, check_indices=False, channels_last=True, out=out))
+            rows[-1]['us_setabstraction_hip_kernels'] = round(tr * 1e6, 2)
         print(rows[-1], flush=True)
 if len(sys.argv) > 1:
     with open(sys.argv[1], 'w') as f:

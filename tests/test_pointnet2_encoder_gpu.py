@@ -299,3 +299,27 @@ def test_tile_kernel_with_128_row_tiles(cuda_device, B, N, S, K, D, mlp):
     assert _relerr(got.cpu(), ref) <= 1e-5
     got_cs = prim.group_mlp_max(xyz.cuda(), pts.cuda() if D else None, new_xyz.cuda(), idx.cuda(), W)
     assert torch.equal(got_cs.permute(0, 2, 1), got)
+
+
+@pytest.mark.parametrize('D,K,mlp', [(13, 64, [128, 128, 256]), (6, 32, [64, 96, 128]), (3, 16, [32, 32, 64, 64]), (6, 40, [256])])
+def test_first_level_shapes_on_both_kernel_families(cuda_device, D, K, mlp):
+    """First-level shapes outside the register kernel's signatures go to the tile kernel by default (round 5: 1.3 - 1.9 x the LDS-strip
+    kernel); the strip kernel of setabstraction.hip stays reachable (kind='reg') and both agree with the torch ops."""
+    from catgrasp_amd import pointnet2 as p2
+    from catgrasp_amd import primitives as prim
+    torch.manual_seed(5)
+    B, N, S = 2, 800, 60
+    xyz = torch.rand(B, N, 3) * 0.4; pts = torch.randn(B, N, D) * 0.5
+    sa = p2.PointNetSetAbstraction(S, 0.1, K, 3 + D, mlp); _randomize_bn(sa, 7); sa.eval()
+    layers = sref.layers_of(sa.state_dict(), '', len(mlp))
+    start = torch.tensor([1, 2])
+    new_xyz = oref.index_points(xyz, oref.farthest_point_sample(xyz, S, start))
+    idx = p2.query_ball_point(0.1, K, xyz.cuda(), new_xyz.cuda())
+    _, ref, _, _ = sref.sa_forward(xyz, pts, S, 0.1, K, layers, start, idx=idx.cpu())
+    packed = [(w.double().numpy(), b.double().numpy(), tuple(t.double().numpy() for t in (ga, be, mu, var))) for w, b, ga, be, mu, var in layers]
+    auto = prim.SetAbstractionWeights(packed, 3 + D, cuda_device)
+    assert auto.kind == ('reg' if max(mlp) <= 64 else 'tile')
+    for kind in ('reg', 'tile'):
+        W = prim.SetAbstractionWeights(packed, 3 + D, cuda_device, kind=kind)
+        got = prim.group_mlp_max(xyz.cuda(), pts.cuda(), new_xyz.cuda(), idx, W, channels_last=True)
+        assert _relerr(got.cpu(), ref) <= 1e-5, kind
