@@ -80,3 +80,44 @@ def test_set_abstraction_weights_layouts():
     w1 = rng.normal(size=(128, 131))
     t2 = SetAbstractionWeights([(w1, rng.normal(size=128), None), (rng.normal(size=(256, 128)), rng.normal(size=256), None)], 131, 'cpu')
     assert t2.kind == 'tile' and t2.cin == [136, 128] and t2.cout == [128, 256] and t2.hidden_max == 128
+
+
+def _encoder_golden():
+    import os
+    import numpy as np
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'pp_encoder_golden.npz'))
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith('sd.')}
+    x = torch.from_numpy(g['x'])
+    B, N = x.shape[:2]
+    starts = []
+    for seed, n in zip(g['seeds'], (N, 96)):
+        torch.manual_seed(int(seed))
+        starts.append(torch.randint(0, n, (B,), dtype=torch.long))          # the reference's own draw, pointnet2.py:66
+    return g, sd, x, tuple(starts)
+
+
+ENC_GOLDEN_CFG = dict(channel=6, npoints=(96, 24), radii=(0.25, 0.5), nsamples=(16, 32), mlps=((32, 64, 64), (64, 128, 128), (128, 256, 512)))
+
+
+def test_oracle_stack_and_torch_path_reproduce_the_stack_built_from_the_real_reference_primitives():
+    """tests/golden/pp_encoder_golden.npz was computed by tests/golden/make_golden_encoder.py with the REAL reference's sample_and_group /
+    sample_and_group_all (imported /root/reference/pointnet2.py) + torch.nn Conv2d / BatchNorm2d / ReLU / max: the oracle stack
+    (oracle/setabstraction_ref.py) and the module's differentiable torch path must reproduce its samples exactly and its features to
+    float32 rounding."""
+    from catgrasp_amd import pointnet2 as p2
+    g, sd, x, start = _encoder_golden()
+    xyz, feats = x[:, :, :3].contiguous(), x[:, :, 3:].contiguous()
+    nx1, r1, f1, _ = sref.sa_forward(xyz, feats, 96, 0.25, 16, sref.layers_of(sd, 'sa1.', 3), start[0])
+    nx2, r2, f2, _ = sref.sa_forward(nx1, r1, 24, 0.5, 32, sref.layers_of(sd, 'sa2.', 3), start[1])
+    r3 = sref.sa_all_forward(nx2, r2, sref.layers_of(sd, 'sa3.', 3))
+    assert torch.equal(f1, torch.from_numpy(g['fps1'])) and torch.equal(f2, torch.from_numpy(g['fps2']))
+    assert torch.equal(nx1, torch.from_numpy(g['l1_xyz'])) and torch.equal(nx2, torch.from_numpy(g['l2_xyz']))
+    for got, key in ((r1, 'l1_points'), (r2, 'l2_points'), (r3, 'global_feat')):
+        assert (got - torch.from_numpy(g[key])).abs().max().item() <= 2e-6, key
+    enc = p2.PointNet2Encoder(**ENC_GOLDEN_CFG)
+    enc.load_state_dict(sd); enc.eval()
+    with torch.enable_grad():
+        gf, ((x1, p1), (x2, p2_)) = enc(x, start=start)
+    assert torch.equal(x1, torch.from_numpy(g['l1_xyz'])) and torch.equal(x2, torch.from_numpy(g['l2_xyz']))
+    assert (p1.detach() - torch.from_numpy(g['l1_points'])).abs().max().item() <= 2e-6
+    assert (gf.detach() - torch.from_numpy(g['global_feat'])).abs().max().item() <= 2e-6

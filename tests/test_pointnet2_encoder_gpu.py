@@ -323,3 +323,19 @@ def test_first_level_shapes_on_both_kernel_families(cuda_device, D, K, mlp):
         W = prim.SetAbstractionWeights(packed, 3 + D, cuda_device, kind=kind)
         got = prim.group_mlp_max(xyz.cuda(), pts.cuda(), new_xyz.cuda(), idx, W, channels_last=True)
         assert _relerr(got.cpu(), ref) <= 1e-5, kind
+
+
+def test_encoder_against_the_stack_built_from_the_real_reference_primitives(cuda_device):
+    """The HIP encoder against tests/golden/pp_encoder_golden.npz: samples, neighbour lists and grouped tensors of that file come out of
+    the REAL reference's sample_and_group / sample_and_group_all (tests/golden/make_golden_encoder.py), the MLPs out of torch.nn."""
+    import test_pointnet2_encoder_cpu as cpu
+    from catgrasp_amd import pointnet2 as p2
+    g, sd, x, start = cpu._encoder_golden()
+    enc = p2.PointNet2Encoder(**cpu.ENC_GOLDEN_CFG)
+    enc.load_state_dict(sd); enc.eval().to(cuda_device)
+    with torch.no_grad():
+        gf, ((x1, p1), (x2, p2_)) = enc(x.to(cuda_device), start=start)
+    assert torch.equal(x1.cpu(), torch.from_numpy(g['l1_xyz'])) and torch.equal(x2.cpu(), torch.from_numpy(g['l2_xyz']))
+    assert _relerr(p1.cpu(), torch.from_numpy(g['l1_points'])) <= 1e-4
+    assert _relerr(p2_.cpu(), torch.from_numpy(g['l2_points'])) <= 1e-4
+    assert _relerr(gf.cpu(), torch.from_numpy(g['global_feat'])) <= 1e-4
