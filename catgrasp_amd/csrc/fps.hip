@@ -77,6 +77,59 @@ __device__ __forceinline__ int wave_min_i32(int v) {
   return __builtin_amdgcn_readlane(v, 63);
 }
 
+// ---------------------------------------------------------------- small clouds: ONE wavefront per cloud (round 5)
+// A cloud of <= 1,024 points -- the second level of a PointNet++ stack samples 128 of 512 -- fits one wavefront's registers (lane l
+// holds points l, l + 64, ...).  With a single wavefront a round needs no LDS exchange and no workgroup barrier, which are what a round
+// of fps_kernel<512, 4> mostly consists of at these sizes (0.6 us per round for 512 points, whatever the arithmetic): distance update,
+// one DPP max over the wave, a search for the first slot that holds it, one DPP min over the candidate indices ("first index among
+// equal maxima", pointnet2.py:74), the new centre's coordinates by a broadcast LDS read of the staged cloud.  Same float expression,
+// same unsigned-bit-pattern compares as the kernels above: same samples.
+template <int SLOTS>
+__global__ __launch_bounds__(64) void fps_wave_kernel(const float* __restrict__ xyz, const long long* __restrict__ start, int N, int npoint,
+                                                      long long* __restrict__ out, float* __restrict__ out_xyz) {
+  extern __shared__ float pts[];                     // the cloud, (N,3): where a round reads its centre from
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const float* xb = xyz + (size_t)b * N * 3;
+  for (int i = lane; i < N * 3; i += 64) pts[i] = xb[i];
+  float px[SLOTS], py[SLOTS], pz[SLOTS];
+  unsigned dist[SLOTS];                              // bit patterns of the running distances (all >= +0)
+#pragma unroll
+  for (int k = 0; k < SLOTS; ++k) {
+    const int p = lane + k * 64;
+    float x = 0.f, y = 0.f, z = 0.f, d0 = 0.0f;      // padding: distance 0 never shrinks and, with index "none", never wins a tie
+    if (p < N) { x = xb[p * 3 + 0]; y = xb[p * 3 + 1]; z = xb[p * 3 + 2]; d0 = 1e10f; }
+    px[k] = x; py[k] = y; pz[k] = z; dist[k] = __float_as_uint(d0);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  int far = (int)start[b];
+  long long* ob = out + (size_t)b * npoint;
+  float* oxb = out_xyz ? out_xyz + (size_t)b * npoint * 3 : nullptr;
+  for (int it = 0; it < npoint; ++it) {
+    const float cx = pts[far * 3 + 0], cy = pts[far * 3 + 1], cz = pts[far * 3 + 2];
+    if (lane == 0) {
+      ob[it] = far;
+      if (oxb) { oxb[it * 3 + 0] = cx; oxb[it * 3 + 1] = cy; oxb[it * 3 + 2] = cz; }
+    }
+    unsigned best = 0u;
+#pragma unroll
+    for (int k = 0; k < SLOTS; ++k) {
+      const float dx = px[k] - cx, dy = py[k] - cy, dz = pz[k] - cz;
+      const unsigned d = __float_as_uint((dx * dx + dy * dy) + dz * dz);       // the reference's sum over the last axis, term by term
+      dist[k] = d < dist[k] ? d : dist[k];
+      best = dist[k] > best ? dist[k] : best;
+    }
+    const unsigned wmax = wave_max_u32(best);
+    int mi = 0x7fffffff;
+#pragma unroll
+    for (int k = SLOTS - 1; k >= 0; --k) {
+      const int p = lane + k * 64;
+      mi = (dist[k] == wmax && p < N) ? p : mi;                                // ends on this lane's SMALLEST index holding the maximum
+    }
+    far = wave_min_i32(mi);
+  }
+}
+
 // registers of slot k (wave-uniform k) by a uniform binary search: log2(PPT) scalar branches instead of a select per slot
 template <int LO, int HI, int H>
 __device__ __forceinline__ void fps_pick(int k, const f32x2 (&px)[H], const f32x2 (&py)[H], const f32x2 (&pz)[H], float& x, float& y, float& z) {
@@ -617,6 +670,14 @@ static int fps_launch(const float* xyz, const long long* start, int B, int N, in
   if (N > 512 * 48) {
     if (!dist_scratch) return CG_ERR_ARG;   // (B,N) floats needed for clouds beyond the register paths
     hipLaunchKernelGGL(fps_kernel_global, grid, block, 0, s, xyz, start, N, npoint, dist_scratch, out, out_xyz);
+  }
+  // <= 1,024 points: one wavefront per cloud, no exchange between wavefronts (fps_wave_kernel); CATGRASP_AMD_FPS=plain keeps the
+  // workgroup kernel below for comparison
+  else if (N <= 1024 && !fps_plain()) {
+    const size_t lds = (size_t)N * 3 * sizeof(float);
+    if (N <= 256) hipLaunchKernelGGL((fps_wave_kernel<4>), grid, dim3(64), lds, s, xyz, start, N, npoint, out, out_xyz);
+    else if (N <= 512) hipLaunchKernelGGL((fps_wave_kernel<8>), grid, dim3(64), lds, s, xyz, start, N, npoint, out, out_xyz);
+    else hipLaunchKernelGGL((fps_wave_kernel<16>), grid, dim3(64), lds, s, xyz, start, N, npoint, out, out_xyz);
   }
   // <= 2,048 points: 512 threads x 4 points, every point every round (0.54 us per round at N = 2,048; the blob-skipping kernel with one
   // 256-point blob per wavefront: 0.56, and its prologue is not amortised over few rounds -- 0.76 against 0.56 at 1,024 -> 512)

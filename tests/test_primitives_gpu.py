@@ -49,7 +49,8 @@ def fps_kernel(request, monkeypatch):
 
 
 @pytest.mark.parametrize('B,N,npoint', [(2, 1000, 64), (1, 2049, 100), (2, 4096, 96), (1, 5000, 128), (1, 8192, 64), (2, 8193, 64), (1, 12288, 64),
-                                        (1, 15000, 64), (1, 20000, 256), (2, 20480, 48), (1, 24576, 48), (1, 30000, 40), (3, 64, 64)])
+                                        (1, 15000, 64), (1, 20000, 256), (2, 20480, 48), (1, 24576, 48), (1, 30000, 40), (3, 64, 64),
+                                        (4, 512, 128), (2, 513, 100), (2, 1024, 1024), (1, 1, 1), (2, 65, 65), (3, 256, 256), (2, 257, 30), (2, 1025, 64)])
 def test_farthest_point_sample_exact(cuda_device, fps_kernel, B, N, npoint):
     from catgrasp_amd import pointnet2 as p2
     xyz = _cloud(B, N, 4 + N)
@@ -60,7 +61,7 @@ def test_farthest_point_sample_exact(cuda_device, fps_kernel, B, N, npoint):
     assert torch.equal(got, ref)
 
 
-@pytest.mark.parametrize('N,npoint', [(700, 200), (3000, 200), (6000, 300), (10000, 100), (20000, 200), (22000, 64)])
+@pytest.mark.parametrize('N,npoint', [(700, 200), (512, 300), (1000, 400), (200, 200), (3000, 200), (6000, 300), (10000, 100), (20000, 200), (22000, 64)])
 def test_farthest_point_sample_ties_take_the_first_index(cuda_device, fps_kernel, N, npoint):
     """Equal running distances -- duplicate points (a cloud resampled with replacement) and an integer lattice -- must resolve to the
     smallest point index like torch.max (pointnet2.py:74), in every kernel geometry, also when the tied points sit in different
@@ -88,6 +89,22 @@ def test_farthest_point_sample_degenerate_clouds(cuda_device, fps_kernel):
     start = torch.tensor([5, 5, 7])
     got = p2.farthest_point_sample(xyz.to(cuda_device), 24, start=start).cpu()
     assert torch.equal(got, oref.farthest_point_sample(xyz, 24, start))
+
+
+def test_farthest_point_sample_degenerate_small_clouds(cuda_device, fps_kernel):
+    """The one-wavefront kernel of clouds up to 1,024 points on the same degenerate inputs: one repeated point (the padding slots tie with
+    the real points at distance 0 and must lose), a single outlier, fewer distinct points than samples."""
+    from catgrasp_amd import pointnet2 as p2
+    for n in (70, 300, 512, 900):
+        same = np.full((n, 3), -0.5, np.float32)
+        outlier = same.copy(); outlier[n - 1] = (1.0, 2.0, 3.0)
+        few = np.random.default_rng(0).normal(size=(3, 3)).astype(np.float32)[np.random.default_rng(1).integers(0, 3, n)]
+        xyz = torch.from_numpy(np.stack([same, outlier, few]))
+        start = torch.tensor([n - 1, 0, n // 2])
+        got, got_xyz = p2.farthest_point_sample(xyz.to(cuda_device), 40, start=start, return_xyz=True)
+        ref = oref.farthest_point_sample(xyz, 40, start)
+        assert torch.equal(got.cpu(), ref), n
+        assert torch.equal(got_xyz.cpu(), oref.index_points(xyz, ref)), n
 
 
 def test_farthest_point_sample_skips_nothing_it_should_not(cuda_device, fps_kernel):
