@@ -78,7 +78,7 @@ __device__ __forceinline__ int wave_min_i32(int v) {
 }
 
 // ---------------------------------------------------------------- small clouds: ONE wavefront per cloud (round 5)
-// A cloud of <= 1,024 points -- the second level of a PointNet++ stack samples 128 of 512 -- fits one wavefront's registers (lane l
+// A cloud of <= 512 points -- the second level of a PointNet++ stack samples 128 of 512 -- fits one wavefront's registers (lane l
 // holds points l, l + 64, ...).  With a single wavefront a round needs no LDS exchange and no workgroup barrier, which are what a round
 // of fps_kernel<512, 4> mostly consists of at these sizes (0.6 us per round for 512 points, whatever the arithmetic): distance update,
 // one DPP max over the wave, a search for the first slot that holds it, one DPP min over the candidate indices ("first index among
@@ -671,13 +671,14 @@ static int fps_launch(const float* xyz, const long long* start, int B, int N, in
     if (!dist_scratch) return CG_ERR_ARG;   // (B,N) floats needed for clouds beyond the register paths
     hipLaunchKernelGGL(fps_kernel_global, grid, block, 0, s, xyz, start, N, npoint, dist_scratch, out, out_xyz);
   }
-  // <= 1,024 points: one wavefront per cloud, no exchange between wavefronts (fps_wave_kernel); CATGRASP_AMD_FPS=plain keeps the
-  // workgroup kernel below for comparison
-  else if (N <= 1024 && !fps_plain()) {
+  // <= 512 points: one wavefront per cloud, no exchange between wavefronts (fps_wave_kernel); CATGRASP_AMD_FPS=plain keeps the
+  // workgroup kernel below for comparison.  us per round incl. the launch (scripts/fps_time.py, one / eight clouds): 512 -> 128:
+  // 0.81 / 0.72 against 0.94 / 0.84; 256 -> 64: 0.77 against 1.19; at 1,024 points (16 slots per lane) the one wavefront LOSES,
+  // 0.70 against 0.64 -- a round is then 16 dependent distance updates long and nothing hides them -- so it stops at 512.
+  else if (N <= 512 && !fps_plain()) {
     const size_t lds = (size_t)N * 3 * sizeof(float);
     if (N <= 256) hipLaunchKernelGGL((fps_wave_kernel<4>), grid, dim3(64), lds, s, xyz, start, N, npoint, out, out_xyz);
-    else if (N <= 512) hipLaunchKernelGGL((fps_wave_kernel<8>), grid, dim3(64), lds, s, xyz, start, N, npoint, out, out_xyz);
-    else hipLaunchKernelGGL((fps_wave_kernel<16>), grid, dim3(64), lds, s, xyz, start, N, npoint, out, out_xyz);
+    else hipLaunchKernelGGL((fps_wave_kernel<8>), grid, dim3(64), lds, s, xyz, start, N, npoint, out, out_xyz);
   }
   // <= 2,048 points: 512 threads x 4 points, every point every round (0.54 us per round at N = 2,048; the blob-skipping kernel with one
   // 256-point blob per wavefront: 0.56, and its prologue is not amortised over few rounds -- 0.76 against 0.56 at 1,024 -> 512)

@@ -92,7 +92,7 @@ def test_farthest_point_sample_degenerate_clouds(cuda_device, fps_kernel):
 
 
 def test_farthest_point_sample_degenerate_small_clouds(cuda_device, fps_kernel):
-    """The one-wavefront kernel of clouds up to 1,024 points on the same degenerate inputs: one repeated point (the padding slots tie with
+    """The one-wavefront kernel of clouds up to 512 points (and its neighbours in size) on the same degenerate inputs: one repeated point (the padding slots tie with
     the real points at distance 0 and must lose), a single outlier, fewer distinct points than samples."""
     from catgrasp_amd import pointnet2 as p2
     for n in (70, 300, 512, 900):
