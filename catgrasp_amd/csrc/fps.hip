@@ -87,18 +87,22 @@ __device__ __forceinline__ int wave_min_i32(int v) {
 template <int SLOTS>
 __global__ __launch_bounds__(64) void fps_wave_kernel(const float* __restrict__ xyz, const long long* __restrict__ start, int N, int npoint,
                                                       long long* __restrict__ out, float* __restrict__ out_xyz) {
+  static_assert(SLOTS % 2 == 0, "points are held in pairs (packed float math)");
+  constexpr int H = SLOTS / 2;
   extern __shared__ float pts[];                     // the cloud, (N,3): where a round reads its centre from
   const int b = blockIdx.x, lane = threadIdx.x;
   const float* xb = xyz + (size_t)b * N * 3;
   for (int i = lane; i < N * 3; i += 64) pts[i] = xb[i];
-  float px[SLOTS], py[SLOTS], pz[SLOTS];
+  // lane l holds the CONSECUTIVE points l * SLOTS .. l * SLOTS + SLOTS - 1: index order is (lane, slot) order, so "the first index among
+  // equal maxima" is the first lane that holds the maximum (one ballot + s_ff1) and that lane's first slot -- no reduction over indices
+  f32x2 px[H], py[H], pz[H];
   unsigned dist[SLOTS];                              // bit patterns of the running distances (all >= +0)
 #pragma unroll
   for (int k = 0; k < SLOTS; ++k) {
-    const int p = lane + k * 64;
-    float x = 0.f, y = 0.f, z = 0.f, d0 = 0.0f;      // padding: distance 0 never shrinks and, with index "none", never wins a tie
-    if (p < N) { x = xb[p * 3 + 0]; y = xb[p * 3 + 1]; z = xb[p * 3 + 2]; d0 = 1e10f; }
-    px[k] = x; py[k] = y; pz[k] = z; dist[k] = __float_as_uint(d0);
+    const int p = lane * SLOTS + k;
+    float x = 0.f, y = 0.f, z = 0.f, d0 = 0.0f;      // padding (the highest indices): distance 0 never shrinks; it can only tie at maximum 0,
+    if (p < N) { x = xb[p * 3 + 0]; y = xb[p * 3 + 1]; z = xb[p * 3 + 2]; d0 = 1e10f; }       // where point 0 (lane 0, slot 0) comes first
+    px[k >> 1][k & 1] = x; py[k >> 1][k & 1] = y; pz[k >> 1][k & 1] = z; dist[k] = __float_as_uint(d0);
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
   __builtin_amdgcn_wave_barrier();
@@ -111,22 +115,25 @@ __global__ __launch_bounds__(64) void fps_wave_kernel(const float* __restrict__ 
       ob[it] = far;
       if (oxb) { oxb[it * 3 + 0] = cx; oxb[it * 3 + 1] = cy; oxb[it * 3 + 2] = cz; }
     }
+    const f32x2 cx2 = {cx, cx}, cy2 = {cy, cy}, cz2 = {cz, cz};
     unsigned best = 0u;
 #pragma unroll
-    for (int k = 0; k < SLOTS; ++k) {
-      const float dx = px[k] - cx, dy = py[k] - cy, dz = pz[k] - cz;
-      const unsigned d = __float_as_uint((dx * dx + dy * dy) + dz * dz);       // the reference's sum over the last axis, term by term
-      dist[k] = d < dist[k] ? d : dist[k];
-      best = dist[k] > best ? dist[k] : best;
+    for (int h = 0; h < H; ++h) {
+      const f32x2 dx = px[h] - cx2, dy = py[h] - cy2, dz = pz[h] - cz2;
+      const f32x2 d = (dx * dx + dy * dy) + dz * dz;                            // the reference's sum over the last axis, term by term
+      const unsigned d0 = __float_as_uint(d[0]), d1 = __float_as_uint(d[1]);
+      dist[2 * h] = d0 < dist[2 * h] ? d0 : dist[2 * h];
+      dist[2 * h + 1] = d1 < dist[2 * h + 1] ? d1 : dist[2 * h + 1];
+      const unsigned m = dist[2 * h] > dist[2 * h + 1] ? dist[2 * h] : dist[2 * h + 1];
+      best = m > best ? m : best;
     }
     const unsigned wmax = wave_max_u32(best);
-    int mi = 0x7fffffff;
+    int ms = 0;
 #pragma unroll
-    for (int k = SLOTS - 1; k >= 0; --k) {
-      const int p = lane + k * 64;
-      mi = (dist[k] == wmax && p < N) ? p : mi;                                // ends on this lane's SMALLEST index holding the maximum
-    }
-    far = wave_min_i32(mi);
+    for (int k = SLOTS - 1; k >= 0; --k) ms = dist[k] == wmax ? k : ms;        // this lane's first slot holding the maximum (if any)
+    const unsigned long long holders = __ballot(best == wmax);
+    const int L = (int)__builtin_ctzll(holders);                                // never empty: some lane holds the maximum
+    far = L * SLOTS + __builtin_amdgcn_readlane(ms, L);
   }
 }
 
