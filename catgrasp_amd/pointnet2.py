@@ -466,18 +466,23 @@ class PointNet2Encoder(nn.Module):
             # a side stream while level 1's ball query and fused kernel use the rest of the chip (a sampling chain occupies one CU per
             # cloud).  Measured (profiles/r5_pp_encoder_side_stream.json): 16 clouds 0.973 -> 0.948 ms, 8 clouds unchanged, ONE cloud
             # 0.771 -> 0.830 ms -- the two cross-stream waits cost more than the 41 us of level-1 work they hide -- hence the threshold.
-            _, l1_xyz = farthest_point_sample(xyz, self.sa1.npoint, s1, return_xyz=True)
+            # both levels' FPS starts are drawn / validated / uploaded BEFORE the first kernel is queued (the reference's draw order, level
+            # 1 then level 2, is kept): a pageable upload between the levels would wait for the stream to drain
+            s1 = _prim.prepare_start(s1, B, N, x.device)
+            s2 = _prim.prepare_start(s2, B, self.sa1.npoint, x.device)
+            fps = lambda pts, n, st: farthest_point_sample(pts, n, st, return_xyz=True, start_prepared=True)
+            _, l1_xyz = fps(xyz, self.sa1.npoint, s1)
             if B >= SIDE_STREAM_MIN_CLOUDS:
                 cur, side = torch.cuda.current_stream(x.device), _side_stream(x.device)
                 side.wait_stream(cur)
                 with torch.cuda.stream(side):
-                    _, l2_xyz = farthest_point_sample(l1_xyz, self.sa2.npoint, s2, return_xyz=True)
+                    _, l2_xyz = fps(l1_xyz, self.sa2.npoint, s2)
                 _, l1_points = self.sa1(xyz, feats, _new_xyz=l1_xyz, **kw)
                 cur.wait_stream(side)
                 l2_xyz.record_stream(cur)
             else:
                 _, l1_points = self.sa1(xyz, feats, _new_xyz=l1_xyz, **kw)
-                _, l2_xyz = farthest_point_sample(l1_xyz, self.sa2.npoint, s2, return_xyz=True)
+                _, l2_xyz = fps(l1_xyz, self.sa2.npoint, s2)
             # level 2 writes [features | xyz | pad] rows: what the group-all level's first GEMM reads (no concatenation pass)
             c2 = self.sa3.in_channel - 3
             rows = torch.empty((B, self.sa2.npoint, (c2 + 3 + 7) & ~7), dtype=torch.float32, device=x.device)

@@ -49,22 +49,31 @@ def index_points(points, idx):
     return out
 
 
-def farthest_point_sample(xyz, npoint, start=None, return_xyz=False):
-    """xyz (B,N,3) -> centroids (B,npoint) int64 (pointnet2.py:54-75).  `start` defaults to the reference's
-    draw, `torch.randint(0, N, (B,), dtype=torch.long)` on the CPU generator (:66), so seeding torch
-    reproduces the reference's samples exactly.  return_xyz=True also returns the sampled points,
-    (B,npoint,3) == index_points(xyz, centroids), written by the same launch."""
-    require_cuda(xyz)
-    xyz = _f32(xyz)
-    B, N, C = xyz.shape
-    if C != 3:
-        raise NotImplementedError('farthest_point_sample HIP kernel is built for 3-D points')
+def prepare_start(start, B, N, device):
+    """The FPS start indices of one call, validated on the host and uploaded: what farthest_point_sample does at its top, available
+    separately so that a stack can upload the starts of ALL its levels before it queues the first kernel (a pageable host-to-device
+    copy in the middle of the stack waits for the stream to drain: the levels behind it would be queued one launch latency at a time).
+    start None = the reference's draw, torch.randint(0, N, (B,)) on the CPU generator (pointnet2.py:66)."""
     if start is None:
         start = torch.randint(0, N, (B,), dtype=torch.long)
     start = torch.as_tensor(start).long()
     if start.numel() != B or (B > 0 and bool(((start < 0) | (start >= N)).any())):      # one read-back when `start` lives on the device, none otherwise
         raise ValueError('start must hold one valid point index per cloud')
-    start = start.to(xyz.device).contiguous()
+    return start.to(device).contiguous()
+
+
+def farthest_point_sample(xyz, npoint, start=None, return_xyz=False, start_prepared=False):
+    """xyz (B,N,3) -> centroids (B,npoint) int64 (pointnet2.py:54-75).  `start` defaults to the reference's
+    draw, `torch.randint(0, N, (B,), dtype=torch.long)` on the CPU generator (:66), so seeding torch
+    reproduces the reference's samples exactly.  return_xyz=True also returns the sampled points,
+    (B,npoint,3) == index_points(xyz, centroids), written by the same launch.  start_prepared: `start` is prepare_start's result."""
+    require_cuda(xyz)
+    xyz = _f32(xyz)
+    B, N, C = xyz.shape
+    if C != 3:
+        raise NotImplementedError('farthest_point_sample HIP kernel is built for 3-D points')
+    if not start_prepared:           # start_prepared: the caller already ran prepare_start (validated device tensor)
+        start = prepare_start(start, B, N, xyz.device)
     out = torch.empty((B, npoint), dtype=torch.int64, device=xyz.device)
     scratch = torch.empty((B, N), dtype=torch.float32, device=xyz.device) if N > 24576 else None
     if return_xyz:
