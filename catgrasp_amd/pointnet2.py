@@ -408,7 +408,7 @@ def _torch_ball(radius, nsample, xyz, new_xyz):
 
 
 _SIDE_STREAMS = {}
-SIDE_STREAM_MIN_CLOUDS = 12     # PointNet2Encoder: batches from this size on overlap level 2's sampling with level 1's grouping
+SIDE_STREAM_MIN_CLOUDS = int(_os.environ.get('CATGRASP_AMD_ENCODER_SIDE_STREAM_MIN', 12))     # PointNet2Encoder: batches from this size on overlap level 2's sampling with level 1's grouping
 
 
 def _side_stream(device):
