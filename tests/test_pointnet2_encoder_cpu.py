@@ -121,3 +121,36 @@ def test_oracle_stack_and_torch_path_reproduce_the_stack_built_from_the_real_ref
     assert torch.equal(x1, torch.from_numpy(g['l1_xyz'])) and torch.equal(x2, torch.from_numpy(g['l2_xyz']))
     assert (p1.detach() - torch.from_numpy(g['l1_points'])).abs().max().item() <= 2e-6
     assert (gf.detach() - torch.from_numpy(g['global_feat'])).abs().max().item() <= 2e-6
+
+
+def test_prepare_start_and_kernel_routing_host_logic():
+    """Host logic of the round-5 additions that needs no GPU: the FPS start preparation (the reference's torch.randint draw under a seed,
+    validation) and the routing of set-abstraction shapes to the kernel families."""
+    import numpy as np
+    import pytest
+    from catgrasp_amd import primitives as prim
+    torch.manual_seed(42)
+    want = torch.randint(0, 700, (3,), dtype=torch.long)          # pointnet2.py:66
+    torch.manual_seed(42)
+    got = prim.prepare_start(None, 3, 700, 'cpu')
+    assert torch.equal(got, want) and got.dtype == torch.int64
+    assert torch.equal(prim.prepare_start([1, 2, 699], 3, 700, 'cpu'), torch.tensor([1, 2, 699]))
+    for bad in ([1, 2], [0, 1, 700], [-1, 0, 0]):
+        with pytest.raises(ValueError):
+            prim.prepare_start(bad, 3, 700, 'cpu')
+    rng = np.random.default_rng(1)
+
+    def W(cin, widths, **kw):
+        prev, layers = cin, []
+        for c in widths:
+            layers.append((rng.normal(size=(c, prev)), rng.normal(size=c), None)); prev = c
+        return prim.SetAbstractionWeights(layers, cin, 'cpu', **kw)
+    assert W(9, [64, 64, 128]).kind == 'reg'                       # the register-resident kernel's shapes
+    assert W(6, [32, 32, 64, 64]).kind == 'reg'                    # narrow odd nets: its LDS-strip fallback
+    assert W(9, [64, 128, 256]).kind == 'tile' and W(9, [64, 96, 128]).kind == 'tile'
+    assert W(131, [128, 128, 256]).kind == 'tile' and W(643, [256, 512, 1024]).cin[0] == 648
+    assert W(9, [64, 128, 256], kind='reg').kind == 'reg'          # still reachable on request
+    with pytest.raises(ValueError):
+        W(131, [128, 128, 256], kind='reg')
+    with pytest.raises(NotImplementedError):
+        W(9, [64, 100])
