@@ -134,47 +134,50 @@ GRIPPER_SUBDIVISIONS = 4                                # the step's gripper mes
 PEAK_L2_GBS = 34500.0                                   # MI355X_MICROARCH.md: L2 4 MiB per XCD, ~34.5 TB/s aggregate
 
 
-def filter_roofline_block(batch, device, reps=5, issue=None, repeat=1):
-    """roofline_filter: the collision filter of the step, object 0's two segments (canonical grasps x symmetries with nudging; cone poses),
-    alone on the stream: HIP-event time of the three launches of a call (pose composition, grid kernel, exhaustive finisher) against the
-    chip's vector-instruction issue rate (`issue` = pmc_filter_issue's counters of the same two calls), with, beside it, the
-    CACHE-LEVEL bytes the grid kernel itself counts (cg_filter_grasp_pose_accel work_stats: 8 B per voxel key read, 8 B per grid cell
-    looked up, 48 B of triangle + 4 B of list entry per (voxel, triangle) pair tested) plus the algorithmic HBM bytes (64 B pose in,
-    66 B out per evaluation).  HBM-wise the kernel is trivial; the voxel keys, cell table and triangles are L2 / L1 resident."""
-    from catgrasp_amd import my_cpp
-    I4 = np.eye(4, dtype=np.float32)
+def step_filter_rects(batch):
+    """The rectangles (segment, i0, i1, j0, j1) of the step's filter: every evaluation of the batch, as score_slice(0, n_total) issues them."""
+    from catgrasp_amd import workload
+    return [(s, *r) for s, a, b_ in workload.intersect(batch.segs, 0, batch.n_total) for r in workload.split_eval_range(s.n_sym, a, b_)]
+
+
+def filter_roofline_block(batch, device, reps=5, issue=None):
+    """roofline_filter: the collision filter of the STEP -- every segment of every object (canonical grasps x symmetries with nudging; cone
+    poses) in the one launch sequence the step issues (cg_filter_grasp_pose_multi: pose composition, grid kernel, exhaustive finisher),
+    alone on the stream: HIP-event time of the sequence against the chip's vector-instruction issue rate (`issue` = pmc_filter_issue's
+    counters of the same sequence), with, beside it, the CACHE-LEVEL bytes the grid kernel itself counts (work_stats: 8 B per voxel key
+    read, 8 B per grid cell looked up, 48 B of triangle + 4 B of list entry per (voxel, triangle) pair tested) plus the algorithmic HBM
+    bytes (64 B pose in, 66 B out per evaluation).  HBM-wise the kernel is trivial; the voxel keys, cell table and triangles are L2 / L1
+    resident."""
     g = batch.gripper
-    tot_ms, tot_bytes, E_tot, w_tot = 0.0, 0, 0, np.zeros(3, dtype=np.int64)
-    for seg in [s for s in batch.segs if s.obj == 0 and s.replica == 0]:
-        P = batch.segment_poses(seg)
-        if repeat > 1:                      # the same poses `repeat` times over: what a launch of that many evaluations costs per evaluation
-            P = P.repeat(repeat, 1).contiguous()
-        sym, nocs = (batch.syms[batch.cats[0]], batch.nocs_pose[0]) if seg.kind == 'nocs' else (batch.eye, I4)
-        call = lambda ws=None: my_cpp.filter_on_device(batch.scenes[0], P, sym, nocs, I4, I4, I4, g['gripper_in_grasp'], True, False, seg.adjust,
-                                                       keep_rejected_pose=True, work_stats=ws)
-        stats = torch.zeros(3, dtype=torch.int64, device=device)
-        out = call(stats)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            call()
-        e1.record(); torch.cuda.synchronize()
-        w = stats.cpu().numpy()
-        E = int(out[0].numel())
-        tot_ms += e0.elapsed_time(e1) / reps; E_tot += E; w_tot += w
-        tot_bytes += int(8 * w[0] + 8 * w[1] + 52 * w[2] + 130 * E)
+    rects = step_filter_rects(batch)
+    key = ('roofline', 0, batch.n_total)
+    batch.run_filter_many(key, rects)                       # builds the plan
+    plan = batch._plans[key]
+    stats = torch.zeros(3, dtype=torch.int64, device=device)
+    out = plan.run(g['gripper_in_grasp'], True, keep_rejected_pose=True, work_stats=stats)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        plan.run(g['gripper_in_grasp'], True, keep_rejected_pose=True)
+    e1.record(); torch.cuda.synchronize()
+    w = stats.cpu().numpy()
+    E_tot = int(out[0].numel())
+    tot_ms = e0.elapsed_time(e1) / reps
+    tot_bytes = int(8 * w[0] + 8 * w[1] + 52 * w[2] + 130 * E_tot)
     gbs = tot_bytes / (tot_ms * 1e-3) / 1e9
     cache = {'cache_level_bytes': tot_bytes, 'cache_level_GBps': round(gbs, 1), 'frac_of_l2_peak': round(gbs / PEAK_L2_GBS, 4), 'l2_peak_GBps': PEAK_L2_GBS,
-             'voxel_keys_read': int(w_tot[0]), 'grid_cells_looked_up': int(w_tot[1]), 'pairs_tested': int(w_tot[2]),
+             'voxel_keys_read': int(w[0]), 'grid_cells_looked_up': int(w[1]), 'pairs_tested': int(w[2]),
              'note': 'what the lanes load from L1 / L2 (counted by the kernel itself), not HBM: 8 B per voxel key, 8 B per grid cell, 52 B per pair'}
-    out = {'bound': 'valu-issue', 'kernel': 'compose_grasp_pose_kernel + filter_grasp_pose_kernel<true> (+ the exhaustive finisher, which finds nothing to do)',
+    out = {'bound': 'valu-issue', 'kernel': 'compose_grasp_pose_multi_kernel + filter_grasp_pose_kernel<true, true> (+ the exhaustive finisher, which finds nothing to do)',
            'achieved': None, 'peak': round(PEAK_VALU_WAVE_INSTS_PER_S / 1e9, 1), 'unit': 'G wave-instructions/s', 'frac': None, 'traffic': None,
-           'evaluations': E_tot, 'ms': round(tot_ms, 4), 'evaluations_per_s': round(E_tot / (tot_ms * 1e-3), 1),
+           'launch_sequences_per_step': 1, 'segments': len(rects), 'evaluations': E_tot, 'ms': round(tot_ms, 4),
+           'evaluations_per_s': round(E_tot / (tot_ms * 1e-3), 1),
            'gripper_triangles': [int(len(g['faces'])), int(len(g['enclosed_faces']))], 'hbm_algorithmic_bytes': 130 * E_tot, 'cache_level': cache,
-           'note': 'the kernel is bound by vector-instruction issue (broad-phase arithmetic per voxel, the 13-axis separating-axis test per pair), '
-                   'neither by HBM (130 B per evaluation) nor by cache bytes: `achieved` = wavefront-level VALU instructions of the grid kernel '
-                   '(SQ_INSTS_VALU, PMC child pass of this run) / the HIP-event time of the calls; peak = one wave64 instruction per CU per clock '
-                   '(256 CUs x 2.4 GHz); wait_share = SQ_WAIT_ANY / SQ_WAVE_CYCLES'}
+           'note': 'the whole step\'s filter (all objects, both call shapes) is ONE launch sequence since round 6 (rounds 3-5: 16 calls x 3 launches of '
+                   '~6k evaluations on 8 streams).  The kernel is bound by vector-instruction issue (broad-phase arithmetic per voxel, the 13-axis '
+                   'separating-axis test per pair), neither by HBM (130 B per evaluation) nor by cache bytes: `achieved` = wavefront-level VALU '
+                   'instructions of the grid kernel (SQ_INSTS_VALU, PMC child pass of this run) / the HIP-event time of the sequence; peak = one wave64 '
+                   'instruction per CU per clock (256 CUs x 2.4 GHz); wait_share = SQ_WAIT_ANY / SQ_WAVE_CYCLES'}
     if issue is not None and issue[0] is not None:
         c = issue[0]
         ach = c['valu_wave_insts'] / (tot_ms * 1e-3)
@@ -182,7 +185,7 @@ def filter_roofline_block(batch, device, reps=5, issue=None, repeat=1):
                    valu_wave_insts_per_evaluation=round(c['valu_wave_insts'] / max(E_tot, 1), 1), wait_share=round(c['wait_any'] / c['wave_cycles'], 4),
                    counters_source=issue[1])
     elif issue is not None:
-        out['counters_source'] = f'not measured in this run ({issue[1]}); profiles/r4_pmc_sq_filter.csv holds the round-4 counters'
+        out['counters_source'] = f'not measured in this run ({issue[1]})'
     return out
 
 
@@ -428,9 +431,9 @@ def cpu_baseline(batch, sd_cls, sd_seg, n_score=100, n_coll=4096):
 PEAK_VALU_WAVE_INSTS_PER_S = 256 * 2.4e9                # one wave64 vector instruction per CU and clock (4 SIMD16 x 4 cycles), 256 CUs, 2.4 GHz
 
 
-def pmc_filter_issue(args, repeat=1):
-    """The issue-side counters of the filter's grid kernel for THIS run's scene: one child run of this script (--pmc-filter-child: object
-    0's two filter calls, 1 warm-up + 3 timed) under `rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY` (counters only).
+def pmc_filter_issue(args):
+    """The issue-side counters of the filter's grid kernel for THIS run's scene: one child run of this script (--pmc-filter-child: the
+    step's filter sequence, 4 rounds) under `rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY` (counters only).
     -> ({'valu_wave_insts', 'wave_cycles', 'wait_any'} per pair of calls, source text) or (None, reason)."""
     import csv
     import glob
@@ -445,7 +448,7 @@ def pmc_filter_issue(args, repeat=1):
     counters = ('SQ_INSTS_VALU', 'SQ_WAVE_CYCLES', 'SQ_WAIT_ANY')
     try:
         cmd = [exe, '--pmc', *counters, '--kernel-include-regex', 'filter_grasp_pose_kernel', '--output-format', 'csv', '-d', tmp, '--',
-               sys.executable, os.path.abspath(__file__), '--pmc-filter-child', '--pmc-filter-repeat', str(repeat), '--gpus', '1', '--workload', args.workload,
+               sys.executable, os.path.abspath(__file__), '--pmc-filter-child', '--gpus', '1', '--workload', args.workload,
                '--candidates', str(args.candidates), '--candidates-total', str(args.candidates_total)]
         r = subprocess.run(cmd, cwd='/tmp', env=dict(os.environ, TMPDIR='/tmp'), capture_output=True, text=True, timeout=300)
         if r.returncode != 0:
@@ -459,19 +462,19 @@ def pmc_filter_issue(args, repeat=1):
             with open(path) as f:
                 for row in csv.DictReader(f):
                     name = row.get('Kernel_Name') or row.get('kernel_name') or ''
-                    if 'filter_grasp_pose_kernel<true>' in name.replace('(anonymous namespace)::', '') or 'filter_grasp_pose_kernelILb1' in name:
+                    if 'filter_grasp_pose_kernel<true,' in name.replace('(anonymous namespace)::', '') or 'filter_grasp_pose_kernelILb1' in name:
                         tot[row.get('Counter_Name') or row.get('counter_name')] += float(row.get('Counter_Value') or row.get('counter_value'))
         if not all(tot.get(c) for c in counters):
             return None, f'counters missing in the rocprofv3 output: {dict(tot)}'
         return ({'valu_wave_insts': tot['SQ_INSTS_VALU'] / rounds, 'wave_cycles': tot['SQ_WAVE_CYCLES'] / rounds, 'wait_any': tot['SQ_WAIT_ANY'] / rounds},
-                f'rocprofv3 --pmc {" ".join(counters)} over {rounds} rounds of the two filter calls of object 0 (child pass of this command)')
+                f'rocprofv3 --pmc {" ".join(counters)} over {rounds} rounds of the step\'s filter sequence (child pass of this command)')
     except Exception as e:
         return None, f'{type(e).__name__}: {e}'
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-def pmc_traffic(args, precision):
+def pmc_traffic(args, precision, workload=None, candidates_total=None):
     """roofline.traffic measured for THIS run's workload instead of quoted from profiles/ (opt-in: --pmc-traffic, N = 1): two child
     runs of this script under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes, counters only -- no tracing
     domain next to --pmc; MI355X_MICROARCH.md, HBM section), one warm-up + one step each; HBM bytes of the encoder-pass kernel =
@@ -494,8 +497,8 @@ def pmc_traffic(args, precision):
         for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
             d = os.path.join(tmp, counter)
             cmd = [exe, '--pmc', counter, '--output-format', 'csv', '-d', d, '--', sys.executable, os.path.abspath(__file__), '--pmc-child',
-                   '--gpus', '1', '--precision', precision, '--workload', args.workload, '--candidates', str(args.candidates),
-                   '--candidates-total', str(args.candidates_total), '--steps', '1', '--warmup', '1']
+                   '--gpus', '1', '--precision', precision, '--workload', workload or args.workload, '--candidates', str(args.candidates),
+                   '--candidates-total', str(candidates_total or args.candidates_total), '--steps', '1', '--warmup', '1']
             r = subprocess.run(cmd, cwd='/tmp', env=env, capture_output=True, text=True, timeout=300)
             if r.returncode != 0:
                 return None, f'rocprofv3 --pmc {counter} exited with {r.returncode}: {r.stderr[-300:]}'
@@ -601,10 +604,10 @@ def main():
     ap.add_argument('--no-pmc-traffic', dest='pmc_traffic', action='store_false', help='quote the constant from profiles/ instead')
     ap.add_argument('--pmc-traffic-all', action='store_true', help='measure the traffic of every secondary precision too (two child passes each)')
     ap.add_argument('--no-projection', action='store_true', help='skip the projected_scaling block (N = 1: slice timings of the 2 / 4 / 8-rank shards)')
+    ap.add_argument('--no-configs', action='store_true', help='skip the `configs` block of the default line (C4 and C5 at full size, 2 warm-ups + 3 steps each)')
     ap.add_argument('--no-rccl-selftest', action='store_true', help='skip the one-rank RCCL all-gather check after the timed region (N = 1)')
     ap.add_argument('--pmc-child', action='store_true', help=argparse.SUPPRESS)      # the child run of --pmc-traffic: workload only
     ap.add_argument('--pmc-filter-child', action='store_true', help=argparse.SUPPRESS)   # the child run of pmc_filter_issue: object 0's filter calls
-    ap.add_argument('--pmc-filter-repeat', type=int, default=1, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.scaling == 'weak' and args.workload != 'C3':
         ap.error(f'--workload {args.workload} is a strong-scaling workload')
@@ -639,53 +642,56 @@ def main():
     from catgrasp_amd import engine, ops, synth
     from catgrasp_amd.predicter import DEFAULT_GRASP_CFG, DEFAULT_NUNOCS_CFG, GraspPredicter, NunocsPredicter
     from catgrasp_amd.workload import SceneBatch
-    cats = {'C3': ['nut'], 'C4': ['screw'], 'C5': ['nut', 'hnm', 'screw']}[args.workload]
-    # one GraspPredicter / NunocsPredicter per category, each with its own seeded random-init weights (run_grasp_simulation.py:701-702)
-    sds = {c: (synth.make_state_dict('cls', 6, 10, seed=2 * i), synth.make_state_dict('seg', 6, 300, seed=2 * i + 1)) for i, c in enumerate(cats)}
-    sd_cls, sd_seg = sds[cats[0]]
     gp_kw = {'chunk': args.chunk} if args.chunk else {}
-    gps = {c: GraspPredicter(c, cfg=DEFAULT_GRASP_CFG, state_dict=sds[c][0], device=device, **gp_kw) for c in cats}
-    npreds = {c: NunocsPredicter(c, cfg=DEFAULT_NUNOCS_CFG, state_dict=sds[c][1], device=device) for c in cats}
-    gp = gps[cats[0]]
+    clock = {'start': time.perf_counter()}
+    timing = {}
 
-    def make_batch(scaling):
-        """-> (SceneBatch, n_total).  strong: one fixed batch cut into `world` contiguous slices (C3: --candidates in total; C4 / C5:
-        --candidates-total); weak (C3): every rank scores its own replica of the candidate set (global order is replica-major: slice r
-        == replica r).  A rank only generates the candidate poses of its own slice."""
+    def lap(name):
+        now = time.perf_counter()
+        timing[name] = round(timing.get(name, 0.0) + now - clock['start'], 2)
+        clock['start'] = now
+
+    def build_workload(workload, scaling='strong', n=None):
+        """-> dict(batch, n_total, cats, sds, gps, npreds).  One GraspPredicter / NunocsPredicter per category, each with its own seeded
+        random-init weights (run_grasp_simulation.py:701-702).  strong: one fixed batch cut into `world` contiguous slices (C3: --candidates
+        in total; C4 / C5: --candidates-total); weak (C3): every rank scores its own replica of the candidate set (global order is
+        replica-major: slice r == replica r).  A rank only generates the candidate poses of its own slice."""
+        cats = {'C3': ['nut'], 'C4': ['screw'], 'C5': ['nut', 'hnm', 'screw']}[workload]
+        sds = {c: (synth.make_state_dict('cls', 6, 10, seed=2 * i), synth.make_state_dict('seg', 6, 300, seed=2 * i + 1)) for i, c in enumerate(cats)}
+        gps = {c: GraspPredicter(c, cfg=DEFAULT_GRASP_CFG, state_dict=sds[c][0], device=device, **gp_kw) for c in cats}
+        npreds = {c: NunocsPredicter(c, cfg=DEFAULT_NUNOCS_CFG, state_dict=sds[c][1], device=device) for c in cats}
         if scaling == 'weak':
             n = args.candidates * world
-            return SceneBatch(device, gps, npreds, kind='nut', n_objects=8, pts_per_object=2500, per_replica=args.candidates, replicas=world,
-                              materialize=(rank * args.candidates, (rank + 1) * args.candidates), gripper_subdivisions=GRIPPER_SUBDIVISIONS), n
-        n = args.candidates if args.workload == 'C3' else args.candidates_total
-        _, bounds = cgd.shard_bounds(n, world)
-        kind, n_obj = {'C3': ('nut', 8), 'C4': ('screw', 16), 'C5': ('bin', 24)}[args.workload]
-        return SceneBatch(device, gps, npreds, kind=kind, n_objects=n_obj, pts_per_object=2500, per_replica=n, replicas=1, materialize=bounds[rank],
-                          gripper_subdivisions=GRIPPER_SUBDIVISIONS), n
+            b = SceneBatch(device, gps, npreds, kind='nut', n_objects=8, pts_per_object=2500, per_replica=args.candidates, replicas=world,
+                           materialize=(rank * args.candidates, (rank + 1) * args.candidates), gripper_subdivisions=GRIPPER_SUBDIVISIONS)
+        else:
+            if n is None and workload == 'C3':
+                n = args.candidates
+            elif n is None:
+                n = args.candidates_total if workload == args.workload else {'C4': 200000, 'C5': 500000}[workload]
+            _, bounds = cgd.shard_bounds(n, world)
+            kind, n_obj = {'C3': ('nut', 8), 'C4': ('screw', 16), 'C5': ('bin', 24)}[workload]
+            b = SceneBatch(device, gps, npreds, kind=kind, n_objects=n_obj, pts_per_object=2500, per_replica=n, replicas=1, materialize=bounds[rank],
+                           gripper_subdivisions=GRIPPER_SUBDIVISIONS)
+        assert b.n_total == n
+        return {'batch': b, 'n_total': n, 'cats': cats, 'sds': sds, 'gps': gps, 'npreds': npreds}
 
-    batch, n_total = make_batch(args.scaling)
-    assert batch.n_total == n_total
+    wl = build_workload(args.workload, args.scaling)
+    batch, n_total, cats, gps, npreds = wl['batch'], wl['n_total'], wl['cats'], wl['gps'], wl['npreds']
+    sd_cls, sd_seg = wl['sds'][cats[0]]
+    gp = gps[cats[0]]
+    lap('build the workload (scene, candidates, predicters)')
 
     def barrier():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    if args.pmc_filter_child:   # counter pass of pmc_filter_issue: the two filter calls of object 0, 1 warm-up + 3 rounds
-        from catgrasp_amd import my_cpp
-        I4 = np.eye(4, dtype=np.float32)
-        g = batch.gripper
-        segs0 = [s_ for s_ in batch.segs if s_.obj == 0 and s_.replica == 0]
-
-        def one_round():
-            for seg in segs0:
-                P = batch.segment_poses(seg)
-                if args.pmc_filter_repeat > 1:
-                    P = P.repeat(args.pmc_filter_repeat, 1).contiguous()
-                sym, nocs = (batch.syms[batch.cats[0]], batch.nocs_pose[0]) if seg.kind == 'nocs' else (batch.eye, I4)
-                my_cpp.filter_on_device(batch.scenes[0], P, sym, nocs, I4, I4, I4, g['gripper_in_grasp'], True, False, seg.adjust, keep_rejected_pose=True)
+    if args.pmc_filter_child:   # counter pass of pmc_filter_issue: the step's filter sequence, 4 rounds
+        rects = step_filter_rects(batch)
         rounds = 4
         for _ in range(rounds):
-            one_round()
+            batch.run_filter_many(('roofline', 0, batch.n_total), rects)
         torch.cuda.synchronize()
         emit({'pmc_filter_child': True, 'rounds': rounds})
         return
@@ -701,16 +707,18 @@ def main():
         emit({'pmc_child': True, 'launches': len(ev), 'candidate_equivalents': float(sum(B * N / 2048.0 for _, _, (B, N) in ev))})
         return
 
-    def measure(precision, batch=batch, n_total=n_total):
+    def measure(precision, batch=batch, n_total=n_total, steps=None, warmup=None):
+        steps = args.steps if steps is None else steps
+        warmup = args.warmup if warmup is None else warmup
         engine.set_precision(precision)
         marks = []
         with torch.no_grad():
-            for _ in range(args.warmup):
+            for _ in range(warmup):
                 cgd.score_sharded(batch.score_slice, n_total)
             barrier()
             ops.KERNEL_TIMER = {'mid_mode': 2, 'events': [], 'bgi_events': []}
             t0 = time.perf_counter()
-            for _ in range(args.steps):
+            for _ in range(steps):
                 out = cgd.score_sharded(batch.score_slice, n_total, marks=marks)
             barrier()
             dt_local = time.perf_counter() - t0
@@ -721,7 +729,7 @@ def main():
         dt = float(t.item())
         score_ms = float(np.mean([a.elapsed_time(b) for a, b, _ in marks]))
         gather_ms = float(np.mean([b.elapsed_time(c) for _, b, c in marks]))
-        per_rank = [score_ms, gather_ms, dt_local / args.steps * 1e3]
+        per_rank = [score_ms, gather_ms, dt_local / steps * 1e3]
         if world > 1:
             lst = [None] * world
             torch.distributed.all_gather_object(lst, per_rank)
@@ -746,12 +754,14 @@ def main():
 
     measured_traffic = {}
 
-    def roofline(precision, r):
+    def roofline(precision, r, traffic=None):
         # traffic is reported only when it was MEASURED for this run (primary precision, N = 1, rocprofv3 present); otherwise null plus
         # the round-2 PMC constant under its own name -- not a counter read in this run
         per, source = None, ('not measured in this run; `traffic_round2_constant` = profiles/r2_pmc_hbm_pointmlp_{f32,split,f16fp8x2}.csv '
                              '(2*FETCH_SIZE + WRITE_SIZE per candidate at B=4096) x candidates per launch; algorithmic bytes are 69,632 B/candidate')
-        if precision in measured_traffic:
+        if traffic is not None:
+            per, source = traffic
+        elif precision in measured_traffic:
             per, source = measured_traffic[precision]
         hbm_gbs = ALG_HBM_BYTES_PER_CANDIDATE * r['avg_cand'] / (r['avg_ms'] * 1e-3) / 1e9
         common = {'achieved': round(r['tflops'], 2), 'unit': 'TFLOP/s', 'avg_launch_ms': round(r['avg_ms'], 4), 'launches': r['launches'],
@@ -783,6 +793,7 @@ def main():
 
     prim = measure(args.precision)
     ref_out = prim['out'].clone()
+    lap('primary measurement (warm-up + timed steps)')
     # the reference-API wall-clock right behind the primary measurement (same clock / thermal state as `value`), before the minutes of
     # split-precision runs below
     api = api_block(batch, gp, device) if (rank == 0 and world == 1 and not args.no_api) else None
@@ -791,6 +802,7 @@ def main():
             api['pick_cycle'] = pick_cycle_block(batch, gp, npreds[cats[0]], device)
         except Exception as e:          # an extra: never let it take the bench line down
             api['pick_cycle'] = {'error': f'{type(e).__name__}: {e}'[:300]}
+    lap('api block (reference entry points, pick cycle)')
     secondary = []
     for other in [p for p in args.secondary.split(',') if p and p != args.precision]:
         r = measure(other)
@@ -800,14 +812,16 @@ def main():
                           'codes_identical_to_primary': bool(torch.equal(r['out'][:, 1], ref_out[:, 1]))})
     if world > 1 and args.workload == 'C3' and args.scaling == 'strong':
         # the weak-scaling figure of the same scene next to the strong one: every rank scores its own --candidates (different seeds)
-        wbatch, wn = make_batch('weak')
+        ww = build_workload('C3', 'weak')
+        wbatch, wn = ww['batch'], ww['n_total']
         r = measure(args.precision, wbatch, wn)
         secondary.append({'scaling': 'weak', 'precision': args.precision, 'dtype': DTYPE[args.precision], 'candidates_per_gpu': args.candidates,
                           'candidates_total': wn, 'value': round(wn * args.steps / r['dt'], 1), 'ms_per_step': round(r['dt'] / args.steps * 1e3, 3),
                           'per_rank_ms': [[round(v, 3) for v in pr] for pr in r['per_rank']],
                           'note': 'per-GPU work fixed: N x the single-GPU batch, gathered by the same one all_gather'})
-        del wbatch, r
+        del wbatch, ww, r
     engine.set_precision(args.precision)
+    lap('secondary precisions')
 
     projected = None
     if world == 1 and rank == 0 and args.scaling == 'strong' and not args.no_projection:
@@ -815,6 +829,7 @@ def main():
     selftest = None
     if world == 1 and not args.no_rccl_selftest and backend == 'nccl':
         selftest = rccl_selftest(batch, n_total, ref_out, device)
+    lap('projected scaling + rccl self-test')
 
     if rank == 0 and world == 1 and args.pmc_traffic:
         # the primary arithmetic and, when it is among the secondaries, bf16x3 (the C5 arithmetic); --pmc-traffic-all: every secondary
@@ -831,37 +846,78 @@ def main():
                 per, source = measured_traffic[x['precision']]
                 x['roofline']['traffic'] = int(per * x['roofline']['candidates_per_launch'])
                 x['roofline']['traffic_source'] = source
-    if rank == 0:
+    lap('traffic counter passes (rocprofv3 --pmc children)')
+    METRIC = {'C3': 'grasp candidates scored+collision-checked /sec, 20k-pt clutter scene',
+              'C4': 'grasp candidates scored+collision-checked /sec, 40k-pt scene, candidates sharded over the GPUs',
+              'C5': 'grasp candidates scored+collision-checked /sec, 60k-pt mixed-category bin, candidates sharded over the GPUs'}
+
+    def describe(workload, batch, n_total, cats, out, scaling='strong'):
+        """The `config` object of a workload's line: what was run, on what, and the reject-code histogram of its records."""
         from catgrasp_amd.workload import SYMMETRY_COUNT
         sym_txt = ' / '.join(str(SYMMETRY_COUNT[c]) for c in cats)
+        codes = out[:, 1].long()
+        return {'workload': {'C3': 'C3 (BASELINE.json configs[2]): nut clutter pile, 20k-pt scene (8 objects x 2500 pts), ' +
+                                   (f'{args.candidates} candidates/GPU' if scaling == 'weak' else
+                                    f'{n_total} candidates in total over {world} GPU(s)'),
+                             'C4': 'C4 (BASELINE.json configs[3]): screw category, 40k-pt scene (16 objects x 2500 pts), '
+                                   f'{n_total} candidates in total over {world} GPU(s)',
+                             'C5': 'C5 (BASELINE.json configs[4]): mixed-category bin, 60k-pt scene (24 objects x 2500 pts: nut / hnm / screw '
+                                   'in turn, one GraspPredicter + NunocsPredicter per category), '
+                                   f'{n_total} candidates in total over {world} GPU(s)'}[workload] +
+                            f': NUNOCS PointNetSeg(8192x6) per object + filterGraspPose [{len(batch.gripper["faces"])} / {len(batch.gripper["enclosed_faces"])}-triangle '
+                            f'gripper meshes; canonical grasps x {sym_txt} symmetries with '
+                            'adjust_collision_pose=True (grasp_sampler.py:345) and cone poses with symmetry=[I] (grasp_sampler.py:216)] + '
+                            'device pose inverse + per-candidate resampling draw + grasp-Q PointNetCls(2048x6) + softmax/p_G for EVERY candidate',
+                'candidates_per_gpu': n_total // world, 'candidates_total': n_total, 'scene_points': int(batch.cloud_xyz.shape[0]),
+                'symmetries': {c: SYMMETRY_COUNT[c] for c in cats} if len(cats) > 1 else batch.n_sym,
+                'evaluations_nocs_shape_adjust_true': int(sum(s.count for s in batch.segs if s.kind == 'nocs')),
+                'evaluations_cone_shape_adjust_false': int(sum(s.count for s in batch.segs if s.kind == 'cone')),
+                'reject_code_histogram_0keep_1dir_2ik_3open_4enclosed': torch.bincount(codes, minlength=5).tolist(),
+                'parallelism': f'candidate-shard x{world} ({scaling})'}
+
+    def config_block(workload, precision, steps=3, warmup=2, pmc_total=None):
+        """One further BASELINE.json configuration measured in this same process (the default N = 1 run carries C4 and C5 under `configs`):
+        the workload of `--workload <workload>` at its full size, `warmup` + `steps` steps, the dominant kernel's roofline from its own
+        HIP events, the projected 2 / 4 / 8-rank speed-ups from slice timings, and -- when rocprofv3 is on the box -- `traffic` from
+        two counter passes of the same workload at `pmc_total` candidates (bytes per candidate x the candidates per launch of the
+        full-size run: the kernel's traffic per candidate does not depend on how many launches the job has)."""
+        import hashlib
+        t0 = time.perf_counter()
+        w = build_workload(workload)
+        b, n = w['batch'], w['n_total']
+        t1 = time.perf_counter()
+        r = measure(precision, b, n, steps=steps, warmup=warmup)
+        t2 = time.perf_counter()
+        blk = {'metric': METRIC[workload], 'value': round(n * steps / r['dt'], 1), 'unit': 'candidates/s', 'n_gpus': world, 'steps': steps, 'warmup': warmup,
+               'ms_per_step': round(r['dt'] / steps * 1e3, 3), 'scaling': 'strong', 'dtype': DTYPE[precision],
+               'config': describe(workload, b, n, w['cats'], r['out']),
+               'records_sha256': hashlib.sha256(r['out'].cpu().numpy().tobytes()).hexdigest()}
+        traffic = None
+        if args.pmc_traffic and pmc_total:
+            per, why = pmc_traffic(args, precision, workload=workload, candidates_total=pmc_total)
+            if per is not None:
+                traffic = (per, why + f' [counter passes at {pmc_total} candidates of this workload]; algorithmic bytes are 69,632 B/candidate')
+            else:
+                print(f'bench.py: counter passes for {workload} failed ({why})', file=sys.stderr)
+        blk['roofline'] = roofline(precision, r, traffic=traffic)
+        t3 = time.perf_counter()
+        if not args.no_projection:
+            blk['projected_scaling'] = projected_scaling_block(b, n, r['dt'] / steps, steps=2)
+        engine.set_precision(args.precision)
+        t4 = time.perf_counter()
+        blk['wall_s'] = {'build': round(t1 - t0, 2), 'warm-up + steps': round(t2 - t1, 2), 'traffic counter passes': round(t3 - t2, 2),
+                         'projected scaling': round(t4 - t3, 2), 'total': round(t4 - t0, 2)}
+        return blk
+
+    if rank == 0:
         dt = prim['dt']
-        codes = ref_out[:, 1].long()
         line = {
-            'metric': {'C3': 'grasp candidates scored+collision-checked /sec, 20k-pt clutter scene',
-                       'C4': 'grasp candidates scored+collision-checked /sec, 40k-pt scene, candidates sharded over the GPUs',
-                       'C5': 'grasp candidates scored+collision-checked /sec, 60k-pt mixed-category bin, candidates sharded over the GPUs'}[args.workload],
+            'metric': METRIC[args.workload],
             'value': round(n_total * args.steps / dt, 1), 'unit': 'candidates/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None,
             'dtype': DTYPE[args.precision],
             'data': 'synthetic (seeded clouds/candidates/gripper, random-init weights)',
-            'config': {'workload': {'C3': 'C3 (BASELINE.json configs[2]): nut clutter pile, 20k-pt scene (8 objects x 2500 pts), ' +
-                                          (f'{args.candidates} candidates/GPU' if args.scaling == 'weak' else
-                                           f'{n_total} candidates in total over {world} GPU(s)'),
-                                    'C4': 'C4 (BASELINE.json configs[3]): screw category, 40k-pt scene (16 objects x 2500 pts), '
-                                          f'{n_total} candidates in total over {world} GPU(s)',
-                                    'C5': 'C5 (BASELINE.json configs[4]): mixed-category bin, 60k-pt scene (24 objects x 2500 pts: nut / hnm / screw '
-                                          'in turn, one GraspPredicter + NunocsPredicter per category), '
-                                          f'{n_total} candidates in total over {world} GPU(s)'}[args.workload] +
-                                   f': NUNOCS PointNetSeg(8192x6) per object + filterGraspPose [{len(batch.gripper["faces"])} / {len(batch.gripper["enclosed_faces"])}-triangle '
-                                   f'gripper meshes; canonical grasps x {sym_txt} symmetries with '
-                                   'adjust_collision_pose=True (grasp_sampler.py:345) and cone poses with symmetry=[I] (grasp_sampler.py:216)] + '
-                                   'device pose inverse + per-candidate resampling draw + grasp-Q PointNetCls(2048x6) + softmax/p_G for EVERY candidate',
-                       'candidates_per_gpu': n_total // world, 'candidates_total': n_total, 'scene_points': int(batch.cloud_xyz.shape[0]),
-                       'symmetries': {c: SYMMETRY_COUNT[c] for c in cats} if len(cats) > 1 else batch.n_sym,
-                       'evaluations_nocs_shape_adjust_true': int(sum(s.count for s in batch.segs if s.kind == 'nocs')),
-                       'evaluations_cone_shape_adjust_false': int(sum(s.count for s in batch.segs if s.kind == 'cone')),
-                       'reject_code_histogram_0keep_1dir_2ik_3open_4enclosed': torch.bincount(codes, minlength=5).tolist(),
-                       'parallelism': f'candidate-shard x{world} ({args.scaling})'},
+            'config': describe(args.workload, batch, n_total, cats, ref_out, args.scaling),
             'roofline': roofline(args.precision, prim),
             'per_rank_ms': {'columns': ['local scoring (HIP events)', 'all_gather of the (p_G, code) records (HIP events)', 'step wall-clock'],
                             'ranks': [[round(v, 3) for v in pr] for pr in prim['per_rank']]},
@@ -877,12 +933,6 @@ def main():
         if world == 1:
             try:
                 line['roofline_filter'] = filter_roofline_block(batch, device, issue=pmc_filter_issue(args) if args.pmc_traffic else (None, '--no-pmc-traffic'))
-                if args.pmc_traffic and args.workload == 'C3':
-                    # the step's launches are 6,250 evaluations each (three launches of ~0.1 ms: launch- and tail-bound); the same calls with
-                    # 8 x the poses show the kernel's rate when a launch fills the chip
-                    big = filter_roofline_block(batch, device, issue=pmc_filter_issue(args, repeat=8), repeat=8)
-                    line['roofline_filter']['at_8x_the_evaluations_per_launch'] = {k: big.get(k) for k in (
-                        'achieved', 'frac', 'evaluations', 'ms', 'evaluations_per_s', 'valu_wave_insts', 'valu_wave_insts_per_evaluation', 'wait_share')}
             except Exception as e:          # an extra: never let it take the bench line down
                 line['roofline_filter'] = {'error': f'{type(e).__name__}: {e}'[:300]}
         if secondary:
@@ -893,8 +943,21 @@ def main():
                 line['pp_encoder'] = encoder_block(batch, device)
             except Exception as e:          # an extra: never let it take the bench line down
                 line['pp_encoder'] = {'error': f'{type(e).__name__}: {e}'[:300]}
+        lap('filter roofline, encoder block')
+        if world == 1 and args.workload == 'C3' and args.scaling == 'strong' and not args.no_configs:
+            # the other two GPU configurations of BASELINE.json in the same driver-run line
+            line['configs'] = {}
+            for wl_name, prec, pmc_total in (('C4', 'f32', 28800), ('C5', 'bf16x3', 60000)):
+                try:
+                    line['configs'][wl_name] = config_block(wl_name, prec, pmc_total=pmc_total)
+                except Exception as e:      # an extra: never let it take the bench line down
+                    line['configs'][wl_name] = {'error': f'{type(e).__name__}: {e}'[:300]}
+                torch.cuda.empty_cache()
+                lap(f'configs.{wl_name}')
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(batch, sd_cls, sd_seg)
+            lap('cpu baseline')
+        line['timing_s'] = dict(timing, total=round(sum(timing.values()), 2))
         emit(line)
     if world > 1:
         torch.distributed.barrier()

@@ -100,6 +100,25 @@ struct Mesh { const float* V; const int* F; int nf; Grid grid; int has_grid; };
 struct Voxels { const short* keys; int nk; const short* blocks; };   // keys (nk,4) int16: key-32768 per axis, 4th unused; blocks (optional):
                                                                      // (ceil(nk/64), 2, 4) int16 = lowest / highest key of every run of 64 keys
 
+// How the collision loops see a voxel set.  Single call: the kernel argument itself (its loads are rematerialisable, so they cost no
+// register between uses).  MULTI: the segment's sets live in the wave's LDS row and every use reads them back from there -- loaded
+// from the device table into registers they would have to stay alive across the loops, which have no scalar register to spare
+// (36 spilled in the first form of the MULTI kernel).
+struct SegLds { const short* keys[2]; const short* blocks[2]; int nk[2]; int adjust; int sg; };
+template <bool MULTI> struct VoxView;
+template <> struct VoxView<false> {
+  const Voxels& v;
+  __device__ __forceinline__ const short* keys() const { return v.keys; }
+  __device__ __forceinline__ const short* blocks() const { return v.blocks; }
+  __device__ __forceinline__ int nk() const { return v.nk; }
+};
+template <> struct VoxView<true> {
+  const SegLds* sl; int m;
+  __device__ __forceinline__ const short* keys() const { return sl->keys[m]; }
+  __device__ __forceinline__ const short* blocks() const { return sl->blocks[m]; }
+  __device__ __forceinline__ int nk() const { return __builtin_amdgcn_readfirstlane(sl->nk[m]); }
+};
+
 constexpr int PAIR_CAP = 512;              // (voxel, triangle) pairs a wave queues in LDS before it tests them
 constexpr int PAIR_DRAIN = 256;            // ... and the fill from which it does (a test round occupies all 64 lanes but the last)
 constexpr int BMASK_WORDS = 64;           // voxel blocks whose relevance is decided up front: 64 x 64 blocks = 262,144 voxels per set
@@ -193,14 +212,16 @@ __device__ __forceinline__ bool wave_test_pairs(const Mesh& mesh, const PairList
 // Which of the 64 voxel blocks bb .. bb+63 can hold a voxel whose cell has a triangle list?  Lane j looks at block bb + j: the box of
 // its keys, mapped into grid coordinates (centre by the affine map, extent by |A|), against the grid's bounds and -- when the box covers
 // at most 3 x 3 x 3 coarse cells -- against the coarse occupancy.  Conservative (1e-3 cells of slack for the two roundings of f).
-__device__ __forceinline__ unsigned long long relevant_blocks(const Grid& g, const PairList* pl, const Voxels& vox, int nblocks, int bb, int lane) {
+template <class VOX>
+__device__ __forceinline__ unsigned long long relevant_blocks(const Grid& g, const PairList* pl, const VOX& vox, int nblocks, int bb, int lane) {
   float A[9], b[3];
   { const float4 q0 = *(const float4*)(pl->Ab), q1 = *(const float4*)(pl->Ab + 4), q2 = *(const float4*)(pl->Ab + 8);
     A[0] = q0.x; A[1] = q0.y; A[2] = q0.z; A[3] = q0.w; A[4] = q1.x; A[5] = q1.y; A[6] = q1.z; A[7] = q1.w; A[8] = q2.x; b[0] = q2.y; b[1] = q2.z; b[2] = q2.w; }
   const int blk = bb + lane;
   bool keep = blk < nblocks;
-  if (keep && vox.blocks) {
-    const short4 lo = ((const short4*)vox.blocks)[2 * blk], hi = ((const short4*)vox.blocks)[2 * blk + 1];
+  const short* vblocks = vox.blocks();
+  if (keep && vblocks) {
+    const short4 lo = ((const short4*)vblocks)[2 * blk], hi = ((const short4*)vblocks)[2 * blk + 1];
     const float cx = 0.5f * ((float)lo.x + (float)hi.x), cy = 0.5f * ((float)lo.y + (float)hi.y), cz = 0.5f * ((float)lo.z + (float)hi.z);
     const float hx = 0.5f * ((float)hi.x - (float)lo.x), hy = 0.5f * ((float)hi.y - (float)lo.y), hz = 0.5f * ((float)hi.z - (float)lo.z);
     int c0[3], c1[3];
@@ -229,10 +250,11 @@ __device__ __forceinline__ unsigned long long relevant_blocks(const Grid& g, con
   return __ballot(keep);
 }
 
-__device__ __forceinline__ bool wave_grid_collide(const Mesh& mesh, const Voxels& vox, float res, PairList* pl, int lane, unsigned* work) {
+template <class VOX>
+__device__ __forceinline__ bool wave_grid_collide(const Mesh& mesh, const VOX& vox, float res, PairList* pl, int lane, unsigned* work) {
   const Grid& g = mesh.grid;
   int fill = 0;
-  const int nblocks = (vox.nk + 63) >> 6;
+  const int nblocks = (vox.nk() + 63) >> 6;
   // which blocks of 64 voxels are worth a visit: decided for the whole set up front (a bit per block, kept in LDS), so that the state of
   // that decision -- block boxes, coarse occupancy -- is not alive in the loop below
   const int nwords = (nblocks + 63) >> 6;
@@ -273,8 +295,8 @@ __device__ __forceinline__ bool wave_grid_collide(const Mesh& mesh, const Voxels
     for (int u = 0; u < 2; ++u) {
       const int v = blk[u] * 64 + lane;
       k[u] = make_short4(0, 0, 0, 0);
-      if (blk[u] >= 0 && v < vox.nk) {
-        k[u] = ((const short4*)vox.keys)[v];
+      if (blk[u] >= 0 && v < vox.nk()) {
+        k[u] = ((const short4*)vox.keys())[v];
         work[0] += 1u;
         const float kx = (float)k[u].x, ky = (float)k[u].y, kz = (float)k[u].z;
         const float fx = fmaf(A[0], kx, fmaf(A[1], ky, fmaf(A[2], kz, b[0])));
@@ -316,8 +338,9 @@ __device__ __forceinline__ bool wave_grid_collide(const Mesh& mesh, const Voxels
 
 // Exhaustive form (no grid, or a pose outside the grid's validity): posed triangles staged in LDS, every voxel against every
 // triangle whose box it touches.
-__device__ bool wave_mesh_voxels_collide(const Mesh& mesh, const float* T, const Voxels& vox, float res, float* tl, int lane) {
-  if (vox.nk == 0 || mesh.nf == 0) return false;
+template <class VOX>
+__device__ bool wave_mesh_voxels_collide(const Mesh& mesh, const float* T, const VOX& vox, float res, float* tl, int lane) {
+  if (vox.nk() == 0 || mesh.nf == 0) return false;
   const float h = 0.5f * res;
   const float slack = 1e-5f;     // conservative culls only; never changes the predicate
   bool hit = false;
@@ -350,11 +373,11 @@ __device__ bool wave_mesh_voxels_collide(const Mesh& mesh, const float* T, const
       lo[r] -= slack; hi[r] += slack;
     }
     wave_lds_sync();
-    for (int v0 = 0; v0 < vox.nk; v0 += 64) {
+    for (int v0 = 0; v0 < vox.nk(); v0 += 64) {
       const int v = v0 + lane;
       bool hv = false;
-      if (v < vox.nk) {
-        const short4 k = ((const short4*)vox.keys)[v];
+      if (v < vox.nk()) {
+        const short4 k = ((const short4*)vox.keys())[v];
         float c[3];
         c[0] = ((float)k.x + 0.5f) * res; c[1] = ((float)k.y + 0.5f) * res; c[2] = ((float)k.z + 0.5f) * res;
         int out = 0;                                   // (selects, not ||: a chain of boolean ORs lives in scalar register pairs)
@@ -424,6 +447,46 @@ __global__ __launch_bounds__(256) void compose_grasp_pose_kernel(ComposeArgs a) 
   a.nudge[e] = (signed char)-1;
 }
 
+// The same for the evaluations of SEVERAL filterGraspPose calls at once (cg_filter_grasp_pose_multi): evaluation e belongs to the segment
+// whose [first, first + n_pose * n_sym) holds it (binary search in the device table), inside it e - first = i * n_sym + j.
+struct ComposeMultiArgs {
+  const cg_filter_segment* segs; int n_segs; long E;
+  int filter_dir;
+  const unsigned char* ik_ok;
+  signed char* codes; float* poses_out; signed char* nudge;
+};
+
+__global__ __launch_bounds__(256) void compose_grasp_pose_multi_kernel(ComposeMultiArgs a) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= a.E) return;
+  int lo = 0, hi = a.n_segs - 1;
+  while (lo < hi) {                                        // the last segment whose first <= e
+    const int mid = (lo + hi + 1) >> 1;
+    if ((long)a.segs[mid].first <= e) lo = mid; else hi = mid - 1;
+  }
+  const cg_filter_segment& sg = a.segs[lo];
+  const long le = e - (long)sg.first;
+  const int i = (int)(le / sg.n_sym), j = (int)(le - (long)i * sg.n_sym);
+  float P[16], S[16], C[16], tmp[16], gic[16];
+#pragma unroll
+  for (int k = 0; k < 16; k += 4) {
+    *(float4*)(P + k) = *(const float4*)(sg.grasp_poses + (size_t)i * 16 + k);
+    *(float4*)(S + k) = *(const float4*)(sg.symmetry_tfs + (size_t)j * 16 + k);
+  }
+#pragma unroll
+  for (int k = 0; k < 16; ++k) C[k] = sg.c2c[k];
+  mat4_mul(S, P, tmp);
+  mat4_mul(C, tmp, gic);
+  normalize_col(gic, 0); normalize_col(gic, 1); normalize_col(gic, 2);
+  int code = 0;
+  if (a.filter_dir && gic[2 * 4 + 0] < 0.0f) code = 1;
+  if (code == 0 && a.ik_ok && a.ik_ok[e] == 0) code = 2;
+#pragma unroll
+  for (int k = 0; k < 16; k += 4) *(float4*)(a.poses_out + e * 16 + k) = *(float4*)(gic + k);
+  a.codes[e] = (signed char)code;
+  a.nudge[e] = (signed char)-1;
+}
+
 // ---- stage 2: collision, one WAVEFRONT per evaluation that is still alive (common.cpp:233-299) -------------------------------
 constexpr signed char CODE_PENDING = -128;    // written by the grid kernel for an evaluation it leaves to the exhaustive kernel
 
@@ -438,6 +501,7 @@ struct FilterArgs {
   int keep_rejected_pose;                     // poses_out of a rejected evaluation: 0 -> zeros, 1 -> its (un-nudged) grasp_in_cam
   int only_pending;                           // exhaustive kernel: evaluate only what the grid kernel marked CODE_PENDING
   unsigned long long* work_stats;             // optional (3): voxel keys read, grid cells looked up, (voxel, triangle) pairs tested
+  const cg_filter_segment* segs; int n_segs;  // MULTI: the device table; `adjust` and `vox` above are per segment then
 };
 
 // GRID: both meshes through their broad-phase grids (an evaluation whose pose a grid does not cover is marked CODE_PENDING);
@@ -462,16 +526,21 @@ __device__ __forceinline__ T karg_load(const __attribute__((address_space(4))) c
 }
 #define CG_KARG(field) karg_load<decltype(FilterArgs::field), (int)offsetof(FilterArgs, field)>(kargs)
 
-template <bool GRID>
+// MULTI (cg_filter_grasp_pose_multi): the evaluations of several calls in one launch -- the voxel sets and the nudge flag of an
+// evaluation come from its segment's row of the device table (wave-uniform: scalar loads where they are used) instead of the kernel
+// arguments; the gripper meshes, the resolution and gripper_in_grasp are the launch's.  Everything else is the same code.
+template <bool GRID, bool MULTI>
 __global__ __launch_bounds__(64 * WAVES, 4) void filter_grasp_pose_kernel(FilterArgs a) {
   const __attribute__((address_space(4))) char* kargs = (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
   __shared__ __attribute__((aligned(16))) char lds_raw[WAVES * (GRID ? sizeof(PairList) : sizeof(float) * TRI_CHUNK * TRI_FLOATS)];   // cast to PairList (alignas 16)
   __shared__ float gig_lds[16];                // gripper_in_grasp: read back (broadcast) where a pose is composed, costs no register between
+  __shared__ SegLds seg_lds[MULTI ? WAVES : 1];   // MULTI: the current segment of every wave (its voxel sets, nudge flag, table row)
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   PairList* pl = (PairList*)lds_raw + wv;
   float* tl = (float*)lds_raw + wv * TRI_CHUNK * TRI_FLOATS;
   if (threadIdx.x < 16) gig_lds[threadIdx.x] = a.gripper_in_grasp.m[threadIdx.x];
+  if (MULTI && lane == 0) seg_lds[wv].sg = -1;
   __syncthreads();
   unsigned work[3] = {0u, 0u, 0u};             // per-lane counts of the grid kernel's memory work (reported only when asked for)
   // One wavefront per evaluation.  (One WORKGROUP per evaluation, its wavefronts dealing the voxel passes among themselves, was
@@ -492,6 +561,23 @@ __global__ __launch_bounds__(64 * WAVES, 4) void filter_grasp_pose_kernel(Filter
     float acc_t[3] = {0.f, 0.f, 0.f};
     bool found = false, stop = false;
     int idx = 0;
+    if constexpr (MULTI) {       // the segment of evaluation e (e only grows: the search resumes at the wave's current row)
+      SegLds* sl = seg_lds + wv;
+      const cg_filter_segment* tab = CG_KARG(segs);
+      const int ns = CG_KARG(n_segs);
+      const int sg0 = __builtin_amdgcn_readfirstlane(sl->sg);
+      int sg = sg0 < 0 ? 0 : sg0;
+      while (sg + 1 < ns && (int)tab[sg + 1].first <= e) ++sg;
+      if (sg != sg0) {
+        wave_lds_sync();
+        if (lane == 0) {
+          const cg_filter_segment& row = tab[sg];
+          sl->keys[0] = row.open_keys; sl->keys[1] = row.bg_keys; sl->blocks[0] = row.open_blocks; sl->blocks[1] = row.bg_blocks;
+          sl->nk[0] = row.n_open_keys; sl->nk[1] = row.n_bg_keys; sl->adjust = row.adjust_collision_pose; sl->sg = sg;
+        }
+        wave_lds_sync();
+      }
+    }
     // common.cpp:255: `for (float step = 0; step <= 0.003; step += 0.001f)` visits 0, 0.001f and 0.001f + 0.001f -- the third
     // addition gives 0.0030000000261 > 0.003 (the comparison is in double) -- so the loop is counted here and `step` takes exactly
     // those three float values (one float compare and one conversion less per trip, both evaluated by the vector unit)
@@ -523,8 +609,8 @@ __global__ __launch_bounds__(64 * WAVES, 4) void filter_grasp_pose_kernel(Filter
 #pragma unroll 1
         for (int m = 0; m < 2 && !hit; ++m) {
           const Mesh& mesh = a.mesh[m];
-          const Voxels& vox = a.vox[m];
-          if (vox.nk == 0 || mesh.nf == 0) continue;
+          VoxView<MULTI> vox = [&]() { if constexpr (MULTI) return VoxView<true>{seg_lds + wv, m}; else return VoxView<false>{a.vox[m]}; }();
+          if (vox.nk() == 0 || mesh.nf == 0) continue;
           if (GRID) {
             float T[12];
 #pragma unroll
@@ -543,7 +629,7 @@ __global__ __launch_bounds__(64 * WAVES, 4) void filter_grasp_pose_kernel(Filter
 #pragma unroll
           for (int r = 0; r < 3; ++r) acc_t[r] = cur_t[r];              // cur differs from grasp_in_cam in its translation only
           found = true; nud = idx;
-        } else if (!CG_KARG(adjust)) {
+        } else if (!(MULTI ? seg_lds[wv].adjust : CG_KARG(adjust))) {
           code = hit; stop = true;
         }
       }
@@ -586,7 +672,7 @@ __global__ __launch_bounds__(64 * WAVES) void mesh_voxels_collide_kernel(Mesh me
     float T[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) T[k] = poses[e * 16 + k];
-    const bool hit = wave_mesh_voxels_collide(mesh, T, vox, res, tl_all[wv], lane);
+    const bool hit = wave_mesh_voxels_collide(mesh, T, VoxView<false>{vox}, res, tl_all[wv], lane);
     if (lane == 0) out[e] = hit ? 1 : 0;
   }
 }
@@ -695,10 +781,84 @@ extern "C" int cg_filter_grasp_pose_accel(const float* grasp_poses, int n_pose, 
     if (a.mesh[m].nf > 0 && a.vox[m].nk > 0 && !a.mesh[m].has_grid) grids = false;
   a.only_pending = 0;
   if (grids) {
-    hipLaunchKernelGGL(filter_grasp_pose_kernel<true>, dim3((unsigned)blocks), dim3(64 * WAVES), 0, st, a);
+    hipLaunchKernelGGL((filter_grasp_pose_kernel<true, false>), dim3((unsigned)blocks), dim3(64 * WAVES), 0, st, a);
     a.only_pending = 1;
   }
-  hipLaunchKernelGGL(filter_grasp_pose_kernel<false>, dim3((unsigned)blocks), dim3(64 * WAVES), 0, st, a);
+  hipLaunchKernelGGL((filter_grasp_pose_kernel<false, false>), dim3((unsigned)blocks), dim3(64 * WAVES), 0, st, a);
+  return cg_hip_status(hipGetLastError());
+}
+
+// ---- several filterGraspPose calls in ONE launch sequence ------------------------------------------------------------------------------
+// A pick cycle filters every object of the scene twice (cone poses; canonical grasps x symmetries) against that object's own voxel
+// sets: 2 x objects calls of a few thousand evaluations each, three launches per call, every one too small to fill 256 CUs.  The
+// segments of all those calls go through the three kernels together.
+extern "C" long cg_filter_segments_prepare(cg_filter_segment* h_segments, int n_segments) {
+  if (n_segments < 0 || (n_segments > 0 && !h_segments)) return CG_ERR_ARG;
+  long E = 0;
+  for (int s = 0; s < n_segments; ++s) {
+    cg_filter_segment& g = h_segments[s];
+    if (g.n_pose < 0 || g.n_sym < 0 || g.n_open_keys < 0 || g.n_bg_keys < 0) return CG_ERR_ARG;
+    const long n = (long)g.n_pose * g.n_sym;
+    if (n > 0 && (!g.grasp_poses || !g.symmetry_tfs)) return CG_ERR_ARG;
+    if ((((uintptr_t)g.grasp_poses | (uintptr_t)g.symmetry_tfs) & 15) != 0) return CG_ERR_ARG;
+    if ((g.n_open_keys > 0 && !g.open_keys) || (g.n_bg_keys > 0 && !g.bg_keys)) return CG_ERR_ARG;
+    host_mat4_mul(g.nocs_pose, g.canonical_to_nocs, g.c2c);
+    g.first = E;
+    E += n;
+    if (E >= (1L << 31) - 64 * 1024) return CG_ERR_ARG;
+  }
+  return E;
+}
+
+extern "C" int cg_filter_grasp_pose_multi(const cg_filter_segment* h_segments, const cg_filter_segment* d_segments, int n_segments,
+                                          const float* h_gripper_in_grasp, int filter_approach_dir_face_camera, const unsigned char* ik_ok,
+                                          const float* gripper_vertices, const int* gripper_faces, int n_gripper_faces,
+                                          const float* enclosed_vertices, const int* enclosed_faces, int n_enclosed_faces,
+                                          float resolution, signed char* codes, float* poses_out, signed char* nudge,
+                                          const cg_mesh_grid* h_open_grid, const cg_mesh_grid* h_enc_grid, int keep_rejected_pose,
+                                          unsigned long long* work_stats, void* stream) {
+  if (n_segments < 0) return CG_ERR_ARG;
+  if (n_segments == 0) return CG_OK;
+  if (!h_segments || !d_segments || !h_gripper_in_grasp || !codes || !poses_out || !nudge) return CG_ERR_ARG;
+  if (n_gripper_faces < 0 || n_enclosed_faces < 0 || !(resolution > 0.f)) return CG_ERR_ARG;
+  if ((n_gripper_faces > 0 && (!gripper_vertices || !gripper_faces)) || (n_enclosed_faces > 0 && (!enclosed_vertices || !enclosed_faces)))
+    return CG_ERR_ARG;
+  if (((uintptr_t)poses_out & 15) != 0) return CG_ERR_ARG;
+  // the table must be a prepared one: firsts consecutive from 0 (cg_filter_segments_prepare wrote them)
+  long E = 0;
+  bool any_open = false, any_bg = false;
+  for (int s = 0; s < n_segments; ++s) {
+    const cg_filter_segment& g = h_segments[s];
+    if (g.n_pose < 0 || g.n_sym < 0 || (long)g.first != E) return CG_ERR_ARG;
+    E += (long)g.n_pose * g.n_sym;
+    any_open |= g.n_open_keys > 0; any_bg |= g.n_bg_keys > 0;
+  }
+  if (E == 0) return CG_OK;
+  if (E >= (1L << 31) - 64 * 1024) return CG_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  ComposeMultiArgs c{d_segments, n_segments, E, filter_approach_dir_face_camera, ik_ok, codes, poses_out, nudge};
+  hipLaunchKernelGGL(compose_grasp_pose_multi_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, st, c);
+  FilterArgs a;
+  a.E = E;
+  a.gripper_in_grasp = load_mat(h_gripper_in_grasp);
+  a.adjust = 0;
+  a.mesh[0] = make_mesh(gripper_vertices, gripper_faces, n_gripper_faces, h_open_grid);
+  a.mesh[1] = make_mesh(enclosed_vertices, enclosed_faces, n_enclosed_faces, h_enc_grid);
+  a.vox[0] = Voxels{nullptr, 0, nullptr}; a.vox[1] = Voxels{nullptr, 0, nullptr};
+  a.res = resolution; a.codes = codes; a.poses_out = poses_out; a.nudge = nudge;
+  a.keep_rejected_pose = keep_rejected_pose; a.work_stats = work_stats;
+  a.segs = d_segments; a.n_segs = n_segments;
+  long blocks = (E + WAVES - 1) / WAVES;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  bool grids = true;
+  if (a.mesh[0].nf > 0 && any_open && !a.mesh[0].has_grid) grids = false;
+  if (a.mesh[1].nf > 0 && any_bg && !a.mesh[1].has_grid) grids = false;
+  a.only_pending = 0;
+  if (grids) {
+    hipLaunchKernelGGL((filter_grasp_pose_kernel<true, true>), dim3((unsigned)blocks), dim3(64 * WAVES), 0, st, a);
+    a.only_pending = 1;
+  }
+  hipLaunchKernelGGL((filter_grasp_pose_kernel<false, true>), dim3((unsigned)blocks), dim3(64 * WAVES), 0, st, a);
   return cg_hip_status(hipGetLastError());
 }
 

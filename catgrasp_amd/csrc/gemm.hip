@@ -30,20 +30,29 @@ struct GemmArgs {
 // accumulator tile `c` (rows row_base ..., column col) is not stored; relu(c + bias) >= 0 is folded into y[group][col] with an integer
 // atomic max on the float bits (y pre-zeroed: the order of non-negative floats is the order of their bit patterns).  A tile inside one
 // group reduces in registers first (one atomic per column); a tile across a group boundary falls back to one atomic per element.
+// fmaxf drops a NaN operand where torch.relu / torch.max keep it: a NaN activation is folded in as the quiet-NaN pattern 0x7fc00000,
+// which as an integer lies above every finite float, so it wins the max and the pooled feature is NaN as in the reference's ops.
+__device__ __forceinline__ int relu_bits_keep_nan(float v) { return v != v ? 0x7fc00000 : __float_as_int(fmaxf(v, 0.f)); }
+
 __device__ __forceinline__ void gemm_fold_groupmax(const GemmArgs& a, const f32x16& c, int row_base, int col, float bias, int lane) {
   const int last = min(row_base + 31, a.M - 1);
   if (row_base >= a.M) return;
   const int g0 = row_base / a.gmax_rows;
   if (last / a.gmax_rows == g0 && row_base + 31 < a.M) {
     float m = max16(c);
-    m = fmaxf(m, __shfl_xor(m, 32));
-    if (lane < 32) atomicMax((int*)(a.y + (size_t)g0 * a.ldy + col), __float_as_int(fmaxf(m + bias, 0.f)));
+    bool nan = false;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) nan |= c[r] != c[r];
+    m = nan ? __int_as_float(0x7fc00000) : m;
+    const float o = __shfl_xor(m, 32);
+    m = (o != o) ? o : (m != m ? m : fmaxf(m, o));
+    if (lane < 32) atomicMax((int*)(a.y + (size_t)g0 * a.ldy + col), relu_bits_keep_nan(m + bias));
     return;
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int row = row_base + acc_row(r, lane);
-    if (row < a.M) atomicMax((int*)(a.y + (size_t)(row / a.gmax_rows) * a.ldy + col), __float_as_int(fmaxf(c[r] + bias, 0.f)));
+    if (row < a.M) atomicMax((int*)(a.y + (size_t)(row / a.gmax_rows) * a.ldy + col), relu_bits_keep_nan(c[r] + bias));
   }
 }
 

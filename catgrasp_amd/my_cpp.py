@@ -357,6 +357,74 @@ class GripperScene:
         self.keys_bg, self.blocks_bg = cloud(gripper_enclosed_collision_pts)
 
 
+class _FilterSegmentC(ctypes.Structure):
+    """cg_filter_segment (include/catgrasp_amd.h)."""
+    _fields_ = [('grasp_poses', ctypes.c_void_p), ('symmetry_tfs', ctypes.c_void_p), ('n_pose', ctypes.c_int), ('n_sym', ctypes.c_int),
+                ('nocs_pose', ctypes.c_float * 16), ('canonical_to_nocs', ctypes.c_float * 16), ('c2c', ctypes.c_float * 16),
+                ('adjust_collision_pose', ctypes.c_int), ('n_open_keys', ctypes.c_int),
+                ('open_keys', ctypes.c_void_p), ('open_blocks', ctypes.c_void_p), ('bg_keys', ctypes.c_void_p), ('bg_blocks', ctypes.c_void_p),
+                ('n_bg_keys', ctypes.c_int), ('reserved', ctypes.c_int), ('first', ctypes.c_longlong)]
+
+
+class FilterPlan:
+    """Several filterGraspPose calls prepared as ONE launch sequence (cg_filter_grasp_pose_multi): the segment table on the host and its
+    device copy.  segments: [(scene, grasp_poses (n,16) f32 cuda, symmetry_tfs (m,16) f32 cuda, nocs_pose 4x4, canonical_to_nocs 4x4,
+    adjust_collision_pose)], all scenes on one device with the SAME gripper meshes and resolution (one gripper per run, as in the
+    reference).  The plan keeps references to the tensors its table points at; build it once for a fixed set of calls (bench step,
+    pick cycle) and run it as often as needed -- run() itself moves no table and synchronises nothing."""
+
+    def __init__(self, segments):
+        if not segments:
+            raise ValueError('FilterPlan needs at least one segment')
+        self.scene0 = sc0 = segments[0][0]
+        self.keep = []
+        tab = (_FilterSegmentC * len(segments))()
+        for r, (scene, gp, st, nocs_pose, c2n, adjust) in zip(tab, segments):
+            if scene.device != sc0.device or scene.res != sc0.res or scene.V is not sc0.V or scene.F is not sc0.F or scene.Ve is not sc0.Ve \
+                    or scene.Fe is not sc0.Fe:
+                raise ValueError('the segments of one FilterPlan must share the gripper meshes, the resolution and the device')
+            for t, name in ((gp, 'grasp_poses'), (st, 'symmetry_tfs')):
+                if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.shape[1] == 16 and t.is_contiguous()):
+                    raise ValueError(f'{name}: a contiguous (n,16) float32 device tensor is expected')
+            self.keep.append((scene, gp, st))
+            r.grasp_poses, r.symmetry_tfs, r.n_pose, r.n_sym = gp.data_ptr(), st.data_ptr(), gp.shape[0], st.shape[0]
+            r.nocs_pose[:] = [float(v) for v in _mat4(nocs_pose, 'nocs_pose').reshape(16)]
+            r.canonical_to_nocs[:] = [float(v) for v in _mat4(c2n, 'canonical_to_nocs_transform').reshape(16)]
+            r.adjust_collision_pose = int(bool(adjust))
+            r.open_keys, r.n_open_keys = scene.keys_open.data_ptr(), scene.keys_open.shape[0]
+            r.bg_keys, r.n_bg_keys = scene.keys_bg.data_ptr(), scene.keys_bg.shape[0]
+            bo, bb = getattr(scene, 'blocks_open', None), getattr(scene, 'blocks_bg', None)
+            r.open_blocks = bo.data_ptr() if bo is not None and r.n_open_keys else None
+            r.bg_blocks = bb.data_ptr() if bb is not None and r.n_bg_keys else None
+        L.lib().cg_filter_segments_prepare.restype = ctypes.c_long
+        E = L.lib().cg_filter_segments_prepare(tab, _c_int(len(segments)))
+        if E < 0:
+            raise L.CatgraspAmdError(f'cg_filter_segments_prepare failed with status {E}')
+        self.E, self.table, self.n = int(E), tab, len(segments)
+        self.firsts = [int(r.first) for r in tab]
+        self.counts = [int(r.n_pose) * int(r.n_sym) for r in tab]
+        # one upload per plan, from page-locked memory so that it is queued behind the stream's work instead of waiting for it
+        self._host = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).pin_memory()
+        self.d_table = self._host.to(sc0.device, non_blocking=True)
+
+    def run(self, gripper_in_grasp, filter_approach_dir_face_camera, keep_rejected_pose=False, work_stats=None, ik_ok=None):
+        """-> codes (E) int8, poses (E,4,4) float32, nudge (E) int8 over the plan's evaluations, segment after segment."""
+        sc, dev = self.scene0, self.scene0.device
+        codes = torch.empty((self.E,), dtype=torch.int8, device=dev)
+        poses = torch.empty((self.E, 16), dtype=torch.float32, device=dev)
+        nudge = torch.empty((self.E,), dtype=torch.int8, device=dev)
+        if self.E == 0:
+            return codes, poses.view(0, 4, 4), nudge
+        go = ctypes.byref(sc.grid_open.c) if sc.grid_open is not None else None
+        ge = ctypes.byref(sc.grid_enc.c) if sc.grid_enc is not None else None
+        check(L.lib().cg_filter_grasp_pose_multi(self.table, _p(self.d_table), _c_int(self.n), _h16(_mat4(gripper_in_grasp, 'gripper_in_grasp')),
+                                                 _c_int(int(bool(filter_approach_dir_face_camera))), _p(ik_ok),
+                                                 _p(sc.V), _p(sc.F), _c_int(sc.F.shape[0]), _p(sc.Ve), _p(sc.Fe), _c_int(sc.Fe.shape[0]),
+                                                 ctypes.c_float(sc.res), _p(codes), _p(poses), _p(nudge), go, ge, _c_int(int(bool(keep_rejected_pose))),
+                                                 _p(work_stats), _stream()), 'cg_filter_grasp_pose_multi')
+        return codes, poses.view(self.E, 4, 4), nudge
+
+
 def filter_on_device(scene, grasp_poses, symmetry_tfs, nocs_pose, canonical_to_nocs_transform, cam_in_world, ee_in_grasp,
                      gripper_in_grasp, filter_approach_dir_face_camera, filter_ik, adjust_collision_pose, upper=None, lower=None,
                      keep_rejected_pose=False, work_stats=None):

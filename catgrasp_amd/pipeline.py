@@ -110,16 +110,30 @@ def evaluate_object(ob_pts, ob_normals, scene_pts, K, gripper, grasp_predicter, 
     sym1 = torch.eye(4, device=dev).reshape(1, 16)
     ee_in_grasp = I4 if ik is None else np.asarray(ik['ee_in_grasp'])
     ik_kw = {} if ik is None else dict(upper=list(ik['upper']), lower=list(ik['lower']))
-    codes, poses, _ = my_cpp.filter_on_device(scene, cone.float().reshape(-1, 16), sym1, I4, I4, cam_in_world, ee_in_grasp,
-                                              gripper['gripper_in_grasp'], True, ik is not None, True, **ik_kw)
-    keep = codes == 0
-    surv = [poses[keep]]
-    n_evaluated = int(codes.numel())
-    if canonical is not None and nocs_pose is not None and len(canonical.get('grasps', [])):
-        sym = symmetry_tfs if symmetry_tfs is not None else [np.eye(4)]
-        c2, p2, _ = my_cpp.filter_on_device(scene, np.asarray(canonical['grasps']), np.asarray(sym), nocs_pose, I4, cam_in_world, ee_in_grasp,
-                                            gripper['gripper_in_grasp'], True, ik is not None, True, **ik_kw)
-        surv.append(p2[c2 == 0]); n_evaluated += int(c2.numel())
+    with_canonical = canonical is not None and nocs_pose is not None and len(canonical.get('grasps', []))
+    sym = symmetry_tfs if symmetry_tfs is not None else [np.eye(4)]
+    cone16 = cone.float().reshape(-1, 16).contiguous()
+    if ik is None and cone16.shape[0] > 0:
+        # both call shapes of the object (grasp_sampler.py:216: cone poses, symmetry [I]; :345: canonical grasps x symmetries under the
+        # NUNOCS pose) as ONE launch sequence: each is a few thousand evaluations, a fraction of what fills the chip
+        rows = [(scene, cone16, sym1, I4, I4, True)]
+        if with_canonical:
+            f16 = lambda a: torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=np.float64), dtype=np.float32).reshape(-1, 16)).to(dev)
+            rows.append((scene, f16(canonical['grasps']), f16(sym), nocs_pose, I4, True))
+        plan = my_cpp.FilterPlan(rows)
+        codes, poses, _ = plan.run(gripper['gripper_in_grasp'], True)
+        surv = [poses[codes == 0]]
+        n_evaluated = plan.E
+    else:               # with the IK stage (its pre-pass computes ee_in_base per call) the calls stay separate
+        codes, poses, _ = my_cpp.filter_on_device(scene, cone16, sym1, I4, I4, cam_in_world, ee_in_grasp,
+                                                  gripper['gripper_in_grasp'], True, ik is not None, True, **ik_kw)
+        keep = codes == 0
+        surv = [poses[keep]]
+        n_evaluated = int(codes.numel())
+        if with_canonical:
+            c2, p2, _ = my_cpp.filter_on_device(scene, np.asarray(canonical['grasps']), np.asarray(sym), nocs_pose, I4, cam_in_world, ee_in_grasp,
+                                                gripper['gripper_in_grasp'], True, ik is not None, True, **ik_kw)
+            surv.append(p2[c2 == 0]); n_evaluated += int(c2.numel())
     surv = torch.cat(surv).contiguous()
     lap('filterGraspPose', t0)
     n = surv.shape[0]

@@ -45,13 +45,15 @@ import os as _os
 VALIDATE_INPUTS = _os.environ.get('CATGRASP_AMD_VALIDATE_INPUTS', '1') != '0'
 
 
-def _use_hip(module, x):
+def _use_hip(module, x, validated=False):
+    """validated: the caller (a stack) has already checked this tensor's source for NaN / Inf -- the check is a host synchronisation, and a
+    level's coordinates are copies of input coordinates that passed it."""
     if module.training or torch.is_grad_enabled():
         return False
     if not x.is_cuda:
         raise RuntimeError('catgrasp_amd.pointnet2: eval-mode inference needs a CUDA/HIP tensor '
                            '(the HIP kernels are the only inference path; there is no CPU fallback)')
-    if VALIDATE_INPUTS and not bool(torch.isfinite(x).all()):
+    if VALIDATE_INPUTS and not validated and not bool(torch.isfinite(x).all()):
         raise ValueError('catgrasp_amd.pointnet2: the input contains NaN or Inf')
     return True
 
@@ -266,13 +268,14 @@ class PointNetSetAbstraction(nn.Module):
         return _cached_weights(self, device, lambda sd, dev: _prim.SetAbstractionWeights(_sa_layers_from_state(sd, 'mlp_', n), self.in_channel,
                                                                                           dev, kind=kind))
 
-    def forward(self, xyz, points, start=None, _err=None, _rows=None, _new_xyz=None):
+    def forward(self, xyz, points, start=None, _err=None, _rows=None, _new_xyz=None, _validated=False):
         """_new_xyz (stack-internal): the level's sampled points when the stack has already run its farthest-point sampling (on a side stream).
         _err: a pre-zeroed (1,) int32 device flag shared by the levels of a stack (one read-back for the stack instead of one per layer).
         _rows (stack-internal): for a sampling level, a (B, S, roundup8(C + 3)) buffer to produce the output in -- features in
         [..., :C] (the returned new_points is that view), the level's new_xyz ++ zeros behind them, i.e. the input rows of a following
-        group-all level; for the group-all level, that buffer."""
-        if _use_hip(self, xyz):
+        group-all level; for the group-all level, that buffer.
+        _validated (stack-internal): the stack has checked its input for NaN / Inf once (no further host synchronisation per level)."""
+        if _use_hip(self, xyz, _validated):
             W = self._weights(xyz.device)
             if self.group_all:
                 B = xyz.shape[0]
@@ -329,8 +332,8 @@ class PointNetSetAbstractionMsg(nn.Module):
             self.conv_blocks.append(convs); self.bn_blocks.append(bns)
         self.out_channel = sum(m[-1] for m in mlp_list)
 
-    def forward(self, xyz, points, start=None, _err=None, _rows=None, _new_xyz=None):
-        if _use_hip(self, xyz):
+    def forward(self, xyz, points, start=None, _err=None, _rows=None, _new_xyz=None, _validated=False):
+        if _use_hip(self, xyz, _validated):
             def prep(sd, dev):
                 out = []
                 for i, convs in enumerate(self.conv_blocks):
@@ -457,9 +460,11 @@ class PointNet2Encoder(nn.Module):
         xyz = x[:, :, :3].contiguous()
         feats = x[:, :, 3:].contiguous() if C > 3 else None
         s1, s2 = (None, None) if start is None else start
-        hip = _use_hip(self, x)
+        # the fused stack needs EVERY level in eval mode: a level left in train mode (partial fine-tuning) takes its torch branch, which
+        # ignores the stack-internal arguments -- then each level decides for itself below
+        hip = not any(m.training for m in (self.sa1, self.sa2, self.sa3)) and _use_hip(self, x)
         err = torch.zeros((1,), dtype=torch.int32, device=x.device) if hip else None
-        kw = {'_err': err} if hip else {}
+        kw = {'_err': err, '_validated': True} if hip else {}       # x was checked once, above: no stream drain between the levels
         rows = None
         if hip:
             # Level 2's sampling chain needs level 1's sampled POINTS only, not its features: from SIDE_STREAM_MIN_CLOUDS clouds on it runs on
@@ -490,7 +495,7 @@ class PointNet2Encoder(nn.Module):
         else:
             l1_xyz, l1_points = self.sa1(xyz, feats, start=s1)
             l2_xyz, l2_points = self.sa2(l1_xyz, l1_points, start=s2)
-        _, l3_points = self.sa3(l2_xyz, l2_points, **({'_rows': rows} if rows is not None else {}))
+        _, l3_points = self.sa3(l2_xyz, l2_points, **({'_rows': rows, '_validated': True} if rows is not None else {}))
         if hip:
             _prim._raise_if(err, 'PointNet2Encoder (a query ball was empty or an index is out of range)')
         return l3_points.reshape(B, -1), [(l1_xyz, l1_points), (l2_xyz, l2_points)]

@@ -496,7 +496,8 @@ class NunocsPredicter:
             ids = rows.draw(1)
             heads = transforms.NumpyHeadsDraw(n_pts, 4, len(self.RANSAC_THRESHOLDS) * self.RANSAC_MAX_ITER, state=rows.state())
             h = heads.result(set_state=False)
-            return {'start_state': st0, 'n_valid': int(n_valid), 'ids': ids, 'heads': h, 'end_state': heads.state(), 'seconds': time.perf_counter() - t0}
+            return {'start_state': st0, 'n_valid': int(n_valid), 'ids': ids, 'after_ids_state': rows.state(), 'heads': h, 'end_state': heads.state(),
+                    'seconds': time.perf_counter() - t0}
         return pool.submit(run)
 
     def predict(self, data, ids=None, predrawn=None):
@@ -521,9 +522,13 @@ class NunocsPredicter:
         self._after_draw = start_hypothesis_draw          # one-shot hook of predict_nocs (an overridden predict_nocs simply never calls it)
         try:
             nocs_cloud, _, dt = self.predict_nocs(data, ids)
-        except BaseException:
+        except BaseException as e:
             for d in draw:
                 d.cancel()                     # the reference would not have reached its hypothesis draws either
+            if predrawn is not None and isinstance(e, (FloatingPointError, IndexError)):
+                # raised after the transform's resampling draw: the serial path has consumed that one row by now (draw_ids_reference in
+                # predict_nocs), so the generator is left there whether or not the draws were made ahead
+                np.random.set_state(predrawn['after_ids_state'])
             raise
         finally:
             self._after_draw = None

@@ -116,6 +116,10 @@ class SceneBatch:
     path over global evaluations [lo, hi): NUNOCS net over the slice's objects -> filterGraspPose (both call shapes) -> device
     pose inversion + resampling draw + grasp-Q net -> packed (p_G, code) records."""
 
+    # 'multi': the filter calls of a slice as ONE launch sequence (run_filter_many); 'per_segment': one filterGraspPose call per (object,
+    # call shape) on the objects' side streams -- the round-5 form, kept for the equality test (tests/test_workload_gpu.py)
+    filter_launch = 'multi'
+
     def __init__(self, device, grasp_predicter, nunocs_predicter, kind='nut', n_objects=8, pts_per_object=2500, per_replica=50000,
                  replicas=1, scene_seed=0, nocs_scale=0.02, materialize=None, gripper_subdivisions=0):
         # materialize: (lo, hi) global evaluation range whose candidate poses are generated up front (default: all)
@@ -159,6 +163,7 @@ class SceneBatch:
         self.nunocs_ids = torch.stack([transforms.draw_ids_device(c.n, n_n, 1, device, gen, base=o)[0]
                                        for c, o in zip(self.clouds, self.offsets)]).contiguous()
         self._poses = {}
+        self._plans = {}
         self._streams = [torch.cuda.Stream(device=device) for _ in range(n_objects)]
         self.draw_seed = 0x5eed
         lo, hi = (0, self.n_total) if materialize is None else materialize        # a rank only builds the segments it will evaluate
@@ -201,6 +206,25 @@ class SceneBatch:
                                                   g['gripper_in_grasp'], True, False, seg.adjust, keep_rejected_pose=True)
         return codes, poses.view(-1, 16)
 
+    def run_filter_many(self, key, rects):
+        """Device stage: the filter over the rectangles [(segment, i0, i1, j0, j1)] as ONE launch sequence (my_cpp.FilterPlan /
+        cg_filter_grasp_pose_multi) -> codes (E) int8, grasp_in_cam (E,16) f32 in rectangle order.  The segment table of `key` (a slice)
+        is built and uploaded once and reused by every later step over the same slice."""
+        from . import my_cpp
+        plan = self._plans.get(key)
+        if plan is None:
+            I4 = np.eye(4, dtype=np.float32)
+            rows = []
+            for s, i0, i1, j0, j1 in rects:
+                if s.kind == 'nocs':
+                    sym, nocs = self.syms[self.cats[s.obj]][j0:j1], self.nocs_pose[s.obj]
+                else:
+                    sym, nocs = self.eye, I4
+                rows.append((self.scenes[s.obj], self.segment_poses(s)[i0:i1], sym, nocs, I4, s.adjust))
+            plan = self._plans[key] = my_cpp.FilterPlan(rows)
+        codes, poses, _ = plan.run(self.gripper['gripper_in_grasp'], True, keep_rejected_pose=True)
+        return codes, poses.view(-1, 16)
+
     def run_prep(self, obj, poses, row_offset, pinv_out, ids_out):
         """grasp_in_cam (E,16) of one object -> rows of the scoring inputs: device pose inversion (re-expressed for the object's
         centred cloud) and the per-candidate resampling draw of GraspDataset.transform, keyed by the GLOBAL evaluation index."""
@@ -234,20 +258,23 @@ class SceneBatch:
         if on_gpu:
             main = torch.cuda.current_stream()
             fork = torch.cuda.Event(); fork.record(main)
-        codes, poses = [], []
-        for s, a, b in parts:
-            st = self._streams[s.obj] if on_gpu else None
-            with (torch.cuda.stream(st) if on_gpu else contextlib.nullcontext()):
-                if on_gpu:
-                    st.wait_event(fork)
-                for i0, i1, j0, j1 in split_eval_range(s.n_sym, a, b):
-                    c, p = self.run_filter(s, i0, i1, j0, j1)
-                    codes.append(c); poses.append(p)
-        if on_gpu:
-            for st in {self._streams[s.obj] for s, _, _ in parts}:
-                main.wait_stream(st)
-        codes = torch.cat(codes)
-        poses = torch.cat(poses)
+        if self.filter_launch == 'multi':
+            codes, poses = self.run_filter_many((lo, hi), [(s, *r) for s, a, b in parts for r in split_eval_range(s.n_sym, a, b)])
+        else:
+            codes, poses = [], []
+            for s, a, b in parts:
+                st = self._streams[s.obj] if on_gpu else None
+                with (torch.cuda.stream(st) if on_gpu else contextlib.nullcontext()):
+                    if on_gpu:
+                        st.wait_event(fork)
+                    for i0, i1, j0, j1 in split_eval_range(s.n_sym, a, b):
+                        c, p = self.run_filter(s, i0, i1, j0, j1)
+                        codes.append(c); poses.append(p)
+            if on_gpu:
+                for st in {self._streams[s.obj] for s, _, _ in parts}:
+                    main.wait_stream(st)
+            codes = torch.cat(codes)
+            poses = torch.cat(poses)
         # scoring inputs: one prep per run of consecutive evaluations of the same object (the pose inverse is per object cloud)
         runs = []
         for s, a, b in parts:

@@ -250,6 +250,45 @@ int cg_filter_grasp_pose_accel(const float* grasp_poses, int n_pose, const float
                                int keep_rejected_pose, unsigned long long* work_stats, const short* open_blocks, const short* bg_blocks,
                                void* stream);
 
+/* Several filterGraspPose calls as ONE launch sequence.  A pick cycle filters every object of a scene twice -- the cone sampler's poses
+ * with symmetry_tfs = [I] (dexnet/grasping/grasp_sampler.py:216) and the canonical grasps x the category's symmetries with
+ * adjust_collision_pose = True (:345) -- each against that object's own two voxel sets (run_grasp_simulation.py:131-141): a dozen or more
+ * calls of a few thousand evaluations, three launches per call, none of which fills 256 CUs.  A SEGMENT is one such call's
+ * (grasp_poses x symmetry_tfs) block with its own nocs_pose / canonical_to_nocs, adjust flag and voxel sets; the gripper meshes, their
+ * grids, gripper_in_grasp, the resolution and the approach-direction flag are common to the launch (they are in the reference too:
+ * one gripper per run).  Evaluations are numbered segment after segment, e = first + i * n_sym + j; codes / poses_out / nudge
+ * (and ik_ok) are indexed by that e.  Every evaluation's result is bit-identical to its own cg_filter_grasp_pose_accel call.
+ *   cg_filter_segments_prepare (HOST, no device work): validates the table, composes c2c = nocs_pose . canonical_to_nocs with the
+ *     float32 operation order of the single-call path, writes `first`; returns the total number of evaluations or a negative cg error.
+ *   cg_filter_grasp_pose_multi: h_segments = the prepared HOST table, d_segments = a DEVICE copy of those same n_segments rows (the
+ *     caller uploads it however it likes -- a cached upload costs nothing per call -- and keeps it alive until the stream has passed
+ *     the call).  No pre-IK stage here (ee_in_base): a caller that filters by IK runs that stage per segment and passes ik_ok. */
+typedef struct cg_filter_segment {
+  const float* grasp_poses;        /* device (n_pose,16), 16-byte aligned */
+  const float* symmetry_tfs;       /* device (n_sym,16), 16-byte aligned */
+  int n_pose, n_sym;
+  float nocs_pose[16];             /* row-major 4x4 */
+  float canonical_to_nocs[16];
+  float c2c[16];                   /* written by cg_filter_segments_prepare */
+  int adjust_collision_pose;
+  int n_open_keys;
+  const short* open_keys;          /* device: this segment's voxelised gripper_collision_pts (cg_voxel_keys -> cg_unpack_voxel_keys) */
+  const short* open_blocks;        /* device, optional: key box of every run of 64 keys (see cg_filter_grasp_pose_accel) */
+  const short* bg_keys;            /* device: voxelised gripper_enclosed_collision_pts */
+  const short* bg_blocks;
+  int n_bg_keys;
+  int reserved;
+  long long first;                 /* written by cg_filter_segments_prepare: index of the segment's first evaluation */
+} cg_filter_segment;
+long cg_filter_segments_prepare(cg_filter_segment* h_segments, int n_segments);
+int cg_filter_grasp_pose_multi(const cg_filter_segment* h_segments, const cg_filter_segment* d_segments, int n_segments,
+                               const float* h_gripper_in_grasp, int filter_approach_dir_face_camera, const unsigned char* ik_ok,
+                               const float* gripper_vertices, const int* gripper_faces, int n_gripper_faces,
+                               const float* enclosed_vertices, const int* enclosed_faces, int n_enclosed_faces,
+                               float resolution, signed char* codes, float* poses_out, signed char* nudge,
+                               const cg_mesh_grid* h_open_grid, const cg_mesh_grid* h_enc_grid, int keep_rejected_pose,
+                               unsigned long long* work_stats, void* stream);
+
 /* Device build of cg_mesh_grid (replaces a per-triangle host loop): triangle t is listed in every cell its bounding box,
  * inflated by `inflate`, overlaps (float64 cell arithmetic).  h_origin[3], h_dims[3]: HOST.  Two passes around a host-side
  * exclusive prefix sum: cg_mesh_grid_count adds into counts (prod(dims), pre-zeroed); cg_mesh_grid_fill writes tri_ids
@@ -528,7 +567,8 @@ int cg_sa_tile_mlp_max(const float* xyz, const float* points, const float* new_x
                        const float* const* h_bias, float* out, long out_bs, long out_ss, long out_cs, int append_xyz, int* err_flag,
                        void* stream);
 
-/* Input matrix of the group-all layer when it runs as a GEMM chain (few rows: cg_gemm_bias_act per layer + cg_group_max): rows of
+/* Input matrix of the group-all layer when it runs as a GEMM chain (few rows: cg_gemm_bias_act per hidden layer, then
+ * cg_gemm_bias_relu_groupmax -- the last layer with the max over the points in its epilogue): rows of
  * [D features | xyz | zero pad to ld], the column order of cg_sa_tile_mlp_max's layer 0.  xyz (rows,3), points (rows,D) or NULL
  * -> out (rows, ld), ld >= D + 3.  (sample_and_group_all's cat([grouped_xyz, points]), pointnet2.py:145-148.) */
 int cg_sa_concat_input(const float* xyz, const float* points, long rows, int D, int ld, float* out, void* stream);
@@ -536,7 +576,10 @@ int cg_sa_concat_input(const float* xyz, const float* points, long rows, int D, 
 /* Last layer of the group-all level with its max over the points in the epilogue: out[g][n] = max over the rows_per_group rows of
  * group g of relu(X[M,K] . W^T + bias) -- sample_and_group_all + Conv2d/BN/ReLU + torch.max(.., 2) (pointnet2.py:132-149) without
  * writing the (M, N) activation.  out (M / rows_per_group, N) is zeroed by the call (stream-ordered), then folded into with an
- * integer atomic max on the non-negative float bits.  Same kernels, operands and argument rules as cg_gemm_bias_act. */
+ * integer atomic max on the non-negative float bits.  That ordering is the float ordering ONLY because the ReLU is always applied
+ * (every folded value is >= +0) and out starts at zero; a NaN activation (bits >= 0x7fc00000 as an integer) wins the max, i.e. NaN
+ * propagates to the pooled feature like torch.max does (tests/test_pointnet2_encoder_gpu.py::test_group_all_gemm_epilogue_max...).
+ * Same kernels, operands and argument rules as cg_gemm_bias_act. */
 int cg_gemm_bias_relu_groupmax(const float* x, int M, int K, int ldx, const float* w_packed, int N, const float* bias,
                                int rows_per_group, float* out, void* stream);
 

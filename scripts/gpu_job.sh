@@ -24,10 +24,10 @@ case $JOB in
     head -12 $O/pp_encoder_kernel_stats.csv | cut -c1-160 ;;
   bench)      # the default bench line + its kernel statistics
     ( time timeout 900 python bench.py "$@" ) > $O/bench.json 2> $O/bench.err; tail -c 300 $O/bench.err; head -c 600 $O/bench.json
-    stats bench python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-api --no-pmc-traffic --no-rccl-selftest --no-projection ;;
+    stats bench python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-api --no-pmc-traffic --no-rccl-selftest --no-projection --no-configs ;;
   pick)       # the pick cycle block of the bench alone (api.pick_cycle) + the tests of the pipeline
     timeout 600 python -m pytest tests/test_pipeline_gpu.py tests/test_collision_gpu.py tests/test_dataparallel_gpu.py tests/test_pointnet2_encoder_gpu.py -m gpu -x -q > $O/pytest.log 2>&1; tail -8 $O/pytest.log
-    timeout 600 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pmc-traffic --no-rccl-selftest --no-projection --secondary "" > $O/bench.json 2> $O/bench.err; tail -c 300 $O/bench.err
+    timeout 600 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pmc-traffic --no-rccl-selftest --no-projection --no-configs --secondary "" > $O/bench.json 2> $O/bench.err; tail -c 300 $O/bench.err
     python -c "import json;d=json.load(open('$O/bench.json'));print(json.dumps(d['api']['pick_cycle'],indent=1))" | head -80 ;;
   small)      # small-call latency with / without the channel split + the tests that pin its bits + the multi-rank dev runs
     timeout 900 python -m pytest tests/test_pointnet_gpu.py tests/test_pointnet_blocks_gpu.py tests/test_predicter_gpu.py -m gpu -x -q > $O/pytest.log 2>&1; tail -5 $O/pytest.log
@@ -55,6 +55,14 @@ case $JOB in
     timeout 2400 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; tail -5 $O/pytest.log
     timeout 120 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
     ( time timeout 900 python bench.py ) > $O/bench_default_flags.json 2> $O/bench.err; tail -c 300 $O/bench.err; head -c 500 $O/bench_default_flags.json ;;
+  r6a)        # round 6, first contact: stricter encoder tests, refactored bench (multirank + the default line with `configs`)
+    timeout 1200 python -m pytest tests/test_pointnet2_encoder_gpu.py tests/test_primitives_gpu.py tests/test_bench_multirank_gpu.py -m gpu -q > $O/pytest.log 2>&1; tail -25 $O/pytest.log
+    ( time timeout 900 python bench.py ) > $O/bench_default_flags.json 2> $O/bench.err; tail -c 600 $O/bench.err
+    python -c "import json;d=json.load(open('$O/bench_default_flags.json'));print(json.dumps(d['timing_s'],indent=1));print(json.dumps({k:{kk:v.get(kk) for kk in ("value","ms_per_step","wall_s","error")} for k,v in d['configs'].items()}));print(d['value'],d['ms_per_step'])" ;;
+  r6b)        # round 6: the one-launch filter (FilterPlan) -- parity tests, the step, the default line
+    timeout 1500 python -m pytest tests/test_collision_gpu.py tests/test_workload_gpu.py tests/test_pipeline_gpu.py tests/test_fullsize_properties_gpu.py tests/test_bench_multirank_gpu.py -m gpu -q -x > $O/pytest.log 2>&1; tail -15 $O/pytest.log
+    ( time timeout 900 python bench.py ) > $O/bench_default_flags.json 2> $O/bench.err; tail -c 400 $O/bench.err
+    python -c "import json;d=json.load(open('$O/bench_default_flags.json'));print(json.dumps(d['timing_s'],indent=1));print(json.dumps({k:{kk:v.get(kk) for kk in ('value','ms_per_step','wall_s','error')} for k,v in d['configs'].items()}));print(d['value'],d['ms_per_step']);print(json.dumps({k:v for k,v in d['roofline_filter'].items() if k not in ('note','cache_level')}));print(json.dumps(d['api']['pick_cycle']['default']))" ;;
   py)         # any script:  py scripts/x.py args...
     timeout 1200 python "$@" > $O/out.txt 2>&1; tail -40 $O/out.txt ;;
   *) echo "unknown job $JOB"; exit 2 ;;

@@ -14,7 +14,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 COMMON = ['--steps', '1', '--warmup', '1', '--candidates', '6000', '--secondary', '', '--no-cpu-baseline', '--no-api', '--no-pmc-traffic',
-          '--no-rccl-selftest', '--no-projection']
+          '--no-rccl-selftest', '--no-projection', '--no-configs']
 
 
 def _free_port():
@@ -55,7 +55,7 @@ def test_8_rank_job_of_the_8_gpu_configurations_equals_the_1_rank_job(cuda_devic
     are those of the 1-rank job."""
     env = dict(os.environ, CATGRASP_BENCH_BACKEND='gloo', CATGRASP_BENCH_DEVICE='0', HSA_ENABLE_IPC_MODE_LEGACY='0', OMP_NUM_THREADS='4')
     common = ['--workload', workload, '--candidates-total', '4800', '--steps', '1', '--warmup', '1', '--secondary', '', '--no-cpu-baseline', '--no-api',
-              '--no-pmc-traffic', '--no-rccl-selftest', '--no-projection']
+              '--no-pmc-traffic', '--no-rccl-selftest', '--no-projection', '--no-configs']
     one = _run([sys.executable, 'bench.py', '--gpus', '1'] + common, env)
     eight = _run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '8', '--master-addr', '127.0.0.1',
                   '--master-port', str(_free_port()), 'bench.py', '--gpus', '8'] + common, env)

@@ -668,7 +668,8 @@ def test_hot_kernels_stay_out_of_scratch():
     # pointers) is laid out so that nothing is spilled to VGPR lanes (round 3: 364 spilled SGPRs in filter_grasp_pose_kernel)
     rows = kr.resources(os.path.join(root, 'catgrasp_amd', 'csrc', 'collision.o'))
     names = [r['kernel'] for r in rows]
-    assert any('filter_grasp_pose_kernel<true>' in n for n in names) and any('compose_grasp_pose_kernel' in n for n in names)
+    assert all(any(f'filter_grasp_pose_kernel<{g}, {m}>' in n for n in names) for g in ('true', 'false') for m in ('true', 'false'))
+    assert any('compose_grasp_pose_kernel' in n for n in names) and any('compose_grasp_pose_multi_kernel' in n for n in names)
     for r in rows:
         assert r['sgpr_spill_count'] == 0 and r['vgpr_spill_count'] == 0 and r['private_segment_fixed_size'] == 0, r
 

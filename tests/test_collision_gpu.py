@@ -458,3 +458,53 @@ def test_device_narrow_phase_equals_the_exact_clipping_oracle(cuda_device):
             n_hit += want; n_total += 1
             n_touch += want and not tx.tri_box_intersect(centre, res / 2 * (1 - 2.0 ** -10), a, b, d, exact=True)
     assert 500 < n_hit < n_total - 500 and n_touch > 100, (n_hit, n_total, n_touch)
+
+
+def test_filter_plan_of_several_calls_equals_the_calls_and_the_oracle(cuda_device):
+    """cg_filter_grasp_pose_multi (my_cpp.FilterPlan): the filter calls of several objects -- both call shapes, different symmetry sets,
+    nocs poses, nudge flags and voxel sets, an empty segment, an object without background, partial symmetry ranges -- as ONE launch
+    sequence: every evaluation's code / nudge / pose is bit-identical to its own filter_on_device call, and (for two of the segments)
+    to the C oracle."""
+    from catgrasp_amd import my_cpp, transforms, workload
+    objs, g, _ = _scene(4, n_obj=5, pts=1800)
+    dev = cuda_device
+    rng = np.random.default_rng(8)
+    f32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32).reshape(-1, 16)).to(dev)
+    scenes, bgs = [], []
+    for k, ob in enumerate(objs):
+        bg = synth.background_points(objs, k, g['diameter']) if k != 3 else np.ones((1, 3)) * 99999      # object 3: the sentinel cloud
+        bgs.append(bg)
+        scenes.append(my_cpp.GripperScene(g['vertices'], g['faces'], g['enclosed_vertices'], g['enclosed_faces'], ob['xyz'], bg, 0.0005, dev))
+    eye = f32(np.eye(4)[None])
+    rows, host = [], []
+    for k, ob in enumerate(objs):
+        cat = ('nut', 'hnm', 'screw')[k % 3]
+        sym = np.stack(transforms.get_symmetry_tfs(cat))
+        nocs = workload.scene_nocs_pose(ob)
+        can = np.linalg.inv(nocs) @ synth.make_candidates(ob, 40 + 7 * k, rng, g['hand_depth'], g['init_bite'])
+        cone = synth.make_candidates(ob, 150 + 31 * k, rng, g['hand_depth'], g['init_bite'])
+        j0, j1 = (0, len(sym)) if k != 2 else (5, 61)                # a partial symmetry range, as a shard boundary produces
+        rows.append((scenes[k], f32(can), f32(sym[j0:j1]), nocs, I4, True)); host.append((k, can, sym[j0:j1], nocs, True))
+        rows.append((scenes[k], f32(cone), eye, I4, I4, k % 2 == 1)); host.append((k, cone, np.eye(4)[None], I4, k % 2 == 1))
+        if k == 1:
+            rows.append((scenes[k], f32(np.zeros((0, 4, 4))), eye, I4, I4, False)); host.append((k, np.zeros((0, 4, 4)), np.eye(4)[None], I4, False))
+    plan = my_cpp.FilterPlan(rows)
+    assert plan.E == sum(len(P) * len(S) for _, P, S, _, _ in host)
+    for keep in (True, False):
+        codes, poses, nudge = plan.run(g['gripper_in_grasp'], True, keep_rejected_pose=keep)
+        for (k, P, S, nocs, adj), first, count in zip(host, plan.firsts, plan.counts):
+            c1, p1, n1 = my_cpp.filter_on_device(scenes[k], f32(P), f32(S), nocs, I4, I4, I4, g['gripper_in_grasp'], True, False, adj, keep_rejected_pose=keep)
+            sl = slice(first, first + count)
+            assert torch.equal(codes[sl], c1) and torch.equal(nudge[sl], n1) and torch.equal(poses[sl].view(torch.int32), p1.view(torch.int32))
+    assert len(set(codes.cpu().tolist())) >= 3                        # keeps, direction rejects and collisions all occur
+    # two segments against the C oracle directly (keep_rejected_pose=False: rejected poses are zeros, as the oracle returns them)
+    for q in (0, 3):
+        k, P, S, nocs, adj = host[q]
+        ora = _oracle(P, list(S), nocs, g, objs[k]['xyz'], bgs[k], 1, int(adj))
+        sl = slice(plan.firsts[q], plan.firsts[q] + plan.counts[q])
+        _check((codes[sl].cpu().numpy(), poses[sl].cpu().numpy(), nudge[sl].cpu().numpy()), ora)
+    # a plan must not mix grippers
+    other = synth.make_gripper(subdivisions=1)
+    sc2 = my_cpp.GripperScene(other['vertices'], other['faces'], other['enclosed_vertices'], other['enclosed_faces'], objs[0]['xyz'], bgs[0], 0.0005, dev)
+    with pytest.raises(ValueError):
+        my_cpp.FilterPlan([rows[0], (sc2,) + rows[1][1:]])

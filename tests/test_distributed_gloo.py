@@ -43,6 +43,10 @@ class HostBatch(workload.SceneBatch):
         poses = (e.view(-1, 1) * 16 + torch.arange(16).view(1, -1)).float() * (1.0 if seg.adjust else -1.0)
         return codes, poses
 
+    def run_filter_many(self, key, rects):
+        out = [self.run_filter(*r) for r in rects]
+        return torch.cat([c for c, _ in out]), torch.cat([p for _, p in out])
+
     def alloc(self, n):
         return torch.empty((n, 12)), torch.empty((n, 5), dtype=torch.int32)
 

@@ -96,6 +96,29 @@ def _encoder_golden():
     return g, sd, x, tuple(starts)
 
 
+def _encoder_golden_20k():
+    """-> (golden file, the default-size encoder with the golden's seeded weights [sha256-pinned], x (1,20000,6), FPS starts)."""
+    import hashlib
+    import os
+    import numpy as np
+    from catgrasp_amd import pointnet2 as p2
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'pp_encoder_20k_golden.npz'))
+    torch.manual_seed(15)                                  # make_golden_encoder.py: WEIGHT_SEED_20K / BN_SEED_20K
+    enc = p2.PointNet2Encoder(channel=6)
+    _bn(enc, 16)
+    enc.eval()
+    h = hashlib.sha256()
+    for k, v in enc.state_dict().items():
+        h.update(k.encode()); h.update(v.numpy().tobytes())
+    assert h.hexdigest() == str(g['weights_sha256']), 'the seeded weights of the 20k golden could not be regenerated bit for bit'
+    x = torch.from_numpy(g['x'])
+    starts = []
+    for seed, n in zip(g['seeds'], (x.shape[1], 512)):
+        torch.manual_seed(int(seed))
+        starts.append(torch.randint(0, n, (1,), dtype=torch.long))          # the reference's own draw, pointnet2.py:66
+    return g, enc, x, tuple(starts)
+
+
 ENC_GOLDEN_CFG = dict(channel=6, npoints=(96, 24), radii=(0.25, 0.5), nsamples=(16, 32), mlps=((32, 64, 64), (64, 128, 128), (128, 256, 512)))
 
 
@@ -121,6 +144,22 @@ def test_oracle_stack_and_torch_path_reproduce_the_stack_built_from_the_real_ref
     assert torch.equal(x1, torch.from_numpy(g['l1_xyz'])) and torch.equal(x2, torch.from_numpy(g['l2_xyz']))
     assert (p1.detach() - torch.from_numpy(g['l1_points'])).abs().max().item() <= 2e-6
     assert (gf.detach() - torch.from_numpy(g['global_feat'])).abs().max().item() <= 2e-6
+
+
+def test_oracle_stack_reproduces_the_full_size_20k_point_golden_of_the_real_reference_primitives():
+    """tests/golden/pp_encoder_20k_golden.npz (the real reference's sample_and_group at N = 20,000, S = 512 / 128, then
+    sample_and_group_all): the oracle stack reproduces its samples and neighbour lists exactly and its features to float32 rounding,
+    so the 20k-point GPU tests that use the oracle stand on the reference itself."""
+    g, enc, x, start = _encoder_golden_20k()
+    sd = enc.state_dict()
+    xyz, feats = x[:, :, :3].contiguous(), x[:, :, 3:].contiguous()
+    nx1, r1, f1, i1 = sref.sa_forward(xyz, feats, 512, 0.2, 32, sref.layers_of(sd, 'sa1.', 3), start[0])
+    nx2, r2, f2, i2 = sref.sa_forward(nx1, r1, 128, 0.4, 64, sref.layers_of(sd, 'sa2.', 3), start[1])
+    r3 = sref.sa_all_forward(nx2, r2, sref.layers_of(sd, 'sa3.', 3))
+    assert torch.equal(f1, torch.from_numpy(g['fps1']).long()) and torch.equal(f2, torch.from_numpy(g['fps2']).long())
+    assert torch.equal(i1, torch.from_numpy(g['idx1']).long()) and torch.equal(i2, torch.from_numpy(g['idx2']).long())
+    for got, key in ((r1, 'l1_points'), (r2, 'l2_points'), (r3, 'global_feat')):
+        assert (got - torch.from_numpy(g[key])).abs().max().item() <= 2e-6, key
 
 
 def test_prepare_start_and_kernel_routing_host_logic():

@@ -36,6 +36,24 @@ def test_shard_union_equals_whole(batch, mlp_precision):
     assert (whole[:, 0] >= 0).all() and (whole[:, 0] <= 0.9 + 1e-6).all()
 
 
+def test_one_filter_launch_per_slice_equals_one_call_per_segment(batch, bin_batch):
+    """filter_launch='multi' (the default since round 6: every filter call of a slice through cg_filter_grasp_pose_multi) against
+    'per_segment' (one filterGraspPose call per object and call shape on side streams): identical records, whole batch and odd cuts,
+    single category and mixed bin."""
+    for b in (batch, bin_batch):
+        n = b.n_total
+        assert b.filter_launch == 'multi'
+        with torch.no_grad():
+            multi = [b.score_slice(lo, hi) for lo, hi in ((0, n), (3, 501), (n // 2 - 1, n))]
+            b.filter_launch = 'per_segment'
+            try:
+                per = [b.score_slice(lo, hi) for lo, hi in ((0, n), (3, 501), (n // 2 - 1, n))]
+            finally:
+                b.filter_launch = 'multi'
+        for a, c in zip(multi, per):
+            assert torch.equal(a, c)
+
+
 def test_records_match_the_oracle_on_a_sample(batch, mlp_precision):
     """codes == the C oracle's for both call shapes (incl. nudged poses); p_G == the oracle network on the SAME resampled points
     (ids read back from the device draw, poses = the oracle's own output poses)."""
