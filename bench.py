@@ -637,6 +637,24 @@ def main():
         else:
             torch.distributed.init_process_group(backend, rank=rank, world_size=world)
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    # N > 1: a census of what the process group really is -- how many ranks the collective library saw (an all-reduce of ones), and per
+    # rank the device it computes on (index, name, PCI bus id, which peers it can reach directly) -- so that a SCALE record proves N
+    # ranks on N distinct GPUs were in the job.  Gathered once, outside any timed region.
+    rccl_info = None
+    if world > 1:
+        ones = torch.ones((1,), dtype=torch.float32, device=device if backend == 'nccl' else 'cpu')
+        torch.distributed.all_reduce(ones)
+        prop = torch.cuda.get_device_properties(local_rank)
+        mine = {'rank': rank, 'local_rank': int(os.environ.get('LOCAL_RANK', '0')), 'current_device': int(torch.cuda.current_device()), 'name': prop.name,
+                'pci_bus_id': getattr(prop, 'pci_bus_id', None), 'uuid': str(getattr(prop, 'uuid', '')),
+                'peers_reachable': [j for j in range(torch.cuda.device_count()) if j != local_rank and torch.cuda.can_device_access_peer(local_rank, j)],
+                'visible_devices': torch.cuda.device_count(), 'HIP_VISIBLE_DEVICES': os.environ.get('HIP_VISIBLE_DEVICES'),
+                'HSA_ENABLE_IPC_MODE_LEGACY': os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')}
+        ranks = [None] * world
+        torch.distributed.all_gather_object(ranks, mine)
+        rccl_info = {'backend': backend, 'ranks_seen': int(round(float(ones.item()))), 'world_size': world,
+                     'rccl_version': '.'.join(str(v) for v in torch.cuda.nccl.version()) if backend == 'nccl' else None,
+                     'distinct_devices': len({(r['current_device'], r['pci_bus_id'], r['uuid']) for r in ranks}), 'ranks': ranks}
 
     from catgrasp_amd import distributed as cgd
     from catgrasp_amd import engine, ops, synth
@@ -924,6 +942,8 @@ def main():
         }
         import hashlib
         line['records_sha256'] = hashlib.sha256(ref_out.cpu().numpy().tobytes()).hexdigest()      # (p_G, code) of every candidate, global order
+        if rccl_info is not None:
+            line['rccl'] = rccl_info
         if projected is not None:
             line['projected_scaling'] = projected
         if selftest is not None:

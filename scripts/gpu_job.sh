@@ -63,6 +63,19 @@ case $JOB in
     timeout 1500 python -m pytest tests/test_collision_gpu.py tests/test_workload_gpu.py tests/test_pipeline_gpu.py tests/test_fullsize_properties_gpu.py tests/test_bench_multirank_gpu.py -m gpu -q -x > $O/pytest.log 2>&1; tail -15 $O/pytest.log
     ( time timeout 900 python bench.py ) > $O/bench_default_flags.json 2> $O/bench.err; tail -c 400 $O/bench.err
     python -c "import json;d=json.load(open('$O/bench_default_flags.json'));print(json.dumps(d['timing_s'],indent=1));print(json.dumps({k:{kk:v.get(kk) for kk in ('value','ms_per_step','wall_s','error')} for k,v in d['configs'].items()}));print(d['value'],d['ms_per_step']);print(json.dumps({k:v for k,v in d['roofline_filter'].items() if k not in ('note','cache_level')}));print(json.dumps(d['api']['pick_cycle']['default']))" ;;
+  pmcsplit)   # issue-side counters of the split-precision encoder-pass kernels (C5's dominant kernel: <2, 8, false, false> = bf16x3), 4,096 candidates
+    C1="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE"
+    C2="SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS"
+    C3="SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_MISC SQ_INSTS_SALU SQ_INST_CYCLES_VMEM SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT GRBM_GUI_ACTIVE"
+    for prec in bf16x3 f32; do
+      i=0; for C in "$C1" "$C2" "$C3"; do i=$((i+1))
+        timeout 300 rocprofv3 --pmc $C --kernel-include-regex pointmlp_max --output-format csv -d $O/p${i}_$prec -- python scripts/quick_cls.py 4096 $prec > $O/p${i}_$prec.log 2>&1
+        python scripts/pmc_summary.py $O/p${i}_$prec $O/pmc${i}_$prec.csv > /dev/null; rm -rf $O/p${i}_$prec
+      done
+      timeout 300 rocprofv3 --kernel-trace --kernel-include-regex pointmlp_max --output-format csv -d $O/kt_$prec -- python scripts/quick_cls.py 4096 $prec > $O/kt_$prec.log 2>&1
+      python scripts/pmc_summary.py $O/kt_$prec $O/kt_$prec.csv > /dev/null; rm -rf $O/kt_$prec; tail -1 $O/kt_$prec.log
+      cat $O/pmc1_$prec.csv $O/pmc2_$prec.csv $O/pmc3_$prec.csv $O/kt_$prec.csv | grep -v "^kernel" | grep "kernel<2" > $O/pmc_sq_pointmlp_$prec.csv; cat $O/pmc_sq_pointmlp_$prec.csv
+    done ;;
   py)         # any script:  py scripts/x.py args...
     timeout 1200 python "$@" > $O/out.txt 2>&1; tail -40 $O/out.txt ;;
   *) echo "unknown job $JOB"; exit 2 ;;

@@ -43,6 +43,8 @@ def test_bench_line_of_an_8_rank_job_equals_the_1_rank_job(cuda_device):
         assert line['config']['candidates_total'] == 6000 and line['value'] > 0 and 'workload' in line['config']
         assert set(line['roofline']) >= {'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'}
     assert len(eight['per_rank_ms']['ranks']) == 8 and eight['config']['candidates_per_gpu'] == 750
+    # the census block of an N > 1 line (all 8 ranks sit on this box's one device here; on the driver's node they are 8 devices)
+    assert eight['rccl']['ranks_seen'] == 8 and eight['rccl']['world_size'] == 8 and len(eight['rccl']['ranks']) == 8 and 'rccl' not in one
     assert eight['records_sha256'] == one['records_sha256']              # 8 shards + one all_gather == the unsharded batch, bit for bit
     assert eight['config']['reject_code_histogram_0keep_1dir_2ik_3open_4enclosed'] == one['config']['reject_code_histogram_0keep_1dir_2ik_3open_4enclosed']
 
