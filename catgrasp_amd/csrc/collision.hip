@@ -268,10 +268,12 @@ __device__ __forceinline__ bool wave_grid_collide(const Mesh& mesh, const VOX& v
   unsigned long long km = 0ull;
   // One loop, one place where the queue is tested: a pass either looks up the 2 x 64 voxels of the next two relevant blocks (two per
   // lane: the two dependent load chains key -> cell -> list run side by side) or, once the blocks are exhausted, only flushes the queue.
-  for (;;) {
-    int blk[2] = {-1, -1};
+  // The keys of pass i+1 are requested BEFORE pass i's cells are looked up (the chain key -> cell -> list is three dependent L2 round
+  // trips per pass; the first of them now travels under the previous pass's arithmetic).
+  auto pick = [&](int* b2) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
+      b2[u] = -1;
       while (km == 0ull && bb + 64 < nblocks) {
         bb += 64;
         const int wd = bb >> 6;
@@ -283,20 +285,33 @@ __device__ __forceinline__ bool wave_grid_collide(const Mesh& mesh, const VOX& v
         }
         km = w;
       }
-      if (km != 0ull) { blk[u] = bb + __builtin_ctzll(km); km &= km - 1ull; }
+      if (km != 0ull) { b2[u] = bb + __builtin_ctzll(km); km &= km - 1ull; }
     }
+  };
+  auto fetch = [&](const int* b2, short4* kk) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int v = b2[u] * 64 + lane;
+      kk[u] = make_short4(0, 0, 0, 0);
+      if (b2[u] >= 0 && v < vox.nk()) kk[u] = ((const short4*)vox.keys())[v];
+    }
+  };
+  int blkn[2];
+  short4 kn[2];
+  pick(blkn); fetch(blkn, kn);
+  for (;;) {
+    const int blk[2] = {blkn[0], blkn[1]};
+    const short4 k[2] = {kn[0], kn[1]};
     const bool last = blk[0] < 0;
+    if (!last) { pick(blkn); fetch(blkn, kn); }
     int cnt[2] = {0, 0}, e0[2] = {0, 0};
-    short4 k[2];
     float A[9], b[3];
     { const float4 q0 = *(const float4*)(pl->Ab), q1 = *(const float4*)(pl->Ab + 4), q2 = *(const float4*)(pl->Ab + 8);
       A[0] = q0.x; A[1] = q0.y; A[2] = q0.z; A[3] = q0.w; A[4] = q1.x; A[5] = q1.y; A[6] = q1.z; A[7] = q1.w; A[8] = q2.x; b[0] = q2.y; b[1] = q2.z; b[2] = q2.w; }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int v = blk[u] * 64 + lane;
-      k[u] = make_short4(0, 0, 0, 0);
       if (blk[u] >= 0 && v < vox.nk()) {
-        k[u] = ((const short4*)vox.keys())[v];
         work[0] += 1u;
         const float kx = (float)k[u].x, ky = (float)k[u].y, kz = (float)k[u].z;
         const float fx = fmaf(A[0], kx, fmaf(A[1], ky, fmaf(A[2], kz, b[0])));

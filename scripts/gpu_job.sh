@@ -76,6 +76,23 @@ case $JOB in
       python scripts/pmc_summary.py $O/kt_$prec $O/kt_$prec.csv > /dev/null; rm -rf $O/kt_$prec; tail -1 $O/kt_$prec.log
       cat $O/pmc1_$prec.csv $O/pmc2_$prec.csv $O/pmc3_$prec.csv $O/kt_$prec.csv | grep -v "^kernel" | grep "kernel<2" > $O/pmc_sq_pointmlp_$prec.csv; cat $O/pmc_sq_pointmlp_$prec.csv
     done ;;
+  filterplan) # the step's filter as one launch sequence: in-tree build vs ablation builds (build_abl/lib_*.so), + issue counters of each
+    for lib in in-tree build_abl/lib_*.so; do
+      [ $lib = in-tree ] && unset CATGRASP_AMD_LIB || export CATGRASP_AMD_LIB=$PWD/$lib
+      t=$(basename $lib .so)
+      timeout 300 python scripts/time_filter_plan.py > $O/time_$t.txt 2>&1; tail -1 $O/time_$t.txt
+      timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES --kernel-include-regex filter_grasp_pose_kernel --output-format csv -d $O/p_$t -- python scripts/time_filter_plan.py --pmc > $O/p_$t.log 2>&1
+      python scripts/pmc_summary.py $O/p_$t $O/pmc_$t.csv > /dev/null; rm -rf $O/p_$t; grep "true, true" $O/pmc_$t.csv
+    done; unset CATGRASP_AMD_LIB
+    timeout 900 python -m pytest tests/test_collision_gpu.py tests/test_workload_gpu.py -m gpu -q -x > $O/pytest.log 2>&1; tail -3 $O/pytest.log ;;
+  r6c)        # the chain kernel + census: tests, small-call latency, encoder stage table
+    timeout 1500 python -m pytest tests/test_pointnet_gpu.py tests/test_pointnet2_encoder_gpu.py tests/test_predicter_gpu.py tests/test_bench_multirank_gpu.py tests/test_zzz_rccl_multirank_gpu.py tests/test_pointnet_blocks_gpu.py -m gpu -q -x > $O/pytest.log 2>&1; tail -8 $O/pytest.log
+    timeout 300 python scripts/time_predict_small.py > $O/predict_small.txt 2>&1; tail -1 $O/predict_small.txt > $O/predict_small.json; grep candidates $O/predict_small.txt | head -12
+    CATGRASP_AMD_GEMM_CHAIN=0 timeout 300 python scripts/time_predict_small.py > $O/predict_small_nochain.txt 2>&1; echo --- no chain; grep candidates $O/predict_small_nochain.txt | head -12
+    timeout 300 python scripts/pp_encoder_profile.py $O/pp_encoder.json > $O/pp_encoder.txt 2>&1; tail -4 $O/pp_encoder.txt
+    CATGRASP_AMD_GEMM_CHAIN=0 timeout 300 python scripts/pp_encoder_profile.py $O/pp_encoder_nochain.json > $O/pp_encoder_nochain.txt 2>&1; tail -4 $O/pp_encoder_nochain.txt
+    stats pp_encoder python scripts/pp_encoder_profile.py --trace
+    head -14 $O/pp_encoder_kernel_stats.csv | cut -c1-170 ;;
   py)         # any script:  py scripts/x.py args...
     timeout 1200 python "$@" > $O/out.txt 2>&1; tail -40 $O/out.txt ;;
   *) echo "unknown job $JOB"; exit 2 ;;
