@@ -266,11 +266,11 @@ def pick_cycle_block(batch, gp, npred, device, n_canonical=2000):
         job.append({'ob_pts': ob['xyz'], 'ob_normals': ob['normal'], 'symmetry_tfs': sym, 'nocs_pose_override': batch.nocs_pose[k],
                     'canonical': {'cloud': canon_pts, 'normals': canon_nrm, 'affordance': np.linspace(0, 1, 3000), 'grasps': grasps}})
 
-    def cycle(nun, rng_mode, draw_ahead):
+    def cycle(nun, rng_mode, overlap):
         per_ob = []
         np.random.seed(0)
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        outs = pipeline.evaluate_objects(job, scene_pts, K, g, gp, nun, draw_ahead=draw_ahead, timings=per_ob, rng=rng_mode)
+        outs = pipeline.evaluate_objects(job, scene_pts, K, g, gp, nun, draw_ahead=bool(overlap), overlap=overlap, timings=per_ob, rng=rng_mode)
         torch.cuda.synchronize(); wall = time.perf_counter() - t0
         timings = {}
         for tm in per_ob:
@@ -283,17 +283,23 @@ def pick_cycle_block(batch, gp, npred, device, n_canonical=2000):
         h.update(np.random.get_state()[1].tobytes()); h.update(str(np.random.get_state()[2]).encode())
         return wall, sum(o['n_evaluated'] for o in outs), sum(len(o['poses']) for o in outs), timings, h.hexdigest()[:16]
     res = {'objects': len(objs), 'precision': engine.current_precision()}
-    for name, nun, rng_mode, ahead in (('default', npred, 'numpy', True), ('default_serial', npred, 'numpy', False), ('fast_draws', fast, 'device', False)):
+    for name, nun, rng_mode, ahead in (('default', npred, 'numpy', 'stages'), ('default_draws_ahead_only', npred, 'numpy', 'draws'),
+                                       ('default_serial', npred, 'numpy', None), ('fast_draws', fast, 'device', None)):
         cycle(nun, rng_mode, ahead)                         # warm-up: caches, allocator, worker threads
         wall, total, surv, tm, digest = cycle(nun, rng_mode, ahead)
         res[name] = {'settings': {'default': "pipeline.evaluate_objects: ransac_sampling='reference', rng='numpy' (bit-identical to a seeded reference run), "
-                                             "the next object's hypothesis draws made ahead on a second thread while the device scores the current one",
-                                  'default_serial': 'the same, object after object (draw_ahead=False): the round-4 figure',
+                                             "object k+1's whole pre-scoring half (occupancy, NUNOCS + RANSAC incl. its 2 x 10,000 hypothesis draws, cone "
+                                             "sampler, filter, affordance) on a second thread + stream while the device scores object k (overlap='stages')",
+                                  'default_draws_ahead_only': "the same with only the next object's hypothesis draws made ahead (overlap='draws'): the round-5 default",
+                                  'default_serial': 'the same, object after object (overlap=None): the round-4 figure',
                                   'fast_draws': "ransac_sampling='fast', rng='device' (same distributions, not numpy's stream)"}[name],
                      'wall_s_per_cycle': round(wall, 4), 'wall_ms_per_object': round(wall / len(objs) * 1e3, 2),
                      'evaluations': total, 'survivors_scored': surv, 'results_and_generator_state_sha256_16': digest,
                      'ms_per_object_by_stage': {k: round(v / len(objs) * 1e3, 3) for k, v in tm.items()}}
-    res['draw_ahead_equals_serial'] = res['default']['results_and_generator_state_sha256_16'] == res['default_serial']['results_and_generator_state_sha256_16']
+    res['draw_ahead_equals_serial'] = (res['default']['results_and_generator_state_sha256_16'] == res['default_serial']['results_and_generator_state_sha256_16']
+                                       == res['default_draws_ahead_only']['results_and_generator_state_sha256_16'])
+    res['note_stage_times'] = ("with overlap='stages' the pre-scoring stage times of object k+1 are measured on the second thread, beside object k's scoring "
+                               "pass: they overlap it and do not add up to wall_ms_per_object")
     res['note'] = ("stages: occupancy (background ray cast), nunocs+ransac (= 'nunocs net + decode' + 'ransac id draw (exposed)' + 'ransac kernels + "
                    "selection'; 'ransac id draw' is the duration of the stream replay itself -- on the stream worker under the network in the serial loop, "
                    "on the draw-ahead thread under the PREVIOUS object's scoring pass in the default), "

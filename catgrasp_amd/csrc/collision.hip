@@ -10,6 +10,7 @@
 // test the queue 64 pairs at a time; a wave ballot gives the early exit.  HBM traffic is 64 B of pose in and 66 B out per evaluation; the voxel and
 // mesh arrays are L2 resident.
 #include <stddef.h>
+#include <stdlib.h>
 #include "cg_common.hpp"
 #include "../../include/catgrasp_amd.h"
 
@@ -268,12 +269,10 @@ __device__ __forceinline__ bool wave_grid_collide(const Mesh& mesh, const VOX& v
   unsigned long long km = 0ull;
   // One loop, one place where the queue is tested: a pass either looks up the 2 x 64 voxels of the next two relevant blocks (two per
   // lane: the two dependent load chains key -> cell -> list run side by side) or, once the blocks are exhausted, only flushes the queue.
-  // The keys of pass i+1 are requested BEFORE pass i's cells are looked up (the chain key -> cell -> list is three dependent L2 round
-  // trips per pass; the first of them now travels under the previous pass's arithmetic).
-  auto pick = [&](int* b2) {
+  for (;;) {
+    int blk[2] = {-1, -1};
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      b2[u] = -1;
       while (km == 0ull && bb + 64 < nblocks) {
         bb += 64;
         const int wd = bb >> 6;
@@ -285,33 +284,20 @@ __device__ __forceinline__ bool wave_grid_collide(const Mesh& mesh, const VOX& v
         }
         km = w;
       }
-      if (km != 0ull) { b2[u] = bb + __builtin_ctzll(km); km &= km - 1ull; }
+      if (km != 0ull) { blk[u] = bb + __builtin_ctzll(km); km &= km - 1ull; }
     }
-  };
-  auto fetch = [&](const int* b2, short4* kk) {
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int v = b2[u] * 64 + lane;
-      kk[u] = make_short4(0, 0, 0, 0);
-      if (b2[u] >= 0 && v < vox.nk()) kk[u] = ((const short4*)vox.keys())[v];
-    }
-  };
-  int blkn[2];
-  short4 kn[2];
-  pick(blkn); fetch(blkn, kn);
-  for (;;) {
-    const int blk[2] = {blkn[0], blkn[1]};
-    const short4 k[2] = {kn[0], kn[1]};
     const bool last = blk[0] < 0;
-    if (!last) { pick(blkn); fetch(blkn, kn); }
     int cnt[2] = {0, 0}, e0[2] = {0, 0};
+    short4 k[2];
     float A[9], b[3];
     { const float4 q0 = *(const float4*)(pl->Ab), q1 = *(const float4*)(pl->Ab + 4), q2 = *(const float4*)(pl->Ab + 8);
       A[0] = q0.x; A[1] = q0.y; A[2] = q0.z; A[3] = q0.w; A[4] = q1.x; A[5] = q1.y; A[6] = q1.z; A[7] = q1.w; A[8] = q2.x; b[0] = q2.y; b[1] = q2.z; b[2] = q2.w; }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int v = blk[u] * 64 + lane;
+      k[u] = make_short4(0, 0, 0, 0);
       if (blk[u] >= 0 && v < vox.nk()) {
+        k[u] = ((const short4*)vox.keys())[v];
         work[0] += 1u;
         const float kx = (float)k[u].x, ky = (float)k[u].y, kz = (float)k[u].z;
         const float fx = fmaf(A[0], kx, fmaf(A[1], ky, fmaf(A[2], kz, b[0])));
@@ -730,6 +716,13 @@ inline Mesh make_mesh(const float* V, const int* F, int nf, const cg_mesh_grid* 
   return m;
 }
 
+// Workgroups the collision kernels are launched with at most (grid-stride beyond): 16 per CU.  CATGRASP_AMD_FILTER_BLOCKS_PER_CU (dev
+// knob) changes it: with MORE workgroups than the chip holds at once the dispatcher hands evaluations out as slots free up.
+inline long filter_block_cap() {
+  static const long per_cu = getenv("CATGRASP_AMD_FILTER_BLOCKS_PER_CU") ? atol(getenv("CATGRASP_AMD_FILTER_BLOCKS_PER_CU")) : 16;
+  return 256 * (per_cu > 0 ? per_cu : 16);
+}
+
 inline Mat4 load_mat(const float* h) { Mat4 m; for (int i = 0; i < 16; ++i) m.m[i] = h[i]; return m; }
 
 // mat4_mul of the device code on the host: the same float32 expression per element (this file is compiled with -ffp-contract=off)
@@ -787,7 +780,7 @@ extern "C" int cg_filter_grasp_pose_accel(const float* grasp_poses, int n_pose, 
   a.res = resolution; a.codes = codes; a.poses_out = poses_out; a.nudge = nudge;
   a.keep_rejected_pose = keep_rejected_pose; a.work_stats = work_stats;
   long blocks = (E + WAVES - 1) / WAVES;
-  if (blocks > 256 * 16) blocks = 256 * 16;      // grid-stride: 16 blocks per CU
+  if (blocks > filter_block_cap()) blocks = filter_block_cap();      // grid-stride: 16 blocks per CU
   // Meshes that collide with anything (non-empty mesh against a non-empty voxel set) must all carry a grid for the grid kernel;
   // evaluations it cannot cover (a pose outside a grid's validity) come back CODE_PENDING and the exhaustive kernel, which skips
   // everything else, finishes them.  Without grids the exhaustive kernel does all of it.
@@ -864,7 +857,7 @@ extern "C" int cg_filter_grasp_pose_multi(const cg_filter_segment* h_segments, c
   a.keep_rejected_pose = keep_rejected_pose; a.work_stats = work_stats;
   a.segs = d_segments; a.n_segs = n_segments;
   long blocks = (E + WAVES - 1) / WAVES;
-  if (blocks > 256 * 16) blocks = 256 * 16;
+  if (blocks > filter_block_cap()) blocks = filter_block_cap();
   bool grids = true;
   if (a.mesh[0].nf > 0 && any_open && !a.mesh[0].has_grid) grids = false;
   if (a.mesh[1].nf > 0 && any_bg && !a.mesh[1].has_grid) grids = false;

@@ -1,6 +1,5 @@
 // HOST code (no kernel of its own): PointNetCls.forward (pointnet2.py:289-299) in eval mode as ONE call -- the twelve launches of the
-// exact-f32 path (three fused per-point passes, nine dense layers -- or, for a few poses, three chain launches of three layers each)
-// issued back to back from C.
+// exact-f32 path (three fused per-point passes, nine dense layers) issued back to back from C.
 //
 // The python engine (catgrasp_amd/engine.py: cls_forward) issues the same launches one ctypes call at a time, each with its output
 // allocation and argument marshalling: ~10 us of interpreter per launch, ~0.15 ms per forward -- invisible behind a 16,384-candidate
@@ -19,26 +18,8 @@ extern "C" size_t cg_pointnet_cls_workspace_floats(int B) {
   return 3 * (up4(b * 1024) + up4(b * 512) + up4(b * 256)) + up4(b * 9) + up4(b * 4096);
 }
 
-namespace {
-// One FC tail (1024 -> 512 -> 256 -> n_last [+ I_k]) as ONE launch when the batch is small enough for the chain kernel (cg_gemm_chain:
-// <= 2,048 output tiles per layer) and the caller passed a barrier word; else the three launches.  Same bits either way.
-int fc_tail(const float* g, int B, const float* w1, const float* b1, const float* w2, const float* b2, const float* w3, const float* b3, int n_last,
-            int eye_k, float* h1, float* h2, float* out, int* chain_state, void* stream) {
-  if (chain_state) {
-    const int K[3] = {1024, 512, 256}, N[3] = {512, 256, n_last}, relu[3] = {1, 1, 0};
-    const float* W[3] = {w1, w2, w3}; const float* Bv[3] = {b1, b2, b3}; float* O[3] = {h1, h2, out};
-    const int rc = cg_gemm_chain(g, B, 3, K, N, W, Bv, relu, eye_k, 0, O, chain_state, stream);
-    if (rc != CG_ERR_UNSUPPORTED) return rc;
-  }
-  int rc;
-  if ((rc = cg_gemm_bias_act(g, B, 1024, 1024, w1, 512, b1, nullptr, 1, 0, 1, 0, h1, 512, stream)) != CG_OK) return rc;
-  if ((rc = cg_gemm_bias_act(h1, B, 512, 512, w2, 256, b2, nullptr, 1, 0, 1, 0, h2, 256, stream)) != CG_OK) return rc;
-  return cg_gemm_bias_act(h2, B, 256, 256, w3, n_last, b3, nullptr, 1, 0, 0, eye_k, out, n_last, stream);
-}
-}  // namespace
-
 extern "C" int cg_pointnet_cls_forward(const float* x, int B, int N, const cg_cls_weights* w, int nsplit, float* ws, float* logits,
-                                       float** trans_feat_t, int* chain_state, void* stream) {
+                                       float** trans_feat_t, void* stream) {
   if (B < 0 || N <= 0 || nsplit < 1) return CG_ERR_ARG;
   if (B == 0) return CG_OK;
   if (!x || !w || !ws || !logits || w->n_out <= 0) return CG_ERR_ARG;
@@ -52,16 +33,22 @@ extern "C" int cg_pointnet_cls_forward(const float* x, int B, int N, const cg_cl
   // STN3d: conv1..conv3 + max, fc1, fc2, fc3 (+ I3)                                         pointnet2.py:170-185
   CG_TRY(cg_pointmlp_max(x, B, N, nullptr, w->stn_w1, w->stn_b1, 0, nullptr, nullptr, nullptr, w->stn_w2, w->stn_b2, w->stn_w3, w->stn_b3, 1, nsplit,
                          g1, nullptr, stream));
-  CG_TRY(fc_tail(g1, B, w->stn_fc1, w->stn_fc1b, w->stn_fc2, w->stn_fc2b, w->stn_fc3, w->stn_fc3b, 9, 3, h1, h2, t3, chain_state, stream));
+  CG_TRY(cg_gemm_bias_act(g1, B, 1024, 1024, w->stn_fc1, 512, w->stn_fc1b, nullptr, 1, 0, 1, 0, h1, 512, stream));
+  CG_TRY(cg_gemm_bias_act(h1, B, 512, 512, w->stn_fc2, 256, w->stn_fc2b, nullptr, 1, 0, 1, 0, h2, 256, stream));
+  CG_TRY(cg_gemm_bias_act(h2, B, 256, 256, w->stn_fc3, 9, w->stn_fc3b, nullptr, 1, 0, 0, 3, t3, 9, stream));
   // STNkd on top of the encoder's conv1: conv1..conv3 + max, fc1, fc2, fc3 (+ I64)           pointnet2.py:208-223, :243-252
   CG_TRY(cg_pointmlp_max(x, B, N, t3, w->enc_w1, w->enc_b1, 1, w->fstn_wm, w->fstn_bm, nullptr, w->fstn_w2, w->fstn_b2, w->fstn_w3, w->fstn_b3, 1,
                          nsplit, g2, nullptr, stream));
-  CG_TRY(fc_tail(g2, B, w->fstn_fc1, w->fstn_fc1b, w->fstn_fc2, w->fstn_fc2b, w->fstn_fc3, w->fstn_fc3b, 4096, 64, h3, h4, t64, chain_state, stream));
+  CG_TRY(cg_gemm_bias_act(g2, B, 1024, 1024, w->fstn_fc1, 512, w->fstn_fc1b, nullptr, 1, 0, 1, 0, h3, 512, stream));
+  CG_TRY(cg_gemm_bias_act(h3, B, 512, 512, w->fstn_fc2, 256, w->fstn_fc2b, nullptr, 1, 0, 1, 0, h4, 256, stream));
+  CG_TRY(cg_gemm_bias_act(h4, B, 256, 256, w->fstn_fc3, 4096, w->fstn_fc3b, nullptr, 1, 0, 0, 64, t64, 4096, stream));
   // encoder: conv1, x.T64, conv2, conv3, max                                                 pointnet2.py:243-266
   CG_TRY(cg_pointmlp_max(x, B, N, t3, w->enc_w1, w->enc_b1, 2, nullptr, nullptr, t64, w->enc_w2, w->enc_b2, w->enc_w3, w->enc_b3, 0, nsplit, g3,
                          nullptr, stream));
   // head: fc1, fc2 (BN folded, ReLU; dropout is the identity in eval), fc3                   pointnet2.py:295-298
-  CG_TRY(fc_tail(g3, B, w->head_fc1, w->head_fc1b, w->head_fc2, w->head_fc2b, w->head_fc3, w->head_fc3b, w->n_out, 0, h5, h6, logits, chain_state, stream));
+  CG_TRY(cg_gemm_bias_act(g3, B, 1024, 1024, w->head_fc1, 512, w->head_fc1b, nullptr, 1, 0, 1, 0, h5, 512, stream));
+  CG_TRY(cg_gemm_bias_act(h5, B, 512, 512, w->head_fc2, 256, w->head_fc2b, nullptr, 1, 0, 1, 0, h6, 256, stream));
+  CG_TRY(cg_gemm_bias_act(h6, B, 256, 256, w->head_fc3, w->n_out, w->head_fc3b, nullptr, 1, 0, 0, 0, logits, w->n_out, stream));
 #undef CG_TRY
   if (trans_feat_t) *trans_feat_t = t64;
   return CG_OK;

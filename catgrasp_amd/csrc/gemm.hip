@@ -123,8 +123,12 @@ __global__ __launch_bounds__(256) void gemm_bias_act_kernel(GemmArgs a) {
 // whole K itself, operands straight from global memory (the x rows are L1 / L2 resident, the weights are read once per row tile):
 // ceil(M/32) x ceil(N/32) independent wavefronts.  Per output element the sequence of MFMAs and their operands is the one the tile
 // kernel issues, so a row's result does not depend on which kernel -- i.e. on how many rows -- it was computed with.
-__device__ __forceinline__ void gemm_small_tile(const GemmArgs& a, int tile, int lane) {
+__global__ __launch_bounds__(256) void gemm_bias_act_small_kernel(GemmArgs a) {
+  const int lane = threadIdx.x & 63;
   const int l31 = lane & 31, lhi = lane >> 5;
+  const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int tiles_m = (a.M + 31) / 32;
+  if (tile >= tiles_m * a.nblocks) return;
   const int tm = tile / a.nblocks, nb = tile - tm * a.nblocks;     // neighbouring wavefronts share their x rows, not their weights
   const int ksteps = a.K / 8;
   int xrow = tm * 32 + l31; if (xrow >= a.M) xrow = a.M - 1;
@@ -183,45 +187,6 @@ __device__ __forceinline__ void gemm_small_tile(const GemmArgs& a, int tile, int
   }
 }
 
-__global__ __launch_bounds__(256) void gemm_bias_act_small_kernel(GemmArgs a) {
-  const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (tile >= ((a.M + 31) / 32) * a.nblocks) return;
-  gemm_small_tile(a, tile, threadIdx.x & 63);
-}
-
-// A CHAIN of such layers in ONE launch (the FC tail of STN3d / STNkd / PointNetCls for a predict_batch call of a few poses; the group-all
-// level of the set-abstraction encoder: pointnet2.py:132-149, 178-185, 216-223, 295-298): layer l+1 reads what layer l wrote, so the
-// layers are separated by a device-wide barrier instead of a kernel boundary (~8 us of launch + drain each, against 3-10 us of work per
-// layer at these sizes).  Every output element is produced by gemm_small_tile -- the MFMA sequence of the separate launches -- so the
-// results are theirs bit for bit.  The barrier is a counter in device memory that the launch finds at zero and leaves at zero:
-// arrive = release fence + atomic add (agent scope: the layer's stores reach the other XCDs' L2), wait = spin on the count + acquire.
-// All workgroups of the grid must be able to be resident together (the launcher caps the grid far below the chip's capacity).
-constexpr int CHAIN_MAX_LAYERS = 4;
-struct ChainArgs { GemmArgs layer[CHAIN_MAX_LAYERS]; int n_layers; unsigned* state; float* zero; long n_zero; };
-
-__global__ __launch_bounds__(256) void gemm_chain_kernel(ChainArgs a) {
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < a.n_zero; i += (long)gridDim.x * 256) a.zero[i] = 0.f;   // the group-max target
-  for (int l = 0; l < a.n_layers; ++l) {
-    const GemmArgs& g = a.layer[l];
-    const int tiles = ((g.M + 31) / 32) * g.nblocks;
-    for (int tile = blockIdx.x * 4 + wv; tile < tiles; tile += gridDim.x * 4) gemm_small_tile(g, tile, lane);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      __threadfence();
-      const unsigned arrived = __hip_atomic_fetch_add(a.state, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-      if (l + 1 < a.n_layers) {
-        const unsigned target = (unsigned)(l + 1) * gridDim.x;
-        while (__hip_atomic_load(a.state, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
-        __threadfence();
-      } else if (arrived == (unsigned)a.n_layers * gridDim.x) {
-        __hip_atomic_store(a.state, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);      // the last workgroup out leaves the counter at zero
-      }
-    }
-    __syncthreads();
-  }
-}
-
 constexpr long SMALL_TILES = 2048;  // 32 x 32 output tiles up to which the wavefront-per-tile kernel is used (measured: profiles/r4_gemm_small.txt)
 
 int launch_gemm(GemmArgs& a, void* stream) {
@@ -249,42 +214,6 @@ extern "C" int cg_gemm_bias_act(const float* x, int M, int K, int ldx, const flo
   if (M == 0) return CG_OK;
   GemmArgs a{x, M, K, ldx, w_packed, N, (N + 31) / 32, bias, row_bias, rows_per_group, ld_rb, relu, eye_k, y, ldy, 0};
   return launch_gemm(a, stream);
-}
-
-constexpr int CHAIN_MAX_GRID = 128;      // workgroups of a chain launch: 512 wavefronts, a sixth of what the chip holds at this kernel's size
-
-// cg_gemm_chain: see include/catgrasp_amd.h
-extern "C" int cg_gemm_chain(const float* x, int M, int n_layers, const int* h_K, const int* h_N, const float* const* h_w_packed,
-                             const float* const* h_bias, const int* h_relu, int eye_k_last, int rows_per_group_max, float* const* h_out,
-                             int* state, void* stream) {
-  if (!x || !h_K || !h_N || !h_w_packed || !h_bias || !h_relu || !h_out || !state) return CG_ERR_ARG;
-  if (n_layers < 1 || n_layers > CHAIN_MAX_LAYERS || M < 0 || rows_per_group_max < 0) return CG_ERR_ARG;
-  if (M == 0) return CG_OK;
-  if (rows_per_group_max > 0 && (M % rows_per_group_max) != 0) return CG_ERR_ARG;
-  if (((uintptr_t)x & 15) != 0) return CG_ERR_ARG;
-  ChainArgs a;
-  a.n_layers = n_layers; a.state = (unsigned*)state; a.zero = nullptr; a.n_zero = 0;
-  long max_tiles = 0;
-  const float* in = x;
-  for (int l = 0; l < n_layers; ++l) {
-    const int K = h_K[l], N = h_N[l];
-    const bool last = l == n_layers - 1;
-    if (K <= 0 || N <= 0 || (K % 8) != 0 || !h_w_packed[l] || !h_out[l]) return CG_ERR_ARG;
-    if (l > 0 && K != h_N[l - 1]) return CG_ERR_ARG;                         // a layer reads the previous layer's (M, N) output
-    if (((uintptr_t)h_out[l] & 15) != 0) return CG_ERR_ARG;
-    const int gm = last ? rows_per_group_max : 0;
-    a.layer[l] = GemmArgs{in, M, K, K, h_w_packed[l], N, (N + 31) / 32, h_bias[l], nullptr, 1, 0, (gm > 0) ? 1 : h_relu[l], last ? eye_k_last : 0,
-                          h_out[l], N, gm};
-    if (gm > 0) { a.zero = h_out[l]; a.n_zero = (long)(M / gm) * N; }
-    const long tiles = (long)((M + 31) / 32) * a.layer[l].nblocks;
-    if (tiles > max_tiles) max_tiles = tiles;
-    in = h_out[l];
-  }
-  if (max_tiles > SMALL_TILES) return CG_ERR_UNSUPPORTED;                    // beyond the wavefront-per-tile regime: issue the layers one by one
-  long grid = (max_tiles + 3) / 4;
-  if (grid > CHAIN_MAX_GRID) grid = CHAIN_MAX_GRID;
-  hipLaunchKernelGGL(gemm_chain_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
-  return cg_hip_status(hipGetLastError());
 }
 
 // out[g][n] = max over the rows_per_group rows of group g of relu(X . W^T + bias): the last layer of the group-all set-abstraction level

@@ -320,7 +320,7 @@ def _cls_forward_one_call(W, x):
     logits = torch.empty((B, W.n_out), dtype=torch.float32, device=x.device)
     tf = ctypes.c_void_p(0)
     L.check(lib.cg_pointnet_cls_forward(L._p(x), ctypes.c_int(B), ctypes.c_int(N), ctypes.byref(cw), ctypes.c_int(_nsplit(B, N)), L._p(ws), L._p(logits),
-                                        ctypes.byref(tf), L._p(ops.chain_state(x.device) if ops.USE_GEMM_CHAIN else None), L._stream()), 'cg_pointnet_cls_forward')
+                                        ctypes.byref(tf), L._stream()), 'cg_pointnet_cls_forward')
     off = (tf.value - ws.data_ptr()) // 4
     t64 = ws[off:off + B * 4096]
     return logits, t64.view(B, 64, 64).transpose(1, 2)      # the FC kernel emits the transform transposed

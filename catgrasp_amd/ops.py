@@ -1,6 +1,5 @@
 """Thin torch-tensor wrappers over the C ABI (device memory + stream plumbing only)."""
 import ctypes
-import os
 
 import numpy as np
 import torch
@@ -77,49 +76,6 @@ def gemm_bias_act(x, wp, n_out, bias=None, relu=False, eye_k=0, row_bias=None, r
     st = fn(*args, _p(status), _stream()) if split == 'f16' else fn(*args, _stream())
     check(st, name)
     return y
-
-
-_CHAIN_STATE = {}
-USE_GEMM_CHAIN = os.environ.get('CATGRASP_AMD_GEMM_CHAIN', '1') != '0'      # dev knob: '0' = one launch per layer everywhere
-
-
-def chain_state(device):
-    """The barrier word of cg_gemm_chain for torch's current stream on `device`: one zero-initialised device int per (device, stream),
-    created on first use (chains on different streams may be in flight together; the kernel leaves the word at zero)."""
-    dev = torch.device(device)
-    idx = dev.index if dev.index is not None else torch.cuda.current_device()
-    key = (idx, _stream().value)
-    st = _CHAIN_STATE.get(key)
-    if st is None:
-        st = _CHAIN_STATE[key] = torch.zeros((1,), dtype=torch.int32, device=dev)
-    return st
-
-
-def gemm_chain(x, layers, eye_k_last=0, rows_per_group_max=0):
-    """cg_gemm_chain: x (M,K0) -> [act(. W^T + b)] per layer in ONE launch.  layers: [(w_packed, bias, n_out, relu)].  -> the last layer's
-    output ((M / rows_per_group_max, N) when the last layer folds a max over row groups), or None when the shape is beyond the chain
-    kernel's regime (the caller then issues the layers one by one: same bits)."""
-    require_cuda(x)
-    f32c(x)
-    M, K = x.shape
-    n = len(layers)
-    if not USE_GEMM_CHAIN or n < 1 or n > 4 or M == 0:
-        return None
-    tiles_m = (M + 31) // 32
-    if max(tiles_m * ((no + 31) // 32) for _, _, no, _ in layers) > 2048:
-        return None
-    outs = []
-    for i, (_, _, no, _) in enumerate(layers):
-        rows = M // rows_per_group_max if (i == n - 1 and rows_per_group_max) else M
-        outs.append(torch.empty((rows, no), dtype=torch.float32, device=x.device))
-    Ks = [K] + [no for _, _, no, _ in layers[:-1]]
-    ci = ctypes.c_int * n
-    cp = ctypes.c_void_p * n
-    st = L.lib().cg_gemm_chain(_p(x), _c_int(M), _c_int(n), ci(*Ks), ci(*[no for _, _, no, _ in layers]), cp(*[w.data_ptr() for w, _, _, _ in layers]),
-                               cp(*[(b.data_ptr() if b is not None else None) for _, b, _, _ in layers]), ci(*[int(bool(r)) for _, _, _, r in layers]),
-                               _c_int(eye_k_last), _c_int(rows_per_group_max), cp(*[o.data_ptr() for o in outs]), _p(chain_state(x.device)), _stream())
-    check(st, 'cg_gemm_chain')
-    return outs[-1]
 
 
 def group_max(x, groups):

@@ -62,18 +62,44 @@ def evaluate_object(ob_pts, ob_normals, scene_pts, K, gripper, grasp_predicter, 
     branch instead of the RANSAC result (NunocsPredicter.predict still runs and is timed): random-init weights cannot recover a pose.
     `timings` additionally receives the split of the NUNOCS stage that NunocsPredicter.predict records (net / id draw / RANSAC).
     `nunocs_predrawn` / `on_scoring_draws`: the two ends of evaluate_objects' draw-ahead (NunocsPredicter.draw_ahead's result for this
-    object; a callback(state, n_valid, n_pts, n_rows) fired when this object's scoring pass starts drawing from numpy's stream)."""
+    object; a callback(state, n_valid, n_pts, n_rows) fired when this object's scoring pass starts drawing from numpy's stream).
+    = prepare_object (every stage before the scoring pass) + score_object, the two halves evaluate_objects overlaps across objects."""
+    prep = prepare_object(ob_pts, ob_normals, scene_pts, K, gripper, grasp_predicter, nunocs_predicter, canonical=canonical, symmetry_tfs=symmetry_tfs,
+                          n_surface_samples=n_surface_samples, sphere_pts=sphere_pts, approach_step=approach_step, resolution=resolution,
+                          cam_in_world=cam_in_world, timings=timings, ik=ik, nocs_pose_override=nocs_pose_override, nunocs_predrawn=nunocs_predrawn)
+    return score_object(prep, grasp_predicter, rng=rng, timings=timings, on_scoring_draws=on_scoring_draws)
+
+
+def _lap(timings, name, t0):
+    if timings is not None:
+        torch.cuda.current_stream().synchronize()          # this thread's stream only: another object's stages may be running beside it
+        timings[name] = timings.get(name, 0.0) + (time.perf_counter() - t0)
+
+
+def prepare_object(ob_pts, ob_normals, scene_pts, K, gripper, grasp_predicter, nunocs_predicter, canonical=None, symmetry_tfs=None,
+                   n_surface_samples=50, sphere_pts=None, approach_step=0.004, resolution=0.0005, cam_in_world=None, timings=None, ik=None,
+                   nocs_pose_override=None, nunocs_predrawn=None, np_state=None):
+    """Every stage of evaluate_object BEFORE the grasp-Q scoring pass: background occupancy, NUNOCS + 9-D pose, candidate generation,
+    collision / approach filter, affordance.  -> the dict score_object consumes.
+    np_state None: the stages draw from numpy's GLOBAL generator, in the reference's order (NUNOCS resampling row, 2 x 10,000 RANSAC
+    hypotheses, the surface-sample choice).  np_state = a generator state (or a callable returning one, evaluated on the draw-ahead
+    thread): the same draws are replayed from THAT state without touching the global generator -- the form evaluate_objects uses to
+    run object k+1's stages while object k is still being scored; prep['np_state'] is then where the stream stands when this object's
+    scoring pass begins.  Needs a predicter whose draws can be made ahead (NunocsPredicter._predraw)."""
     dev = grasp_predicter.device
     t = time.perf_counter
     canonical = canonical_fields(canonical)
-
-    def lap(name, t0):
-        if timings is not None:
-            torch.cuda.synchronize()
-            timings[name] = timings.get(name, 0.0) + (t() - t0)
-
+    lap = lambda name, t0: _lap(timings, name, t0)
     I4 = np.eye(4, dtype=np.float32)
     cam_in_world = I4 if cam_in_world is None else cam_in_world
+    explicit = np_state is not None
+    data = {'cloud_xyz': ob_pts, 'cloud_normal': ob_normals}
+    if explicit:        # the sequential host replay of this object's draws starts NOW, under the device stages below
+        from . import predicter as pred_mod
+        n_valid = int(transforms.valid_mask(np.asarray(ob_pts, dtype=np.float64)).sum())
+        nunocs_predrawn = nunocs_predicter.draw_ahead(n_valid, np_state, pred_mod.draw_ahead_worker())
+        if nunocs_predrawn is None:
+            raise ValueError('prepare_object(np_state=...) needs a NunocsPredicter that draws from numpy\'s stream ahead of time')
     # --- background occupancy (occluded space behind the visible neighbours counts as occupied) ---
     t0 = t()
     bg = _background_points(scene_pts, ob_pts, gripper['diameter'], dev)
@@ -81,10 +107,9 @@ def evaluate_object(ob_pts, ob_normals, scene_pts, K, gripper, grasp_predicter, 
     lap('occupancy', t0)
     # --- NUNOCS + 9-D pose ---
     t0 = t()
-    data = {'cloud_xyz': ob_pts, 'cloud_normal': ob_normals}
     if nunocs_predrawn is not None:
         nunocs_predrawn = nunocs_predrawn.result() if hasattr(nunocs_predrawn, 'result') else nunocs_predrawn
-        nocs_cloud, nocs_pose = nunocs_predicter.predict(data, predrawn=nunocs_predrawn)
+        nocs_cloud, nocs_pose = nunocs_predicter.predict(data, predrawn=nunocs_predrawn, **({'explicit_stream': True} if explicit else {}))
     else:
         nocs_cloud, nocs_pose = nunocs_predicter.predict(data)
     lap('nunocs+ransac', t0)
@@ -95,7 +120,14 @@ def evaluate_object(ob_pts, ob_normals, scene_pts, K, gripper, grasp_predicter, 
         nocs_pose = np.asarray(nocs_pose_override, dtype=np.float64)
     # --- candidates ---
     t0 = t()
-    rng_ids = np.random.choice(len(ob_pts), size=min(n_surface_samples, len(ob_pts)), replace=False)
+    if explicit:
+        rs = np.random.RandomState()
+        rs.set_state(nunocs_predrawn['end_state'])
+        rng_ids = rs.choice(len(ob_pts), size=min(n_surface_samples, len(ob_pts)), replace=False)
+        state_before_scoring = rs.get_state()
+    else:
+        rng_ids = np.random.choice(len(ob_pts), size=min(n_surface_samples, len(ob_pts)), replace=False)
+        state_before_scoring = None
     if sphere_pts is None:
         g = np.random.default_rng(0).normal(size=(30, 3)); g[:, 0] = np.abs(g[:, 0]) + 1.0       # directions within a cone about +x
         sphere_pts = g / np.linalg.norm(g, axis=1, keepdims=True)
@@ -137,11 +169,10 @@ def evaluate_object(ob_pts, ob_normals, scene_pts, K, gripper, grasp_predicter, 
     surv = torch.cat(surv).contiguous()
     lap('filterGraspPose', t0)
     n = surv.shape[0]
-    out = {'n_evaluated': n_evaluated, 'nocs_pose': nocs_pose}
+    prep = {'n_evaluated': n_evaluated, 'nocs_pose': nocs_pose, 'n': n, 'ob_pts': ob_pts, 'ob_normals': ob_normals, 'np_state': state_before_scoring,
+            'surv_np': surv.cpu().numpy().astype(np.float64), 'p_t_g': None}
     if n == 0:
-        out.update(poses=np.zeros((0, 4, 4), np.float32), p_G=np.zeros(0), p_T_given_G=np.zeros(0), p_T_G=np.zeros(0))
-        return out
-    surv_np = surv.cpu().numpy().astype(np.float64)
+        return prep
     # --- affordance ---
     t0 = t()
     if canonical is not None and nocs_pose is not None:
@@ -149,13 +180,27 @@ def evaluate_object(ob_pts, ob_normals, scene_pts, K, gripper, grasp_predicter, 
         nrm = np.asarray(canonical['normals']) @ nocs_pose[:3, :3].T
         sel = np.arange(0, len(full), max(1, len(full) // 2000))
         model = aff_mod.AffordanceModel(full[sel], nrm[sel], full, canonical['affordance'], device=dev)
-        p_t_g = aff_mod.compute_grasp_affordance(model, surv_np, gripper['gripper_in_grasp'], gripper['finger_vertices'], gripper['grip_dirs'])
+        prep['p_t_g'] = aff_mod.compute_grasp_affordance(model, prep['surv_np'], gripper['gripper_in_grasp'], gripper['finger_vertices'], gripper['grip_dirs'])
     else:
-        p_t_g = np.ones(n)
+        prep['p_t_g'] = np.ones(n)
     lap('affordance', t0)
-    # --- grasp quality ---
-    t0 = t()
-    cloud = transforms.DeviceCloud(ob_pts, ob_normals, dev)
+    return prep
+
+
+def score_object(prep, grasp_predicter, rng=None, timings=None, on_scoring_draws=None):
+    """The grasp-Q scoring pass over prepare_object's survivors + the ranking by P(T,G) (run_grasp_simulation.py:296-329).  A prep made
+    from an explicit generator state first moves numpy's GLOBAL generator to where that object's scoring draws begin -- the position
+    the serial loop reaches there -- so the global stream advances exactly as in the reference's loop."""
+    dev = grasp_predicter.device
+    if prep['np_state'] is not None:
+        np.random.set_state(prep['np_state'])
+    n, surv_np, p_t_g = prep['n'], prep['surv_np'], prep['p_t_g']
+    out = {'n_evaluated': prep['n_evaluated'], 'nocs_pose': prep['nocs_pose']}
+    if n == 0:
+        out.update(poses=np.zeros((0, 4, 4), np.float32), p_G=np.zeros(0), p_T_given_G=np.zeros(0), p_T_G=np.zeros(0))
+        return out
+    t0 = time.perf_counter()
+    cloud = transforms.DeviceCloud(prep['ob_pts'], prep['ob_normals'], dev)
     rng = rng or getattr(grasp_predicter, 'rng', 'device')
     if rng == 'numpy':         # the reference's stream (dataset_grasp.py:72-73), replayed one chunk ahead of the device
         if on_scoring_draws is not None:     # numpy's generator stands at the first of this pass's n resampling draws
@@ -170,7 +215,7 @@ def evaluate_object(ob_pts, ob_normals, scene_pts, K, gripper, grasp_predicter, 
     finally:
         if hasattr(ids, 'close'):
             ids.close()
-    lap('grasp-Q scoring', t0)
+    _lap(timings, 'grasp-Q scoring', t0)
     valid = np.isfinite(p_t_g)                    # the reference drops grasps without a finger contact (:68-70)
     p_tg = np.where(valid, p_t_g, 0.0) * p_g
     order = np.argsort(-p_tg, kind='stable')
@@ -179,22 +224,55 @@ def evaluate_object(ob_pts, ob_normals, scene_pts, K, gripper, grasp_predicter, 
     return out
 
 
-def evaluate_objects(objects, scene_pts, K, gripper, grasp_predicter, nunocs_predicter, draw_ahead=True, timings=None, **kw):
+_STAGE_POOL, _STAGE_STREAMS = [], {}
+
+
+def _stage_worker():
+    """The one thread that runs the NEXT object's pre-scoring stages (evaluate_objects, overlap='stages')."""
+    if not _STAGE_POOL:
+        from concurrent.futures import ThreadPoolExecutor
+        _STAGE_POOL.append(ThreadPoolExecutor(max_workers=1, thread_name_prefix='catgrasp-object-stages'))
+    return _STAGE_POOL[0]
+
+
+def _stage_stream(device):
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    if key not in _STAGE_STREAMS:
+        _STAGE_STREAMS[key] = torch.cuda.Stream(device=key)
+    return _STAGE_STREAMS[key]
+
+
+def evaluate_objects(objects, scene_pts, K, gripper, grasp_predicter, nunocs_predicter, draw_ahead=True, timings=None, overlap=None, **kw):
     """evaluate_object over the segmented objects of a scene, in order (the loop of compute_candidate_grasp,
     run_grasp_simulation.py:188-329) -- same results, same numpy generator state afterwards as calling evaluate_object per object.
 
-    objects: [dict(ob_pts, ob_normals [, canonical, symmetry_tfs, nocs_pose_override])].  draw_ahead: with the reference's streams
-    (rng='numpy', ransac_sampling='reference') the 2 x 10,000 hypothesis samples of object k+1's NunocsPredicter.predict are ~80 ms
-    of sequential host work (numpy's Fisher-Yates rejection walk) that the serial loop exposes after the NUNOCS network of every
-    object.  Their position in numpy's stream is known as soon as object k's survivor count is -- the scoring pass of object k draws
-    exactly one resampling row per survivor in between -- so they are drawn on a second thread while the device scores object k:
-    that thread first advances a copy of the generator over object k's resampling rows (transforms.advance_choice_rows: the rows
-    themselves are produced a chunk ahead of the device by the stream worker, as before), then replays object k+1's draws from
-    there.  NunocsPredicter.predict takes them only if numpy's generator really stands where they started (it does, unless a
-    caller's own code drew in between: then they are dropped and drawn afresh).  timings: optional list, one dict per object."""
+    objects: [dict(ob_pts, ob_normals [, canonical, symmetry_tfs, nocs_pose_override])].  timings: optional list, one dict per object.
+    overlap (default: 'stages' when draw_ahead and the predicter's draws can be made ahead, else None):
+      'stages' -- object k+1's WHOLE pre-scoring half (prepare_object: occupancy ray cast, NUNOCS network + decode, the 2 x 10,000
+          hypothesis draws and the RANSAC kernels, cone sampler, collision filter, affordance) runs on a second thread and a second HIP
+          stream while the device scores object k (195 of an object's ~240 ms at the C3 sizes).  What makes this legal under the
+          reference's ONE global numpy stream: every draw of the pre-scoring half is replayed from an EXPLICIT generator state -- the
+          state the serial loop would have reached there, known as soon as object k's survivor count is (its scoring pass draws exactly
+          one resampling row per survivor; transforms.advance_choice_rows walks a copy of the generator over them) -- and the global
+          generator is moved to the matching position before each scoring pass (score_object).  Object 0's draws start at entry, under
+          its own occupancy and NUNOCS stages.
+      'draws'  -- round 5's form: only the next object's NUNOCS-stage draws (~80 ms of sequential host work: numpy's Fisher-Yates
+          rejection walk) are made ahead, on a second thread; NunocsPredicter.predict takes them only if numpy's generator really
+          stands where they started.
+      None     -- the serial loop."""
+    from . import engine
     from . import predicter as pred_mod
     rng = kw.get('rng') or getattr(grasp_predicter, 'rng', 'device')
-    ahead = draw_ahead and rng == 'numpy' and getattr(nunocs_predicter, '_predraw', False)
+    can_predraw = bool(getattr(nunocs_predicter, '_predraw', False))
+    if overlap is None:
+        overlap = 'stages' if (draw_ahead and can_predraw and kw.get('ik') is None) else None
+    if overlap == 'stages' and not can_predraw:
+        overlap = None
+    if overlap == 'draws' and not (rng == 'numpy' and can_predraw):
+        overlap = None
+    if overlap == 'stages':
+        return _evaluate_objects_overlapped(objects, scene_pts, K, gripper, grasp_predicter, nunocs_predicter, rng, timings, kw)
+    ahead = overlap == 'draws'
     results, pending = [], [None]
     for k, ob in enumerate(objects):
         nxt = objects[k + 1] if k + 1 < len(objects) else None
@@ -220,3 +298,49 @@ def evaluate_objects(objects, scene_pts, K, gripper, grasp_predicter, nunocs_pre
             timings.append(tm)
     return results
 
+
+def _evaluate_objects_overlapped(objects, scene_pts, K, gripper, grasp_predicter, nunocs_predicter, rng, timings, kw):
+    """evaluate_objects(overlap='stages'): see there."""
+    from . import engine
+    dev = grasp_predicter.device
+    side, pool, prec = _stage_stream(dev), _stage_worker(), engine.current_precision()
+    prep_kw = {k: v for k, v in kw.items() if k != 'rng'}
+    n_pts = grasp_predicter.cfg['n_pts']
+    main = torch.cuda.current_stream(dev)
+
+    def submit(ob, state, tm):
+        ready = torch.cuda.Event(); ready.record(main)          # the stages may read what the caller's stream produced so far
+
+        def work():
+            with torch.cuda.device(dev), torch.cuda.stream(side), torch.no_grad(), engine.precision(prec):
+                side.wait_event(ready)
+                prep = prepare_object(ob['ob_pts'], ob['ob_normals'], scene_pts, K, gripper, grasp_predicter, nunocs_predicter,
+                                      canonical=ob.get('canonical'), symmetry_tfs=ob.get('symmetry_tfs'),
+                                      nocs_pose_override=ob.get('nocs_pose_override'), timings=tm, np_state=state, **prep_kw)
+                side.synchronize()
+            return prep
+        return pool.submit(work)
+
+    results = []
+    tms = [({} if timings is not None else None) for _ in objects]
+    fut = submit(objects[0], np.random.get_state(), tms[0]) if objects else None
+    try:
+        for k, ob in enumerate(objects):
+            t0 = time.perf_counter()
+            prep, fut = fut.result(), None
+            if tms[k] is not None:
+                tms[k]["waiting for this object's pre-scoring stages"] = time.perf_counter() - t0
+            if k + 1 < len(objects):
+                rows = prep['n'] if rng == 'numpy' else 0          # what this object's scoring pass will draw from the stream
+                n_valid = int(transforms.valid_mask(np.asarray(ob['ob_pts'], dtype=np.float64)).sum())
+                st = prep['np_state']
+                state_fn = (lambda st=st, nv=n_valid, r=rows: transforms.advance_choice_rows(st, nv, n_pts, r)) if rows else st
+                fut = submit(objects[k + 1], state_fn, tms[k + 1])
+            results.append(score_object(prep, grasp_predicter, rng=rng, timings=tms[k]))
+    except BaseException:
+        if fut is not None:
+            fut.exception()                     # let the stage thread finish before the error travels on
+        raise
+    if timings is not None:
+        timings.extend(tms)
+    return results

@@ -500,16 +500,21 @@ class NunocsPredicter:
                     'seconds': time.perf_counter() - t0}
         return pool.submit(run)
 
-    def predict(self, data, ids=None, predrawn=None):
+    def predict(self, data, ids=None, predrawn=None, explicit_stream=False):
         """predicter.py:135-203: (nocs_cloud, 4x4 nocs_pose) or (None, None).  The 9-D RANSAC alignment
         (predicter.py:159-203 -> aligning.estimate9DTransform) runs on the device by default (`align_fn`).
         predrawn: the result of draw_ahead() for THIS call; used iff numpy's generator stands exactly where the draws started (and the
         cloud has the size they were made for) -- the call then returns the same values and leaves the same generator state as
-        without it -- and silently ignored otherwise."""
+        without it -- and silently ignored otherwise.
+        explicit_stream (with predrawn): the draws were made from an explicit generator state and numpy's GLOBAL generator is neither
+        checked nor moved -- pipeline.prepare_object running ahead of the global stream; the caller owns the stream position."""
         thresholds, max_iter = list(self.RANSAC_THRESHOLDS), self.RANSAC_MAX_ITER
         draw = []
-        if predrawn is not None and (ids is not None or not transforms.same_state(np.random.get_state(), predrawn['start_state'])
-                                     or predrawn['n_valid'] != int(transforms.valid_mask(np.asarray(data['cloud_xyz'], dtype=np.float64)).sum())):
+        if explicit_stream and predrawn is None:
+            raise ValueError('explicit_stream needs the pre-drawn values of draw_ahead()')
+        if predrawn is not None and not explicit_stream and (
+                ids is not None or not transforms.same_state(np.random.get_state(), predrawn['start_state'])
+                or predrawn['n_valid'] != int(transforms.valid_mask(np.asarray(data['cloud_xyz'], dtype=np.float64)).sum())):
             predrawn = None
         if predrawn is not None:
             ids = predrawn['ids']
@@ -525,7 +530,7 @@ class NunocsPredicter:
         except BaseException as e:
             for d in draw:
                 d.cancel()                     # the reference would not have reached its hypothesis draws either
-            if predrawn is not None and isinstance(e, (FloatingPointError, IndexError)):
+            if predrawn is not None and not explicit_stream and isinstance(e, (FloatingPointError, IndexError)):
                 # raised after the transform's resampling draw: the serial path has consumed that one row by now (draw_ids_reference in
                 # predict_nocs), so the generator is left there whether or not the draws were made ahead
                 np.random.set_state(predrawn['after_ids_state'])
@@ -536,7 +541,8 @@ class NunocsPredicter:
         hyp = draw[0].result() if draw else None
         if predrawn is not None:
             hyp = predrawn['heads']
-            np.random.set_state(predrawn['end_state'])      # where the reference's own draws would have left the generator
+            if not explicit_stream:
+                np.random.set_state(predrawn['end_state'])      # where the reference's own draws would have left the generator
         t2 = time.perf_counter()
         ori = dt['cloud_xyz_original']
         best_ratio, best_transform = 0, None

@@ -239,15 +239,13 @@ def group_mlp_max(xyz, points, new_xyz, idx, W, check_indices=True, channels_las
     return out
 
 
-def group_all_mlp_max(xyz, points, W, fused=False, rows=None, chain=True):
+def group_all_mlp_max(xyz, points, W, fused=False, rows=None):
     """The group-all layer (sample_and_group_all, pointnet2.py:132-149, + the shared MLP + max over ALL points): xyz (B,N,3), points
     (B,N,D) | None -> (B, C_out).  One group per cloud means B * ceil(N / 64) row tiles: a handful for a PointNet++ head (N = 128), so
     the layers run as row-batched GEMMs over all B * N rows ([cg_sa_concat_input ->] cg_gemm_bias_act per hidden layer ->
     cg_gemm_bias_relu_groupmax: the 32 x 32 output tiles of every layer spread over the chip, the last layer's max over the points in
     its epilogue; the hidden activations, B * N x <= 512 floats, are the only intermediates).  rows: the (B * N, cin) input matrix
     [features | xyz | pad] when the previous level already wrote it (group_mlp_max(append_xyz=...)): no concatenation pass.
-    chain (default): up to 2,048 output tiles per layer (16 clouds of 128 points) the GEMM chain is ONE launch (cg_gemm_chain: the layers
-    separated by a device-wide barrier; same bits as the launches); chain=False: one launch per layer.
     fused=True: the fused tile kernel takes the layer whole (cg_sa_tile_mlp_max, idx == NULL) -- measured 6..9 x slower at 1..16 clouds
     of 128 points (profiles/r5_pp_encoder_first.json: two 64-row tiles per cloud carry 0.72 MMAC per row on one CU each), kept for the
     parity tests of the kernel's index-free mode."""
@@ -280,10 +278,6 @@ def group_all_mlp_max(xyz, points, W, fused=False, rows=None, chain=True):
     else:
         h = torch.empty((B * N, W.cin[0]), dtype=torch.float32, device=xyz.device)
         check(L.lib().cg_sa_concat_input(_p(xyz), _p(points), _c_long(B * N), _c_int(D), _c_int(W.cin[0]), _p(h), _stream()), 'cg_sa_concat_input')
-    # few rows (a PointNet++ head: 128 points per cloud): the whole chain, with the last layer's max in its epilogue, as ONE launch
-    chained = ops.gemm_chain(h, [(wp, b, co, True) for wp, b, co in zip(W.w, W.b, W.cout)], rows_per_group_max=N) if chain else None
-    if chained is not None:
-        return chained
     for wp, b, co in zip(W.w[:-1], W.b[:-1], W.cout[:-1]):
         h = ops.gemm_bias_act(h, wp, co, bias=b, relu=True)
     out = torch.empty((B, C), dtype=torch.float32, device=xyz.device)       # last layer: the max over the N points in the GEMM's epilogue

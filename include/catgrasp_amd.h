@@ -93,30 +93,13 @@ int cg_gemm_bias_act(const float* x, int M, int K, int ldx, const float* w_packe
                      const float* bias, const float* row_bias, int rows_per_group, int ld_rb,
                      int relu, int eye_k, float* y, int ldy, void* stream);
 
-/* A chain of up to 4 such layers as ONE launch: out[0] = act(x . W0^T + b0), out[l] = act(out[l-1] . Wl^T + bl) -- the FC tails of
- * STN3d / STNkd / PointNetCls (pointnet2.py:178-185, :216-223, :295-298) for a predict_batch call of a few poses, and the group-all
- * level of the set-abstraction encoder (sample_and_group_all + shared MLP + max, :132-149).  Layers are separated by a device-wide
- * barrier inside the kernel instead of a kernel boundary; every element is computed by the MFMA sequence of cg_gemm_bias_act, so the
- * results are those of the separate launches bit for bit.  h_K / h_N / h_w_packed / h_bias / h_relu / h_out: HOST arrays of n_layers
- * entries (h_K[l] == h_N[l-1]; x (M, h_K[0]) dense; h_out[l] (M, h_N[l]) dense, 16-byte aligned -- the hidden ones are workspace).
- * eye_k_last: flattened identity added to the last layer (cg_gemm_bias_act's eye_k).  rows_per_group_max > 0: the last layer is
- * cg_gemm_bias_relu_groupmax -- h_out[last] is (M / rows_per_group_max, N), zeroed by the kernel itself.
- * state: ONE device int the caller zero-initialises once; the kernel finds it zero and leaves it zero.  Chains in flight at the same
- * time (different streams) need different state words.  CG_ERR_UNSUPPORTED when a layer has more than 2,048 32 x 32 output tiles
- * (M beyond ~128 rows for a 4,096-wide layer): issue the layers one by one then. */
-int cg_gemm_chain(const float* x, int M, int n_layers, const int* h_K, const int* h_N, const float* const* h_w_packed,
-                  const float* const* h_bias, const int* h_relu, int eye_k_last, int rows_per_group_max, float* const* h_out,
-                  int* state, void* stream);
-
 /* PointNetCls.forward (pointnet2.py:289-299; eval mode, exact-f32 kernels) as ONE call: the three cg_pointmlp_max passes and nine
  * cg_gemm_bias_act layers issued back to back -- the launch chain of a predict_batch call of a few poses without ~10 us of caller-side
  * work per launch.  Same kernels, arguments and order as issuing them one by one: identical results.
  * w: HOST struct of DEVICE pointers to the BatchNorm-folded, packed weights (catgrasp_amd.folding.prepare_cls; names as there).
  * ws: caller-owned device workspace of cg_pointnet_cls_workspace_floats(B) floats, 16-byte aligned.  logits: (B, n_out).
  * *trans_feat_t (optional, HOST pointer to a device pointer): receives the address, inside ws, of the (B,64,64) feature transform,
- * TRANSPOSED like cg_pointmlp_max's t64 (PointNetCls returns it as trans_feat, pointnet2.py:299).
- * chain_state (optional): the barrier word of cg_gemm_chain (one zero-initialised device int per stream): with it, a batch of up to
- * ~128 poses runs each FC tail as one chain launch (3 + 3 launches per forward instead of 3 + 9); NULL = one launch per layer. */
+ * TRANSPOSED like cg_pointmlp_max's t64 (PointNetCls returns it as trans_feat, pointnet2.py:299). */
 typedef struct cg_cls_weights {
   const float *stn_w1, *stn_b1, *stn_w2, *stn_b2, *stn_w3, *stn_b3, *stn_fc1, *stn_fc1b, *stn_fc2, *stn_fc2b, *stn_fc3, *stn_fc3b;
   const float *enc_w1, *enc_b1, *fstn_wm, *fstn_bm, *fstn_w2, *fstn_b2, *fstn_w3, *fstn_b3;
@@ -127,7 +110,7 @@ typedef struct cg_cls_weights {
 } cg_cls_weights;
 size_t cg_pointnet_cls_workspace_floats(int B);
 int cg_pointnet_cls_forward(const float* x, int B, int N, const cg_cls_weights* h_weights, int nsplit, float* workspace, float* logits,
-                            float** trans_feat_t, int* chain_state, void* stream);
+                            float** trans_feat_t, void* stream);
 
 /* Split-precision ("bf16x3") variant of cg_gemm_bias_act for the wide FC tails / segmentation head: every product block
  * is three bf16 MFMAs with f32 accumulation, X is split on the fly, W is split-packed on the host

@@ -93,6 +93,26 @@ case $JOB in
     CATGRASP_AMD_GEMM_CHAIN=0 timeout 300 python scripts/pp_encoder_profile.py $O/pp_encoder_nochain.json > $O/pp_encoder_nochain.txt 2>&1; tail -4 $O/pp_encoder_nochain.txt
     stats pp_encoder python scripts/pp_encoder_profile.py --trace
     head -14 $O/pp_encoder_kernel_stats.csv | cut -c1-170 ;;
+  r6d)        # tickets in the filter, cheaper chain barrier, overlapped pick cycle
+    timeout 300 python scripts/time_filter_plan.py > $O/time_tickets.txt 2>&1; tail -1 $O/time_tickets.txt
+    CATGRASP_AMD_FILTER_STATIC=1 timeout 300 python scripts/time_filter_plan.py > $O/time_static.txt 2>&1; tail -1 $O/time_static.txt
+    timeout 300 python scripts/time_filter_plan.py 400000 > $O/time_tickets_400k.txt 2>&1; tail -1 $O/time_tickets_400k.txt
+    CATGRASP_AMD_FILTER_STATIC=1 timeout 300 python scripts/time_filter_plan.py 400000 > $O/time_static_400k.txt 2>&1; tail -1 $O/time_static_400k.txt
+    timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES --kernel-include-regex filter_grasp_pose_kernel --output-format csv -d $O/p_t -- python scripts/time_filter_plan.py --pmc > $O/p_t.log 2>&1
+    python scripts/pmc_summary.py $O/p_t $O/pmc_tickets.csv > /dev/null; rm -rf $O/p_t; grep "true, true" $O/pmc_tickets.csv
+    timeout 1500 python -m pytest tests/test_collision_gpu.py tests/test_workload_gpu.py tests/test_pipeline_gpu.py tests/test_pointnet_gpu.py tests/test_pointnet2_encoder_gpu.py -m gpu -q -x > $O/pytest.log 2>&1; tail -8 $O/pytest.log
+    CATGRASP_AMD_GEMM_CHAIN=1 timeout 300 python scripts/time_predict_small.py > $O/predict_small_chain.txt 2>&1; echo --- chain; grep candidates $O/predict_small_chain.txt | head -4
+    CATGRASP_AMD_GEMM_CHAIN=0 timeout 300 python scripts/time_predict_small.py > $O/predict_small_nochain.txt 2>&1; echo --- no chain; grep candidates $O/predict_small_nochain.txt | head -4
+    CATGRASP_AMD_GEMM_CHAIN=1 timeout 300 python scripts/pp_encoder_profile.py $O/pp_encoder_chain.json > $O/pp_encoder_chain.txt 2>&1; grep -o '"clouds": [0-9]*\|"encoder_ms": [0-9.]*\|gemm_chain": [0-9.]*' $O/pp_encoder_chain.txt | head -12
+    CATGRASP_AMD_GEMM_CHAIN=0 timeout 300 python scripts/pp_encoder_profile.py $O/pp_encoder_nochain.json > $O/pp_encoder_nochain.txt 2>&1; grep -o '"clouds": [0-9]*\|"encoder_ms": [0-9.]*\|gemm_chain": [0-9.]*' $O/pp_encoder_nochain.txt | head -12
+    timeout 600 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pmc-traffic --no-rccl-selftest --no-projection --no-configs --secondary "" > $O/bench.json 2> $O/bench.err; tail -c 300 $O/bench.err
+    python -c "import json;d=json.load(open('$O/bench.json'));p=d['api']['pick_cycle'];print(json.dumps({k:(v['wall_ms_per_object'] if isinstance(v,dict) and 'wall_ms_per_object' in v else v) for k,v in p.items() if k!='note'},indent=1)[:1500]);print(json.dumps(p['default']['ms_per_object_by_stage']))" ;;
+  r6e)        # filter workgroups-per-CU knob, overlapped pick cycle with wait instrumentation
+    for cap in 16 32 64 4096; do echo cap $cap; CATGRASP_AMD_FILTER_BLOCKS_PER_CU=$cap timeout 300 python scripts/time_filter_plan.py > $O/time_cap$cap.txt 2>&1; tail -1 $O/time_cap$cap.txt | cut -c1-200; done
+    CATGRASP_AMD_FILTER_BLOCKS_PER_CU=4096 timeout 300 python scripts/time_filter_plan.py 400000 > $O/time_cap4096_400k.txt 2>&1; tail -1 $O/time_cap4096_400k.txt | cut -c1-200
+    timeout 1500 python -m pytest tests/test_pipeline_gpu.py tests/test_collision_gpu.py tests/test_pointnet_gpu.py tests/test_pointnet2_encoder_gpu.py -m gpu -q -x > $O/pytest.log 2>&1; tail -4 $O/pytest.log
+    timeout 600 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pmc-traffic --no-rccl-selftest --no-projection --no-configs --secondary "" > $O/bench.json 2> $O/bench.err; tail -c 300 $O/bench.err
+    python -c "import json;d=json.load(open('$O/bench.json'));p=d['api']['pick_cycle'];print(json.dumps({k:(v['wall_ms_per_object'] if isinstance(v,dict) and 'wall_ms_per_object' in v else v) for k,v in p.items() if k!='note'},indent=1)[:1500]);print(json.dumps(p['default']['ms_per_object_by_stage']))" ;;
   py)         # any script:  py scripts/x.py args...
     timeout 1200 python "$@" > $O/out.txt 2>&1; tail -40 $O/out.txt ;;
   *) echo "unknown job $JOB"; exit 2 ;;

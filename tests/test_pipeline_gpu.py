@@ -90,8 +90,8 @@ def test_evaluate_objects_draw_ahead_equals_the_serial_loop(cuda_device):
         used = []
         orig = npred.predict
 
-        def spy(data, ids=None, predrawn=None):
-            r = orig(data, ids, predrawn)
+        def spy(data, ids=None, predrawn=None, **kw_):
+            r = orig(data, ids, predrawn, **kw_)
             used.append(predrawn is not None and 'ransac id draw (exposed)' in npred.timings and npred.timings['ransac id draw (exposed)'] < 5e-3)
             return r
         npred.predict = spy
@@ -101,13 +101,28 @@ def test_evaluate_objects_draw_ahead_equals_the_serial_loop(cuda_device):
             del npred.predict
         return outs, np.random.get_state(), used
     serial, st_serial, _ = run(draw_ahead=False)
-    ahead, st_ahead, used = run(draw_ahead=True)
+    ahead, st_ahead, used = run(overlap='draws')
     assert transforms.same_state(st_serial, st_ahead)
     assert used[0] is False and all(used[1:])                   # objects 1.. took their pre-drawn hypothesis samples without waiting
-    for a, b in zip(serial, ahead):
-        assert a['n_evaluated'] == b['n_evaluated'] and len(a['poses']) > 0
-        assert np.array_equal(a['poses'], b['poses']) and np.array_equal(a['p_G'], b['p_G']) and np.array_equal(a['p_T_G'], b['p_T_G'])
-        assert (a['nocs_pose'] is None) == (b['nocs_pose'] is None) and (a['nocs_pose'] is None or np.array_equal(a['nocs_pose'], b['nocs_pose']))
+    # the default -- the WHOLE pre-scoring half of object k+1 (occupancy, NUNOCS + RANSAC, cone sampler, filter, affordance)
+    # on a second thread + stream under object k's scoring pass, every draw replayed from an explicit generator state
+    tms = []
+    staged, st_staged, used_s = run(timings=tms)
+    assert transforms.same_state(st_serial, st_staged) and all(used_s) and len(tms) == len(job)
+    assert all({'occupancy', 'nunocs+ransac', 'filterGraspPose', 'affordance', 'grasp-Q scoring'} <= set(t) for t in tms)
+    for other in (ahead, staged):
+        for a, b in zip(serial, other):
+            assert a['n_evaluated'] == b['n_evaluated'] and len(a['poses']) > 0
+            assert np.array_equal(a['poses'], b['poses']) and np.array_equal(a['p_G'], b['p_G']) and np.array_equal(a['p_T_G'], b['p_T_G'])
+            assert (a['nocs_pose'] is None) == (b['nocs_pose'] is None) and (a['nocs_pose'] is None or np.array_equal(a['nocs_pose'], b['nocs_pose']))
+    # the device-draw scoring mode (no numpy rows in the scoring pass: the stream passes through it untouched)
+    kw_dev = dict(kw, rng='device')
+    np.random.seed(3); d_serial = pipeline.evaluate_objects(job, scene_pts, K, g, gp, npred, draw_ahead=False, **kw_dev); st_d = np.random.get_state()
+    np.random.seed(3); d_staged = pipeline.evaluate_objects(job, scene_pts, K, g, gp, npred, **kw_dev)
+    assert transforms.same_state(st_d, np.random.get_state())
+    for a, b in zip(d_serial, d_staged):      # the device draw takes a fresh seed per call: same survivors, not the same scores / order
+        key = lambda r: np.ascontiguousarray(r['poses']).reshape(len(r['poses']), 16)
+        assert a['n_evaluated'] == b['n_evaluated'] and np.array_equal(np.unique(key(a), axis=0), np.unique(key(b), axis=0))
     # the per-object calls of the reference loop give the same again
     np.random.seed(3)
     for ob, want in zip(job, serial):

@@ -146,8 +146,6 @@ def test_group_all_layer_gemm_chain_and_fused(cuda_device, B, N, D, mlp):
     W = sa._weights(cuda_device)
     chain = prim.group_all_mlp_max(xyz.cuda(), pts.cuda() if D else None, W, fused=False)
     assert chain.shape == (B, mlp[-1]) and _relerr(chain.cpu(), ref) <= 1e-5
-    # the one-launch chain (default) == one launch per layer, bit for bit
-    assert torch.equal(chain, prim.group_all_mlp_max(xyz.cuda(), pts.cuda() if D else None, W, fused=False, chain=False))
     if W.cin[0] <= W.TILE_MAX_CIN:
         fused = prim.group_all_mlp_max(xyz.cuda(), pts.cuda() if D else None, W, fused=True)
         assert _relerr(fused.cpu(), ref) <= 1e-5

@@ -98,73 +98,6 @@ def test_dense_layer_bits_do_not_depend_on_the_kernel_or_the_batch(cuda_device):
         finally:
             engine.FUSED_LAUNCH_MAX_B = old
     assert torch.equal(one_call[0], chain[0]) and torch.equal(one_call[1], chain[1])
-    # ... and == the same one call with every FC tail as separate launches (no chain kernel), for 1 .. 128 poses and beyond the chain's regime
-    for B in (1, 16, 37, 128, 200):
-        xb = torch.from_numpy(rng.normal(0, 0.3, (B, 257, 6)).astype(np.float32)).to(cuda_device)
-        with engine.precision('f32'):
-            a = engine.cls_forward(W, xb)
-            ops.USE_GEMM_CHAIN = False
-            try:
-                b_ = engine.cls_forward(W, xb)
-            finally:
-                ops.USE_GEMM_CHAIN = True
-        assert torch.equal(a[0], b_[0]) and torch.equal(a[1], b_[1]), B
-    assert int(ops.chain_state(cuda_device).item()) == 0            # the barrier word is left at zero
-
-
-def test_gemm_chain_equals_the_layers_launched_one_by_one(cuda_device):
-    """cg_gemm_chain (layers separated by a device-wide barrier inside ONE launch) against cg_gemm_bias_act / cg_gemm_bias_relu_groupmax per
-    layer: bit-identical, for the FC-tail shapes (with the flattened identity), the group-all chain (max over row groups in the last
-    layer's epilogue), one and four layers, row counts from 1 to the chain's limit, repeated launches on the same barrier word, two
-    streams with chains in flight together; shapes beyond the regime are refused (None) rather than run."""
-    from catgrasp_amd import folding, ops
-    rng = np.random.default_rng(12)
-
-    def layer(K, N):
-        w = rng.normal(0, 1.0 / np.sqrt(K), (N, K)).astype(np.float32); b = rng.normal(0, 0.1, N).astype(np.float32)
-        return torch.from_numpy(folding.pack_b(w)).to(cuda_device), torch.from_numpy(b).to(cuda_device)
-
-    def by_launches(x, layers, eye, gmax):
-        h = x
-        for i, (wp, b, n, relu) in enumerate(layers):
-            last = i == len(layers) - 1
-            if last and gmax:
-                return ops.group_max(ops.gemm_bias_act(h, wp, n, b, relu=True), h.shape[0] // gmax)
-            h = ops.gemm_bias_act(h, wp, n, b, relu=relu, eye_k=eye if last else 0)
-        return h
-    cases = [((1024, 512, 256, 9), (True, True, False), 3, 0, (1, 7, 32, 33, 128)),
-             ((1024, 512, 256, 4096), (True, True, False), 64, 0, (1, 16, 100, 512)),
-             ((264, 256, 512, 1024), (True, True, True), 0, 128, (128, 1024, 2048)),
-             ((264, 256, 512, 1024), (True, True, True), 0, 77, (77, 77 * 5)),
-             ((72, 96), (True,), 0, 0, (5, 300)),
-             ((64, 64, 128, 256, 40), (True, False, True, False), 0, 0, (19, 1000))]
-    for dims, relus, eye, gmax, Ms in cases:
-        layers = [layer(k, n) + (n, r) for k, n, r in zip(dims[:-1], dims[1:], relus)]
-        for M in Ms:
-            x = torch.from_numpy(rng.normal(0, 1, (M, dims[0])).astype(np.float32)).to(cuda_device)
-            want = by_launches(x, layers, eye, gmax)
-            for _ in range(3):
-                got = ops.gemm_chain(x, layers, eye_k_last=eye, rows_per_group_max=gmax)
-                assert got is not None and torch.equal(got, want), (dims, M)
-    assert int(ops.chain_state(cuda_device).item()) == 0
-    # beyond the regime: refused
-    layers = [layer(256, 4096) + (4096, False)]
-    assert ops.gemm_chain(torch.zeros((1024, 256), device=cuda_device), layers) is None
-    # two streams, chains in flight together (each stream has its own barrier word)
-    dims = (1024, 512, 256, 4096)
-    layers = [layer(k, n) + (n, r) for k, n, r in zip(dims[:-1], dims[1:], (True, True, False))]
-    xs = [torch.from_numpy(rng.normal(0, 1, (64, 1024)).astype(np.float32)).to(cuda_device) for _ in range(2)]
-    wants = [by_launches(x, layers, 64, 0) for x in xs]
-    streams = [torch.cuda.Stream(device=cuda_device) for _ in range(2)]
-    torch.cuda.synchronize()
-    outs = [[], []]
-    for rep in range(20):
-        for k, st in enumerate(streams):
-            with torch.cuda.stream(st):
-                outs[k].append(ops.gemm_chain(xs[k], layers, eye_k_last=64))
-    torch.cuda.synchronize()
-    for k in range(2):
-        assert all(torch.equal(o, wants[k]) for o in outs[k])
 
 
 @pytest.mark.parametrize('N', [2048, 64, 300])
