@@ -719,8 +719,8 @@ inline Mesh make_mesh(const float* V, const int* F, int nf, const cg_mesh_grid* 
 // Workgroups the collision kernels are launched with at most (grid-stride beyond): 16 per CU.  CATGRASP_AMD_FILTER_BLOCKS_PER_CU (dev
 // knob) changes it: with MORE workgroups than the chip holds at once the dispatcher hands evaluations out as slots free up.
 inline long filter_block_cap() {
-  static const long per_cu = getenv("CATGRASP_AMD_FILTER_BLOCKS_PER_CU") ? atol(getenv("CATGRASP_AMD_FILTER_BLOCKS_PER_CU")) : 16;
-  return 256 * (per_cu > 0 ? per_cu : 16);
+  static const long per_cu = getenv("CATGRASP_AMD_FILTER_BLOCKS_PER_CU") ? atol(getenv("CATGRASP_AMD_FILTER_BLOCKS_PER_CU")) : 32;
+  return 256 * (per_cu > 0 ? per_cu : 32);
 }
 
 inline Mat4 load_mat(const float* h) { Mat4 m; for (int i = 0; i < 16; ++i) m.m[i] = h[i]; return m; }

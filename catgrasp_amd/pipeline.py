@@ -184,6 +184,11 @@ def prepare_object(ob_pts, ob_normals, scene_pts, K, gripper, grasp_predicter, n
     else:
         prep['p_t_g'] = np.ones(n)
     lap('affordance', t0)
+    # --- the scoring pass's device inputs that do not depend on its resampling draw: the object's cloud and the survivors' inverse poses
+    t0 = t()
+    prep['cloud'] = transforms.DeviceCloud(ob_pts, ob_normals, dev)
+    prep['pinv'] = torch.from_numpy(transforms.pose_inverse_rows(prep['surv_np'], prep['cloud'].center)).to(dev)
+    lap('scoring inputs (cloud upload, pose inverses)', t0)
     return prep
 
 
@@ -200,7 +205,7 @@ def score_object(prep, grasp_predicter, rng=None, timings=None, on_scoring_draws
         out.update(poses=np.zeros((0, 4, 4), np.float32), p_G=np.zeros(0), p_T_given_G=np.zeros(0), p_T_G=np.zeros(0))
         return out
     t0 = time.perf_counter()
-    cloud = transforms.DeviceCloud(prep['ob_pts'], prep['ob_normals'], dev)
+    cloud, pinv = prep['cloud'], prep['pinv']
     rng = rng or getattr(grasp_predicter, 'rng', 'device')
     if rng == 'numpy':         # the reference's stream (dataset_grasp.py:72-73), replayed one chunk ahead of the device
         if on_scoring_draws is not None:     # numpy's generator stands at the first of this pass's n resampling draws
@@ -208,7 +213,6 @@ def score_object(prep, grasp_predicter, rng=None, timings=None, on_scoring_draws
         ids = grasp_predicter._numpy_id_chunks(cloud.n, grasp_predicter.cfg['n_pts'], n)
     else:
         ids = transforms.draw_ids_device(cloud.n, grasp_predicter.cfg['n_pts'], n, dev)
-    pinv = torch.from_numpy(transforms.pose_inverse_rows(surv_np, cloud.center)).to(dev)
     try:
         _, _, _, p_g = grasp_predicter.score_on_device(cloud.xyz, cloud.normal, ids, pinv)
         p_g = p_g.cpu().numpy().astype(np.float64)
@@ -255,7 +259,8 @@ def evaluate_objects(objects, scene_pts, K, gripper, grasp_predicter, nunocs_pre
           state the serial loop would have reached there, known as soon as object k's survivor count is (its scoring pass draws exactly
           one resampling row per survivor; transforms.advance_choice_rows walks a copy of the generator over them) -- and the global
           generator is moved to the matching position before each scoring pass (score_object).  Object 0's draws start at entry, under
-          its own occupancy and NUNOCS stages.
+          its own occupancy and NUNOCS stages.  The stages thread runs up to two objects ahead of the scoring loop (an object with few
+          survivors scores faster than its successor prepares; the lead absorbs that).
       'draws'  -- round 5's form: only the next object's NUNOCS-stage draws (~80 ms of sequential host work: numpy's Fisher-Yates
           rejection walk) are made ahead, on a second thread; NunocsPredicter.predict takes them only if numpy's generator really
           stands where they started.
@@ -299,48 +304,70 @@ def evaluate_objects(objects, scene_pts, K, gripper, grasp_predicter, nunocs_pre
     return results
 
 
-def _evaluate_objects_overlapped(objects, scene_pts, K, gripper, grasp_predicter, nunocs_predicter, rng, timings, kw):
-    """evaluate_objects(overlap='stages'): see there."""
+def _evaluate_objects_overlapped(objects, scene_pts, K, gripper, grasp_predicter, nunocs_predicter, rng, timings, kw, depth=2):
+    """evaluate_objects(overlap='stages'): see there.  A producer on the stages thread prepares the objects in order, each from the
+    generator state the previous one leaves behind (prep k's state before scoring, advanced over the rows its scoring pass will draw:
+    both known when prep k is done, so the producer needs nothing from the consumer) and runs up to `depth` objects ahead of the scoring
+    loop -- scoring times vary with the survivor counts, a one-object lead would stall the device whenever an object scores faster
+    than its successor prepares."""
+    import queue
     from . import engine
     dev = grasp_predicter.device
     side, pool, prec = _stage_stream(dev), _stage_worker(), engine.current_precision()
     prep_kw = {k: v for k, v in kw.items() if k != 'rng'}
     n_pts = grasp_predicter.cfg['n_pts']
     main = torch.cuda.current_stream(dev)
+    ready = torch.cuda.Event(); ready.record(main)              # the stages may read what the caller's stream produced so far
+    tms = [({} if timings is not None else None) for _ in objects]
+    q, stop = queue.Queue(maxsize=max(1, depth)), [False]
+    state0 = np.random.get_state()
 
-    def submit(ob, state, tm):
-        ready = torch.cuda.Event(); ready.record(main)          # the stages may read what the caller's stream produced so far
-
-        def work():
+    def produce():
+        state = state0
+        try:
             with torch.cuda.device(dev), torch.cuda.stream(side), torch.no_grad(), engine.precision(prec):
                 side.wait_event(ready)
-                prep = prepare_object(ob['ob_pts'], ob['ob_normals'], scene_pts, K, gripper, grasp_predicter, nunocs_predicter,
-                                      canonical=ob.get('canonical'), symmetry_tfs=ob.get('symmetry_tfs'),
-                                      nocs_pose_override=ob.get('nocs_pose_override'), timings=tm, np_state=state, **prep_kw)
-                side.synchronize()
-            return prep
-        return pool.submit(work)
+                for k, ob in enumerate(objects):
+                    if stop[0]:
+                        return
+                    t_start = time.perf_counter()
+                    prep = prepare_object(ob['ob_pts'], ob['ob_normals'], scene_pts, K, gripper, grasp_predicter, nunocs_predicter,
+                                          canonical=ob.get('canonical'), symmetry_tfs=ob.get('symmetry_tfs'),
+                                          nocs_pose_override=ob.get('nocs_pose_override'), timings=tms[k], np_state=state, **prep_kw)
+                    side.synchronize()
+                    if tms[k] is not None:
+                        tms[k]['stages thread: busy'] = time.perf_counter() - t_start
+                    rows = prep['n'] if rng == 'numpy' else 0          # what this object's scoring pass will draw from the stream
+                    st = prep['np_state']
+                    if rows:            # evaluated on the draw-ahead thread, in front of the next object's draws
+                        n_valid = int(transforms.valid_mask(np.asarray(ob['ob_pts'], dtype=np.float64)).sum())
+                        state = (lambda st=st, nv=n_valid, r=rows: transforms.advance_choice_rows(st, nv, n_pts, r))
+                    else:
+                        state = st
+                    q.put(('prep', prep))
+        except BaseException as e:          # travels to the consumer, in order
+            q.put(('error', e))
 
+    fut = pool.submit(produce)
     results = []
-    tms = [({} if timings is not None else None) for _ in objects]
-    fut = submit(objects[0], np.random.get_state(), tms[0]) if objects else None
     try:
-        for k, ob in enumerate(objects):
+        for k in range(len(objects)):
             t0 = time.perf_counter()
-            prep, fut = fut.result(), None
+            kind, item = q.get()
+            if kind == 'error':
+                raise item
             if tms[k] is not None:
                 tms[k]["waiting for this object's pre-scoring stages"] = time.perf_counter() - t0
-            if k + 1 < len(objects):
-                rows = prep['n'] if rng == 'numpy' else 0          # what this object's scoring pass will draw from the stream
-                n_valid = int(transforms.valid_mask(np.asarray(ob['ob_pts'], dtype=np.float64)).sum())
-                st = prep['np_state']
-                state_fn = (lambda st=st, nv=n_valid, r=rows: transforms.advance_choice_rows(st, nv, n_pts, r)) if rows else st
-                fut = submit(objects[k + 1], state_fn, tms[k + 1])
-            results.append(score_object(prep, grasp_predicter, rng=rng, timings=tms[k]))
+            results.append(score_object(item, grasp_predicter, rng=rng, timings=tms[k]))
     except BaseException:
-        if fut is not None:
-            fut.exception()                     # let the stage thread finish before the error travels on
+        stop[0] = True
+        while fut.running() or not q.empty():       # let the stages thread finish (it may be blocked on a full queue) before the error travels on
+            try:
+                q.get(timeout=0.05)
+            except queue.Empty:
+                pass
         raise
+    fut.result()
     if timings is not None:
         timings.extend(tms)
     return results

@@ -305,9 +305,10 @@ int cg_mesh_grid_fill(const float* vertices, const int* faces, int n_faces, cons
 
 /* The per-candidate resampling draw of GraspDataset.transform (dataset_grasp.py:72-73: np.random.choice(M, n_pts,
  * replace = M < n_pts), once per pose in the loop of predicter.py:71-74) for `count` candidates at once:
- * out (count,n_pts) i32 = base + a uniform n_pts-subset of [0,n_valid) in uniform order (n_valid >= n_pts: up to 8,192 points a
- * workgroup per row sorts 48-bit random keys, beyond that and up to 65,535 a lane per row runs a partial Fisher-Yates in LDS, else
- * CG_ERR_UNSUPPORTED) or iid uniform indices (n_valid < n_pts).
+ * out (count,n_pts) i32 = base + an n_pts-subset of [0,n_valid) in random order (n_valid >= n_pts: the first n_pts values of a keyed
+ * permutation of [0,n_valid) -- a 12-round Feistel bijection of the covering power of four, cycle-walked into the range, round keys
+ * from Philox; up to 1,024 points a workgroup per row sorts 48-bit random keys instead) or iid uniform indices (n_valid < n_pts,
+ * n_pts % 4 == 0, else CG_ERR_UNSUPPORTED).
  * Counter-based Philox4x32-10 keyed by `seed` and the global row index row_offset + r: reproducible, independent of how a
  * batch is split into calls (a GPU shard draws exactly what the unsharded batch would), but NOT numpy's stream. */
 int cg_draw_resample_ids(int n_valid, int n_pts, long count, unsigned long long seed, int base, long row_offset, int* out,

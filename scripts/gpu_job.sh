@@ -113,6 +113,16 @@ case $JOB in
     timeout 1500 python -m pytest tests/test_pipeline_gpu.py tests/test_collision_gpu.py tests/test_pointnet_gpu.py tests/test_pointnet2_encoder_gpu.py -m gpu -q -x > $O/pytest.log 2>&1; tail -4 $O/pytest.log
     timeout 600 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pmc-traffic --no-rccl-selftest --no-projection --no-configs --secondary "" > $O/bench.json 2> $O/bench.err; tail -c 300 $O/bench.err
     python -c "import json;d=json.load(open('$O/bench.json'));p=d['api']['pick_cycle'];print(json.dumps({k:(v['wall_ms_per_object'] if isinstance(v,dict) and 'wall_ms_per_object' in v else v) for k,v in p.items() if k!='note'},indent=1)[:1500]);print(json.dumps(p['default']['ms_per_object_by_stage']))" ;;
+  r6f)        # split kernel without SLP-packed f32 ops; stages-thread instrumentation; filter cap at 400k
+    for i in 1 2 3; do
+      timeout 120 python scripts/quick_cls.py 4096 bf16x3 2>/dev/null | tail -1
+      CATGRASP_AMD_LIB=$PWD/build_abl/lib_split_noslp.so timeout 120 python scripts/quick_cls.py 4096 bf16x3 2>/dev/null | tail -1 | sed 's/^/noslp: /'
+    done | tee $O/split_noslp.txt
+    timeout 300 python scripts/time_filter_plan.py 400000 > $O/time_cap32_400k.txt 2>&1; tail -1 $O/time_cap32_400k.txt | cut -c1-200
+    CATGRASP_AMD_FILTER_BLOCKS_PER_CU=16 timeout 300 python scripts/time_filter_plan.py 400000 > $O/time_cap16_400k.txt 2>&1; tail -1 $O/time_cap16_400k.txt | cut -c1-200
+    timeout 300 python scripts/time_filter_plan.py > $O/time_cap32.txt 2>&1; tail -1 $O/time_cap32.txt | cut -c1-200
+    timeout 600 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pmc-traffic --no-rccl-selftest --no-projection --no-configs --secondary "" > $O/bench.json 2> $O/bench.err; tail -c 300 $O/bench.err
+    python -c "import json;d=json.load(open('$O/bench.json'));p=d['api']['pick_cycle'];print(json.dumps({k:(v['wall_ms_per_object'] if isinstance(v,dict) and 'wall_ms_per_object' in v else v) for k,v in p.items() if k!='note'},indent=1)[:1500]);print(json.dumps(p['default']['ms_per_object_by_stage']))" ;;
   py)         # any script:  py scripts/x.py args...
     timeout 1200 python "$@" > $O/out.txt 2>&1; tail -40 $O/out.txt ;;
   *) echo "unknown job $JOB"; exit 2 ;;

@@ -59,7 +59,7 @@ def test_argument_errors_are_reported_not_crashed():
     L, D3, I3 = ctypes.c_long, (ctypes.c_double * 3)(0, 0, 0), (ctypes.c_int * 3)(4, 4, 4)
     assert lib.cg_draw_resample_ids(0, 2048, L(4), ctypes.c_ulonglong(1), 0, L(0), one, null) == -1               # empty cloud
     assert lib.cg_draw_resample_ids(2500, 2048, L(4), ctypes.c_ulonglong(1), 0, L(-1), one, null) == -1           # negative row offset
-    assert lib.cg_draw_resample_ids(70000, 2048, L(4), ctypes.c_ulonglong(1), 0, L(0), one, null) == -2           # > 65535 without replacement
+    assert lib.cg_draw_resample_ids(600, 2050, L(4), ctypes.c_ulonglong(1), 0, L(0), one, null) == -2             # with replacement, n_pts % 4 != 0
     assert lib.cg_draw_resample_ids(2500, 2048, L(0), ctypes.c_ulonglong(1), 0, L(0), null, null) == 0
     bad_pos = ctypes.c_int(700)
     assert lib.cg_host_numpy_choice_rows(one, ctypes.byref(bad_pos), 2500, 2048, L(1), one, one) == -1            # MT position > 624

@@ -127,3 +127,28 @@ def test_explicit_state_replays_draw_ahead_of_the_global_generator():
         assert T.same_state(np.random.get_state(), s0)            # nothing touched numpy itself
         got = T.draw_ids_reference(n_valid, n_pts, rows)          # the real draws, later: same rows, and the stream arrives where predicted
         assert np.array_equal(got, np.array(ref)) and T.same_state(np.random.get_state(), s1)
+
+
+def test_device_resampling_draw_statistics_on_its_restatement():
+    """The rng='device' resampling draw (csrc/hostprep.hip: a keyed Feistel bijection + cycle walking; restated bit for bit in
+    oracle/draw_bijection_ref.py, the GPU suite compares the two): every row is a subset without repetition, every index is included
+    with the binomial spread of a uniform draw, slots are uniform, pairs of slots are independent, neighbouring rows are unrelated."""
+    from oracle import draw_bijection_ref as dref
+    n, k, rows = 2500, 2048, 1500
+    ids = dref.draw_rows(n, k, rows, seed=2 ** 35 + 12345).astype(np.int64)
+    assert ids.min() >= 0 and ids.max() < n and all(len(np.unique(r)) == k for r in ids[::50])
+    p = k / n
+    cnt = np.bincount(ids.reshape(-1), minlength=n)
+    assert abs(cnt.mean() - rows * p) < 1e-9 and 0.9 < cnt.std() / np.sqrt(rows * p * (1 - p)) < 1.1
+    b, e = 6, rows / 36.0
+    for s0, s1 in ((0, 1), (5, k - 7), (1000, 1001)):
+        h = np.zeros((b, b)); np.add.at(h, (ids[:, s0] * b // n, ids[:, s1] * b // n), 1)
+        assert ((h - e) ** 2 / e).sum() < 70                       # chi-square, 35 degrees of freedom: p(> 70) ~ 4e-4
+    assert abs((ids[:, 0] < ids[:, 1]).mean() - 0.5) < 0.05
+    assert abs(np.abs(np.diff(ids, axis=1)).mean() - n / 3) < 5      # E|X - Y| of two distinct uniform draws
+    assert abs(np.corrcoef(ids[:-1, 0], ids[1:, 0])[0, 1]) < 0.1     # row r and row r + 1
+    collisions = (ids[1:] == ids[:-1]).sum()                         # same slot, neighbouring rows: 1 / n each
+    assert abs(collisions - (rows - 1) * k / n) < 6 * np.sqrt((rows - 1) * k / n)
+    # a shard draws what the whole batch would; the base offset is added last
+    assert np.array_equal(dref.draw_rows(n, k, 5, 7, row_offset=100), dref.draw_rows(n, k, 105, 7)[100:])
+    assert np.array_equal(dref.draw_rows(n, k, 3, 7, base=500), dref.draw_rows(n, k, 3, 7) + 500)

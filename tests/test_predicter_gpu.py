@@ -285,6 +285,20 @@ def test_predict_batch_device_rng_and_id_validation(cuda_device):
     cnt = np.bincount(ids.reshape(-1), minlength=2500)
     assert 200 < cnt.min() and cnt.max() <= 300          # binomial(300, 0.82) per index: mean 245.8, sd 6.7
     assert abs(ids[:, 0].mean() - 1249.5) < 150 and abs(ids[:, -1].mean() - 1249.5) < 150
+    # the rows ARE the keyed permutation of oracle/draw_bijection_ref.py, bit for bit: odd sizes, a power of four (no cycle walking), a
+    # cloud beyond the old 65,535-point limit, a 64-bit seed, a base offset, and a shard (row_offset) == the rows of the whole
+    from oracle import draw_bijection_ref as dref
+    assert np.array_equal(ids, dref.draw_rows(2500, 2048, 300, 11))
+    for nv, npts, cnt, seed, base, off in ((4096, 2048, 9, 3, 0, 0), (2049, 2048, 5, 2 ** 40 + 77, 10000, 0), (70000, 2048, 4, 5, 0, 2 ** 33),
+                                            (1025, 1000, 7, 1, 3, 0), (20000, 8192, 3, 9, 0, 41)):
+        got = transforms.draw_ids_device(nv, npts, cnt, cuda_device, seed=seed, base=base, row_offset=off).cpu().numpy()
+        assert np.array_equal(got, dref.draw_rows(nv, npts, cnt, seed, base=base, row_offset=off)), (nv, npts)
+        assert all(len(np.unique(r)) == npts for r in got)
+    whole = transforms.draw_ids_device(2500, 2048, 40, cuda_device, seed=21).cpu().numpy()
+    part = transforms.draw_ids_device(2500, 2048, 15, cuda_device, seed=21, row_offset=25).cpu().numpy()
+    assert np.array_equal(whole[25:], part)
+    small = transforms.draw_ids_device(700, 512, 20, cuda_device, seed=2).cpu().numpy()        # <= 1,024 points: the sort kernel
+    assert all(len(np.unique(r)) == 512 for r in small) and small.max() < 700
     rep = transforms.draw_ids_device(700, 2048, 50, cuda_device, seed=3).cpu().numpy()       # with replacement
     assert rep.min() >= 0 and rep.max() < 700 and rep.shape == (50, 2048)
     ref = tref.predict_batch_post(oref.pointnet_cls_forward(sd, torch.from_numpy(np.stack(
