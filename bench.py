@@ -336,11 +336,11 @@ def ctypes_float0():
     return ctypes.c_float(0.0)
 
 
-def cpu_baseline(batch, sd_cls, sd_seg, n_score=100, n_coll=4096):
+def cpu_baseline(batch, sd_cls, sd_seg, n_score=80, n_coll=4096):
     """BASELINE.md §3 on this box's host cores, bounded to ~30 s: the reference's op sequence (F.conv1d / F.batch_norm / F.linear
     port, oracle/pointnet_ref.py -- the reference package cannot travel to the GPU box) in chunks of 200 (predicter.py:69) fed by
     the restated per-candidate GraspDataset.transform python loop; the C/OpenMP filterGraspPose restatement over all cores with
-    its per-call structure build; one NUNOCS forward per object amortised.  3 warm-ups, median of 5, thread scan logged."""
+    its per-call structure build; one NUNOCS forward per object amortised.  3 warm-ups, median of 3, thread scan logged."""
     from oracle import collision_oracle as co
     from oracle import pointnet_ref as oref
     from oracle import transforms_ref as tref
@@ -377,7 +377,7 @@ def cpu_baseline(batch, sd_cls, sd_seg, n_score=100, n_coll=4096):
     for _ in range(3):
         net(xw)
     t_tr, t_net = [], []
-    for _ in range(5):
+    for _ in range(3):
         t0 = time.perf_counter(); x = torch.from_numpy(transform_loop(n_score)).float(); t1 = time.perf_counter()
         tref.predict_batch_post(net(x).numpy()); t2 = time.perf_counter()
         t_tr.append((t1 - t0) / n_score); t_net.append((t2 - t1) / n_score)
@@ -423,7 +423,7 @@ def cpu_baseline(batch, sd_cls, sd_seg, n_score=100, n_coll=4096):
                          'imported /root/reference/pointnet2.py (tests/golden/make_golden*.py); the reference package itself cannot travel to the GPU box',
             'collision_threads': co.num_threads(),
             'collision_ms_per_evaluation_on_the_steps_subdivided_meshes': None if t_coll_same is None else round(t_coll_same * 1e3, 3),
-            'sample': f'{n_score} candidates x (3 warm-ups, median of 5): python transform loop + PointNetCls fp32 in chunks of 200 through '
+            'sample': f'{n_score} candidates x (3 warm-ups, median of 3): python transform loop + PointNetCls fp32 in chunks of 200 through '
                       f'F.conv1d/F.batch_norm/F.linear on {nthreads} torch threads (best of the scan); {n_can * len(sym) + n_coll // 2} '
                       f'evaluations collision-filtered by the C/OpenMP restatement on {co.num_threads()} threads (both call shapes, structure build '
                       f'included; un-subdivided 36 / 48-triangle meshes of the same gripper surfaces, float32 SAT: the restatement has no BVH); '
@@ -926,7 +926,7 @@ def main():
         blk['roofline'] = roofline(precision, r, traffic=traffic)
         t3 = time.perf_counter()
         if not args.no_projection:
-            blk['projected_scaling'] = projected_scaling_block(b, n, r['dt'] / steps, steps=2)
+            blk['projected_scaling'] = projected_scaling_block(b, n, r['dt'] / steps, steps=1)
         engine.set_precision(args.precision)
         t4 = time.perf_counter()
         blk['wall_s'] = {'build': round(t1 - t0, 2), 'warm-up + steps': round(t2 - t1, 2), 'traffic counter passes': round(t3 - t2, 2),

@@ -2,7 +2,6 @@
 gripper meshes, object models or datasets, so parity and throughput are measured on
 synthetic checkpoints / clouds / candidates / gripper of the same shapes.  numpy only."""
 import numpy as np
-import torch
 
 
 # ---------------------------------------------------------------------------------------------
@@ -43,6 +42,7 @@ def make_state_dict(kind, n_in, n_out, seed=0, prefix='', gain=1.6):
     """Seeded synthetic checkpoint with non-trivial BN statistics so folding is exercised.
     Weights ~ U(-gain/sqrt(fan_in), gain/sqrt(fan_in)); gain=1 is torch's default init, gain=1.6 keeps
     activations O(1) through the stack so logits are O(1-10) rather than ~0."""
+    import torch
     rng = np.random.default_rng(seed)
     shapes = model_shapes(kind, n_in, n_out)
     sd = {}
@@ -65,6 +65,7 @@ def seeded_like(state_dict, seed=0, gain=1.6):
     """A seeded synthetic checkpoint for ANY module of the pointnet2 family, from the names / shapes of its own state_dict (key
     order = the module's): BatchNorm statistics as in make_state_dict, weights ~ U(+-gain/sqrt(fan_in)).  Used for the standalone
     building blocks (STN3d / STNkd / PointNetEncoder with the reference's other constructor arguments)."""
+    import torch
     rng = np.random.default_rng(seed)
     out = {}
     fan = {}

@@ -100,6 +100,63 @@ def segment_poses_host(objs, gripper, nocs_poses, seg):
     return P
 
 
+def segment_poses_many(objs, gripper, nocs_poses, segs, workers=None, min_poses=40000):
+    """segment_poses_host for many segments -> [poses].  The candidate generator is a seeded python loop per pose (rejection sampling
+    of the approach direction: the values are defined by its sequential stream), 0.1 ms per pose: 23 s for the 500,000-candidate bin
+    on one core.  Segments are independent (own generator each), so big batches are generated by worker PROCESSES (plain
+    interpreters that import numpy only: `python -m catgrasp_amd.workload <in> <out>`), the segments dealt out by size; the result is
+    the serial one bit for bit.  Any failure of the worker route falls back to the serial loop."""
+    import os
+    import pickle
+    import shutil
+    import subprocess
+    import sys
+    import tempfile
+    total = sum(s.n_pose for s in segs)
+    w = workers if workers is not None else min(len(segs), 16, max(1, (os.cpu_count() or 2) // 2))
+    serial = lambda: [segment_poses_host(objs, gripper, nocs_poses, s) for s in segs]
+    if total < min_poses or w < 2:
+        return serial()
+    bins = [[] for _ in range(w)]
+    load = [0] * w
+    for i in sorted(range(len(segs)), key=lambda i: -segs[i].n_pose):        # largest first onto the lightest worker
+        k = load.index(min(load)); bins[k].append(i); load[k] += segs[i].n_pose
+    tmp = tempfile.mkdtemp(prefix='cg_poses_')
+    try:
+        slim = [{'xyz': o['xyz'], 'normal': o['normal']} for o in objs]
+        g = {'hand_depth': gripper['hand_depth'], 'init_bite': gripper['init_bite']}
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get('PYTHONPATH', ''), OMP_NUM_THREADS='1')
+        procs = []
+        for k, idx in enumerate(bins):
+            if not idx:
+                continue
+            fin, fout = os.path.join(tmp, f'in{k}.pkl'), os.path.join(tmp, f'out{k}.npz')
+            with open(fin, 'wb') as f:
+                pickle.dump((slim, g, [np.asarray(p) for p in nocs_poses], [segs[i] for i in idx]), f)
+            procs.append((idx, fout, subprocess.Popen([sys.executable, '-m', 'catgrasp_amd.workload', fin, fout], env=env, cwd=root,
+                                                      stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)))
+        out = [None] * len(segs)
+        for idx, fout, pr in procs:
+            if pr.wait(timeout=600) != 0:
+                raise RuntimeError('pose worker failed')
+            with np.load(fout) as z:
+                for j, i in enumerate(idx):
+                    out[i] = z[f'p{j}']
+        return out
+    except Exception:
+        return serial()
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def _poses_worker(fin, fout):
+    import pickle
+    with open(fin, 'rb') as f:
+        objs, g, nocs_poses, segs = pickle.load(f)
+    np.savez(fout, **{f'p{j}': segment_poses_host(objs, g, nocs_poses, s) for j, s in enumerate(segs)})
+
+
 def scene_nocs_pose(ob, nocs_scale=0.02):
     """The synthetic 9-D NUNOCS pose of a scene object (object pose x isotropic scale)."""
     return ob['pose'] @ np.diag([nocs_scale, nocs_scale, nocs_scale, 1.0])
@@ -167,8 +224,9 @@ class SceneBatch:
         self._streams = [torch.cuda.Stream(device=device) for _ in range(n_objects)]
         self.draw_seed = 0x5eed
         lo, hi = (0, self.n_total) if materialize is None else materialize        # a rank only builds the segments it will evaluate
-        for s, _, _ in intersect(self.segs, lo, hi):
-            self.segment_poses(s)
+        mine = [s for s, _, _ in intersect(self.segs, lo, hi)]
+        for s, P in zip(mine, segment_poses_many(self.objs, self.gripper, self.nocs_pose, mine)):
+            self._poses[(s.replica, s.obj, s.kind)] = torch.from_numpy(P.astype(np.float32).reshape(-1, 16)).to(self.device)
 
     # ---- candidate poses of a segment: a deterministic function of (replica, object, kind), so any rank can build any segment
     def segment_poses(self, seg):
@@ -343,3 +401,8 @@ def build_flat_workload(device, G, seed, n_objects=8, pts_per_object=2500, kind=
             'nunocs_ids': torch.stack([transforms.draw_ids_device(c.n, 8192, 1, device, gen, base=o)[0]
                                        for c, o in zip(clouds, offsets)]).contiguous(),
             'G': G}
+
+
+if __name__ == '__main__':          # a pose worker of segment_poses_many
+    import sys
+    _poses_worker(sys.argv[1], sys.argv[2])

@@ -152,3 +152,18 @@ def test_device_resampling_draw_statistics_on_its_restatement():
     # a shard draws what the whole batch would; the base offset is added last
     assert np.array_equal(dref.draw_rows(n, k, 5, 7, row_offset=100), dref.draw_rows(n, k, 105, 7)[100:])
     assert np.array_equal(dref.draw_rows(n, k, 3, 7, base=500), dref.draw_rows(n, k, 3, 7) + 500)
+
+
+def test_candidate_poses_from_worker_processes_equal_the_serial_loop():
+    """workload.segment_poses_many: big batches generate their candidate poses in worker processes (a seeded python loop per pose is the
+    definition of the values) -- same arrays as the serial loop, in segment order; a broken worker route falls back to it."""
+    from catgrasp_amd import synth
+    objs = synth.make_scene(3, 300, seed=1)
+    g = {'hand_depth': 0.04, 'init_bite': 0.005}
+    segs, _ = workload.plan_segments(3, 900, 12, replicas=2)
+    nocs = [workload.scene_nocs_pose(o) for o in objs]
+    serial = [workload.segment_poses_host(objs, g, nocs, s) for s in segs]
+    par = workload.segment_poses_many(objs, g, nocs, segs, workers=3, min_poses=0)
+    assert len(par) == len(segs) and all(np.array_equal(a, b) for a, b in zip(serial, par))
+    small = workload.segment_poses_many(objs, g, nocs, segs[:2])          # below the threshold: the serial loop itself
+    assert all(np.array_equal(a, b) for a, b in zip(serial[:2], small))
