@@ -106,6 +106,19 @@ def api_block(batch, gp, device, n=50000):
                                       'the permutation swap chains on the device)',
                    'precision': prec, 'wall_s': round(t, 4), 'candidates_per_s': round(n / t, 1)})
     out['predict_batch'] = pb
+    # small calls (what the reference issues per object is a few hundred poses, predicter.py:67-94): wall-clock of a whole predict_batch
+    # call at 1 / 16 / 256 poses, median of 15 after 3 warm-ups, exact f32, both draw modes
+    small = []
+    for G in (1, 16, 256):
+        for mode in ('device', 'numpy'):
+            ts = []
+            for i in range(18):
+                np.random.seed(i); torch.cuda.synchronize(); t0 = time.perf_counter()
+                gp.predict_batch(data, poses[:G], rng=mode)
+                torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+            ts = sorted(ts[3:])
+            small.append({'poses': G, 'rng': mode, 'median_ms': round(ts[len(ts) // 2] * 1e3, 3), 'min_ms': round(ts[0] * 1e3, 3)})
+    out['predict_batch_small_calls'] = small
     # filterGraspPose, 20 positional arguments, >= 5k-triangle gripper meshes, nut symmetries, pose nudging on
     g = batch.gripper
     V, F, Ve, Fe = g['vertices'], g['faces'], g['enclosed_vertices'], g['enclosed_faces']       # the batch's gripper: 9,216 / 12,288 triangles

@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void draw_ids_sort_kernel(int n_valid, int n_p
 // The same draw WITHOUT a sort or a swap chain (round 6): a keyed BIJECTION of [0, 2^b), b = the even number of bits that covers n_valid,
 // evaluated at i = 0 .. n_pts-1 and cycle-walked into [0, n_valid) (v <- pi(v) until v < n_valid: the standard way to restrict a
 // permutation of a superset -- the i < n_pts <= n_valid start inside the set, every walk ends at a distinct element of it).  pi is a
-// 12-round Feistel network on two b/2-bit halves whose round function is a 32-bit multiply-xorshift hash of (half, round key); the 12
+// 12-round Feistel network on two b/2-bit halves whose round function is a multiply-xorshift hash of (half, round key); the 12
 // round keys of a row are three Philox4x32-10 blocks of (seed, global row), so rows are independent and a shard draws what the whole
 // batch would.  This is the construction of GPU shuffles without global synchronisation (Mitchell et al., "Bandwidth-optimal random
 // shuffling for GPUs", 2021: a variable-length Feistel bijection + cycle walking); every output costs ~100 integer operations and
@@ -200,12 +200,14 @@ __global__ __launch_bounds__(256) void draw_ids_sort_kernel(int n_valid, int n_p
 // tests/test_predicter_gpu.py checks index and slot frequencies, pair statistics and row independence.)
 constexpr int BIJ_ROUNDS = 12;
 
+// the round function's hash: two 24-BIT multiplies (v_mul_u32_u24 runs at full rate on gfx950, a 32-bit integer multiply at a quarter)
 __device__ __forceinline__ unsigned bij_mix(unsigned x, unsigned k) {
-  x = (x + k) * 0x9E3779B1u;
-  x ^= x >> 15;
-  x *= 0x85EBCA77u;
-  x ^= x >> 13;
-  return x;
+  x += k & 0x7FFFFFu;                       // half < 2^15, key 23 bits: < 2^24
+  unsigned h = __umul24(x, 0x9E3779u);
+  h ^= h >> 15;
+  h = __umul24(h >> 8, 0x85EBCBu);
+  h ^= h >> 13;
+  return h;
 }
 
 __global__ __launch_bounds__(256) void draw_ids_bijection_kernel(int n_valid, int n_pts, long count, unsigned k0, unsigned k1, int base,
@@ -225,19 +227,25 @@ __global__ __launch_bounds__(256) void draw_ids_bijection_kernel(int n_valid, in
 #pragma unroll
     for (int q = 0; q < BIJ_ROUNDS; ++q) rk[q] = rk_lds[q];
     int* o = out + row * n_pts;
-    for (int i = t; i < n_pts; i += 256) {
-      unsigned v = (unsigned)i;
-      do {
-        unsigned l = v >> half_bits, r = v & hmask;
+    // ONE loop over the thread's outputs i = t, t + 256, ... and their walks: a wavefront then runs for the largest SUM of walk
+    // lengths among its lanes (~20 applications of pi for 8 outputs at n_valid / 2^b = 0.61) instead of the sum of the largest walk
+    // per output (~35)
+    int i = t;
+    unsigned v = (unsigned)i;
+    while (i < n_pts) {
+      unsigned l = v >> half_bits, r = v & hmask;
 #pragma unroll
-        for (int q = 0; q < BIJ_ROUNDS; ++q) {
-          const unsigned f = bij_mix(r, rk[q]) >> (32 - half_bits);        // the hash's top bits
-          const unsigned nr = l ^ f;
-          l = r; r = nr;
-        }
-        v = (l << half_bits) | r;
-      } while (v >= (unsigned)n_valid);
-      o[i] = (int)v + base;
+      for (int q = 0; q < BIJ_ROUNDS; ++q) {
+        const unsigned f = bij_mix(r, rk[q]) >> (32 - half_bits);        // the hash's top bits
+        const unsigned nr = l ^ f;
+        l = r; r = nr;
+      }
+      v = (l << half_bits) | r;
+      if (v < (unsigned)n_valid) {
+        o[i] = (int)v + base;
+        i += 256;
+        v = (unsigned)i;
+      }
     }
   }
 }

@@ -26,12 +26,22 @@ def philox4x32_10(c, k0, k1):
     return c.astype(np.uint32)
 
 
+M24 = np.uint64(0xFFFFFF)
+
+
+def _mul24(a, b):
+    """v_mul_u32_u24: the low 32 bits of the product of the operands' low 24 bits."""
+    return ((a & M24) * (b & M24)) & M32
+
+
 def _mix(x, k):
-    x = ((x + k) * np.uint64(0x9E3779B1)) & M32
-    x ^= x >> np.uint64(15)
-    x = (x * np.uint64(0x85EBCA77)) & M32
-    x ^= x >> np.uint64(13)
-    return x
+    """the round function's hash: two 24-bit multiplies (full-rate on gfx950; a 32-bit integer multiply is quarter rate)"""
+    x = x + (k & np.uint64(0x7FFFFF))              # half < 2^15, key 23 bits: < 2^24
+    h = _mul24(x, np.uint64(0x9E3779))
+    h ^= h >> np.uint64(15)
+    h = _mul24(h >> np.uint64(8), np.uint64(0x85EBCB))
+    h ^= h >> np.uint64(13)
+    return h
 
 
 def half_bits(n_valid):

@@ -123,6 +123,13 @@ case $JOB in
     timeout 300 python scripts/time_filter_plan.py > $O/time_cap32.txt 2>&1; tail -1 $O/time_cap32.txt | cut -c1-200
     timeout 600 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pmc-traffic --no-rccl-selftest --no-projection --no-configs --secondary "" > $O/bench.json 2> $O/bench.err; tail -c 300 $O/bench.err
     python -c "import json;d=json.load(open('$O/bench.json'));p=d['api']['pick_cycle'];print(json.dumps({k:(v['wall_ms_per_object'] if isinstance(v,dict) and 'wall_ms_per_object' in v else v) for k,v in p.items() if k!='note'},indent=1)[:1500]);print(json.dumps(p['default']['ms_per_object_by_stage']))" ;;
+  r6lines)    # the round's bench lines: default flags (C3 + configs), C4 and C5 alone, kernel statistics of the default step
+    ( time timeout 900 python bench.py ) > $O/bench_line.json 2> $O/bench.err; tail -c 200 $O/bench.err
+    timeout 900 python bench.py --workload C4 --no-api --no-cpu-baseline --no-rccl-selftest --secondary "" > $O/bench_line_c4_n1.json 2> $O/c4.err; head -c 300 $O/bench_line_c4_n1.json; echo
+    timeout 900 python bench.py --workload C5 --no-api --no-cpu-baseline --no-rccl-selftest --secondary "" > $O/bench_line_c5_n1.json 2> $O/c5.err; head -c 300 $O/bench_line_c5_n1.json; echo
+    stats bench python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-api --no-pmc-traffic --no-rccl-selftest --no-projection --no-configs
+    stats bench_c5 python bench.py --workload C5 --steps 3 --warmup 1 --no-cpu-baseline --no-api --no-pmc-traffic --no-rccl-selftest --no-projection --secondary ""
+    python -c "import json;d=json.load(open('$O/bench_line.json'));print(json.dumps(d['timing_s']));print(d['value'],d['ms_per_step'],{k:(v.get('value'),v.get('ms_per_step'),v.get('wall_s')) for k,v in d['configs'].items()});print(d['api']['predict_batch_small_calls']);print(d['api']['pick_cycle']['default']['wall_ms_per_object'])" ;;
   py)         # any script:  py scripts/x.py args...
     timeout 1200 python "$@" > $O/out.txt 2>&1; tail -40 $O/out.txt ;;
   *) echo "unknown job $JOB"; exit 2 ;;
