@@ -986,7 +986,7 @@ def main():
         if world == 1 and args.workload == 'C3' and args.scaling == 'strong' and not args.no_configs:
             # the other two GPU configurations of BASELINE.json in the same driver-run line
             line['configs'] = {}
-            for wl_name, prec, pmc_total in (('C4', 'f32', 28800), ('C5', 'bf16x3', 60000)):
+            for wl_name, prec, pmc_total in (('C4', 'f32', 50000), ('C5', 'bf16x3', 150000)):
                 try:
                     line['configs'][wl_name] = config_block(wl_name, prec, pmc_total=pmc_total)
                 except Exception as e:      # an extra: never let it take the bench line down
