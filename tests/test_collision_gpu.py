@@ -503,6 +503,14 @@ def test_filter_plan_of_several_calls_equals_the_calls_and_the_oracle(cuda_devic
         ora = _oracle(P, list(S), nocs, g, objs[k]['xyz'], bgs[k], 1, int(adj))
         sl = slice(plan.firsts[q], plan.firsts[q] + plan.counts[q])
         _check((codes[sl].cpu().numpy(), poses[sl].cpu().numpy(), nudge[sl].cpu().numpy()), ora)
+    # scenes without broad-phase grids: the sequence runs on the exhaustive kernel alone -- same results
+    plain = [my_cpp.GripperScene(g['vertices'], g['faces'], g['enclosed_vertices'], g['enclosed_faces'], objs[k]['xyz'], bgs[k], 0.0005, dev, accel=False)
+             for k in (0, 1)]
+    rows_plain = [(plain[k],) + rows[q][1:] for q, (k, _, _, _, _) in enumerate(host) if k in (0, 1)]
+    sel = [q for q, (k, _, _, _, _) in enumerate(host) if k in (0, 1)]
+    c2, p2, n2 = my_cpp.FilterPlan(rows_plain).run(g['gripper_in_grasp'], True)
+    want = torch.cat([codes[plan.firsts[q]:plan.firsts[q] + plan.counts[q]] for q in sel])
+    assert torch.equal(c2, want) and int(c2.numel()) == sum(plan.counts[q] for q in sel)
     # a plan must not mix grippers
     other = synth.make_gripper(subdivisions=1)
     sc2 = my_cpp.GripperScene(other['vertices'], other['faces'], other['enclosed_vertices'], other['enclosed_faces'], objs[0]['xyz'], bgs[0], 0.0005, dev)

@@ -141,3 +141,29 @@ def test_evaluate_objects_draw_ahead_equals_the_serial_loop(cuda_device):
     b_cloud, b_pose = npred.predict({'cloud_xyz': objs[0]['xyz'], 'cloud_normal': objs[0]['normal']})
     assert transforms.same_state(st_after, np.random.get_state())
     assert (a_pose is None) == (b_pose is None) and (a_pose is None or np.array_equal(a_pose, b_pose))
+
+
+def test_overlapped_pick_cycle_propagates_an_error_and_stays_usable(cuda_device):
+    """pipeline.evaluate_objects(overlap='stages'): an object that fails in its pre-scoring stages (a NaN point is refused at the
+    cloud boundary) ends the loop with that error AFTER the objects before it were scored, the stages thread is not left blocked, and
+    the next call works."""
+    from catgrasp_amd import pipeline
+    from catgrasp_amd.predicter import DEFAULT_GRASP_CFG, DEFAULT_NUNOCS_CFG, GraspPredicter, NunocsPredicter
+    objs = synth.make_scene(4, 2200, seed=6)
+    g = synth.make_gripper()
+    g['finger_vertices'] = [g['vertices'][8:16], g['vertices'][16:24]]
+    g['grip_dirs'] = [[0, -1, 0], [0, 1, 0]]
+    gp = GraspPredicter('nut', cfg=DEFAULT_GRASP_CFG, state_dict=synth.make_state_dict('cls', 6, 10, seed=0), device=cuda_device)
+    npred = NunocsPredicter('nut', cfg=DEFAULT_NUNOCS_CFG, state_dict=synth.make_state_dict('seg', 6, 300, seed=1), device=cuda_device)
+    scene_pts = np.concatenate([o['xyz'] for o in objs])
+    K = np.array([[600, 0, 320], [0, 600, 240], [0, 0, 1.0]])
+    job = [{'ob_pts': o['xyz'], 'ob_normals': o['normal']} for o in objs]
+    bad = [dict(j) for j in job]
+    bad[2] = {'ob_pts': bad[2]['ob_pts'].copy(), 'ob_normals': bad[2]['ob_normals']}
+    bad[2]['ob_pts'][5, 1] = np.nan
+    np.random.seed(4)
+    with pytest.raises(ValueError):
+        pipeline.evaluate_objects(bad, scene_pts, K, g, gp, npred, n_surface_samples=8, rng='numpy')
+    np.random.seed(4); again = pipeline.evaluate_objects(job, scene_pts, K, g, gp, npred, n_surface_samples=8, rng='numpy')
+    np.random.seed(4); serial = pipeline.evaluate_objects(job, scene_pts, K, g, gp, npred, n_surface_samples=8, rng='numpy', overlap=None)
+    assert len(again) == 4 and all(np.array_equal(a['poses'], b['poses']) and np.array_equal(a['p_G'], b['p_G']) for a, b in zip(again, serial))
