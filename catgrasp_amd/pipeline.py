@@ -240,6 +240,8 @@ def _stage_worker():
 
 
 def _stage_stream(device):
+    """The stages thread's stream.  (Scoring on a high-priority stream beside it was measured: 225.6 / 225.8 against 230.4 / 223.7 ms per
+    object without, alternating runs of one job -- inside the run-to-run spread, not kept.)"""
     key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
     if key not in _STAGE_STREAMS:
         _STAGE_STREAMS[key] = torch.cuda.Stream(device=key)
@@ -259,7 +261,7 @@ def evaluate_objects(objects, scene_pts, K, gripper, grasp_predicter, nunocs_pre
           state the serial loop would have reached there, known as soon as object k's survivor count is (its scoring pass draws exactly
           one resampling row per survivor; transforms.advance_choice_rows walks a copy of the generator over them) -- and the global
           generator is moved to the matching position before each scoring pass (score_object).  Object 0's draws start at entry, under
-          its own occupancy and NUNOCS stages.  The stages thread runs up to two objects ahead of the scoring loop (an object with few
+          its own occupancy and NUNOCS stages.  The stages thread runs up to three objects ahead of the scoring loop (an object with few
           survivors scores faster than its successor prepares; the lead absorbs that).
       'draws'  -- round 5's form: only the next object's NUNOCS-stage draws (~80 ms of sequential host work: numpy's Fisher-Yates
           rejection walk) are made ahead, on a second thread; NunocsPredicter.predict takes them only if numpy's generator really
@@ -304,7 +306,7 @@ def evaluate_objects(objects, scene_pts, K, gripper, grasp_predicter, nunocs_pre
     return results
 
 
-def _evaluate_objects_overlapped(objects, scene_pts, K, gripper, grasp_predicter, nunocs_predicter, rng, timings, kw, depth=2):
+def _evaluate_objects_overlapped(objects, scene_pts, K, gripper, grasp_predicter, nunocs_predicter, rng, timings, kw, depth=3):
     """evaluate_objects(overlap='stages'): see there.  A producer on the stages thread prepares the objects in order, each from the
     generator state the previous one leaves behind (prep k's state before scoring, advanced over the rows its scoring pass will draw:
     both known when prep k is done, so the producer needs nothing from the consumer) and runs up to `depth` objects ahead of the scoring
