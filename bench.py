@@ -243,14 +243,24 @@ def encoder_block(batch, device, clouds=(1, 8)):
                 idx2 = p2.query_ball_point(0.4, 64, l1_xyz, l2_xyz)
                 t1 = timed(lambda: prim.group_mlp_max(xyz, feats, l1_xyz, idx1, W1, check_indices=False, channels_last=True))
                 t2 = timed(lambda: prim.group_mlp_max(l1_xyz, l1, l2_xyz, idx2, W2, check_indices=False, channels_last=True))
+                l2 = prim.group_mlp_max(l1_xyz, l1, l2_xyz, idx2, W2, check_indices=False, channels_last=True)
+                W3 = enc.sa3._weights(device)
+                stages = {'fps 20000 -> 512': timed(lambda: p2.farthest_point_sample(xyz, 512, start[0], return_xyz=True)),
+                          'ball query r 0.2 K 32': timed(lambda: p2.query_ball_point(0.2, 32, xyz, l1_xyz)),
+                          'level 1 fused 9-64-64-128': t1,
+                          'fps 512 -> 128': timed(lambda: p2.farthest_point_sample(l1_xyz, 128, start[1], return_xyz=True)),
+                          'ball query r 0.4 K 64': timed(lambda: p2.query_ball_point(0.4, 64, l1_xyz, l2_xyz)),
+                          'level 2 fused 131-128-128-256': t2,
+                          'level 3 group-all 259-256-512-1024 (3 launches)': timed(lambda: prim.group_all_mlp_max(l2_xyz, l2, W3, fused=False))}
                 f1 = B * 512 * 32 * 2 * (9 * 64 + 64 * 64 + 64 * 128); f2 = B * 128 * 64 * 2 * (131 * 128 + 128 * 128 + 128 * 256)
                 out['rows'].append({'clouds': B, 'ms_per_forward': round(ms, 4), 'clouds_per_s': round(B / ms * 1e3, 1),
                                     'level1_fused_us': round(t1 * 1e3, 2), 'level1_frac_of_peak': round(f1 / (t1 * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
-                                    'level2_fused_us': round(t2 * 1e3, 2), 'level2_frac_of_peak': round(f2 / (t2 * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)})
+                                    'level2_fused_us': round(t2 * 1e3, 2), 'level2_frac_of_peak': round(f2 / (t2 * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                                    'stages_us': {k: round(v * 1e3, 2) for k, v in stages.items()}})
     finally:
         p2.VALIDATE_INPUTS = was
     out['note'] = ('a forward at one cloud is dominated by the two farthest-point-sampling chains (one CU per cloud, ~0.9 us per round: 512 + 128 rounds); '
-                   'stage table and rocprofv3 kernel statistics: profiles/r5_pp_encoder*.{json,csv}')
+                   '`stages_us`: every stage alone on the stream, as the module issues it; rocprofv3 kernel statistics: profiles/r5_pp_encoder*.csv')
     return out
 
 

@@ -105,8 +105,10 @@ row('filter_grasp_pose_kernel (broad-phase grid)', t_f, Pn * (64 + 66), '64 B po
 G50 = 50000
 ids_out = torch.empty((G50, 2048), dtype=torch.int32, device=dev)
 t_d = timed(lambda: transforms.draw_ids_device(2500, 2048, G50, dev, seed=7, out=ids_out), iters=10)
-row('draw_ids_sort_kernel (resampling draw, 50k candidates)', t_d, G50 * 2048 * 4, '2048 x 4 B ids written per candidate', bound='LDS (bitonic sort of 4096 (key, index) pairs per row: 78 barrier-separated rounds)',
-    extra={'rows_per_s': round(G50 / t_d), 'note': 'one workgroup per candidate: 48-bit Philox keys, bitonic sort in LDS (round 3: one lane per candidate down a Fisher-Yates chain, 0.835 ms per 6,250 rows); the reference draws these on the host: ~75 us per candidate'})
+row('draw_ids_bijection_kernel (resampling draw, 50k candidates)', t_d, G50 * 2048 * 4, '2048 x 4 B ids written per candidate',
+    bound='integer VALU (a 12-round Feistel bijection + cycle walking per index: ~170 instructions per application, ~1.6 applications per index)',
+    extra={'rows_per_s': round(G50 / t_d), 'note': 'round 6: a keyed permutation per candidate, 8 indices per thread, no LDS / no barrier (rounds 4-5: a bitonic sort of 4096 '
+                                                   '(key, index) pairs per row in LDS, 3.08 ms for the same 50k rows); the reference draws these on the host: ~75 us per candidate'})
 poses50 = torch.from_numpy(synth.make_candidates(objs[0], 2000, np.random.default_rng(1)).astype(np.float32).reshape(-1, 16)).to(dev).repeat(25, 1).contiguous()
 t_pi = timed(lambda: transforms.pose_inverse_rows_device(poses50, np.zeros(3)))
 row('pose_inverse_rows_kernel', t_pi, G50 * (64 + 48), '64 B pose in + 48 B rows out per candidate (launch-latency bound at this size)')
