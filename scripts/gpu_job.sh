@@ -130,6 +130,14 @@ case $JOB in
     stats bench python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-api --no-pmc-traffic --no-rccl-selftest --no-projection --no-configs
     stats bench_c5 python bench.py --workload C5 --steps 3 --warmup 1 --no-cpu-baseline --no-api --no-pmc-traffic --no-rccl-selftest --no-projection --secondary ""
     python -c "import json;d=json.load(open('$O/bench_line.json'));print(json.dumps(d['timing_s']));print(d['value'],d['ms_per_step'],{k:(v.get('value'),v.get('ms_per_step'),v.get('wall_s')) for k,v in d['configs'].items()});print(d['api']['predict_batch_small_calls']);print(d['api']['pick_cycle']['default']['wall_ms_per_object'])" ;;
+  r6final)    # the driver's round-end sequence on the final tree (suite, smoke, default bench) + the C4 / C5 lines and the example in the same (warm) state
+    timeout 2400 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; tail -3 $O/pytest.log
+    timeout 120 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
+    ( time timeout 900 python bench.py ) > $O/bench_default_flags.json 2> $O/bench.err; tail -c 200 $O/bench.err
+    timeout 900 python bench.py --workload C4 --no-api --no-cpu-baseline --no-rccl-selftest --secondary "" > $O/bench_line_c4_n1.json 2> $O/c4.err
+    timeout 900 python bench.py --workload C5 --no-api --no-cpu-baseline --no-rccl-selftest --secondary "" > $O/bench_line_c5_n1.json 2> $O/c5.err
+    timeout 300 python examples/run_scene.py > $O/example.txt 2>&1; tail -3 $O/example.txt
+    python -c "import json;d=json.load(open('$O/bench_default_flags.json'));c4=json.load(open('$O/bench_line_c4_n1.json'));c5=json.load(open('$O/bench_line_c5_n1.json'));print(d['value'],d['ms_per_step'],{k:v['value'] for k,v in d['configs'].items()},'standalone',c4['value'],c5['value'],d['api']['pick_cycle']['default']['wall_ms_per_object'],d['api']['predict_batch_small_calls'][:1],d['roofline_filter']['frac'],d['timing_s']['total'])" ;;
   py)         # any script:  py scripts/x.py args...
     timeout 1200 python "$@" > $O/out.txt 2>&1; tail -40 $O/out.txt ;;
   *) echo "unknown job $JOB"; exit 2 ;;
